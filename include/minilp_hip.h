@@ -1,0 +1,107 @@
+/* minilp_hip.h — C ABI of the MI355X-native simplex pivot engine (libminilp_hip.so).
+ *
+ * This is the drop-in boundary for ztlpn/minilp's Problem / Solution API.  The reference has
+ * no FFI seam (pure Rust); these are the entry points a `minilp-sys` Rust shim
+ * binds.  Each function cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - opaque handles, plain pointers and sizes, no C++/torch types;
+ *   - status codes: 0 OK, 1 Infeasible, 2 Unbounded (lib.rs:172-178 `Error`), <0 internal
+ *     (-1 invalid argument / reference panic condition, -2 singular basis, -3 HIP error,
+ *      -4 no GPU / extension unavailable).  mlp_last_error() returns the message;
+ *   - not thread-safe per handle; distinct handles are independent;
+ *   - Solution mutators follow the reference's consume-on-error rule (lib.rs:359, 385): on a
+ *     non-zero status the solution is freed and *s is set to NULL;
+ *   - all solver state (x_B, d, gamma, beta, the basis inverse, A in CSR+CSC) lives in HBM;
+ *     only scalars cross the boundary per pivot.
+ */
+#ifndef MINILP_HIP_H
+#define MINILP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mlp_problem mlp_problem;   /* lib.rs:193-200 `Problem`  */
+typedef struct mlp_solution mlp_solution; /* lib.rs:313-318 `Solution` (owns the device-resident Solver) */
+
+enum { MLP_MINIMIZE = 0, MLP_MAXIMIZE = 1 };      /* lib.rs:61-68  OptimizationDirection */
+enum { MLP_EQ = 0, MLP_LE = 1, MLP_GE = 2 };      /* lib.rs:160-169 ComparisonOp */
+enum { MLP_OK = 0, MLP_INFEASIBLE = 1, MLP_UNBOUNDED = 2,
+       MLP_EINVAL = -1, MLP_ESINGULAR = -2, MLP_EHIP = -3, MLP_ENOGPU = -4 };
+
+const char* mlp_last_error(void);
+/* Number of visible HIP devices (0 => every solve returns MLP_ENOGPU; there is no CPU fallback). */
+int mlp_device_count(void);
+
+/* ---- Problem (lib.rs:215-305) ------------------------------------------------------------ */
+mlp_problem* mlp_problem_new(int direction);                                   /* Problem::new      lib.rs:217 */
+mlp_problem* mlp_problem_clone(const mlp_problem* p);                          /* #[derive(Clone)]  lib.rs:193 */
+void mlp_problem_free(mlp_problem* p);
+/* returns the Variable index (lib.rs:72, 79) */
+uint32_t mlp_problem_add_var(mlp_problem* p, double obj_coeff, double min, double max); /* add_var lib.rs:233 */
+uint32_t mlp_problem_num_vars(const mlp_problem* p);
+/* duplicate or out-of-range variable => MLP_EINVAL (the reference panics, lib.rs:247-249) */
+int mlp_problem_add_constraint(mlp_problem* p, const uint32_t* vars, const double* coeffs, uint64_t k,
+                               int cmp_op, double rhs);                        /* add_constraint lib.rs:276 */
+int mlp_problem_solve(const mlp_problem* p, mlp_solution** out);               /* solve lib.rs:291 */
+
+/* ---- Solution (lib.rs:332-424) ----------------------------------------------------------- */
+mlp_solution* mlp_solution_clone(const mlp_solution* s);  /* #[derive(Clone)] lib.rs:313: deep copy of device state */
+void mlp_solution_free(mlp_solution* s);
+double mlp_solution_objective(const mlp_solution* s);                          /* objective lib.rs:334 */
+uint32_t mlp_solution_num_vars(const mlp_solution* s);
+int mlp_solution_var_value(const mlp_solution* s, uint32_t var, double* out);  /* var_value lib.rs:344 / Index lib.rs:426 */
+int mlp_solution_values(const mlp_solution* s, double* out, uint32_t n);       /* iter lib.rs:350 (bulk form) */
+int mlp_solution_add_constraint(mlp_solution** s, const uint32_t* vars, const double* coeffs, uint64_t k,
+                                int cmp_op, double rhs);                       /* add_constraint lib.rs:368 */
+int mlp_solution_fix_var(mlp_solution** s, uint32_t var, double val);          /* fix_var lib.rs:390 */
+int mlp_solution_unfix_var(mlp_solution** s, uint32_t var, int* was_fixed);    /* unfix_var lib.rs:399 */
+int mlp_solution_add_gomory_cut(mlp_solution** s, uint32_t var);               /* add_gomory_cut lib.rs:419 */
+
+/* ---- Engine-level controls (no counterpart in the reference: its pivot loop exposes no
+ *      counter; these implement the fixed-pivot-budget measurement of §8d) ---- */
+/* Like mlp_problem_solve but stops after `budget` simplex iterations (budget < 0: run to optimality).
+ * flags: bit0 = record a pivot trace, bit1 = time the dominant kernels with HIP events. */
+int mlp_problem_solve_ex(const mlp_problem* p, mlp_solution** out, int64_t budget, uint32_t flags);
+int mlp_solution_continue(mlp_solution* s, int64_t budget);
+int mlp_solution_budget_exhausted(const mlp_solution* s);
+/* Recompute the dense nucleus inverse from A (the counterpart of BasisSolver::reset,
+ * solver.rs:1286-1303); returns max |W_incremental - W_fresh| through *max_diff when non-NULL. */
+int mlp_solution_reinvert(mlp_solution* s, double* max_diff);
+
+typedef struct mlp_stats {
+    uint64_t iterations, basis_changes, bound_flips, primal_iters, dual_iters, reinversions;
+    uint64_t num_constraints, num_total_vars, nucleus_size, nucleus_capacity, nnz;
+    /* algorithmic bytes and HIP-event time of the two dominant kernels */
+    double fused_bytes, fused_ms, sweep_bytes, sweep_ms;
+    uint64_t fused_launches, sweep_launches;
+    double solve_wall_s; /* host wall time spent inside the pivot loops */
+} mlp_stats;
+void mlp_solution_stats(const mlp_solution* s, mlp_stats* out);
+void mlp_solution_reset_stats(mlp_solution* s);
+
+/* pivot trace (flags bit0): phase 0 primal / 1 dual; row = -1 for a bound flip */
+uint64_t mlp_solution_trace_len(const mlp_solution* s);
+void mlp_solution_trace_get(const mlp_solution* s, uint64_t i, int32_t* phase, int64_t* col, int64_t* row,
+                            int64_t* entering_var, int64_t* leaving_var, double* pivot_coeff, double* obj_after);
+/* white-box state for the differential tests (names follow solver.rs:14-58): returns the length,
+ * copies min(len, cap) doubles into out when out != NULL; (uint64_t)-1 for an unknown name. */
+uint64_t mlp_solution_state(const mlp_solution* s, const char* what, double* out, uint64_t cap);
+
+/* ---- MPS (mps.rs:39 MpsFile::parse) ------------------------------------------------------ */
+typedef struct mlp_mps mlp_mps;
+int mlp_mps_parse(const char* text, uint64_t len, int direction, mlp_mps** out);
+void mlp_mps_free(mlp_mps* f);
+const char* mlp_mps_name(const mlp_mps* f);                 /* MpsFile::problem_name mps.rs:11 */
+uint32_t mlp_mps_num_vars(const mlp_mps* f);
+const char* mlp_mps_var_name(const mlp_mps* f, uint32_t i); /* MpsFile::variables mps.rs:13 */
+int64_t mlp_mps_var_index(const mlp_mps* f, const char* name);
+mlp_problem* mlp_mps_problem(const mlp_mps* f);             /* MpsFile::problem mps.rs:15 (a clone) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MINILP_HIP_H */

@@ -1,0 +1,12 @@
+"""minilp_amd — MI355X-native revised-simplex pivot engine behind minilp's Problem/Solution API.
+
+The hot path (pricing, FTRAN/BTRAN, ratio tests, tableau-row product, basis update) is hand-written
+HIP for gfx950 in `csrc/`, reached through the C ABI of `include/minilp_hip.h`.  This package is the
+Python mirror of the reference's public interface (lib.rs:61-464).  There is no CPU fallback: without
+the built extension or without a GPU every solve raises.
+"""
+from .api import (EQ, GE, LE, MAXIMIZE, MINIMIZE, Infeasible, InternalError, MpsFile, Problem, Solution,
+                  Unbounded, device_count, lib, lib_path)
+
+__all__ = ["Problem", "Solution", "MpsFile", "MINIMIZE", "MAXIMIZE", "EQ", "LE", "GE", "Infeasible", "Unbounded",
+           "InternalError", "device_count", "lib", "lib_path"]

@@ -1,0 +1,293 @@
+"""ctypes binding of libminilp_hip.so with the reference's names and argument meaning
+(lib.rs:61-464: OptimizationDirection, ComparisonOp, Problem, Solution, Error; mps.rs: MpsFile)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libminilp_hip.so")
+
+MINIMIZE, MAXIMIZE = 0, 1          # lib.rs:61-68 OptimizationDirection
+EQ, LE, GE = 0, 1, 2               # lib.rs:160-169 ComparisonOp
+
+
+class Infeasible(Exception):       # lib.rs:175 Error::Infeasible
+    pass
+
+
+class Unbounded(Exception):        # lib.rs:177 Error::Unbounded
+    pass
+
+
+class InternalError(Exception):    # where the reference panics (or a HIP error / missing GPU)
+    def __init__(self, code, msg):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+class MlpStats(C.Structure):
+    _fields_ = ([(n, C.c_uint64) for n in ("iterations", "basis_changes", "bound_flips", "primal_iters", "dual_iters",
+                                            "reinversions", "num_constraints", "num_total_vars", "nucleus_size",
+                                            "nucleus_capacity", "nnz")]
+                + [(n, C.c_double) for n in ("fused_bytes", "fused_ms", "sweep_bytes", "sweep_ms")]
+                + [(n, C.c_uint64) for n in ("fused_launches", "sweep_launches")]
+                + [("solve_wall_s", C.c_double)])
+
+
+_lib = None
+
+
+def lib_path():
+    return _SO
+
+
+def lib():
+    """Load the HIP extension.  Fails loudly if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise ImportError(f"{_SO} is missing: build it with `python -m minilp_amd.build` (hipcc, gfx950). "
+                          "minilp_amd has no CPU fallback.")
+    L = C.CDLL(_SO)
+    vp, u64, i64, u32, dbl, i32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_uint32, C.c_double, C.c_int
+    pu32, pdbl = C.POINTER(C.c_uint32), C.POINTER(C.c_double)
+
+    def sig(name, res, *args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    sig("mlp_last_error", C.c_char_p)
+    sig("mlp_device_count", i32)
+    sig("mlp_problem_new", vp, i32)
+    sig("mlp_problem_clone", vp, vp)
+    sig("mlp_problem_free", None, vp)
+    sig("mlp_problem_add_var", u32, vp, dbl, dbl, dbl)
+    sig("mlp_problem_num_vars", u32, vp)
+    sig("mlp_problem_add_constraint", i32, vp, pu32, pdbl, u64, i32, dbl)
+    sig("mlp_problem_solve", i32, vp, C.POINTER(vp))
+    sig("mlp_problem_solve_ex", i32, vp, C.POINTER(vp), i64, u32)
+    sig("mlp_solution_continue", i32, vp, i64)
+    sig("mlp_solution_budget_exhausted", i32, vp)
+    sig("mlp_solution_reinvert", i32, vp, pdbl)
+    sig("mlp_solution_clone", vp, vp)
+    sig("mlp_solution_free", None, vp)
+    sig("mlp_solution_objective", dbl, vp)
+    sig("mlp_solution_num_vars", u32, vp)
+    sig("mlp_solution_var_value", i32, vp, u32, pdbl)
+    sig("mlp_solution_values", i32, vp, pdbl, u32)
+    sig("mlp_solution_add_constraint", i32, C.POINTER(vp), pu32, pdbl, u64, i32, dbl)
+    sig("mlp_solution_fix_var", i32, C.POINTER(vp), u32, dbl)
+    sig("mlp_solution_unfix_var", i32, C.POINTER(vp), u32, C.POINTER(i32))
+    sig("mlp_solution_add_gomory_cut", i32, C.POINTER(vp), u32)
+    sig("mlp_solution_stats", None, vp, C.POINTER(MlpStats))
+    sig("mlp_solution_reset_stats", None, vp)
+    sig("mlp_solution_trace_len", u64, vp)
+    sig("mlp_solution_trace_get", None, vp, u64, C.POINTER(C.c_int32), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64),
+        C.POINTER(i64), pdbl, pdbl)
+    sig("mlp_solution_state", u64, vp, C.c_char_p, pdbl, u64)
+    sig("mlp_mps_parse", i32, C.c_char_p, u64, i32, C.POINTER(vp))
+    sig("mlp_mps_free", None, vp)
+    sig("mlp_mps_name", C.c_char_p, vp)
+    sig("mlp_mps_num_vars", u32, vp)
+    sig("mlp_mps_var_name", C.c_char_p, vp, u32)
+    sig("mlp_mps_var_index", i64, vp, C.c_char_p)
+    sig("mlp_mps_problem", vp, vp)
+    _lib = L
+    return L
+
+
+def device_count():
+    return lib().mlp_device_count()
+
+
+def _raise(st):
+    if st == 0:
+        return
+    if st == 1:
+        raise Infeasible("problem is infeasible")
+    if st == 2:
+        raise Unbounded("problem is unbounded")
+    raise InternalError(st, lib().mlp_last_error().decode())
+
+
+def _terms(expr):
+    pairs = list(expr)
+    idx = np.ascontiguousarray([int(p[0]) for p in pairs], dtype=np.uint32)
+    val = np.ascontiguousarray([float(p[1]) for p in pairs], dtype=np.float64)
+    return idx, val
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class Problem:
+    """lib.rs:193-305.  `Problem(direction)`, `add_var(obj_coeff, (min, max)) -> Variable index`,
+    `add_constraint(expr, cmp_op, rhs)` with expr an iterable of (variable, coeff), `solve()`."""
+
+    def __init__(self, direction, _h=None):
+        self._h = _h if _h is not None else lib().mlp_problem_new(int(direction))
+        self.direction = direction
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().mlp_problem_free(self._h)
+            self._h = None
+
+    def clone(self):
+        return Problem(self.direction, lib().mlp_problem_clone(self._h))
+
+    @property
+    def num_vars(self):
+        return lib().mlp_problem_num_vars(self._h)
+
+    def add_var(self, obj_coeff, bounds):
+        return int(lib().mlp_problem_add_var(self._h, obj_coeff, bounds[0], bounds[1]))
+
+    def add_constraint(self, expr, cmp_op, rhs):
+        idx, val = _terms(expr)
+        _raise(lib().mlp_problem_add_constraint(self._h, _p(idx, C.c_uint32), _p(val, C.c_double), len(idx), cmp_op, rhs))
+
+    def add_constraint_arrays(self, idx, val, cmp_op, rhs):
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        _raise(lib().mlp_problem_add_constraint(self._h, _p(idx, C.c_uint32), _p(val, C.c_double), len(idx), cmp_op, rhs))
+
+    def solve(self, budget=-1, trace=False, profile=False):
+        out = C.c_void_p()
+        _raise(lib().mlp_problem_solve_ex(self._h, C.byref(out), budget, (1 if trace else 0) | (2 if profile else 0)))
+        return Solution(out)
+
+
+class Solution:
+    """lib.rs:313-424.  Mutators consume self like the Rust receivers and return the new Solution;
+    on error the device-resident solver is freed (lib.rs:359, 385)."""
+
+    def __init__(self, h):
+        self._h = C.c_void_p(h.value if isinstance(h, C.c_void_p) else h)
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().mlp_solution_free(self._h)
+            self._h = C.c_void_p()
+
+    def _take(self):
+        h = C.c_void_p(self._h.value)
+        self._h = C.c_void_p()
+        return h
+
+    def clone(self):
+        h = lib().mlp_solution_clone(self._h)
+        if not h:
+            raise InternalError(-3, lib().mlp_last_error().decode())
+        return Solution(C.c_void_p(h))
+
+    def objective(self):
+        return lib().mlp_solution_objective(self._h)
+
+    @property
+    def num_vars(self):
+        return lib().mlp_solution_num_vars(self._h)
+
+    def var_value(self, var):
+        out = C.c_double()
+        _raise(lib().mlp_solution_var_value(self._h, int(var), C.byref(out)))
+        return out.value
+
+    __getitem__ = var_value
+
+    def values(self):
+        a = np.zeros(self.num_vars, dtype=np.float64)
+        _raise(lib().mlp_solution_values(self._h, _p(a, C.c_double), len(a)))
+        return a
+
+    def __iter__(self):  # lib.rs:350 iter()
+        return iter(enumerate(self.values()))
+
+    def add_constraint(self, expr, cmp_op, rhs):
+        idx, val = _terms(expr)
+        h = self._take()
+        _raise(lib().mlp_solution_add_constraint(C.byref(h), _p(idx, C.c_uint32), _p(val, C.c_double), len(idx), cmp_op, rhs))
+        return Solution(h)
+
+    def fix_var(self, var, val):
+        h = self._take()
+        _raise(lib().mlp_solution_fix_var(C.byref(h), int(var), val))
+        return Solution(h)
+
+    def unfix_var(self, var):
+        h = self._take()
+        was = C.c_int()
+        _raise(lib().mlp_solution_unfix_var(C.byref(h), int(var), C.byref(was)))
+        return Solution(h), bool(was.value)
+
+    def add_gomory_cut(self, var):
+        h = self._take()
+        _raise(lib().mlp_solution_add_gomory_cut(C.byref(h), int(var)))
+        return Solution(h)
+
+    # --- engine-level controls (fixed pivot budget, stats, trace)
+    def continue_solve(self, budget):
+        _raise(lib().mlp_solution_continue(self._h, budget))
+
+    @property
+    def budget_exhausted(self):
+        return bool(lib().mlp_solution_budget_exhausted(self._h))
+
+    def reinvert(self):
+        d = C.c_double()
+        _raise(lib().mlp_solution_reinvert(self._h, C.byref(d)))
+        return d.value
+
+    def stats(self):
+        s = MlpStats()
+        lib().mlp_solution_stats(self._h, C.byref(s))
+        return {n: getattr(s, n) for n, _ in MlpStats._fields_}
+
+    def reset_stats(self):
+        lib().mlp_solution_reset_stats(self._h)
+
+    def trace(self):
+        n = lib().mlp_solution_trace_len(self._h)
+        out = []
+        ph, col, row, ev, lv = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        pc, ob = C.c_double(), C.c_double()
+        for i in range(n):
+            lib().mlp_solution_trace_get(self._h, i, C.byref(ph), C.byref(col), C.byref(row), C.byref(ev), C.byref(lv),
+                                         C.byref(pc), C.byref(ob))
+            out.append((ph.value, col.value, row.value, ev.value, lv.value, pc.value, ob.value))
+        return out
+
+    def state(self, what):
+        n = lib().mlp_solution_state(self._h, what.encode(), None, 0)
+        if n == 2 ** 64 - 1:
+            raise KeyError(what)
+        a = np.zeros(n, dtype=np.float64)
+        lib().mlp_solution_state(self._h, what.encode(), _p(a, C.c_double), n)
+        return a
+
+
+class MpsFile:
+    """mps.rs:7-16; MpsFile.parse(text, direction) mirrors MpsFile::parse (mps.rs:39)."""
+
+    def __init__(self, text, direction):
+        if isinstance(text, str):
+            text = text.encode()
+        h = C.c_void_p()
+        st = lib().mlp_mps_parse(text, len(text), int(direction), C.byref(h))
+        if st != 0:
+            raise ValueError(lib().mlp_last_error().decode())  # io::ErrorKind::InvalidData
+        self._h = h
+        self.problem_name = lib().mlp_mps_name(h).decode()
+        n = lib().mlp_mps_num_vars(h)
+        self.variables = {lib().mlp_mps_var_name(h, i).decode(): i for i in range(n)}
+        self.problem = Problem(direction, lib().mlp_mps_problem(h))
+
+    parse = classmethod(lambda cls, text, direction: cls(text, direction))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().mlp_mps_free(self._h)

@@ -1,0 +1,211 @@
+// capi.hip — extern "C" boundary (include/minilp_hip.h).  No C++ exception crosses the ABI.
+#include "../../include/minilp_hip.h"
+
+#include <cstring>
+#include <string>
+
+#include "engine.h"
+
+using namespace mlp;
+
+struct mlp_problem {
+    ProblemData pd;
+};
+struct mlp_solution {
+    Engine* eng = nullptr;
+    ~mlp_solution() { delete eng; }
+};
+struct mlp_mps {
+    MpsData d;
+};
+
+static thread_local std::string g_err;
+
+template <class F>
+static int guarded(F f) {
+    try {
+        f();
+        return MLP_OK;
+    } catch (LpFail& e) {
+        return e.code;
+    } catch (MlpError& e) {
+        g_err = e.what();
+        return e.code;
+    } catch (std::exception& e) {
+        g_err = e.what();
+        return MLP_EINVAL;
+    }
+}
+static int consume_on_error(mlp_solution** s, int st) {  // lib.rs:359, 385
+    if (st != 0) {
+        delete *s;
+        *s = nullptr;
+    }
+    return st;
+}
+
+extern "C" {
+
+const char* mlp_last_error(void) { return g_err.c_str(); }
+int mlp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+mlp_problem* mlp_problem_new(int direction) {
+    mlp_problem* p = new mlp_problem();
+    p->pd.direction = direction == MLP_MAXIMIZE ? 1 : 0;
+    return p;
+}
+mlp_problem* mlp_problem_clone(const mlp_problem* p) { return new mlp_problem(*p); }
+void mlp_problem_free(mlp_problem* p) { delete p; }
+uint32_t mlp_problem_add_var(mlp_problem* p, double c, double mn, double mx) { return (uint32_t)p->pd.add_var(c, mn, mx); }
+uint32_t mlp_problem_num_vars(const mlp_problem* p) { return (uint32_t)p->pd.obj.size(); }
+int mlp_problem_add_constraint(mlp_problem* p, const uint32_t* vars, const double* coeffs, uint64_t k, int op, double rhs) {
+    return guarded([&] { p->pd.add_constraint(vars, coeffs, k, op, rhs); });
+}
+int mlp_problem_solve_ex(const mlp_problem* p, mlp_solution** out, int64_t budget, uint32_t flags) {
+    *out = nullptr;
+    mlp_solution* s = new mlp_solution();
+    int st = guarded([&] {
+        s->eng = new Engine();
+        s->eng->pivot_budget = budget;
+        s->eng->trace = flags & 1u;
+        s->eng->profile = flags & 2u;
+        s->eng->try_new(p->pd);      // lib.rs:292-297
+        s->eng->initial_solve();     // lib.rs:298
+    });
+    if (st != 0) delete s;
+    else *out = s;
+    return st;
+}
+int mlp_problem_solve(const mlp_problem* p, mlp_solution** out) { return mlp_problem_solve_ex(p, out, -1, 0); }
+int mlp_solution_continue(mlp_solution* s, int64_t budget) {
+    return guarded([&] {
+        s->eng->pivot_budget = budget;
+        s->eng->budget_exhausted = false;
+        s->eng->initial_solve();
+    });
+}
+int mlp_solution_budget_exhausted(const mlp_solution* s) { return s->eng->budget_exhausted ? 1 : 0; }
+int mlp_solution_reinvert(mlp_solution* s, double* max_diff) {
+    return guarded([&] {
+        double d = s->eng->reinvert(true);
+        if (max_diff) *max_diff = d;
+    });
+}
+
+mlp_solution* mlp_solution_clone(const mlp_solution* s) {
+    mlp_solution* c = new mlp_solution();
+    int st = guarded([&] { c->eng = s->eng->clone(); });
+    if (st != 0) {
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+void mlp_solution_free(mlp_solution* s) { delete s; }
+double mlp_solution_objective(const mlp_solution* s) {  // lib.rs:334-339
+    double v = 0.0;
+    guarded([&] { v = s->eng->cur_obj_val(); });
+    return s->eng->direction == 1 ? -v : v;
+}
+uint32_t mlp_solution_num_vars(const mlp_solution* s) { return (uint32_t)s->eng->num_vars; }
+int mlp_solution_var_value(const mlp_solution* s, uint32_t var, double* out) {
+    return guarded([&] {
+        if ((int)var >= s->eng->num_vars) throw MlpError(MLP_EINVAL, "variable out of range (lib.rs:345)");
+        *out = s->eng->get_value((int)var);
+    });
+}
+int mlp_solution_values(const mlp_solution* s, double* out, uint32_t n) {
+    return guarded([&] {
+        if ((int)n > s->eng->num_vars) throw MlpError(MLP_EINVAL, "too many values requested");
+        s->eng->get_values(out, (int)n);
+    });
+}
+int mlp_solution_add_constraint(mlp_solution** s, const uint32_t* vars, const double* coeffs, uint64_t k, int op, double rhs) {
+    return consume_on_error(s, guarded([&] {
+        ProblemData tmp;
+        tmp.obj.resize((*s)->eng->num_vars);  // lib.rs:376: dimension = num_vars
+        tmp.add_constraint(vars, coeffs, k, op, rhs);
+        (*s)->eng->pivot_budget = -1;
+        (*s)->eng->add_constraint(tmp.cons[0]);
+    }));
+}
+int mlp_solution_fix_var(mlp_solution** s, uint32_t var, double val) {
+    return consume_on_error(s, guarded([&] {
+        if ((int)var >= (*s)->eng->num_vars) throw MlpError(MLP_EINVAL, "variable out of range (lib.rs:391)");
+        (*s)->eng->pivot_budget = -1;
+        (*s)->eng->fix_var((int)var, val);
+    }));
+}
+int mlp_solution_unfix_var(mlp_solution** s, uint32_t var, int* was_fixed) {
+    return consume_on_error(s, guarded([&] {
+        if ((int)var >= (*s)->eng->num_vars) throw MlpError(MLP_EINVAL, "variable out of range (lib.rs:400)");
+        (*s)->eng->pivot_budget = -1;
+        *was_fixed = (*s)->eng->unfix_var((int)var) ? 1 : 0;
+    }));
+}
+int mlp_solution_add_gomory_cut(mlp_solution** s, uint32_t var) {
+    return consume_on_error(s, guarded([&] {
+        if ((int)var >= (*s)->eng->num_vars) throw MlpError(MLP_EINVAL, "variable out of range (lib.rs:420)");
+        (*s)->eng->pivot_budget = -1;
+        (*s)->eng->add_gomory_cut((int)var);
+    }));
+}
+
+void mlp_solution_stats(const mlp_solution* s, mlp_stats* o) {
+    Engine* e = s->eng;
+    guarded([&] { e->resolve_events(); });
+    const Stats& t = e->stats;
+    std::memset(o, 0, sizeof(*o));
+    o->iterations = t.iterations; o->basis_changes = t.basis_changes; o->bound_flips = t.bound_flips;
+    o->primal_iters = t.primal_iters; o->dual_iters = t.dual_iters; o->reinversions = t.reinversions;
+    o->num_constraints = e->m(); o->num_total_vars = e->total_vars();
+    o->nucleus_size = e->nucleus(); o->nucleus_capacity = e->nucleus_cap(); o->nnz = e->nnz();
+    o->fused_bytes = t.fused_bytes; o->fused_ms = t.fused_ms; o->sweep_bytes = t.sweep_bytes; o->sweep_ms = t.sweep_ms;
+    o->fused_launches = t.fused_launches; o->sweep_launches = t.sweep_launches;
+    o->solve_wall_s = t.solve_wall_s;
+}
+void mlp_solution_reset_stats(mlp_solution* s) {
+    guarded([&] { s->eng->resolve_events(); });
+    s->eng->stats = Stats();
+}
+uint64_t mlp_solution_trace_len(const mlp_solution* s) { return s->eng->trace_log.size(); }
+void mlp_solution_trace_get(const mlp_solution* s, uint64_t i, int32_t* phase, int64_t* col, int64_t* row,
+                            int64_t* entering_var, int64_t* leaving_var, double* pivot_coeff, double* obj_after) {
+    const PivotRecord& r = s->eng->trace_log[i];
+    *phase = r.phase; *col = r.col; *row = r.row; *entering_var = r.entering_var; *leaving_var = r.leaving_var;
+    *pivot_coeff = r.pivot_coeff; *obj_after = r.obj_after;
+}
+uint64_t mlp_solution_state(const mlp_solution* s, const char* what, double* out, uint64_t cap) {
+    uint64_t n = (uint64_t)-1;
+    guarded([&] { n = s->eng->state(what, out, cap); });
+    return n;
+}
+
+int mlp_mps_parse(const char* text, uint64_t len, int direction, mlp_mps** out) {
+    *out = nullptr;
+    mlp_mps* f = new mlp_mps();
+    int st = guarded([&] { f->d = parse_mps(std::string(text, len), direction == MLP_MAXIMIZE ? 1 : 0); });
+    if (st != 0) delete f;
+    else *out = f;
+    return st;
+}
+void mlp_mps_free(mlp_mps* f) { delete f; }
+const char* mlp_mps_name(const mlp_mps* f) { return f->d.name.c_str(); }
+uint32_t mlp_mps_num_vars(const mlp_mps* f) { return (uint32_t)f->d.var_names.size(); }
+const char* mlp_mps_var_name(const mlp_mps* f, uint32_t i) { return f->d.var_names[i].c_str(); }
+int64_t mlp_mps_var_index(const mlp_mps* f, const char* name) {
+    for (size_t i = 0; i < f->d.var_names.size(); ++i)
+        if (f->d.var_names[i] == name) return (int64_t)i;
+    return -1;
+}
+mlp_problem* mlp_mps_problem(const mlp_mps* f) {
+    mlp_problem* p = new mlp_problem();
+    p->pd = f->d.problem;
+    return p;
+}
+
+}  // extern "C"

@@ -1,0 +1,207 @@
+// engine.h — host orchestration of the device-resident revised simplex (the "Solver" of
+// solver.rs:14-58 with every vector in HBM and every hot loop a HIP kernel).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace mlp {
+
+struct MlpError : std::runtime_error {
+    int code;
+    MlpError(int c, const std::string& s) : std::runtime_error(s), code(c) {}
+};
+struct LpFail {  // lib.rs:172-178
+    int code;    // 1 infeasible, 2 unbounded
+};
+
+#define HIPCHECK(expr)                                                                                   \
+    do {                                                                                                 \
+        hipError_t e__ = (expr);                                                                         \
+        if (e__ != hipSuccess)                                                                           \
+            throw ::mlp::MlpError(-3, std::string(#expr) + " failed: " + hipGetErrorString(e__) + " at " + \
+                                          __FILE__ + ":" + std::to_string(__LINE__));                    \
+    } while (0)
+
+struct Constraint {  // lib.rs:199: (CsVec, ComparisonOp, f64) with sorted unique indices
+    std::vector<int> idx;
+    std::vector<double> val;
+    int op;
+    double rhs;
+};
+struct ProblemData {  // lib.rs:193-200
+    int direction = 0;
+    std::vector<double> obj, lo, hi;  // obj already negated for Maximize (lib.rs:235-238)
+    std::vector<Constraint> cons;
+    int add_var(double c, double mn, double mx);
+    void add_constraint(const uint32_t* vars, const double* coeffs, uint64_t k, int op, double rhs);
+};
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    // grow to hold n elements, preserving the first `keep` ones
+    void ensure(size_t n, size_t keep, hipStream_t st) {
+        if (n <= cap) return;
+        size_t ncap = n + n / 2 + 64;
+        T* np = nullptr;
+        HIPCHECK(hipMalloc(&np, ncap * sizeof(T)));
+        if (p && keep) HIPCHECK(hipMemcpyAsync(np, p, keep * sizeof(T), hipMemcpyDeviceToDevice, st));
+        if (p) {
+            HIPCHECK(hipStreamSynchronize(st));
+            (void)hipFree(p);
+        }
+        p = np;
+        cap = ncap;
+    }
+    void alloc_exact(size_t n) {  // fresh allocation of exactly n elements (contents undefined)
+        release();
+        HIPCHECK(hipMalloc(&p, n * sizeof(T)));
+        cap = n;
+    }
+    void upload(const std::vector<T>& h, hipStream_t st) {
+        ensure(h.size(), 0, st);
+        if (!h.empty()) HIPCHECK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    }
+    void copy_from(const DevBuf<T>& o, size_t n, hipStream_t st) {
+        ensure(n, 0, st);
+        if (n) HIPCHECK(hipMemcpyAsync(p, o.p, n * sizeof(T), hipMemcpyDeviceToDevice, st));
+    }
+};
+
+struct PivotRecord {
+    int32_t phase;
+    int64_t col, row, entering_var, leaving_var;
+    double pivot_coeff, obj_after;
+};
+
+struct Stats {
+    uint64_t iterations = 0, basis_changes = 0, bound_flips = 0, primal_iters = 0, dual_iters = 0, reinversions = 0;
+    double fused_bytes = 0, fused_ms = 0, sweep_bytes = 0, sweep_ms = 0;
+    uint64_t fused_launches = 0, sweep_launches = 0;
+    double solve_wall_s = 0;
+};
+
+class Engine {
+public:
+    Engine();
+    ~Engine();
+    Engine(const Engine&) = delete;
+
+    // Solver::try_new (solver.rs:108-369): throws LpFail{1} for min > max / contradictory empty rows
+    void try_new(const ProblemData& pd);
+    void initial_solve();                                                   // solver.rs:470-485
+    void add_constraint(Constraint c);                                      // solver.rs:549-634 (indices < num_total_vars)
+    void fix_var(int var, double val);                                      // solver.rs:378-415
+    bool unfix_var(int var);                                                // solver.rs:418-438
+    void add_gomory_cut(int var);                                           // solver.rs:440-460
+    double get_value(int var);                                              // solver.rs:371-376
+    void get_values(double* out, int n);
+    double cur_obj_val();                                                   // solver.rs:51
+    Engine* clone();                                                        // #[derive(Clone)] solver.rs:14
+    double reinvert(bool replace);  // from-scratch nucleus inversion; returns max |W - W_fresh|
+
+    int num_vars = 0;
+    int direction = 0;
+    int64_t pivot_budget = -1;
+    bool budget_exhausted = false;
+    bool trace = false, profile = false;
+    std::vector<PivotRecord> trace_log;
+    Stats stats;
+    void resolve_events();
+    uint64_t state(const char* what, double* out, uint64_t cap);
+    int m() const { return m_; }
+    int total_vars() const { return N_; }
+    int nucleus() const { return k_; }
+    int nucleus_cap() const { return cap_; }
+    size_t nnz() const { return h_rcol.size(); }
+
+private:
+    // --- host mirror (small integer bookkeeping + the matrix for rebuilds)
+    int m_ = 0, N_ = 0, k_ = 0, cap_ = 0;
+    std::vector<double> h_obj, h_lo, h_hi, h_rhs;
+    std::vector<int> h_rptr, h_rcol;
+    std::vector<double> h_rval;
+    std::vector<int> h_cptr, h_crow;
+    std::vector<double> h_cval;
+    std::vector<int> h_basic_vars, h_nb_vars, h_var_loc;
+    std::vector<int> h_kslot_of_pos, h_srow_of_pos, h_kslot_of_row, h_pos_of_srow, h_pos_of_kslot, h_row_of_kslot;
+    std::vector<double> h_sdiag_of_pos;
+    std::vector<uint8_t> h_nb_fixed;
+    bool enable_pse = false, enable_dse = false, primal_feasible = false, dual_feasible = false;
+    size_t nnz_nonbasic = 0;
+
+    // --- device state
+    hipStream_t st = nullptr;
+    DevBuf<int> d_cptr, d_crow, d_rptr, d_rcol;
+    DevBuf<double> d_cval, d_rval, d_lo, d_hi, d_obj;
+    DevBuf<int> d_var_loc, d_basic_vars, d_nb_vars;
+    DevBuf<double> d_xB, d_loB, d_hiB, d_beta, d_d, d_xN, d_gamma;
+    DevBuf<uint8_t> d_nbflags;
+    DevBuf<int> d_kslot_of_pos, d_srow_of_pos, d_kslot_of_row, d_pos_of_srow, d_pos_of_kslot, d_row_of_kslot;
+    DevBuf<double> d_sdiag_of_pos, d_W;
+    DevBuf<double> d_alpha_q, d_rho, d_tau, d_vvec, d_alpha_r, d_helper;
+    DevBuf<double> d_aK, d_rK, d_tK, d_tauK, d_vK, d_klist_a, d_blist_a, d_part_tau, d_part_v;
+    DevBuf<int> d_klist_s, d_blist_s;
+    DevBuf<double> d_red_key;
+    DevBuf<int> d_red_idx;
+    DevBuf<unsigned> d_ticket;
+    DevBuf<IterState> d_it;
+    IterState* h_it = nullptr;  // pinned
+
+    // cached x for get_value
+    std::vector<double> h_xB, h_xN;
+    bool values_dirty = true;
+
+    // profiling events
+    struct EvPair { hipEvent_t a, b; int kind; };
+    std::vector<EvPair> ev_pending;
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t get_event();
+
+    DevView view();
+    void build_csc();
+    void upload_matrix();
+    void alloc_row_buffers(int m_new);
+    void ensure_nucleus_cap(int need);
+    void sync_iter();
+    void set_iter(int status, int q, int r, double leaving_new_val);
+    bool take_budget();
+    int col_nnz(int var) const { return h_cptr[var + 1] - h_cptr[var]; }
+
+    void optimize();              // solver.rs:487-511
+    void restore_feasibility();   // solver.rs:513-547
+    void recalc_obj_coeffs();     // solver.rs:1199-1231
+    int primal_iteration();       // choose_pivot + pivot (solver.rs:695-853, 1023-1104)
+    int dual_iteration(int forced_row, double forced_val);  // solver.rs:529-533 / 384-391
+    void pivot_post(int phase, bool btran_done);            // everything after (q, r) are known
+    void calc_col_coeffs(int col);                          // solver.rs:671-677
+    void calc_row_coeffs(int row, bool with_sweep);         // solver.rs:680-693
+    void fetch_values();
+    void rebuild_inverse();       // BasisSolver::reset counterpart (solver.rs:1286-1303)
+};
+
+// ---- MPS (mps.rs) on the host side of the product
+struct MpsData {
+    std::string name;
+    std::vector<std::string> var_names;
+    ProblemData problem;
+};
+MpsData parse_mps(const std::string& text, int direction);  // throws MlpError(-1, ..) on syntax errors
+
+}  // namespace mlp

@@ -1,0 +1,942 @@
+// engine.hip — host orchestration of the device-resident simplex.  Control flow mirrors the
+// reference's Solver (solver.rs:108-1241); every per-pivot vector stays in HBM and every hot loop
+// is a kernel from kernels.hip.  One host<->device scalar exchange per pivot (IterState).
+#include "engine.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace mlp {
+
+static const double INF = std::numeric_limits<double>::infinity();
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ------------------------------------------------------------------ ProblemData (lib.rs:215-283)
+int ProblemData::add_var(double c, double mn, double mx) {
+    int v = (int)obj.size();
+    obj.push_back(direction == 1 ? -c : c);  // lib.rs:235-238
+    lo.push_back(mn);
+    hi.push_back(mx);
+    return v;
+}
+static Constraint make_constraint(const uint32_t* vars, const double* coeffs, uint64_t k, int op, double rhs, size_t dim) {
+    // sprs CsVec::new behaviour relied on at lib.rs:279: sort by index, reject duplicates / out of range
+    std::vector<size_t> ord(k);
+    for (size_t i = 0; i < k; ++i) ord[i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return vars[a] < vars[b]; });
+    Constraint c;
+    c.op = op;
+    c.rhs = rhs;
+    c.idx.resize(k);
+    c.val.resize(k);
+    for (size_t i = 0; i < k; ++i) {
+        c.idx[i] = (int)vars[ord[i]];
+        c.val[i] = coeffs[ord[i]];
+    }
+    for (size_t i = 0; i + 1 < k; ++i)
+        if (c.idx[i] == c.idx[i + 1]) throw MlpError(-1, "variable added more than once to a constraint (lib.rs:247-249)");
+    if (k && (size_t)c.idx[k - 1] >= dim) throw MlpError(-1, "variable index out of range");
+    return c;
+}
+void ProblemData::add_constraint(const uint32_t* vars, const double* coeffs, uint64_t k, int op, double rhs) {
+    if (op < 0 || op > 2) throw MlpError(-1, "bad comparison op");
+    cons.push_back(make_constraint(vars, coeffs, k, op, rhs, obj.size()));
+}
+
+// ------------------------------------------------------------------ Engine basics
+Engine::Engine() {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        throw MlpError(-4, "no HIP device visible: the simplex hot path has no CPU fallback");
+    HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIPCHECK(hipHostMalloc((void**)&h_it, sizeof(IterState), hipHostMallocDefault));
+    std::memset(h_it, 0, sizeof(IterState));
+}
+Engine::~Engine() {
+    if (st) (void)hipStreamSynchronize(st);
+    for (auto& e : ev_pending) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    for (auto e : ev_pool) (void)hipEventDestroy(e);
+    if (h_it) (void)hipHostFree(h_it);
+    if (st) (void)hipStreamDestroy(st);
+}
+
+hipEvent_t Engine::get_event() {
+    if (!ev_pool.empty()) {
+        hipEvent_t e = ev_pool.back();
+        ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    HIPCHECK(hipEventCreate(&e));
+    return e;
+}
+void Engine::resolve_events() {
+    if (ev_pending.empty()) return;
+    HIPCHECK(hipStreamSynchronize(st));
+    for (auto& p : ev_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            if (p.kind == 0) stats.fused_ms += ms;
+            else stats.sweep_ms += ms;
+        }
+        ev_pool.push_back(p.a);
+        ev_pool.push_back(p.b);
+    }
+    ev_pending.clear();
+}
+
+DevView Engine::view() {
+    DevView v;
+    v.m = m_; v.n = num_vars; v.k = k_; v.ld = cap_;
+    v.csc_ptr = d_cptr.p; v.csc_row = d_crow.p; v.csc_val = d_cval.p;
+    v.csr_ptr = d_rptr.p; v.csr_col = d_rcol.p; v.csr_val = d_rval.p;
+    v.var_lo = d_lo.p; v.var_hi = d_hi.p; v.obj_c = d_obj.p;
+    v.var_loc = d_var_loc.p;
+    v.basic_vars = d_basic_vars.p; v.xB = d_xB.p; v.loB = d_loB.p; v.hiB = d_hiB.p; v.beta = d_beta.p;
+    v.nb_vars = d_nb_vars.p; v.d = d_d.p; v.xN = d_xN.p; v.gamma = d_gamma.p; v.nbflags = d_nbflags.p;
+    v.kslot_of_pos = d_kslot_of_pos.p; v.srow_of_pos = d_srow_of_pos.p; v.sdiag_of_pos = d_sdiag_of_pos.p;
+    v.kslot_of_row = d_kslot_of_row.p; v.pos_of_srow = d_pos_of_srow.p;
+    v.pos_of_kslot = d_pos_of_kslot.p; v.row_of_kslot = d_row_of_kslot.p; v.W = d_W.p;
+    v.alpha_q = d_alpha_q.p; v.rho = d_rho.p; v.tau = d_tau.p; v.vvec = d_vvec.p;
+    v.alpha_r = d_alpha_r.p; v.helper = d_helper.p;
+    v.aK = d_aK.p; v.rK = d_rK.p; v.tK = d_tK.p; v.tauK = d_tauK.p; v.vK = d_vK.p;
+    v.klist_s = d_klist_s.p; v.klist_a = d_klist_a.p; v.blist_s = d_blist_s.p; v.blist_a = d_blist_a.p;
+    v.part_tau = d_part_tau.p; v.part_v = d_part_v.p;
+    v.red_key = d_red_key.p; v.red_idx = d_red_idx.p; v.ticket = d_ticket.p;
+    v.it = d_it.p;
+    return v;
+}
+
+void Engine::build_csc() {  // counting transpose of the CSR: ascending row index inside each column
+    h_cptr.assign(N_ + 1, 0);
+    for (int c : h_rcol) h_cptr[c + 1] += 1;
+    for (int c = 0; c < N_; ++c) h_cptr[c + 1] += h_cptr[c];
+    h_crow.resize(h_rcol.size());
+    h_cval.resize(h_rcol.size());
+    std::vector<int> next(h_cptr.begin(), h_cptr.end() - 1);
+    for (int r = 0; r < m_; ++r)
+        for (int p = h_rptr[r]; p < h_rptr[r + 1]; ++p) {
+            int dst = next[h_rcol[p]]++;
+            h_crow[dst] = r;
+            h_cval[dst] = h_rval[p];
+        }
+}
+void Engine::upload_matrix() {
+    d_cptr.upload(h_cptr, st); d_crow.upload(h_crow, st); d_cval.upload(h_cval, st);
+    d_rptr.upload(h_rptr, st); d_rcol.upload(h_rcol, st); d_rval.upload(h_rval, st);
+    d_lo.upload(h_lo, st); d_hi.upload(h_hi, st); d_obj.upload(h_obj, st);
+}
+
+void Engine::alloc_row_buffers(int m_new) {
+    size_t keep = (size_t)m_;
+    size_t mm = (size_t)m_new;
+    d_basic_vars.ensure(mm, keep, st); d_xB.ensure(mm, keep, st); d_loB.ensure(mm, keep, st);
+    d_hiB.ensure(mm, keep, st); d_beta.ensure(mm, keep, st);
+    d_kslot_of_pos.ensure(mm, keep, st); d_srow_of_pos.ensure(mm, keep, st); d_sdiag_of_pos.ensure(mm, keep, st);
+    d_kslot_of_row.ensure(mm, keep, st); d_pos_of_srow.ensure(mm, keep, st);
+    d_alpha_q.ensure(mm, 0, st); d_rho.ensure(mm, 0, st); d_tau.ensure(mm, 0, st); d_vvec.ensure(mm, 0, st);
+    d_klist_s.ensure(mm, 0, st); d_klist_a.ensure(mm, 0, st);
+    d_blist_s.ensure(mm + num_vars + 64, 0, st); d_blist_a.ensure(mm + num_vars + 64, 0, st);
+    d_var_loc.ensure((size_t)num_vars + mm, (size_t)num_vars + keep, st);
+}
+
+void Engine::ensure_nucleus_cap(int need) {
+    if (need <= cap_) return;
+    int ncap = std::max(256, cap_ * 2);
+    while (ncap < need) ncap *= 2;
+    DevBuf<double> nW;
+    nW.alloc_exact((size_t)ncap * ncap);
+    if (k_ > 0)
+        HIPCHECK(hipMemcpy2DAsync(nW.p, (size_t)ncap * sizeof(double), d_W.p, (size_t)cap_ * sizeof(double),
+                                  (size_t)k_ * sizeof(double), (size_t)k_, hipMemcpyDeviceToDevice, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    d_W.release();
+    d_W.p = nW.p; d_W.cap = nW.cap; nW.p = nullptr; nW.cap = 0;
+    size_t keep = (size_t)k_;
+    d_pos_of_kslot.ensure(ncap, keep, st); d_row_of_kslot.ensure(ncap, keep, st);
+    // the slot vectors of the pivot in flight (aK, rK, ...) must survive a mid-pivot growth
+    d_aK.ensure(ncap, keep, st); d_rK.ensure(ncap, keep, st); d_tK.ensure(ncap, keep, st);
+    d_tauK.ensure(ncap, keep, st); d_vK.ensure(ncap, keep, st);
+    int nstripes = (ncap + FW_TR - 1) / FW_TR + 1, nchunks = (ncap + FW_TC - 1) / FW_TC + 1;
+    d_part_v.ensure((size_t)nstripes * ncap, 0, st);
+    d_part_tau.ensure((size_t)nchunks * ncap, 0, st);
+    cap_ = ncap;
+    h_pos_of_kslot.resize(ncap, -1);
+    h_row_of_kslot.resize(ncap, -1);
+}
+
+void Engine::sync_iter() {
+    HIPCHECK(hipMemcpyAsync(h_it, d_it.p, sizeof(IterState), hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+}
+
+__global__ void k_set_iter(IterState* it, int status, int q, int r, double lnv, int entering_var, int leaving_var) {
+    it->status = status;
+    it->q = q;
+    it->r = r;
+    it->leaving_new_val = lnv;
+    it->entering_var = entering_var;
+    it->leaving_var = leaving_var;
+    it->klist_n = 0;
+    it->blist_n = 0;
+}
+void Engine::set_iter(int status, int q, int r, double lnv) {
+    int ev = q >= 0 ? h_nb_vars[q] : -1;
+    int lv = r >= 0 ? h_basic_vars[r] : -1;
+    hipLaunchKernelGGL(k_set_iter, dim3(1), dim3(1), 0, st, d_it.p, status, q, r, lnv, ev, lv);
+}
+
+// ------------------------------------------------------------------ Solver::try_new (solver.rs:108-369)
+void Engine::try_new(const ProblemData& pd) {
+    direction = pd.direction;
+    num_vars = (int)pd.obj.size();
+    const int n = num_vars;
+    h_lo = pd.lo;
+    h_hi = pd.hi;
+    std::vector<double> xN(n), d(n), gamma;
+    std::vector<uint8_t> flags(n);
+    double obj_val = 0.0;
+    dual_feasible = true;
+    h_nb_vars.resize(n);
+    h_var_loc.resize(n);
+    for (int v = 0; v < n; ++v) {  // solver.rs:133-187: initial non-basic values, aiming at dual feasibility
+        double mn = h_lo[v], mx = h_hi[v], c = pd.obj[v];
+        if (mn > mx) throw LpFail{1};
+        h_nb_vars[v] = v;
+        h_var_loc[v] = -1 - v;
+        double init;
+        if (mn == mx) init = mn;
+        else if (std::isinf(mn) && std::isinf(mx)) {
+            if (c != 0.0) dual_feasible = false;
+            init = 0.0;
+        } else if (c > 0.0) {
+            if (std::isfinite(mn)) init = mn;
+            else { dual_feasible = false; init = mx; }
+        } else if (c < 0.0) {
+            if (std::isfinite(mx)) init = mx;
+            else { dual_feasible = false; init = mn; }
+        } else if (std::isfinite(mn)) init = mn;
+        else init = mx;
+        xN[v] = init;
+        obj_val += init * c;
+        flags[v] = (uint8_t)((init == mn ? NB_AT_MIN : 0) | (init == mx ? NB_AT_MAX : 0));
+    }
+
+    // rows: slack per non-empty constraint, all slacks basic (solver.rs:198-253)
+    h_rptr.assign(1, 0);
+    h_rcol.clear();
+    h_rval.clear();
+    h_rhs.clear();
+    std::vector<double> xB, loB, hiB;
+    std::vector<const Constraint*> kept;
+    for (const Constraint& c : pd.cons) {
+        if (c.idx.empty()) {
+            bool taut = c.op == 0 ? (0.0 == c.rhs) : c.op == 1 ? (0.0 <= c.rhs) : (0.0 >= c.rhs);
+            if (taut) continue;
+            throw LpFail{1};
+        }
+        kept.push_back(&c);
+    }
+    m_ = (int)kept.size();
+    N_ = n + m_;
+    h_obj = pd.obj;
+    h_obj.resize(N_, 0.0);
+    h_lo.resize(N_);
+    h_hi.resize(N_);
+    h_basic_vars.resize(m_);
+    h_var_loc.resize(N_);
+    for (int r = 0; r < m_; ++r) {
+        const Constraint& c = *kept[r];
+        double smin = c.op == 1 ? 0.0 : c.op == 2 ? -INF : 0.0;
+        double smax = c.op == 1 ? INF : 0.0;
+        int sv = n + r;
+        h_lo[sv] = smin;
+        h_hi[sv] = smax;
+        loB.push_back(smin);
+        hiB.push_back(smax);
+        h_basic_vars[r] = sv;
+        h_var_loc[sv] = r;
+        double lhs = 0.0;
+        for (size_t p = 0; p < c.idx.size(); ++p) {
+            lhs += c.val[p] * xN[c.idx[p]];
+            h_rcol.push_back(c.idx[p]);
+            h_rval.push_back(c.val[p]);
+        }
+        h_rcol.push_back(sv);  // slack coefficient is always +1 (solver.rs:250)
+        h_rval.push_back(1.0);
+        h_rptr.push_back((int)h_rcol.size());
+        h_rhs.push_back(c.rhs);
+        xB.push_back(c.rhs - lhs);
+    }
+    build_csc();
+
+    primal_feasible = true;  // solver.rs:255-259
+    for (int r = 0; r < m_; ++r)
+        if (!(xB[r] >= loB[r] && xB[r] <= hiB[r])) { primal_feasible = false; break; }
+    bool need_artificial = !primal_feasible && !dual_feasible;  // solver.rs:261
+    enable_dse = true;                                          // solver.rs:263
+    enable_pse = !dual_feasible;                                // solver.rs:272
+    for (int c = 0; c < n; ++c) {                               // solver.rs:281-300
+        uint8_t f = flags[c];
+        bool amin = f & NB_AT_MIN, amax = f & NB_AT_MAX;
+        if (need_artificial) d[c] = (amin && !amax) ? 1.0 : (amax && !amin) ? -1.0 : 0.0;
+        else d[c] = h_obj[c];
+    }
+    gamma.assign(n, 1.0);
+    if (enable_pse)
+        for (int c = 0; c < n; ++c) {
+            double s = 0.0;
+            for (int p = h_cptr[c]; p < h_cptr[c + 1]; ++p) s += h_cval[p] * h_cval[p];
+            gamma[c] = s + 1.0;
+        }
+    double cur_obj = need_artificial ? 0.0 : obj_val;  // solver.rs:302
+
+    // basis inverse: every initial basic column is a slack singleton => empty nucleus (the
+    // reference factorises the identity here, solver.rs:304-317)
+    k_ = 0;
+    h_kslot_of_pos.assign(m_, -1);
+    h_srow_of_pos.resize(m_);
+    h_sdiag_of_pos.assign(m_, 1.0);
+    h_kslot_of_row.assign(m_, -1);
+    h_pos_of_srow.resize(m_);
+    for (int r = 0; r < m_; ++r) h_srow_of_pos[r] = h_pos_of_srow[r] = r;
+    h_nb_fixed.assign(n, 0);
+    nnz_nonbasic = 0;
+    for (int c = 0; c < n; ++c) nnz_nonbasic += col_nnz(c);
+
+    // ---- upload
+    upload_matrix();
+    int m_keep = m_;
+    m_ = 0;  // nothing to preserve
+    alloc_row_buffers(m_keep);
+    m_ = m_keep;
+    d_var_loc.upload(h_var_loc, st);
+    d_basic_vars.upload(h_basic_vars, st);
+    d_xB.upload(xB, st); d_loB.upload(loB, st); d_hiB.upload(hiB, st);
+    std::vector<double> beta(m_, 1.0);
+    d_beta.upload(beta, st);
+    d_nb_vars.upload(h_nb_vars, st);
+    d_d.upload(d, st); d_xN.upload(xN, st); d_gamma.upload(gamma, st); d_nbflags.upload(flags, st);
+    d_alpha_r.ensure(n, 0, st); d_helper.ensure(n, 0, st);
+    d_kslot_of_pos.upload(h_kslot_of_pos, st); d_srow_of_pos.upload(h_srow_of_pos, st);
+    d_sdiag_of_pos.upload(h_sdiag_of_pos, st);
+    d_kslot_of_row.upload(h_kslot_of_row, st); d_pos_of_srow.upload(h_pos_of_srow, st);
+    d_red_key.ensure(1024, 0, st); d_red_idx.ensure(1024, 0, st);
+    d_ticket.ensure(4, 0, st);
+    HIPCHECK(hipMemsetAsync(d_ticket.p, 0, 4 * sizeof(unsigned), st));
+    d_it.ensure(1, 0, st);
+    IterState init;
+    std::memset(&init, 0, sizeof(init));
+    init.obj = cur_obj;
+    init.status = ITER_OPTIMAL;
+    *h_it = init;
+    HIPCHECK(hipMemcpyAsync(d_it.p, h_it, sizeof(IterState), hipMemcpyHostToDevice, st));
+    ensure_nucleus_cap(256);
+    HIPCHECK(hipStreamSynchronize(st));
+    values_dirty = true;
+}
+
+// ------------------------------------------------------------------ values / objective
+void Engine::fetch_values() {
+    if (!values_dirty) return;
+    h_xB.resize(m_);
+    h_xN.resize(num_vars);
+    if (m_) HIPCHECK(hipMemcpyAsync(h_xB.data(), d_xB.p, sizeof(double) * m_, hipMemcpyDeviceToHost, st));
+    if (num_vars) HIPCHECK(hipMemcpyAsync(h_xN.data(), d_xN.p, sizeof(double) * num_vars, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    values_dirty = false;
+}
+double Engine::get_value(int var) {  // solver.rs:371-376
+    fetch_values();
+    int loc = h_var_loc[var];
+    return loc >= 0 ? h_xB[loc] : h_xN[-1 - loc];
+}
+void Engine::get_values(double* out, int n) {
+    fetch_values();
+    for (int v = 0; v < n; ++v) {
+        int loc = h_var_loc[v];
+        out[v] = loc >= 0 ? h_xB[loc] : h_xN[-1 - loc];
+    }
+}
+double Engine::cur_obj_val() {
+    sync_iter();
+    return h_it->obj;
+}
+
+// ------------------------------------------------------------------ loops (solver.rs:470-547)
+bool Engine::take_budget() {
+    if (pivot_budget < 0) return true;
+    if (pivot_budget == 0) {
+        budget_exhausted = true;
+        return false;
+    }
+    pivot_budget -= 1;
+    return true;
+}
+void Engine::initial_solve() {
+    double t0 = now_s();
+    if (!primal_feasible) restore_feasibility();
+    if (!budget_exhausted && !dual_feasible) {
+        recalc_obj_coeffs();
+        optimize();
+    }
+    if (!budget_exhausted) enable_pse = false;  // solver.rs:482
+    stats.solve_wall_s += now_s() - t0;
+}
+void Engine::optimize() {
+    for (;;) {
+        if (!take_budget()) return;
+        int st_ = primal_iteration();
+        if (st_ == ITER_OPTIMAL) break;
+        if (st_ == ITER_UNBOUNDED) throw LpFail{2};
+    }
+    dual_feasible = true;
+}
+void Engine::restore_feasibility() {
+    for (;;) {
+        if (!take_budget()) return;
+        int st_ = dual_iteration(-1, 0.0);
+        if (st_ == ITER_FEASIBLE) break;
+        if (st_ == ITER_INFEASIBLE) throw LpFail{1};
+    }
+    primal_feasible = true;
+}
+
+// ------------------------------------------------------------------ one primal iteration
+int Engine::primal_iteration() {
+    DevView v = view();
+    launch_price_primal(v, enable_pse, st);   // K1
+    launch_ftran_col(v, st);                  // K2 (device-driven by it->q)
+    launch_ratio_primal(v, st);               // K5
+    launch_btran_unit(v, st);                 // K3 (device-driven by it->r; no-op unless ITER_PIVOT)
+    sync_iter();
+    int status = h_it->status;
+    if (status == ITER_OPTIMAL || status == ITER_UNBOUNDED) return status;
+    stats.iterations += 1;
+    stats.primal_iters += 1;
+    values_dirty = true;
+    if (status == ITER_FLIP) {
+        launch_update_flip(v, st);
+        stats.bound_flips += 1;
+        if (trace) trace_log.push_back({0, h_it->q, -1, h_it->entering_var, -1, 0.0, h_it->obj});
+        return status;
+    }
+    pivot_post(0, true);
+    return status;
+}
+
+// ------------------------------------------------------------------ one dual iteration
+int Engine::dual_iteration(int forced_row, double forced_val) {
+    DevView v = view();
+    if (forced_row < 0) launch_price_dual(v, enable_dse, st);  // K6
+    else set_iter(ITER_PIVOT, -1, forced_row, forced_val);     // fix_var on a basic var (solver.rs:384-391)
+    launch_btran_unit(v, st);       // K3
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (profile) {
+        e0 = get_event(); e1 = get_event();
+        HIPCHECK(hipEventRecord(e0, st));
+    }
+    launch_sweep(v, 0, 0, st);      // K4: alpha_r = rho^T N
+    if (profile) {
+        HIPCHECK(hipEventRecord(e1, st));
+        ev_pending.push_back({e0, e1, 1});
+        stats.sweep_bytes += 12.0 * (double)nnz_nonbasic + 16.0 * num_vars;
+        stats.sweep_launches += 1;
+    }
+    launch_ratio_dual(v, st);       // K7
+    launch_ftran_col(v, st);        // K2 (device-driven by it->q)
+    sync_iter();
+    int status = h_it->status;
+    if (status == ITER_FEASIBLE || status == ITER_INFEASIBLE) return status;
+    stats.iterations += 1;
+    stats.dual_iters += 1;
+    values_dirty = true;
+    pivot_post(1, true);
+    return status;
+}
+
+// ------------------------------------------------------------------ Solver::pivot (solver.rs:1023-1104)
+// Preconditions: IterState holds (q, r, pivot_coeff, ...) with status ITER_PIVOT; alpha_q, rho, rK
+// (and for the dual path alpha_r) are in HBM.
+void Engine::pivot_post(int phase, bool btran_done) {
+    const int q = h_it->q, r = h_it->r;
+    const int ev = h_nb_vars[q], lv = h_basic_vars[r];
+    const bool old_nuc = h_kslot_of_pos[r] >= 0;
+    const bool new_sing = col_nnz(ev) == 1;
+    StructUpdate u;
+    std::memset(&u, 0, sizeof(u));
+    u.r = r;
+    u.kase = old_nuc ? (new_sing ? 2 : 0) : (new_sing ? 3 : 1);
+    u.sr = old_nuc ? h_kslot_of_pos[r] : -1;
+    u.i_r = old_nuc ? -1 : h_srow_of_pos[r];
+    u.inv_diag_r = old_nuc ? 0.0 : 1.0 / h_sdiag_of_pos[r];
+    if (new_sing) {
+        u.i_q = h_crow[h_cptr[ev]];
+        u.diag_q = h_cval[h_cptr[ev]];
+        u.cq = h_kslot_of_row[u.i_q];
+        if (u.cq < 0) {
+            // the entering singleton sits on an S-row: legal only when it replaces the singleton
+            // that covers that very row (then alpha_K = 0, W is unchanged, only the diagonal moves)
+            if (!old_nuc && u.i_q == u.i_r) u.kase = 4;
+            else throw MlpError(-2, "singular basis: two singleton columns on one row");
+        }
+    }
+    if (u.kase == 1) ensure_nucleus_cap(k_ + 1);
+    DevView v = view();
+    if (!btran_done) launch_btran_unit(v, st);
+    if (enable_pse) launch_prep_v(v, st);  // alpha_sq, y_S, tK
+    // fused pass: tauK = W rK, vK = W^T tK, W -= (aK - e_r) rK^T / alpha_q[r]
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (profile && k_ > 0) {
+        e0 = get_event(); e1 = get_event();
+        HIPCHECK(hipEventRecord(e0, st));
+    }
+    launch_fused_w(v, enable_pse, 1, u.sr, st);
+    if (profile && k_ > 0) {
+        HIPCHECK(hipEventRecord(e1, st));
+        ev_pending.push_back({e0, e1, 0});
+        stats.fused_bytes += 16.0 * (double)k_ * (double)k_;
+        stats.fused_launches += 1;
+    }
+    launch_finish_tau(v, st);
+    if (enable_pse) launch_finish_v(v, st);
+    launch_structure_update(v, u, st);
+    // tableau row(s): primal computes alpha_r (+ helper) in one pass over A; dual only needs helper
+    bool need_sweep = (phase == 0) || enable_pse;
+    if (need_sweep) {
+        if (profile) {
+            e0 = get_event(); e1 = get_event();
+            HIPCHECK(hipEventRecord(e0, st));
+        }
+        if (phase == 0) launch_sweep(v, enable_pse, 0, st);
+        else launch_sweep(v, 1, 1, st);
+        if (profile) {
+            HIPCHECK(hipEventRecord(e1, st));
+            ev_pending.push_back({e0, e1, 1});
+            stats.sweep_bytes += 12.0 * (double)nnz_nonbasic + 16.0 * num_vars;
+            stats.sweep_launches += 1;
+        }
+    }
+    launch_update_pivot(v, enable_dse, enable_pse, st);  // K8
+
+    // ---- host mirror of the bookkeeping (solver.rs:1088-1091) and of the partition change
+    switch (u.kase) {
+        case 0: break;
+        case 1: {
+            int s = k_;
+            h_kslot_of_pos[r] = s; h_pos_of_kslot[s] = r;
+            h_kslot_of_row[u.i_r] = s; h_row_of_kslot[s] = u.i_r;
+            k_ += 1;
+            break;
+        }
+        case 2: {
+            int last = k_ - 1;
+            if (u.sr != last) {
+                int pl = h_pos_of_kslot[last];
+                h_pos_of_kslot[u.sr] = pl; h_kslot_of_pos[pl] = u.sr;
+            }
+            h_kslot_of_pos[r] = -1; h_srow_of_pos[r] = u.i_q; h_sdiag_of_pos[r] = u.diag_q;
+            if (u.cq != last) {
+                int il = h_row_of_kslot[last];
+                h_row_of_kslot[u.cq] = il; h_kslot_of_row[il] = u.cq;
+            }
+            h_kslot_of_row[u.i_q] = -1; h_pos_of_srow[u.i_q] = r;
+            k_ -= 1;
+            break;
+        }
+        case 3:
+            h_srow_of_pos[r] = u.i_q; h_sdiag_of_pos[r] = u.diag_q;
+            h_kslot_of_row[u.i_q] = -1; h_pos_of_srow[u.i_q] = r;
+            h_kslot_of_row[u.i_r] = u.cq; h_row_of_kslot[u.cq] = u.i_r;
+            break;
+        case 4:
+            h_sdiag_of_pos[r] = u.diag_q;
+            break;
+    }
+    h_basic_vars[r] = ev; h_var_loc[ev] = r;
+    h_nb_vars[q] = lv; h_var_loc[lv] = -1 - q;
+    nnz_nonbasic += (size_t)col_nnz(lv);
+    nnz_nonbasic -= (size_t)col_nnz(ev);
+    stats.basis_changes += 1;
+    if (trace) trace_log.push_back({phase, q, r, ev, lv, h_it->pivot_coeff, h_it->obj});
+    if (profile && ev_pending.size() >= 2048) resolve_events();
+}
+
+// ------------------------------------------------------------------ helpers used by the warm-start API
+void Engine::calc_col_coeffs(int col) {  // solver.rs:671-677
+    set_iter(ITER_PIVOT, col, -1, 0.0);
+    launch_ftran_col(view(), st);
+}
+void Engine::calc_row_coeffs(int row, bool with_sweep) {  // solver.rs:680-693
+    set_iter(ITER_PIVOT, -1, row, 0.0);
+    DevView v = view();
+    launch_btran_unit(v, st);
+    if (with_sweep) launch_sweep(v, 0, 0, st);
+}
+
+// solver.rs:1199-1231.  There is no eta file to flush: W is always current.
+void Engine::recalc_obj_coeffs() {
+    DevView v = view();
+    // c_B by position -> alpha_q buffer; y = B^-T c_B -> rho buffer
+    launch_gather_basic_obj(v, d_alpha_q.p, st);
+    launch_btran_dense(v, d_alpha_q.p, d_rho.p, st);
+    launch_recalc_d(v, d_rho.p, st);
+}
+
+void Engine::fix_var(int var, double val) {  // solver.rs:378-415
+    double t0 = now_s();
+    if (val < h_lo[var] || val > h_hi[var]) throw LpFail{1};
+    int col;
+    if (h_var_loc[var] >= 0) {
+        int row = h_var_loc[var];
+        int st_ = dual_iteration(row, val);
+        if (st_ == ITER_INFEASIBLE) throw LpFail{1};
+        col = h_it->q;
+    } else {
+        col = -1 - h_var_loc[var];
+        calc_col_coeffs(col);
+        launch_shift_nonbasic(view(), col, val, st);
+        values_dirty = true;
+    }
+    uint8_t f = NB_AT_MIN | NB_AT_MAX | NB_FIXED;
+    HIPCHECK(hipMemcpyAsync(d_nbflags.p + col, &f, 1, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    h_nb_fixed[col] = 1;
+    primal_feasible = false;
+    restore_feasibility();
+    stats.solve_wall_s += now_s() - t0;
+}
+
+bool Engine::unfix_var(int var) {  // solver.rs:418-438
+    if (h_var_loc[var] >= 0) return false;
+    int col = -1 - h_var_loc[var];
+    if (!h_nb_fixed[col]) return false;
+    h_nb_fixed[col] = 0;
+    fetch_values();
+    double cur = h_xN[col];
+    uint8_t f = (uint8_t)((cur == h_lo[var] ? NB_AT_MIN : 0) | (cur == h_hi[var] ? NB_AT_MAX : 0));
+    HIPCHECK(hipMemcpyAsync(d_nbflags.p + col, &f, 1, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    dual_feasible = false;
+    double t0 = now_s();
+    try {
+        optimize();
+    } catch (LpFail&) {
+        throw MlpError(-1, "unfix_var: optimize failed (solver.rs:433 unwrap)");
+    }
+    stats.solve_wall_s += now_s() - t0;
+    return true;
+}
+
+void Engine::add_gomory_cut(int var) {  // solver.rs:440-460
+    if (h_var_loc[var] < 0) throw MlpError(-1, "add_gomory_cut: variable is not basic (solver.rs:458)");
+    int row = h_var_loc[var];
+    calc_row_coeffs(row, true);
+    std::vector<double> ar(num_vars);
+    HIPCHECK(hipMemcpyAsync(ar.data(), d_alpha_r.p, sizeof(double) * num_vars, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    fetch_values();
+    std::vector<std::pair<int, double>> terms;
+    for (int c = 0; c < num_vars; ++c) {
+        double coeff = ar[c];
+        double f = std::floor(coeff) - coeff;
+        if (f != 0.0) terms.push_back({h_nb_vars[c], f});  // exact zeros carry no information
+    }
+    std::sort(terms.begin(), terms.end());
+    Constraint c;
+    c.op = 1;
+    c.rhs = std::floor(h_xB[row]) - h_xB[row];
+    for (auto& t : terms) {
+        c.idx.push_back(t.first);
+        c.val.push_back(t.second);
+    }
+    add_constraint(std::move(c));
+}
+
+// solver.rs:549-634.  The new slack is a singleton basic column on the new row, so the nucleus
+// inverse is unchanged unless the new row touches a basic singleton column (then: rebuild).
+void Engine::add_constraint(Constraint c) {
+    double t0 = now_s();
+    if (!primal_feasible || !dual_feasible) throw MlpError(-1, "add_constraint: model not solved (solver.rs:555-556)");
+    if (c.idx.empty()) {
+        bool taut = c.op == 0 ? (0.0 == c.rhs) : c.op == 1 ? (0.0 <= c.rhs) : (0.0 >= c.rhs);
+        if (taut) return;
+        throw LpFail{1};
+    }
+    fetch_values();
+    const int slack = N_, row = m_;
+    double smin = c.op == 1 ? 0.0 : c.op == 2 ? -INF : 0.0;
+    double smax = c.op == 1 ? INF : 0.0;
+    double lhs = 0.0;  // solver.rs:587-595
+    bool touches_basic_singleton = false;
+    for (size_t p = 0; p < c.idx.size(); ++p) {
+        int var = c.idx[p];
+        int loc = h_var_loc[var];
+        lhs += (loc >= 0 ? h_xB[loc] : h_xN[-1 - loc]) * c.val[p];
+        if (loc >= 0 && h_kslot_of_pos[loc] < 0) touches_basic_singleton = true;
+    }
+    double xnew = c.rhs - lhs;
+    // matrix: append the CSR row (+ slack), rebuild the CSC (O(nnz), like solver.rs:597-610)
+    for (size_t p = 0; p < c.idx.size(); ++p) {
+        h_rcol.push_back(c.idx[p]);
+        h_rval.push_back(c.val[p]);
+    }
+    h_rcol.push_back(slack);
+    h_rval.push_back(1.0);
+    h_rptr.push_back((int)h_rcol.size());
+    h_rhs.push_back(c.rhs);
+    h_obj.push_back(0.0);
+    h_lo.push_back(smin);
+    h_hi.push_back(smax);
+    alloc_row_buffers(m_ + 1);
+    m_ += 1;
+    N_ += 1;
+    build_csc();
+    upload_matrix();
+    for (size_t p = 0; p < c.idx.size(); ++p)
+        if (h_var_loc[c.idx[p]] < 0) nnz_nonbasic += 1;
+    // new basic position `row` holding the slack (singleton on the new row)
+    h_basic_vars.push_back(slack);
+    h_var_loc.push_back(row);
+    h_kslot_of_pos.push_back(-1); h_srow_of_pos.push_back(row); h_sdiag_of_pos.push_back(1.0);
+    h_kslot_of_row.push_back(-1); h_pos_of_srow.push_back(row);
+    int neg1 = -1;
+    double one = 1.0, beta0 = 1.0;
+    HIPCHECK(hipMemcpyAsync(d_basic_vars.p + row, &slack, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_var_loc.p + slack, &row, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_xB.p + row, &xnew, sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_loB.p + row, &smin, sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_hiB.p + row, &smax, sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_beta.p + row, &beta0, sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_kslot_of_pos.p + row, &neg1, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_srow_of_pos.p + row, &row, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_sdiag_of_pos.p + row, &one, sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_kslot_of_row.p + row, &neg1, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_pos_of_srow.p + row, &row, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    values_dirty = true;
+    if (touches_basic_singleton) rebuild_inverse();  // a singleton column just gained an entry
+
+    if (enable_pse || enable_dse) {  // solver.rs:615-630: last tableau row feeds the edge norms
+        calc_row_coeffs(m_ - 1, enable_pse);
+        if (enable_pse) launch_sq_norms_add_row(view(), st);
+        if (enable_dse)
+            HIPCHECK(hipMemcpyAsync(d_beta.p + row, &d_it.p->rho_sq, sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    primal_feasible = false;
+    restore_feasibility();
+    stats.solve_wall_s += now_s() - t0;
+}
+
+// ------------------------------------------------------------------ from-scratch nucleus inverse
+// Counterpart of BasisSolver::reset (solver.rs:1286-1303): classify the basic columns (singleton vs
+// nucleus), build K = B[R_K, P_K] densely from the CSC and invert it on the device.
+void Engine::rebuild_inverse() {
+    std::vector<int> claimed(m_, -1);
+    k_ = 0;
+    std::vector<int> nuc_pos;
+    for (int p = 0; p < m_; ++p) {
+        int var = h_basic_vars[p];
+        if (col_nnz(var) == 1) {
+            int i = h_crow[h_cptr[var]];
+            if (claimed[i] >= 0) throw MlpError(-2, "singular basis: two singleton columns on one row");
+            claimed[i] = p;
+            h_kslot_of_pos[p] = -1;
+            h_srow_of_pos[p] = i;
+            h_sdiag_of_pos[p] = h_cval[h_cptr[var]];
+        } else {
+            nuc_pos.push_back(p);
+        }
+    }
+    int k = (int)nuc_pos.size();
+    ensure_nucleus_cap(std::max(k, 1));
+    int s = 0;
+    for (int i = 0; i < m_; ++i) {
+        if (claimed[i] >= 0) {
+            h_kslot_of_row[i] = -1;
+            h_pos_of_srow[i] = claimed[i];
+        } else {
+            if (s >= k) throw MlpError(-2, "singular basis: more uncovered rows than nucleus columns");
+            h_kslot_of_row[i] = s;
+            h_row_of_kslot[s] = i;
+            s += 1;
+        }
+    }
+    if (s != k) throw MlpError(-2, "singular basis: nucleus is not square");
+    for (int b = 0; b < k; ++b) {
+        h_kslot_of_pos[nuc_pos[b]] = b;
+        h_pos_of_kslot[b] = nuc_pos[b];
+    }
+    k_ = k;
+    d_kslot_of_pos.upload(h_kslot_of_pos, st); d_srow_of_pos.upload(h_srow_of_pos, st);
+    d_sdiag_of_pos.upload(h_sdiag_of_pos, st);
+    d_kslot_of_row.upload(h_kslot_of_row, st); d_pos_of_srow.upload(h_pos_of_srow, st);
+    d_pos_of_kslot.upload(h_pos_of_kslot, st); d_row_of_kslot.upload(h_row_of_kslot, st);
+    if (k > 0) {
+        DevBuf<double> Kd, scratch;
+        DevBuf<int> flag;
+        Kd.ensure((size_t)k * cap_, 0, st);
+        scratch.ensure((size_t)k + 8, 0, st);
+        flag.ensure(1, 0, st);
+        HIPCHECK(hipMemsetAsync(flag.p, 0, sizeof(int), st));
+        DevView v = view();
+        launch_build_nucleus(v, Kd.p, st);
+        launch_gauss_jordan(Kd.p, d_W.p, k, cap_, flag.p, scratch.p, st);
+        int hflag = 0;
+        HIPCHECK(hipMemcpyAsync(&hflag, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        if (hflag) throw MlpError(-2, "singular basis matrix (solver.rs:1301)");
+    }
+    stats.reinversions += 1;
+}
+
+double Engine::reinvert(bool replace) {
+    HIPCHECK(hipStreamSynchronize(st));
+    if (k_ == 0) return 0.0;
+    // keep the incremental W aside, rebuild, compare
+    DevBuf<double> oldW;
+    DevBuf<int> old_pk, old_rk;
+    std::vector<int> hp = h_pos_of_kslot, hr = h_row_of_kslot, hkp = h_kslot_of_pos, hkr = h_kslot_of_row,
+                     hsr = h_srow_of_pos, hps = h_pos_of_srow;
+    std::vector<double> hsd = h_sdiag_of_pos;
+    int kold = k_, capold = cap_;
+    oldW.ensure((size_t)capold * capold, 0, st);
+    HIPCHECK(hipMemcpyAsync(oldW.p, d_W.p, sizeof(double) * (size_t)capold * capold, hipMemcpyDeviceToDevice, st));
+    rebuild_inverse();
+    double diff = -1.0;
+    if (k_ == kold && cap_ == capold) {
+        // fresh slots are assigned in ascending position/row order; map the old block onto them
+        std::vector<double> a((size_t)capold * capold), b((size_t)cap_ * cap_);
+        HIPCHECK(hipMemcpy(a.data(), oldW.p, sizeof(double) * a.size(), hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(b.data(), d_W.p, sizeof(double) * b.size(), hipMemcpyDeviceToHost));
+        diff = 0.0;
+        for (int s1 = 0; s1 < kold; ++s1)
+            for (int s2 = 0; s2 < kold; ++s2) {
+                int p = hp[s1], i = hr[s2];
+                double x = a[(size_t)s1 * capold + s2];
+                double y = b[(size_t)h_kslot_of_pos[p] * cap_ + h_kslot_of_row[i]];
+                double dlt = std::fabs(x - y);
+                if (!(dlt <= diff)) diff = dlt;
+            }
+    }
+    if (!replace) {  // restore the incremental representation
+        h_pos_of_kslot = hp; h_row_of_kslot = hr; h_kslot_of_pos = hkp; h_kslot_of_row = hkr;
+        h_srow_of_pos = hsr; h_pos_of_srow = hps; h_sdiag_of_pos = hsd;
+        k_ = kold;
+        HIPCHECK(hipMemcpyAsync(d_W.p, oldW.p, sizeof(double) * (size_t)capold * capold, hipMemcpyDeviceToDevice, st));
+        d_kslot_of_pos.upload(h_kslot_of_pos, st); d_srow_of_pos.upload(h_srow_of_pos, st);
+        d_sdiag_of_pos.upload(h_sdiag_of_pos, st);
+        d_kslot_of_row.upload(h_kslot_of_row, st); d_pos_of_srow.upload(h_pos_of_srow, st);
+        d_pos_of_kslot.upload(h_pos_of_kslot, st); d_row_of_kslot.upload(h_row_of_kslot, st);
+        HIPCHECK(hipStreamSynchronize(st));
+    }
+    return diff;
+}
+
+// ------------------------------------------------------------------ clone (lib.rs:313 / solver.rs:14)
+Engine* Engine::clone() {
+    HIPCHECK(hipStreamSynchronize(st));
+    Engine* e = new Engine();
+    e->num_vars = num_vars; e->direction = direction;
+    e->m_ = m_; e->N_ = N_; e->k_ = k_; e->cap_ = 0;
+    e->h_obj = h_obj; e->h_lo = h_lo; e->h_hi = h_hi; e->h_rhs = h_rhs;
+    e->h_rptr = h_rptr; e->h_rcol = h_rcol; e->h_rval = h_rval;
+    e->h_cptr = h_cptr; e->h_crow = h_crow; e->h_cval = h_cval;
+    e->h_basic_vars = h_basic_vars; e->h_nb_vars = h_nb_vars; e->h_var_loc = h_var_loc;
+    e->h_kslot_of_pos = h_kslot_of_pos; e->h_srow_of_pos = h_srow_of_pos; e->h_kslot_of_row = h_kslot_of_row;
+    e->h_pos_of_srow = h_pos_of_srow; e->h_sdiag_of_pos = h_sdiag_of_pos; e->h_nb_fixed = h_nb_fixed;
+    e->enable_pse = enable_pse; e->enable_dse = enable_dse;
+    e->primal_feasible = primal_feasible; e->dual_feasible = dual_feasible;
+    e->nnz_nonbasic = nnz_nonbasic;
+    e->trace = trace; e->profile = profile;
+    hipStream_t s2 = e->st;
+    e->upload_matrix();
+    int mk = m_;
+    e->m_ = 0;
+    e->alloc_row_buffers(mk);
+    e->m_ = mk;
+    size_t mm = (size_t)m_, nn = (size_t)num_vars;
+    e->d_var_loc.copy_from(d_var_loc, (size_t)N_, s2);
+    e->d_basic_vars.copy_from(d_basic_vars, mm, s2);
+    e->d_xB.copy_from(d_xB, mm, s2); e->d_loB.copy_from(d_loB, mm, s2); e->d_hiB.copy_from(d_hiB, mm, s2);
+    e->d_beta.copy_from(d_beta, mm, s2);
+    e->d_nb_vars.copy_from(d_nb_vars, nn, s2); e->d_d.copy_from(d_d, nn, s2); e->d_xN.copy_from(d_xN, nn, s2);
+    e->d_gamma.copy_from(d_gamma, nn, s2); e->d_nbflags.copy_from(d_nbflags, nn, s2);
+    e->d_alpha_r.ensure(nn, 0, s2); e->d_helper.ensure(nn, 0, s2);
+    e->d_kslot_of_pos.copy_from(d_kslot_of_pos, mm, s2); e->d_srow_of_pos.copy_from(d_srow_of_pos, mm, s2);
+    e->d_sdiag_of_pos.copy_from(d_sdiag_of_pos, mm, s2);
+    e->d_kslot_of_row.copy_from(d_kslot_of_row, mm, s2); e->d_pos_of_srow.copy_from(d_pos_of_srow, mm, s2);
+    e->d_red_key.ensure(1024, 0, s2); e->d_red_idx.ensure(1024, 0, s2);
+    e->d_ticket.ensure(4, 0, s2);
+    HIPCHECK(hipMemsetAsync(e->d_ticket.p, 0, 4 * sizeof(unsigned), s2));
+    e->d_it.copy_from(d_it, 1, s2);
+    // nucleus: same capacity so the block copies 1:1
+    int kk = k_;
+    e->k_ = 0;
+    e->ensure_nucleus_cap(cap_);
+    e->k_ = kk;
+    if (cap_ == e->cap_ && k_ > 0)
+        HIPCHECK(hipMemcpyAsync(e->d_W.p, d_W.p, sizeof(double) * (size_t)cap_ * cap_, hipMemcpyDeviceToDevice, s2));
+    e->h_pos_of_kslot = h_pos_of_kslot; e->h_row_of_kslot = h_row_of_kslot;
+    e->d_pos_of_kslot.upload(e->h_pos_of_kslot, s2); e->d_row_of_kslot.upload(e->h_row_of_kslot, s2);
+    HIPCHECK(hipStreamSynchronize(s2));
+    *e->h_it = *h_it;
+    e->values_dirty = true;
+    return e;
+}
+
+// ------------------------------------------------------------------ white-box state (tests)
+uint64_t Engine::state(const char* what, double* out, uint64_t cap) {
+    HIPCHECK(hipStreamSynchronize(st));
+    std::string w(what);
+    std::vector<double> tmp;
+    auto from_dev_d = [&](const DevBuf<double>& b, size_t n) {
+        tmp.resize(n);
+        if (n) HIPCHECK(hipMemcpy(tmp.data(), b.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    };
+    auto from_dev_i = [&](const DevBuf<int>& b, size_t n) {
+        std::vector<int> t(n);
+        if (n) HIPCHECK(hipMemcpy(t.data(), b.p, n * sizeof(int), hipMemcpyDeviceToHost));
+        tmp.assign(t.begin(), t.end());
+    };
+    size_t mm = m_, nn = num_vars;
+    if (w == "basic_vars") from_dev_i(d_basic_vars, mm);
+    else if (w == "basic_var_vals") from_dev_d(d_xB, mm);
+    else if (w == "basic_var_mins") from_dev_d(d_loB, mm);
+    else if (w == "basic_var_maxs") from_dev_d(d_hiB, mm);
+    else if (w == "dual_edge_sq_norms") from_dev_d(d_beta, mm);
+    else if (w == "nb_vars") from_dev_i(d_nb_vars, nn);
+    else if (w == "nb_var_obj_coeffs") from_dev_d(d_d, nn);
+    else if (w == "nb_var_vals") from_dev_d(d_xN, nn);
+    else if (w == "primal_edge_sq_norms") from_dev_d(d_gamma, nn);
+    else if (w == "var_loc") from_dev_i(d_var_loc, (size_t)N_);
+    else if (w == "col_coeffs") from_dev_d(d_alpha_q, mm);
+    else if (w == "inv_basis_row_coeffs") from_dev_d(d_rho, mm);
+    else if (w == "row_coeffs") from_dev_d(d_alpha_r, nn);
+    else if (w == "tau") from_dev_d(d_tau, mm);
+    else if (w == "nb_flags") {
+        std::vector<uint8_t> t(nn);
+        if (nn) HIPCHECK(hipMemcpy(t.data(), d_nbflags.p, nn, hipMemcpyDeviceToHost));
+        tmp.assign(t.begin(), t.end());
+    } else if (w == "cur_obj_val") tmp = {cur_obj_val()};
+    else if (w == "orig_obj_coeffs") tmp = h_obj;
+    else if (w == "orig_var_mins") tmp = h_lo;
+    else if (w == "orig_var_maxs") tmp = h_hi;
+    else if (w == "orig_rhs") tmp = h_rhs;
+    else if (w == "flags") tmp = {(double)primal_feasible, (double)dual_feasible, (double)enable_pse, (double)enable_dse};
+    else if (w == "host_basic_vars") tmp.assign(h_basic_vars.begin(), h_basic_vars.end());
+    else if (w == "host_nb_vars") tmp.assign(h_nb_vars.begin(), h_nb_vars.end());
+    else return (uint64_t)-1;
+    if (out) for (size_t i = 0; i < tmp.size() && i < cap; ++i) out[i] = tmp[i];
+    return tmp.size();
+}
+
+}  // namespace mlp

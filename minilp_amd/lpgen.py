@@ -1,0 +1,151 @@
+"""Deterministic synthetic LP generators for the BASELINE.json configs.
+
+RNG = SplitMix64 (u -> (u >> 11) * 2^-53), vectorised with numpy so the same bytes feed
+every solver (oracle, HIP engine, HiGHS fixture generator).  Instances are returned as a
+plain dict in CSR form; `build_problem` replays them through any object exposing the
+reference's Problem API (lib.rs:217-283: add_var / add_constraint).
+"""
+import numpy as np
+
+MINIMIZE, MAXIMIZE = 0, 1
+EQ, LE, GE = 0, 1, 2
+
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+
+
+def splitmix64(seed, n, offset=0):
+    """n outputs of SplitMix64 seeded with `seed`, starting at stream position `offset`."""
+    with np.errstate(over="ignore"):
+        i = np.arange(offset + 1, offset + n + 1, dtype=np.uint64)
+        z = np.uint64(seed) + i * _GOLDEN
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform01(seed, n, offset=0):
+    return (splitmix64(seed, n, offset) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def _stream(seed, tag):
+    """Derive an independent sub-seed for a named stream."""
+    return int(splitmix64(seed * 1000003 + tag, 1)[0])
+
+
+def gen_dense_lp(m, n, seed=2):
+    """Config 2 family: A_ij ~ U[0,1), b_i = rowsum * U[0.5,1.5), c_j ~ U[0.1,1); Max c'x, Ax<=b, x>=0."""
+    A = uniform01(_stream(seed, 1), m * n).reshape(m, n)
+    b = A.sum(axis=1) * (0.5 + uniform01(_stream(seed, 2), m))
+    c = 0.1 + 0.9 * uniform01(_stream(seed, 3), n)
+    indptr = np.arange(0, m * n + 1, n, dtype=np.int64)
+    indices = np.tile(np.arange(n, dtype=np.int64), m)
+    return dict(name=f"dense_{m}x{n}_s{seed}", direction=MAXIMIZE, m=m, n=n, obj=c,
+                lo=np.zeros(n), hi=np.full(n, np.inf), indptr=indptr, indices=indices,
+                data=A.reshape(-1).copy(), ops=np.full(m, LE, dtype=np.int32), rhs=b)
+
+
+def gen_sparse_lp(m, n, k, seed=4):
+    """Config 4 family: exactly k distinct columns per row (first k distinct of a 2k-draw stream,
+    sorted), values U[0,1), b = rowsum * U[0.5,1.5), c ~ U[0.1,1); Max c'x, Ax<=b, x>=0."""
+    assert k <= n
+    if k == n:
+        return gen_dense_lp(m, n, seed)
+    draws = 2 * k + 16
+    cand = (splitmix64(_stream(seed, 11), m * draws) % np.uint64(n)).astype(np.int64).reshape(m, draws)
+    cols = np.empty((m, k), dtype=np.int64)
+    # fast path: rows whose first k candidates are already distinct
+    first = np.sort(cand[:, :k], axis=1)
+    ok = (first[:, 1:] != first[:, :-1]).all(axis=1)
+    cols[ok] = first[ok]
+    for r in np.nonzero(~ok)[0]:
+        _, idx = np.unique(cand[r], return_index=True)
+        keep = np.sort(idx)[:k]
+        assert len(keep) == k, "not enough distinct candidates"
+        cols[r] = np.sort(cand[r][keep])
+    vals = uniform01(_stream(seed, 12), m * k).reshape(m, k)
+    b = vals.sum(axis=1) * (0.5 + uniform01(_stream(seed, 13), m))
+    c = 0.1 + 0.9 * uniform01(_stream(seed, 14), n)
+    return dict(name=f"sparse_{m}x{n}_k{k}_s{seed}", direction=MAXIMIZE, m=m, n=n, obj=c,
+                lo=np.zeros(n), hi=np.full(n, np.inf), indptr=np.arange(0, m * k + 1, k, dtype=np.int64),
+                indices=cols.reshape(-1), data=vals.reshape(-1), ops=np.full(m, LE, dtype=np.int32), rhs=b)
+
+
+def gen_mixed_lp(m, n, k, seed=3):
+    """Config 3 stand-in (no NETLIB file is available offline): sparse rows with E/L/G operators,
+    finite/infinite/fixed/free bounds and mixed-sign costs, built around a known feasible point so
+    the instance is feasible; Minimize.  Starts neither primal- nor dual-feasible, which exercises
+    the dual simplex (a7/a8) and the artificial objective (solver.rs:261)."""
+    base = gen_sparse_lp(m, n, k, seed)
+    u = uniform01(_stream(seed, 21), n)
+    x0 = np.floor(4.0 * uniform01(_stream(seed, 22), n))  # feasible point, small integers
+    kind = (splitmix64(_stream(seed, 23), n) % np.uint64(10)).astype(np.int64)
+    lo = np.where(kind < 6, 0.0, np.where(kind < 8, x0 - 1.0, -np.inf))
+    hi = np.where(kind < 4, np.inf, np.where(kind < 8, x0 + 2.0, np.inf))
+    fixed = kind == 8
+    lo = np.where(fixed, x0, lo)
+    hi = np.where(fixed, x0, hi)
+    x0 = np.where((kind < 6) | (kind == 9), np.maximum(x0, 0.0), x0)
+    # free vars (kind 9) get zero-sum pressure from rows only; costs: mixed sign, free vars cost 0
+    c = np.where(kind == 9, 0.0, np.round(4.0 * u - 1.0, 3))
+    c = np.where((hi == np.inf) & (c < 0), -c, c)  # keep the LP bounded
+    data = np.round(base["data"] * 8.0 - 3.0)      # small integer coefficients, some negative
+    data = np.where(data == 0.0, 1.0, data)
+    lhs = np.add.reduceat(data * x0[base["indices"]], base["indptr"][:-1])
+    opk = (splitmix64(_stream(seed, 24), m) % np.uint64(4)).astype(np.int64)
+    ops = np.where(opk == 0, EQ, np.where(opk < 3, LE, GE)).astype(np.int32)
+    slack = np.floor(3.0 * uniform01(_stream(seed, 25), m))
+    rhs = np.where(ops == EQ, lhs, np.where(ops == LE, lhs + slack, lhs - slack))
+    out = dict(base)
+    out.update(name=f"mixed_{m}x{n}_k{k}_s{seed}", direction=MINIMIZE, obj=c, lo=lo, hi=hi, data=data, ops=ops, rhs=rhs)
+    return out
+
+
+def build_problem(problem_cls, lp):
+    """Replay an instance through the reference's Problem API (any backend)."""
+    p = problem_cls(lp["direction"])
+    for j in range(lp["n"]):
+        p.add_var(float(lp["obj"][j]), (float(lp["lo"][j]), float(lp["hi"][j])))
+    ip, ix, dv = lp["indptr"], lp["indices"], lp["data"]
+    for i in range(lp["m"]):
+        b, e = int(ip[i]), int(ip[i + 1])
+        p.add_constraint_arrays(ix[b:e], dv[b:e], int(lp["ops"][i]), float(lp["rhs"][i]))
+    return p
+
+
+def to_mps(lp):
+    """Free-format MPS text of an instance (mps.rs reader; always the Minimize convention of
+    examples/solve_mps.rs:32 is up to the caller — the objective row is written as given)."""
+    m, n = lp["m"], lp["n"]
+    out = [f"NAME {lp['name']}", "ROWS", " N COST"]
+    tag = {EQ: "E", LE: "L", GE: "G"}
+    for i in range(m):
+        out.append(f" {tag[int(lp['ops'][i])]} R{i}")
+    out.append("COLUMNS")
+    ip, ix, dv = lp["indptr"], lp["indices"], lp["data"]
+    rows_of = [[] for _ in range(n)]
+    for i in range(m):
+        for q in range(int(ip[i]), int(ip[i + 1])):
+            rows_of[int(ix[q])].append((i, float(dv[q])))
+    for j in range(n):
+        if lp["obj"][j] != 0.0 or not rows_of[j]:
+            out.append(f"    X{j} COST {float(lp['obj'][j])!r}")
+        for i, a in rows_of[j]:
+            out.append(f"    X{j} R{i} {a!r}")
+    out.append("RHS")
+    for i in range(m):
+        if lp["rhs"][i] != 0.0:
+            out.append(f"    RHS R{i} {float(lp['rhs'][i])!r}")
+    out.append("BOUNDS")
+    for j in range(n):
+        lo, hi = float(lp["lo"][j]), float(lp["hi"][j])
+        if lo == -np.inf and hi == np.inf:
+            out.append(f" FR BND X{j}")
+        elif lo == hi:
+            out.append(f" FX BND X{j} {lo!r}")
+        else:
+            if lo != 0.0:
+                out.append(f" LO BND X{j} {lo!r}" if lo != -np.inf else f" LO BND X{j} -1e30")
+            if hi != np.inf:
+                out.append(f" UP BND X{j} {hi!r}")
+    out.append("ENDATA")
+    return "\n".join(out) + "\n"
