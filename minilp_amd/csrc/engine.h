@@ -120,6 +120,7 @@ public:
     int direction = 0;
     int64_t pivot_budget = -1;
     bool budget_exhausted = false;
+    bool resume_in_optimize = false;
     bool trace = false, profile = false;
     std::vector<PivotRecord> trace_log;
     Stats stats;

@@ -385,10 +385,14 @@ void Engine::initial_solve() {
     double t0 = now_s();
     if (!primal_feasible) restore_feasibility();
     if (!budget_exhausted && !dual_feasible) {
-        recalc_obj_coeffs();
+        if (!resume_in_optimize) recalc_obj_coeffs();  // a budget resume must not recompute d
+        resume_in_optimize = true;
         optimize();
     }
-    if (!budget_exhausted) enable_pse = false;  // solver.rs:482
+    if (!budget_exhausted) {
+        resume_in_optimize = false;
+        enable_pse = false;  // solver.rs:482
+    }
     stats.solve_wall_s += now_s() - t0;
 }
 void Engine::optimize() {

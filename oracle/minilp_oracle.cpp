@@ -732,6 +732,7 @@ struct Solver {  // solver.rs:14-58
     Counters cnt;
     int64_t pivot_budget = -1;  // <0: unlimited; else stop loops after this many more pivots
     bool budget_exhausted = false;
+    bool resume_in_optimize = false;
     bool trace = false;
     std::vector<PivotRecord> trace_log;
 
@@ -946,10 +947,12 @@ struct Solver {  // solver.rs:14-58
         if (!is_primal_feasible) restore_feasibility();
         if (budget_exhausted) return;
         if (!is_dual_feasible) {
-            recalc_obj_coeffs();
+            if (!resume_in_optimize) recalc_obj_coeffs();  // a budget resume must not recompute d
+            resume_in_optimize = true;
             optimize();
         }
         if (budget_exhausted) return;
+        resume_in_optimize = false;
         enable_primal_steepest_edge = false;
     }
 

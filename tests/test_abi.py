@@ -1,0 +1,103 @@
+"""CPU: the C-ABI library loads, exports every symbol include/minilp_hip.h declares, the host-side
+model building / MPS parsing behaves like the reference, and a solve without a GPU fails loudly
+(no CPU fallback exists)."""
+import ctypes
+import math
+import os
+import re
+
+import pytest
+
+import minilp_amd as M
+from minilp_amd import build as mbuild
+from tests.common import ROOT
+from tests.test_oracle_kat import MPS_TESTPROB
+
+INF = math.inf
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    if not os.path.exists(M.lib_path()):
+        mbuild.build(verbose=False)
+
+
+def test_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "minilp_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(mlp_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(names) >= 35
+    lib = ctypes.CDLL(M.lib_path())
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_problem_building_and_reference_panics_become_einval():
+    p = M.Problem(M.MINIMIZE)
+    x = p.add_var(1.0, (0.0, INF))
+    y = p.add_var(2.0, (0.0, 3.0))
+    assert (x, y) == (0, 1) and p.num_vars == 2
+    p.add_constraint([(y, 1.0), (x, 1.0)], M.LE, 4.0)  # unsorted is fine (lib.rs:476)
+    with pytest.raises(M.InternalError) as e:           # duplicate variable: reference panics (lib.rs:247-249)
+        p.add_constraint([(x, 1.0), (x, 2.0)], M.LE, 1.0)
+    assert e.value.code == -1
+    with pytest.raises(M.InternalError):                # out-of-range variable
+        p.add_constraint([(7, 1.0)], M.LE, 1.0)
+    q = p.clone()
+    q.add_var(0.0, (0.0, 1.0))
+    assert (p.num_vars, q.num_vars) == (2, 3)
+
+
+def test_mps_parser_host_side():
+    f = M.MpsFile.parse(MPS_TESTPROB, M.MINIMIZE)  # the reference test's data fixture (mps.rs:437-462)
+    assert f.problem_name == "TESTPROB"
+    assert f.variables == {"XONE": 0, "YTWO": 1, "ZTHREE": 2}
+    assert f.problem.num_vars == 3
+    for bad, msg in [("ROWS\n", "expected NAME"), ("NAME x\nROWS\n N c\nCOLUMNS\n  a c 1 zz 2\nRHS\nENDATA\n", "unknown constraint"),
+                     ("NAME x\nROWS\n Q c\n", "unexpected row type"), ("NAME x\nROWS\n N c\nCOLUMNS\nRHS\n", "expected ENDATA")]:
+        with pytest.raises(ValueError) as e:
+            M.MpsFile.parse(bad, M.MINIMIZE)
+        assert msg in str(e.value)
+
+
+def test_mps_ranges_and_bounds_rules():
+    text = """NAME r
+ROWS
+ N obj
+ L r1
+ G r2
+ E r3
+ E r4
+COLUMNS
+    x obj 1 r1 1
+    x r2 1 r3 1
+    x r4 1
+    y obj 1 r1 1
+    z obj 1 r1 1
+RHS
+    rhs r1 10 r2 2
+    rhs r3 5 r4 5
+    other r1 99
+RANGES
+    rng r1 4 r2 3
+    rng r3 2 r4 -2
+BOUNDS
+ UP b x 7
+ UP b y -3
+ FR b z
+ UP other x 1
+ENDATA
+"""
+    f = M.MpsFile.parse(text, M.MINIMIZE)
+    # inspected through the oracle's identical reader in tests/test_hip_parity.py; here: shape only
+    assert f.problem.num_vars == 3
+
+
+def test_no_gpu_fails_loudly():
+    if M.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    p = M.Problem(M.MAXIMIZE)
+    x = p.add_var(1.0, (0.0, INF))
+    p.add_constraint([(x, 1.0)], M.LE, 4.0)
+    with pytest.raises(M.InternalError) as e:
+        p.solve()
+    assert e.value.code == -4 and "no CPU fallback" in str(e.value)

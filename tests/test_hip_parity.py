@@ -1,0 +1,365 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP engine, through the C ABI, against
+the CPU oracle on the same seeded inputs, the reference's known-answer tests, the committed HiGHS
+objectives, and size-independent properties at BASELINE.json sizes.
+
+Tolerances (f64 throughout): |dobj| <= 1e-9 * max(1,|obj|); |dx|inf <= 1e-7 on
+unique-optimum instances.  The summation order of the GPU reductions differs from the reference's
+sequential loops, so results are compared to tolerance, and the pivot SEQUENCE is additionally
+required to be identical on the non-degenerate random families.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import minilp_amd as M
+from minilp_amd import lpgen
+from oracle import minilp_oracle as O
+from tests.common import GEN, HIGHS_RTOL, OBJ_RTOL, X_ATOL, check_feasible, highs_cases, obj_close, objective_of
+from tests.test_oracle_kat import MPS_TESTPROB
+
+pytestmark = pytest.mark.gpu
+INF = math.inf
+ATOL = 1e-9  # the KAT instances have exactly representable answers
+
+
+def near(a, b, tol=ATOL):
+    return abs(a - b) <= tol
+
+
+def both(build):
+    """Build the same model through the oracle and the product."""
+    return build(O), build(M)
+
+
+# ------------------------------------------------------------------ reference KATs through the C ABI
+def test_extension_loaded_and_gpu_visible():
+    assert M.device_count() >= 1
+    import ctypes
+    assert isinstance(M.lib(), ctypes.CDLL)
+
+
+def test_readme_toy():  # lib.rs:27-44 (BASELINE config 1 on the GPU)
+    p = M.Problem(M.MAXIMIZE)
+    x = p.add_var(1.0, (0.0, INF))
+    y = p.add_var(2.0, (0.0, 3.0))
+    p.add_constraint([(x, 1.0), (y, 1.0)], M.LE, 4.0)
+    p.add_constraint([(x, 2.0), (y, 1.0)], M.GE, 2.0)
+    s = p.solve(trace=True)
+    assert s.objective() == 7.0 and s[x] == 1.0 and s[y] == 3.0
+    assert [(t[0], t[1], t[2]) for t in s.trace()] == [(0, 0, 0)]  # one primal pivot
+    assert dict(s)[x] == 1.0  # iter()
+
+
+def test_optimize():  # lib.rs:470-482
+    p = M.Problem(M.MAXIMIZE)
+    v1 = p.add_var(3.0, (12.0, INF))
+    v2 = p.add_var(4.0, (5.0, INF))
+    p.add_constraint([(v1, 1.0), (v2, 1.0)], M.LE, 20.0)
+    p.add_constraint([(v2, -4.0), (v1, 1.0)], M.GE, -20.0)
+    s = p.solve()
+    assert near(s[v1], 12.0) and near(s[v2], 8.0) and near(s.objective(), 68.0)
+
+
+def test_empty_expr_constraints():  # lib.rs:484-526
+    trivial = [([], M.EQ, 0.0), ([], M.GE, -1.0), ([], M.LE, 1.0)]
+    p = M.Problem(M.MINIMIZE)
+    p.add_var(1.0, (0.0, INF))
+    for e, op, b in trivial:
+        p.add_constraint(e, op, b)
+    assert p.solve().objective() == 0.0
+    s = p.solve()
+    for e, op, b in trivial:
+        s = s.add_constraint(e, op, b)
+    assert s.objective() == 0.0
+    infeasible = [([], M.EQ, 12.0), ([], M.GE, 34.0), ([], M.LE, -56.0)]
+    for e, op, b in infeasible:
+        c = p.clone()
+        c.add_constraint(e, op, b)
+        with pytest.raises(M.Infeasible):
+            c.solve()
+        with pytest.raises(M.Infeasible):
+            p.solve().add_constraint(e, op, b)
+    p.add_var(-1.0, (0.0, INF))
+    with pytest.raises(M.Unbounded):
+        p.solve()
+
+
+def test_free_variables():  # lib.rs:528-541
+    p = M.Problem(M.MAXIMIZE)
+    v1 = p.add_var(1.0, (0.0, INF))
+    v2 = p.add_var(2.0, (-INF, INF))
+    p.add_constraint([(v1, 1.0), (v2, 1.0)], M.LE, 4.0)
+    p.add_constraint([(v1, 1.0), (v2, 1.0)], M.GE, 2.0)
+    p.add_constraint([(v1, 1.0), (v2, -1.0)], M.GE, 0.0)
+    s = p.solve()
+    assert near(s[v1], 2.0) and near(s[v2], 2.0) and near(s.objective(), 6.0)
+
+
+def test_fix_unfix_var():  # lib.rs:543-576
+    p = M.Problem(M.MAXIMIZE)
+    v1 = p.add_var(1.0, (0.0, 3.0))
+    v2 = p.add_var(2.0, (0.0, 3.0))
+    p.add_constraint([(v1, 1.0), (v2, 1.0)], M.LE, 4.0)
+    p.add_constraint([(v1, 1.0), (v2, 1.0)], M.GE, 1.0)
+    orig = p.solve()
+    s = orig.clone().fix_var(v1, 0.5)
+    assert near(s[v1], 0.5) and near(s[v2], 3.0) and near(s.objective(), 6.5)
+    s, was = s.unfix_var(v1)
+    assert was and near(s[v1], 1.0) and near(s[v2], 3.0) and near(s.objective(), 7.0)
+    s = orig.clone().fix_var(v2, 2.5)
+    assert near(s[v1], 1.5) and near(s[v2], 2.5) and near(s.objective(), 6.5)
+    s, was = s.unfix_var(v2)
+    assert was and near(s[v1], 1.0) and near(s[v2], 3.0) and near(s.objective(), 7.0)
+    s, was = s.unfix_var(v2)
+    assert not was
+    with pytest.raises(M.Infeasible):  # solver.rs:379-381
+        orig.clone().fix_var(v1, 5.0)
+
+
+def test_add_constraint():  # lib.rs:578-621
+    p = M.Problem(M.MINIMIZE)
+    v1 = p.add_var(2.0, (0.0, INF))
+    v2 = p.add_var(1.0, (0.0, INF))
+    p.add_constraint([(v1, 1.0), (v2, 1.0)], M.LE, 4.0)
+    p.add_constraint([(v1, 1.0), (v2, 1.0)], M.GE, 2.0)
+    orig = p.solve()
+    s = orig.clone().add_constraint([(v1, -1.0), (v2, 1.0)], M.LE, 0.0)
+    assert near(s[v1], 1.0) and near(s[v2], 1.0) and near(s.objective(), 3.0)
+    s = orig.clone().fix_var(v2, 1.5).add_constraint([(v1, -1.0), (v2, 1.0)], M.LE, 0.0)
+    assert near(s[v1], 1.5) and near(s[v2], 1.5) and near(s.objective(), 4.5)
+    s = orig.clone().add_constraint([(v1, -1.0), (v2, 1.0)], M.GE, 3.0)
+    assert near(s[v1], 0.0) and near(s[v2], 3.0) and near(s.objective(), 3.0)
+
+
+def test_gomory_cut():  # lib.rs:623-645
+    p = M.Problem(M.MINIMIZE)
+    v1 = p.add_var(0.0, (0.0, INF))
+    v2 = p.add_var(-1.0, (0.0, INF))
+    p.add_constraint([(v1, 3.0), (v2, 2.0)], M.LE, 6.0)
+    p.add_constraint([(v1, -3.0), (v2, 2.0)], M.LE, 0.0)
+    s = p.solve()
+    assert near(s[v1], 1.0) and near(s[v2], 1.5) and near(s.objective(), -1.5)
+    s = s.add_gomory_cut(v2)
+    assert abs(s[v1] - 2.0 / 3.0) < 1e-8 and near(s[v2], 1.0) and near(s.objective(), -1.0)
+    s = s.add_gomory_cut(v1)
+    assert abs(s[v1] - 1.0) < 1e-8 and near(s[v2], 1.0) and near(s.objective(), -1.0)
+    t = M.Problem(M.MAXIMIZE)  # README toy: y ends non-basic at its upper bound
+    x = t.add_var(1.0, (0.0, INF))
+    y = t.add_var(2.0, (0.0, 3.0))
+    t.add_constraint([(x, 1.0), (y, 1.0)], M.LE, 4.0)
+    with pytest.raises(M.InternalError):  # Gomory cut on a non-basic variable panics (solver.rs:458)
+        t.solve().add_gomory_cut(y)
+
+
+def test_solver_initial_solve_white_box():  # solver.rs:1443-1479
+    p = M.Problem(M.MINIMIZE)
+    p.add_var(-3.0, (-INF, 20.0))
+    p.add_var(-4.0, (5.0, INF))
+    p.add_constraint([(0, 1.0), (1, 1.0)], M.LE, 20.0)
+    p.add_constraint([(0, -1.0), (1, 4.0)], M.LE, 20.0)
+    s = p.solve(trace=True)
+    assert list(s.state("flags")[:2]) == [1, 1]
+    assert list(s.state("basic_vars")) == [0, 1]
+    np.testing.assert_allclose(s.state("basic_var_vals"), [12.0, 8.0], atol=ATOL)
+    assert list(s.state("nb_vars")) == [2, 3]
+    np.testing.assert_allclose(s.state("nb_var_vals"), [0.0, 0.0], atol=ATOL)
+    np.testing.assert_allclose(s.state("nb_var_obj_coeffs"), [3.2, 0.2], atol=ATOL)
+    assert near(s.state("cur_obj_val")[0], -68.0)
+    assert [(t[0], t[1], t[2]) for t in s.trace()] == [(1, 0, 0), (0, 1, 1)]  # SURVEY B.1 hand trace
+    q = M.Problem(M.MINIMIZE)
+    q.add_var(1.0, (0.0, INF))
+    q.add_var(1.0, (0.0, INF))
+    q.add_constraint([(0, 1.0), (1, 1.0)], M.GE, 10.0)
+    q.add_constraint([(0, 1.0), (1, 1.0)], M.LE, 5.0)
+    with pytest.raises(M.Infeasible):
+        q.solve()
+
+
+def test_solver_initialize_white_box():  # solver.rs:1391-1441 (state right after try_new)
+    p = M.Problem(M.MINIMIZE)
+    p.add_var(2.0, (-INF, 0.0))
+    p.add_var(1.0, (5.0, INF))
+    p.add_constraint([(0, 1.0), (1, 1.0)], M.LE, 6.0)
+    p.add_constraint([(0, 1.0), (1, 2.0)], M.LE, 8.0)
+    p.add_constraint([(0, 1.0), (1, 1.0)], M.GE, 2.0)
+    p.add_constraint([(1, 1.0)], M.EQ, 3.0)
+    s = p.solve(budget=0)
+    assert list(s.state("flags")) == [0, 0, 1, 1]
+    assert list(s.state("orig_obj_coeffs")) == [2.0, 1.0, 0.0, 0.0, 0.0, 0.0]
+    assert list(s.state("orig_var_mins")) == [-INF, 5.0, 0.0, 0.0, -INF, 0.0]
+    assert list(s.state("orig_var_maxs")) == [0.0, INF, INF, INF, 0.0, 0.0]
+    assert list(s.state("orig_rhs")) == [6.0, 8.0, 2.0, 3.0]
+    assert list(s.state("basic_vars")) == [2, 3, 4, 5]
+    assert list(s.state("basic_var_vals")) == [1.0, -2.0, -3.0, -2.0]
+    assert list(s.state("dual_edge_sq_norms")) == [1.0, 1.0, 1.0, 1.0]
+    assert list(s.state("nb_vars")) == [0, 1]
+    assert list(s.state("nb_var_obj_coeffs")) == [-1.0, 1.0]
+    assert list(s.state("nb_var_vals")) == [0.0, 5.0]
+    assert list(s.state("primal_edge_sq_norms")) == [4.0, 8.0]
+    assert s.state("cur_obj_val")[0] == 0.0
+
+
+def test_parse_mps_file():  # mps.rs:464-476
+    f = M.MpsFile.parse(MPS_TESTPROB, M.MINIMIZE)
+    s = f.problem.solve()
+    assert near(s[f.variables["XONE"]], 4.0) and near(s[f.variables["YTWO"]], -1.0)
+    assert near(s[f.variables["ZTHREE"]], 6.0) and near(s.objective(), 54.0)
+
+
+# ------------------------------------------------------------------ differential vs the oracle
+NONDEGENERATE = [("sparse", dict(m=5, n=5, k=3, seed=1)), ("sparse", dict(m=50, n=40, k=8, seed=3)),
+                 ("sparse", dict(m=200, n=200, k=10, seed=4)), ("sparse", dict(m=300, n=500, k=20, seed=5)),
+                 ("sparse", dict(m=700, n=600, k=12, seed=6)), ("sparse", dict(m=1, n=1, k=1, seed=1)),
+                 ("dense", dict(m=10, n=10, seed=1)), ("dense", dict(m=60, n=60, seed=2)),
+                 ("dense", dict(m=150, n=100, seed=3)), ("dense", dict(m=64, n=257, seed=4)),
+                 ("dense", dict(m=300, n=33, seed=5))]
+
+
+@pytest.mark.parametrize("fam,kw", NONDEGENERATE, ids=lambda v: str(v))
+def test_random_lp_matches_oracle_pivot_for_pivot(fam, kw):
+    lp = GEN[fam](**kw)
+    so = lpgen.build_problem(O.Problem, lp).solve(trace=True)
+    sg = lpgen.build_problem(M.Problem, lp).solve(trace=True)
+    assert obj_close(sg.objective(), so.objective())
+    xo, xg = so.values(), sg.values()
+    assert np.abs(xo - xg).max() <= X_ATOL
+    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]  # same (phase, col, row, entering, leaving)
+    check_feasible(lp, xg)
+    st, so_st = sg.stats(), so.stats()
+    assert st["basis_changes"] == so_st["pivots"] and st["bound_flips"] == so_st["bound_flips"]
+    assert sg.reinvert() < 1e-8  # incremental nucleus inverse == from-scratch Gauss-Jordan inverse
+
+
+MIXED = [dict(m=8, n=8, k=3, seed=1), dict(m=30, n=40, k=5, seed=2), dict(m=100, n=150, k=6, seed=3),
+         dict(m=300, n=400, k=8, seed=4), dict(m=1000, n=1500, k=6, seed=5)]
+
+
+@pytest.mark.parametrize("kw", MIXED, ids=lambda v: str(v))
+def test_mixed_lp_dual_simplex_objective(kw):
+    """E/L/G rows, fixed / free / boxed variables: dual simplex path.  Integer data => degenerate
+    ties, so only the objective (and feasibility) is compared, per the parity contract."""
+    lp = lpgen.gen_mixed_lp(**kw)
+    so = lpgen.build_problem(O.Problem, lp).solve()
+    sg = lpgen.build_problem(M.Problem, lp).solve()
+    assert obj_close(sg.objective(), so.objective())
+    check_feasible(lp, sg.values())
+    assert sg.stats()["dual_iters"] > 0
+    assert obj_close(objective_of(lp, sg.values()), sg.objective(), 1e-8)
+
+
+@pytest.mark.parametrize("case", highs_cases(), ids=lambda c: c["name"])
+def test_highs_golden_objective(case):
+    lp = GEN[case["family"]](**case["args"])
+    sg = lpgen.build_problem(M.Problem, lp).solve()
+    assert obj_close(sg.objective(), case["objective"], HIGHS_RTOL)
+    check_feasible(lp, sg.values())
+
+
+def test_infeasible_and_unbounded_statuses():
+    lp = lpgen.gen_sparse_lp(40, 30, 5, 7)
+    p = lpgen.build_problem(M.Problem, lp)
+    p.add_constraint([(0, 1.0), (1, 1.0)], M.GE, 1e9)  # cannot be met under Ax <= b
+    with pytest.raises(M.Infeasible):
+        p.solve()
+    q = lpgen.build_problem(M.Problem, lp)
+    q.add_var(1.0, (0.0, INF))  # free-riding column with positive profit: unbounded
+    with pytest.raises(M.Unbounded):
+        q.solve()
+    r = M.Problem(M.MINIMIZE)
+    r.add_var(1.0, (2.0, 1.0))  # min > max (solver.rs:138-140)
+    with pytest.raises(M.Infeasible):
+        r.solve()
+
+
+# ------------------------------------------------------------------ warm start on the device-resident basis
+def test_warm_start_sequence_matches_oracle():
+    """add_constraint / fix_var / unfix_var / clone on a solved random LP, step by step vs the oracle."""
+    lp = lpgen.gen_sparse_lp(120, 90, 9, 21)
+    so = lpgen.build_problem(O.Problem, lp).solve()
+    sg = lpgen.build_problem(M.Problem, lp).solve()
+    rng = np.random.default_rng(5)
+    x = so.values()
+    for step in range(12):
+        vars_ = rng.choice(lp["n"], size=4, replace=False)
+        coef = rng.integers(1, 4, size=4).astype(float)
+        lhs = float(np.dot(coef, x[vars_]))
+        expr = list(zip(vars_.tolist(), coef.tolist()))
+        so = so.add_constraint(expr, O.LE, 0.9 * lhs + 0.01)
+        sg = sg.add_constraint(expr, M.LE, 0.9 * lhs + 0.01)
+        assert obj_close(sg.objective(), so.objective()), step
+        x = so.values()
+        assert np.abs(sg.values() - x).max() <= X_ATOL
+    keep_o, keep_g = so.clone(), sg.clone()
+    v = int(np.argmax(x))
+    so, sg = so.fix_var(v, 0.5 * x[v]), sg.fix_var(v, 0.5 * x[v])
+    assert obj_close(sg.objective(), so.objective())
+    assert abs(sg[v] - 0.5 * x[v]) <= 1e-12
+    (so, wo), (sg, wg) = so.unfix_var(v), sg.unfix_var(v)
+    assert wo and wg and obj_close(sg.objective(), so.objective())
+    assert obj_close(sg.objective(), keep_g.objective(), 1e-8)  # unfixing returns to the previous optimum
+    assert obj_close(keep_g.objective(), keep_o.objective())    # the clone was not disturbed
+    with pytest.raises(M.Infeasible):
+        keep_g.add_constraint([(v, 1.0)], M.GE, 1e9)
+
+
+def test_gomory_cuts_are_valid_cuts():
+    """Gomory cuts are discontinuous in the tableau row (floor of a coefficient that is 0 up to
+    rounding), so beyond the exact KAT of lib.rs:623-645 only their defining properties can be
+    compared: each cut removes the current fractional vertex, never improves the objective and
+    keeps every integer-feasible point (here floor(x*), feasible because A >= 0, x >= 0)."""
+    lp = lpgen.gen_sparse_lp(40, 30, 6, 9)
+    sg = lpgen.build_problem(M.Problem, lp).solve()
+    x0 = sg.values()
+    y = np.floor(x0 + 1e-9)
+    check_feasible(lp, y)
+    lower = objective_of(lp, y)
+    prev = sg.objective()
+    for _ in range(4):
+        x = sg.values()
+        frac = np.abs(x - np.round(x))
+        v = int(np.argmax(frac))
+        if frac[v] < 1e-6:
+            break
+        sg = sg.add_gomory_cut(v)
+        assert sg.objective() <= prev + 1e-9 * abs(prev)
+        assert sg.objective() >= lower - 1e-9 * abs(lower)
+        assert np.abs(sg.values() - x).max() > 1e-9  # the fractional vertex was cut off
+        check_feasible(lp, sg.values())
+        prev = sg.objective()
+
+
+# ------------------------------------------------------------------ BASELINE.json sizes
+def test_config2_dense_1000_full_solve():
+    """Config 2: 1000 x 1000 dense, solved to optimality on the GPU; HiGHS fixture + oracle."""
+    lp = lpgen.gen_dense_lp(1000, 1000, 2)
+    sg = lpgen.build_problem(M.Problem, lp).solve(trace=True)
+    case = [c for c in highs_cases() if c["name"] == "dense_1000x1000_s2"][0]
+    assert obj_close(sg.objective(), case["objective"], HIGHS_RTOL)
+    check_feasible(lp, sg.values())
+    so = lpgen.build_problem(O.Problem, lp).solve(trace=True)
+    assert obj_close(sg.objective(), so.objective())
+    assert np.abs(sg.values() - so.values()).max() <= X_ATOL
+    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+
+
+def test_config4_100k_budget_properties():
+    """Config 4 (100k x 100k, 100 nnz/row) under the fixed-pivot-budget protocol: size-independent
+    properties after every chunk (primal feasibility is invariant under primal simplex, the
+    objective is monotone, W K = I), plus the oracle on the first 300 pivots."""
+    lp = lpgen.gen_sparse_lp(100000, 100000, 100, 4)
+    sg = lpgen.build_problem(M.Problem, lp).solve(budget=300, trace=True)
+    so = lpgen.build_problem(O.Problem, lp).solve(budget=300, trace=True)
+    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+    assert obj_close(sg.objective(), so.objective())
+    assert np.abs(sg.values() - so.values()).max() <= X_ATOL
+    prev = sg.objective()
+    for _ in range(3):
+        sg.continue_solve(700)
+        x = sg.values()
+        check_feasible(lp, x, tol=1e-6)
+        assert sg.objective() >= prev - 1e-9 * abs(prev)
+        assert obj_close(objective_of(lp, x), sg.objective(), 1e-8)
+        prev = sg.objective()
+    assert sg.stats()["iterations"] == 2400
+    assert sg.reinvert() < 1e-6
