@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""bench.py — simplex pivots/sec on BASELINE.json's headline workload (config 4: random LP,
+100 000 vars x 100 000 constraints, 100 nnz/row), fixed-pivot-budget protocol.
+
+A "step" is ONE simplex iteration (pricing -> FTRAN -> ratio test -> BTRAN -> tableau row ->
+basis-inverse update -> x_B/d/gamma/beta updates) of the device-resident solver.  W warm-up
+pivots from the slack basis, then exactly K timed pivots bracketed by barrier + synchronize.
+N > 1: one process per GPU (torch.distributed, RCCL); see DESIGN.md §6 for what is sharded.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--rows", type=int, default=100000)
+    ap.add_argument("--cols", type=int, default=100000)
+    ap.add_argument("--nnz-per-row", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=4)
+    ap.add_argument("--cpu-pivots", type=int, default=300, help="bounded CPU-baseline sample (pivots after warm-up)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(lp, warmup, sample):
+    """The oracle (single-threaded C++ restatement of minilp 0.2.2) timed on this box's host cores:
+    same instance, same warm-up, then `sample` timed pivots.  kind = "port" (the Rust reference
+    cannot be built here)."""
+    from minilp_amd import lpgen
+    from oracle import minilp_oracle as O
+    s = lpgen.build_problem(O.Problem, lp).solve(budget=warmup)
+    it0 = s.stats()
+    t0 = time.perf_counter()
+    s.continue_solve(sample)
+    dt = time.perf_counter() - t0
+    it1 = s.stats()
+    n = (it1["primal_iters"] + it1["dual_iters"]) - (it0["primal_iters"] + it0["dual_iters"])
+    return dict(value=n / dt, unit="pivots/s", cores=1, kind="port",
+                sample=f"oracle (C++ restatement of minilp 0.2.2, 1 thread) on the same instance: pivots "
+                       f"{warmup}..{warmup + n} from the slack basis in {dt:.2f}s (its fastest stretch; "
+                       f"the GPU figure covers pivots {warmup}..{warmup}+steps)",
+                host_cpus=os.cpu_count())
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import minilp_amd as M
+    from minilp_amd import lpgen
+    M.set_device(local_rank if world > 1 else 0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # N > 1: every rank pivots its own instance of the same family (independent LPs, no data-path
+    # collective) => weak scaling.  Rank 0 solves the BASELINE seed.
+    lp = lpgen.gen_sparse_lp(a.rows, a.cols, a.nnz_per_row, a.seed + rank)
+    p = lpgen.build_problem(M.Problem, lp)
+    s = p.solve(budget=0, profile=True)
+    s.continue_solve(a.warmup)           # W untimed warm-up pivots
+    s.reset_stats()
+    barrier()
+    t0 = time.perf_counter()
+    s.continue_solve(a.steps)            # exactly K timed pivots
+    barrier()
+    dt = time.perf_counter() - t0
+    st = s.stats()
+    done = st["iterations"]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        c = torch.tensor([float(done)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        total = float(c.item())
+    else:
+        total = float(done)
+    if rank == 0:
+        kern = {}
+        for name in ("fused", "sweep"):
+            n_l = st[name + "_launches"]
+            if n_l:
+                us = st[name + "_ms"] * 1e3 / n_l
+                gbs = st[name + "_bytes"] / (st[name + "_ms"] * 1e-3) / 1e9
+                kern[name] = dict(launches=n_l, avg_us=us, algorithmic_bytes_per_launch=st[name + "_bytes"] / n_l, gbs=gbs,
+                                  total_ms=st[name + "_ms"])
+        dom = max(kern, key=lambda k: kern[k]["total_ms"]) if kern else None
+        roofline = None
+        if dom:
+            kname = {"fused": "k_fused_w (tau=W*rho, v=W^T*t, eta update of the nucleus inverse)",
+                     "sweep": "k_sweep (tableau row rho^T N [+ PSE helper] as a CSC pull over A)"}[dom]
+            roofline = dict(bound="hbm", kernel=kname, achieved=kern[dom]["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=kern[dom]["gbs"] / HBM_PEAK_GBS, traffic=None,
+                            avg_launch_us=kern[dom]["avg_us"], launches=kern[dom]["launches"],
+                            algorithmic_bytes_per_launch=kern[dom]["algorithmic_bytes_per_launch"],
+                            other_kernels={k: v for k, v in kern.items() if k != dom})
+        out = dict(metric="simplex pivots/sec", value=total / dt, unit="pivots/s", n_gpus=world, steps=a.steps,
+                   warmup=a.warmup, ms_per_step=dt * 1e3 / max(done, 1), higher_is_better=True, scaling="weak",
+                   vs_baseline=None, dtype="f64", data="synthetic",
+                   config=dict(workload=f"config 4: random LP {a.rows} vars x {a.cols} constraints, {a.nnz_per_row} nnz/row "
+                                        f"(0.1% fill), Max c'x, Ax<=b, x>=0; primal simplex with PSE+DSE from the slack basis; "
+                                        f"timed pivots {a.warmup}..{a.warmup + a.steps}",
+                               rows=a.rows, cols=a.cols, nnz=int(st["nnz"]), seed=a.seed,
+                               parallelism=("1 GPU" if world == 1 else f"{world} GPUs, one independent LP of the family per rank"),
+                               nucleus_size_at_end=int(st["nucleus_size"]), objective_at_end=s.objective(),
+                               completed_steps=int(done), bound_flips=int(st["bound_flips"])),
+                   roofline=roofline)
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(lp, a.warmup, a.cpu_pivots)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -35,6 +35,8 @@ enum { MLP_OK = 0, MLP_INFEASIBLE = 1, MLP_UNBOUNDED = 2,
 const char* mlp_last_error(void);
 /* Number of visible HIP devices (0 => every solve returns MLP_ENOGPU; there is no CPU fallback). */
 int mlp_device_count(void);
+/* Select the HIP device used by solutions created afterwards on this thread (one process per GPU). */
+int mlp_set_device(int device);
 
 /* ---- Problem (lib.rs:215-305) ------------------------------------------------------------ */
 mlp_problem* mlp_problem_new(int direction);                                   /* Problem::new      lib.rs:217 */

@@ -61,6 +61,7 @@ def lib():
 
     sig("mlp_last_error", C.c_char_p)
     sig("mlp_device_count", i32)
+    sig("mlp_set_device", i32, i32)
     sig("mlp_problem_new", vp, i32)
     sig("mlp_problem_clone", vp, vp)
     sig("mlp_problem_free", None, vp)
@@ -101,6 +102,10 @@ def lib():
 
 def device_count():
     return lib().mlp_device_count()
+
+
+def set_device(device):
+    _raise(lib().mlp_set_device(int(device)))
 
 
 def _raise(st):

@@ -53,6 +53,10 @@ int mlp_device_count(void) {
     return n;
 }
 
+int mlp_set_device(int device) {
+    return guarded([&] { HIPCHECK(hipSetDevice(device)); });
+}
+
 mlp_problem* mlp_problem_new(int direction) {
     mlp_problem* p = new mlp_problem();
     p->pd.direction = direction == MLP_MAXIMIZE ? 1 : 0;
