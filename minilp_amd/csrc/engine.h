@@ -124,7 +124,7 @@ public:
     bool trace = false, profile = false;
     std::vector<PivotRecord> trace_log;
     Stats stats;
-    void resolve_events();
+    void resolve_events() {}
     uint64_t state(const char* what, double* out, uint64_t cap);
     int m() const { return m_; }
     int total_vars() const { return N_; }
@@ -133,7 +133,7 @@ public:
     size_t nnz() const { return h_rcol.size(); }
 
 private:
-    // --- host mirror (small integer bookkeeping + the matrix for rebuilds)
+    // --- host mirror (integer bookkeeping + the matrix for rebuilds)
     int m_ = 0, N_ = 0, k_ = 0, cap_ = 0;
     std::vector<double> h_obj, h_lo, h_hi, h_rhs;
     std::vector<int> h_rptr, h_rcol;
@@ -141,6 +141,7 @@ private:
     std::vector<int> h_cptr, h_crow;
     std::vector<double> h_cval;
     std::vector<int> h_basic_vars, h_nb_vars, h_var_loc;
+    // slot maps live on the device; pulled on demand (reinvert, add_constraint, clone)
     std::vector<int> h_kslot_of_pos, h_srow_of_pos, h_kslot_of_row, h_pos_of_srow, h_pos_of_kslot, h_row_of_kslot;
     std::vector<double> h_sdiag_of_pos;
     std::vector<uint8_t> h_nb_fixed;
@@ -148,7 +149,9 @@ private:
     size_t nnz_nonbasic = 0;
 
     // --- device state
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr, st2 = nullptr;  // st2: side branch of the iteration graph
+    hipEvent_t evFork[3] = {nullptr, nullptr, nullptr}, evJoin[3] = {nullptr, nullptr, nullptr};
+    uint64_t batches_run = 0;
     DevBuf<int> d_cptr, d_crow, d_rptr, d_rcol;
     DevBuf<double> d_cval, d_rval, d_lo, d_hi, d_obj;
     DevBuf<int> d_var_loc, d_basic_vars, d_nb_vars;
@@ -156,41 +159,53 @@ private:
     DevBuf<uint8_t> d_nbflags;
     DevBuf<int> d_kslot_of_pos, d_srow_of_pos, d_kslot_of_row, d_pos_of_srow, d_pos_of_kslot, d_row_of_kslot;
     DevBuf<double> d_sdiag_of_pos, d_W;
-    DevBuf<double> d_alpha_q, d_rho, d_tau, d_vvec, d_alpha_r, d_helper;
+    DevBuf<double> d_work;  // alpha_q | tau | rv (2m)  — one memset per pivot
+    DevBuf<double> d_alpha_r, d_helper;
+    DevBuf<int2> d_nb_rng;
+    int sweep_variant = 0;
     DevBuf<double> d_aK, d_rK, d_tK, d_tauK, d_vK, d_klist_a, d_blist_a, d_part_tau, d_part_v;
     DevBuf<int> d_klist_s, d_blist_s;
-    DevBuf<double> d_red_key;
+    DevBuf<double> d_red_key, d_red_key2;
     DevBuf<int> d_red_idx;
     DevBuf<unsigned> d_ticket;
-    DevBuf<IterState> d_it;
-    IterState* h_it = nullptr;  // pinned
+    DevBuf<Ctl> d_ctl;
+    DevBuf<DevView> d_view;
+    DevView hview;
+    bool view_dirty = true;
+    Ctl* h_ctl = nullptr;  // pinned
 
     // cached x for get_value
     std::vector<double> h_xB, h_xN;
     bool values_dirty = true;
 
-    // profiling events
-    struct EvPair { hipEvent_t a, b; int kind; };
-    std::vector<EvPair> ev_pending;
-    std::vector<hipEvent_t> ev_pool;
-    hipEvent_t get_event();
+    // --- iteration graphs: [phase][pse]
+    bool use_graph = true, use_branches = false;
+    int batch = 16;
+    hipGraphExec_t gexec[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    hipGraph_t ggraph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    Geom ggeom[2][2];
+    bool gprof[2][2] = {{false, false}, {false, false}};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // sweep0, sweep1, fused0, fused1
+    void drop_graphs();
+    hipGraphExec_t get_graph(int phase);
 
-    DevView view();
+    Geom geom() const;
+    DevView* sync_view();
     void build_csc();
     void upload_matrix();
     void alloc_row_buffers(int m_new);
     void ensure_nucleus_cap(int need);
-    void sync_iter();
-    void set_iter(int status, int q, int r, double leaving_new_val);
-    bool take_budget();
+    void pull_ctl();
+    void pull_maps();
+    void push_maps();
     int col_nnz(int var) const { return h_cptr[var + 1] - h_cptr[var]; }
 
+    void record_iteration(int phase, bool with_events);  // enqueue the kernel sequence of ONE iteration
+    int run_loop(int phase);                             // batches of replays until terminal / budget
+    int process_records(int phase, int launched);
     void optimize();              // solver.rs:487-511
     void restore_feasibility();   // solver.rs:513-547
     void recalc_obj_coeffs();     // solver.rs:1199-1231
-    int primal_iteration();       // choose_pivot + pivot (solver.rs:695-853, 1023-1104)
-    int dual_iteration(int forced_row, double forced_val);  // solver.rs:529-533 / 384-391
-    void pivot_post(int phase, bool btran_done);            // everything after (q, r) are known
     void calc_col_coeffs(int col);                          // solver.rs:671-677
     void calc_row_coeffs(int row, bool with_sweep);         // solver.rs:680-693
     void fetch_values();

@@ -1,11 +1,14 @@
 // engine.hip — host orchestration of the device-resident simplex.  Control flow mirrors the
 // reference's Solver (solver.rs:108-1241); every per-pivot vector stays in HBM and every hot loop
-// is a kernel from kernels.hip.  One host<->device scalar exchange per pivot (IterState).
+// is a kernel from kernels.hip.  A simplex iteration is a fixed kernel sequence driven entirely by
+// device-resident state (Ctl), captured once into a hipGraph and replayed in batches; the host
+// reads back one small record per pivot, once per batch.
 #include "engine.h"
 
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -54,48 +57,62 @@ Engine::Engine() {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         throw MlpError(-4, "no HIP device visible: the simplex hot path has no CPU fallback");
     HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    HIPCHECK(hipHostMalloc((void**)&h_it, sizeof(IterState), hipHostMallocDefault));
-    std::memset(h_it, 0, sizeof(IterState));
+    HIPCHECK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+    for (int i = 0; i < 3; ++i) {
+        HIPCHECK(hipEventCreateWithFlags(&evFork[i], hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&evJoin[i], hipEventDisableTiming));
+    }
+    HIPCHECK(hipHostMalloc((void**)&h_ctl, sizeof(Ctl), hipHostMallocDefault));
+    std::memset(h_ctl, 0, sizeof(Ctl));
+    std::memset(&hview, 0, sizeof(hview));
+    const char* ng = std::getenv("MLP_NO_GRAPH");
+    use_graph = !(ng && ng[0] == '1');
+    const char* br = std::getenv("MLP_BRANCH");
+    use_branches = br && br[0] == '1';
+    const char* sv = std::getenv("MLP_SWEEP");
+    if (sv) sweep_variant = std::atoi(sv);
+    const char* bs = std::getenv("MLP_BATCH");
+    if (bs) batch = std::max(1, std::min(RING, std::atoi(bs)));
 }
 Engine::~Engine() {
     if (st) (void)hipStreamSynchronize(st);
-    for (auto& e : ev_pending) {
-        (void)hipEventDestroy(e.a);
-        (void)hipEventDestroy(e.b);
+    drop_graphs();
+    for (auto& e : ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h_ctl) (void)hipHostFree(h_ctl);
+    for (int i = 0; i < 3; ++i) {
+        if (evFork[i]) (void)hipEventDestroy(evFork[i]);
+        if (evJoin[i]) (void)hipEventDestroy(evJoin[i]);
     }
-    for (auto e : ev_pool) (void)hipEventDestroy(e);
-    if (h_it) (void)hipHostFree(h_it);
+    if (st2) (void)hipStreamDestroy(st2);
     if (st) (void)hipStreamDestroy(st);
 }
-
-hipEvent_t Engine::get_event() {
-    if (!ev_pool.empty()) {
-        hipEvent_t e = ev_pool.back();
-        ev_pool.pop_back();
-        return e;
-    }
-    hipEvent_t e;
-    HIPCHECK(hipEventCreate(&e));
-    return e;
-}
-void Engine::resolve_events() {
-    if (ev_pending.empty()) return;
-    HIPCHECK(hipStreamSynchronize(st));
-    for (auto& p : ev_pending) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-            if (p.kind == 0) stats.fused_ms += ms;
-            else stats.sweep_ms += ms;
+void Engine::drop_graphs() {
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+            if (gexec[a][b]) (void)hipGraphExecDestroy(gexec[a][b]);
+            if (ggraph[a][b]) (void)hipGraphDestroy(ggraph[a][b]);
+            gexec[a][b] = nullptr;
+            ggraph[a][b] = nullptr;
         }
-        ev_pool.push_back(p.a);
-        ev_pool.push_back(p.b);
-    }
-    ev_pending.clear();
 }
 
-DevView Engine::view() {
-    DevView v;
-    v.m = m_; v.n = num_vars; v.k = k_; v.ld = cap_;
+Geom Engine::geom() const {
+    Geom g;
+    g.m = m_;
+    g.n = num_vars;
+    g.cap = cap_;
+    double avg = num_vars > 0 ? (double)(h_rcol.size() - (size_t)m_) / (double)num_vars : 1.0;  // structural columns
+    g.lanes = avg >= 40.0 ? 64 : (avg >= 6.0 ? 16 : 4);
+    g.sweep_variant = sweep_variant;
+    return g;
+}
+
+DevView* Engine::sync_view() {
+    if (!view_dirty) return &hview;
+    DevView old = hview;
+    DevView& v = hview;
+    v.m = m_; v.n = num_vars; v.ld = cap_; v.pad0 = 0;
     v.csc_ptr = d_cptr.p; v.csc_row = d_crow.p; v.csc_val = d_cval.p;
     v.csr_ptr = d_rptr.p; v.csr_col = d_rcol.p; v.csr_val = d_rval.p;
     v.var_lo = d_lo.p; v.var_hi = d_hi.p; v.obj_c = d_obj.p;
@@ -105,14 +122,22 @@ DevView Engine::view() {
     v.kslot_of_pos = d_kslot_of_pos.p; v.srow_of_pos = d_srow_of_pos.p; v.sdiag_of_pos = d_sdiag_of_pos.p;
     v.kslot_of_row = d_kslot_of_row.p; v.pos_of_srow = d_pos_of_srow.p;
     v.pos_of_kslot = d_pos_of_kslot.p; v.row_of_kslot = d_row_of_kslot.p; v.W = d_W.p;
-    v.alpha_q = d_alpha_q.p; v.rho = d_rho.p; v.tau = d_tau.p; v.vvec = d_vvec.p;
+    v.alpha_q = d_work.p;
+    v.tau = d_work.p + (size_t)m_;
+    v.rv = reinterpret_cast<double2*>(d_work.p + 2 * (size_t)m_);
     v.alpha_r = d_alpha_r.p; v.helper = d_helper.p;
     v.aK = d_aK.p; v.rK = d_rK.p; v.tK = d_tK.p; v.tauK = d_tauK.p; v.vK = d_vK.p;
     v.klist_s = d_klist_s.p; v.klist_a = d_klist_a.p; v.blist_s = d_blist_s.p; v.blist_a = d_blist_a.p;
     v.part_tau = d_part_tau.p; v.part_v = d_part_v.p;
-    v.red_key = d_red_key.p; v.red_idx = d_red_idx.p; v.ticket = d_ticket.p;
-    v.it = d_it.p;
-    return v;
+    v.red_key = d_red_key.p; v.red_key2 = d_red_key2.p; v.red_idx = d_red_idx.p; v.ticket = d_ticket.p;
+    v.ctl = d_ctl.p;
+    v.nb_rng = d_nb_rng.p;
+    if (std::memcmp(&old, &hview, sizeof(DevView)) != 0) {
+        HIPCHECK(hipStreamSynchronize(st));
+        drop_graphs();  // kernel arguments (the view, by value) are baked into the captured graphs
+    }
+    view_dirty = false;
+    return &hview;
 }
 
 void Engine::build_csc() {  // counting transpose of the CSR: ascending row index inside each column
@@ -133,6 +158,7 @@ void Engine::upload_matrix() {
     d_cptr.upload(h_cptr, st); d_crow.upload(h_crow, st); d_cval.upload(h_cval, st);
     d_rptr.upload(h_rptr, st); d_rcol.upload(h_rcol, st); d_rval.upload(h_rval, st);
     d_lo.upload(h_lo, st); d_hi.upload(h_hi, st); d_obj.upload(h_obj, st);
+    view_dirty = true;
 }
 
 void Engine::alloc_row_buffers(int m_new) {
@@ -142,14 +168,17 @@ void Engine::alloc_row_buffers(int m_new) {
     d_hiB.ensure(mm, keep, st); d_beta.ensure(mm, keep, st);
     d_kslot_of_pos.ensure(mm, keep, st); d_srow_of_pos.ensure(mm, keep, st); d_sdiag_of_pos.ensure(mm, keep, st);
     d_kslot_of_row.ensure(mm, keep, st); d_pos_of_srow.ensure(mm, keep, st);
-    d_alpha_q.ensure(mm, 0, st); d_rho.ensure(mm, 0, st); d_tau.ensure(mm, 0, st); d_vvec.ensure(mm, 0, st);
+    d_work.ensure(4 * mm + 8, 0, st);
     d_klist_s.ensure(mm, 0, st); d_klist_a.ensure(mm, 0, st);
     d_blist_s.ensure(mm + num_vars + 64, 0, st); d_blist_a.ensure(mm + num_vars + 64, 0, st);
     d_var_loc.ensure((size_t)num_vars + mm, (size_t)num_vars + keep, st);
+    view_dirty = true;
 }
 
 void Engine::ensure_nucleus_cap(int need) {
+    if (need > m_) need = m_;  // the nucleus can never exceed the number of rows
     if (need <= cap_) return;
+    HIPCHECK(hipStreamSynchronize(st));
     int ncap = std::max(256, cap_ * 2);
     while (ncap < need) ncap *= 2;
     DevBuf<double> nW;
@@ -162,36 +191,45 @@ void Engine::ensure_nucleus_cap(int need) {
     d_W.p = nW.p; d_W.cap = nW.cap; nW.p = nullptr; nW.cap = 0;
     size_t keep = (size_t)k_;
     d_pos_of_kslot.ensure(ncap, keep, st); d_row_of_kslot.ensure(ncap, keep, st);
-    // the slot vectors of the pivot in flight (aK, rK, ...) must survive a mid-pivot growth
     d_aK.ensure(ncap, keep, st); d_rK.ensure(ncap, keep, st); d_tK.ensure(ncap, keep, st);
     d_tauK.ensure(ncap, keep, st); d_vK.ensure(ncap, keep, st);
     int nstripes = (ncap + FW_TR - 1) / FW_TR + 1, nchunks = (ncap + FW_TC - 1) / FW_TC + 1;
     d_part_v.ensure((size_t)nstripes * ncap, 0, st);
     d_part_tau.ensure((size_t)nchunks * ncap, 0, st);
     cap_ = ncap;
-    h_pos_of_kslot.resize(ncap, -1);
-    h_row_of_kslot.resize(ncap, -1);
+    view_dirty = true;
 }
 
-void Engine::sync_iter() {
-    HIPCHECK(hipMemcpyAsync(h_it, d_it.p, sizeof(IterState), hipMemcpyDeviceToHost, st));
+void Engine::pull_ctl() {
+    HIPCHECK(hipMemcpyAsync(h_ctl, d_ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    k_ = h_ctl->k;
+}
+static void d2h_i(std::vector<int>& h, const DevBuf<int>& d, size_t n, hipStream_t st) {
+    h.resize(n);
+    if (n) HIPCHECK(hipMemcpyAsync(h.data(), d.p, n * sizeof(int), hipMemcpyDeviceToHost, st));
+}
+void Engine::pull_maps() {
+    HIPCHECK(hipStreamSynchronize(st));
+    pull_ctl();
+    size_t mm = m_;
+    d2h_i(h_kslot_of_pos, d_kslot_of_pos, mm, st); d2h_i(h_srow_of_pos, d_srow_of_pos, mm, st);
+    d2h_i(h_kslot_of_row, d_kslot_of_row, mm, st); d2h_i(h_pos_of_srow, d_pos_of_srow, mm, st);
+    d2h_i(h_pos_of_kslot, d_pos_of_kslot, (size_t)cap_, st); d2h_i(h_row_of_kslot, d_row_of_kslot, (size_t)cap_, st);
+    h_sdiag_of_pos.resize(mm);
+    if (mm) HIPCHECK(hipMemcpyAsync(h_sdiag_of_pos.data(), d_sdiag_of_pos.p, mm * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
 }
-
-__global__ void k_set_iter(IterState* it, int status, int q, int r, double lnv, int entering_var, int leaving_var) {
-    it->status = status;
-    it->q = q;
-    it->r = r;
-    it->leaving_new_val = lnv;
-    it->entering_var = entering_var;
-    it->leaving_var = leaving_var;
-    it->klist_n = 0;
-    it->blist_n = 0;
-}
-void Engine::set_iter(int status, int q, int r, double lnv) {
-    int ev = q >= 0 ? h_nb_vars[q] : -1;
-    int lv = r >= 0 ? h_basic_vars[r] : -1;
-    hipLaunchKernelGGL(k_set_iter, dim3(1), dim3(1), 0, st, d_it.p, status, q, r, lnv, ev, lv);
+void Engine::push_maps() {
+    d_kslot_of_pos.upload(h_kslot_of_pos, st); d_srow_of_pos.upload(h_srow_of_pos, st);
+    d_sdiag_of_pos.upload(h_sdiag_of_pos, st);
+    d_kslot_of_row.upload(h_kslot_of_row, st); d_pos_of_srow.upload(h_pos_of_srow, st);
+    h_pos_of_kslot.resize(cap_, -1);
+    h_row_of_kslot.resize(cap_, -1);
+    d_pos_of_kslot.upload(h_pos_of_kslot, st); d_row_of_kslot.upload(h_row_of_kslot, st);
+    HIPCHECK(hipMemcpyAsync(&d_ctl.p->k, &k_, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    view_dirty = true;
 }
 
 // ------------------------------------------------------------------ Solver::try_new (solver.rs:108-369)
@@ -325,21 +363,20 @@ void Engine::try_new(const ProblemData& pd) {
     d_beta.upload(beta, st);
     d_nb_vars.upload(h_nb_vars, st);
     d_d.upload(d, st); d_xN.upload(xN, st); d_gamma.upload(gamma, st); d_nbflags.upload(flags, st);
-    d_alpha_r.ensure(n, 0, st); d_helper.ensure(n, 0, st);
-    d_kslot_of_pos.upload(h_kslot_of_pos, st); d_srow_of_pos.upload(h_srow_of_pos, st);
-    d_sdiag_of_pos.upload(h_sdiag_of_pos, st);
-    d_kslot_of_row.upload(h_kslot_of_row, st); d_pos_of_srow.upload(h_pos_of_srow, st);
-    d_red_key.ensure(1024, 0, st); d_red_idx.ensure(1024, 0, st);
+    d_alpha_r.ensure(n, 0, st); d_helper.ensure(n, 0, st); d_nb_rng.ensure(n, 0, st);
+    d_red_key.ensure(1024, 0, st); d_red_key2.ensure(1024, 0, st); d_red_idx.ensure(1024, 0, st);
     d_ticket.ensure(4, 0, st);
     HIPCHECK(hipMemsetAsync(d_ticket.p, 0, 4 * sizeof(unsigned), st));
-    d_it.ensure(1, 0, st);
-    IterState init;
-    std::memset(&init, 0, sizeof(init));
-    init.obj = cur_obj;
-    init.status = ITER_OPTIMAL;
-    *h_it = init;
-    HIPCHECK(hipMemcpyAsync(d_it.p, h_it, sizeof(IterState), hipMemcpyHostToDevice, st));
+    d_ctl.ensure(1, 0, st);
+    std::memset(h_ctl, 0, sizeof(Ctl));
+    h_ctl->it.obj = cur_obj;
+    h_ctl->it.status = ITER_NONE;
+    h_ctl->up.kase = -1;
+    HIPCHECK(hipMemcpyAsync(d_ctl.p, h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, st));
     ensure_nucleus_cap(256);
+    push_maps();
+    sync_view();
+    launch_init_nb_rng(hview, geom(), st);
     HIPCHECK(hipStreamSynchronize(st));
     values_dirty = true;
 }
@@ -367,22 +404,183 @@ void Engine::get_values(double* out, int n) {
     }
 }
 double Engine::cur_obj_val() {
-    sync_iter();
-    return h_it->obj;
+    pull_ctl();
+    return h_ctl->it.obj;
+}
+
+// ------------------------------------------------------------------ one iteration = a fixed kernel sequence
+// primal: choose_pivot + pivot (solver.rs:695-853, 1023-1104); dual: solver.rs:529-533.
+void Engine::record_iteration(int phase, bool with_events) {
+    const DevView& dv = hview;
+    const Geom g = geom();
+    const int pse = enable_pse ? 1 : 0, dse = enable_dse ? 1 : 0;
+    // fork/join: work that is off the critical path runs on the side stream st2 (a parallel
+    // branch of the captured graph; real concurrency in eager mode too)
+    // (measured: graph branches cost more in cross-queue signalling than they hide at these kernel
+    //  sizes — 4.6-4.9k vs 5.4k pivots/s on config 4 — so the default is a linear chain)
+    hipStream_t st2 = use_branches ? this->st2 : st;
+    auto fork = [&](int i) {
+        if (!use_branches) return;
+        HIPCHECK(hipEventRecord(evFork[i], st));
+        HIPCHECK(hipStreamWaitEvent(st2, evFork[i], 0));
+    };
+    auto join = [&](int i) {
+        if (!use_branches) return;
+        HIPCHECK(hipEventRecord(evJoin[i], st2));
+        HIPCHECK(hipStreamWaitEvent(st, evJoin[i], 0));
+    };
+    fork(0);
+    launch_clear_work(hview, st2);             // alpha_q, tau, rho|v := 0   (branch)
+    if (phase == 0) {
+        launch_price_primal(dv, g, pse, st);   // K1
+        join(0);
+        launch_ftran_col(dv, g, 0, st);        // K2 (device-driven by it.q)
+        launch_ratio_primal(dv, g, pse, st);   // K5 (+ ||alpha||^2, y_S); p2 ends the decision
+        launch_btran_unit(dv, g, 1, st);       // K3 (device-driven by it.r) + partition plan
+    } else {
+        launch_price_dual(dv, g, dse, st);     // K6
+        join(0);
+        launch_btran_unit(dv, g, 0, st);       // K3
+        if (with_events) HIPCHECK(hipEventRecord(ev[0], st));
+        launch_sweep(dv, g, 0, st);            // K4: alpha_r = rho^T N
+        if (with_events) HIPCHECK(hipEventRecord(ev[1], st));
+        launch_ratio_dual(dv, g, st);          // K7
+        launch_ftran_col(dv, g, 0, st);        // K2
+        launch_post_ftran(dv, g, pse, st);     // alpha_sq, y_S, partition plan
+    }
+    if (pse) launch_btran_rhs(dv, g, st);      // tK = alpha_K - F^T y_S
+    if (with_events) HIPCHECK(hipEventRecord(ev[2], st));
+    launch_fused_w(dv, g, pse, st);            // tauK, vK, eta update of W (+ scatter of v)
+    if (with_events) HIPCHECK(hipEventRecord(ev[3], st));
+    fork(1);
+    launch_tau_push(dv, g, st2);               // tau by position (F push)        (branch)
+    launch_structure_update(dv, g, st2);       // new / dropped nucleus slots      (branch)
+    if (phase == 0) {
+        if (with_events) HIPCHECK(hipEventRecord(ev[0], st));
+        launch_sweep(dv, g, pse ? 1 : 0, st);  // K4 (+ PSE helper in the same pass over A)
+        if (with_events) HIPCHECK(hipEventRecord(ev[1], st));
+    } else if (pse) {
+        launch_sweep(dv, g, 2, st);
+    }
+    join(1);
+    launch_update_pivot(dv, g, phase, dse, pse, st);  // K8 + per-pivot record
+}
+
+hipGraphExec_t Engine::get_graph(int phase) {
+    const int pse = enable_pse ? 1 : 0;
+    const Geom g = geom();
+    if (gexec[phase][pse] && std::memcmp(&ggeom[phase][pse], &g, sizeof(Geom)) == 0)
+        return gexec[phase][pse];
+    if (gexec[phase][pse]) {
+        (void)hipGraphExecDestroy(gexec[phase][pse]);
+        (void)hipGraphDestroy(ggraph[phase][pse]);
+        gexec[phase][pse] = nullptr;
+        ggraph[phase][pse] = nullptr;
+    }
+    HIPCHECK(hipStreamSynchronize(st));
+    HIPCHECK(hipStreamSynchronize(st2));
+    HIPCHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    try {
+        record_iteration(phase, false);
+    } catch (...) {
+        hipGraph_t junk = nullptr;
+        (void)hipStreamEndCapture(st, &junk);
+        if (junk) (void)hipGraphDestroy(junk);
+        throw;
+    }
+    HIPCHECK(hipStreamEndCapture(st, &ggraph[phase][pse]));
+    HIPCHECK(hipGraphInstantiate(&gexec[phase][pse], ggraph[phase][pse], nullptr, nullptr, 0));
+    ggeom[phase][pse] = g;
+    gprof[phase][pse] = profile;
+    return gexec[phase][pse];
+}
+
+// Consume the per-pivot records of a batch: statistics, trace and the host mirror of the basis
+// bookkeeping (solver.rs:1088-1091).  Returns the terminal status or ITER_PIVOT to continue.
+int Engine::process_records(int phase, int launched) {
+    (void)launched;
+    int n = std::min(h_ctl->ring_n, RING);
+    int result = ITER_PIVOT;
+    for (int i = 0; i < n; ++i) {
+        const PivotRec& r = h_ctl->ring[i];
+        if (pivot_budget > 0) pivot_budget -= 1;
+        if (r.status == ITER_PIVOT || r.status == ITER_FLIP) {
+            stats.iterations += 1;
+            if (r.phase == 0) stats.primal_iters += 1;
+            else stats.dual_iters += 1;
+            values_dirty = true;
+            if (r.status == ITER_FLIP) {
+                stats.bound_flips += 1;
+                if (trace) trace_log.push_back({r.phase, r.q, -1, r.entering_var, -1, 0.0, r.obj});
+            } else {
+                int ev_ = r.entering_var, lv = r.leaving_var;
+                h_basic_vars[r.r] = ev_;
+                h_var_loc[ev_] = r.r;
+                h_nb_vars[r.q] = lv;
+                h_var_loc[lv] = -1 - r.q;
+                nnz_nonbasic += (size_t)col_nnz(lv);
+                nnz_nonbasic -= (size_t)col_nnz(ev_);
+                stats.basis_changes += 1;
+                if (trace) trace_log.push_back({r.phase, r.q, r.r, ev_, lv, r.pivot_coeff, r.obj});
+            }
+        } else {
+            result = r.status;
+        }
+    }
+    (void)phase;
+    return result;
+}
+
+int Engine::run_loop(int phase) {
+    for (;;) {
+        if (pivot_budget == 0) {
+            budget_exhausted = true;
+            return ITER_PIVOT;
+        }
+        // profile mode: every 8th batch is ONE eager iteration bracketed by HIP events on the
+        // launch stream (sweep and fused pass), the others are graph replays as usual
+        const bool sample = profile && (batches_run % 8 == 0);
+        batches_run += 1;
+        int B = (use_graph && !sample) ? batch : 1;
+        if (pivot_budget > 0 && (int64_t)B > pivot_budget) B = (int)pivot_budget;
+        ensure_nucleus_cap(k_ + B + 1);
+        sync_view();
+        const DevView& dv = hview;
+        launch_reset_ring(dv, st);
+        if (use_graph && !sample) {
+            hipGraphExec_t ge = get_graph(phase);
+            for (int i = 0; i < B; ++i) HIPCHECK(hipGraphLaunch(ge, st));
+        } else {
+            if (sample)
+                for (auto& e : ev)
+                    if (!e) HIPCHECK(hipEventCreate(&e));
+            record_iteration(phase, sample);
+        }
+        const size_t nnz_before = nnz_nonbasic;
+        const int k_before = k_;
+        pull_ctl();
+        int res = process_records(phase, B);
+        if (sample && h_ctl->ring_n >= 1 && h_ctl->ring[0].status == ITER_PIVOT) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) {
+                stats.sweep_ms += ms;
+                stats.sweep_bytes += 12.0 * (double)nnz_before + 16.0 * num_vars + 16.0 * m_;
+                stats.sweep_launches += 1;
+            }
+            if (k_before > 1 && hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) {
+                stats.fused_ms += ms;
+                stats.fused_bytes += 16.0 * (double)k_before * (double)k_before;
+                stats.fused_launches += 1;
+            }
+        }
+        if (res != ITER_PIVOT) return res;
+    }
 }
 
 // ------------------------------------------------------------------ loops (solver.rs:470-547)
-bool Engine::take_budget() {
-    if (pivot_budget < 0) return true;
-    if (pivot_budget == 0) {
-        budget_exhausted = true;
-        return false;
-    }
-    pivot_budget -= 1;
-    return true;
-}
 void Engine::initial_solve() {
     double t0 = now_s();
+    budget_exhausted = false;
     if (!primal_feasible) restore_feasibility();
     if (!budget_exhausted && !dual_feasible) {
         if (!resume_in_optimize) recalc_obj_coeffs();  // a budget resume must not recompute d
@@ -396,203 +594,46 @@ void Engine::initial_solve() {
     stats.solve_wall_s += now_s() - t0;
 }
 void Engine::optimize() {
-    for (;;) {
-        if (!take_budget()) return;
-        int st_ = primal_iteration();
-        if (st_ == ITER_OPTIMAL) break;
-        if (st_ == ITER_UNBOUNDED) throw LpFail{2};
-    }
+    int res = run_loop(0);
+    if (budget_exhausted) return;
+    if (res == ITER_UNBOUNDED) throw LpFail{2};
+    if (res == ITER_SINGULAR) throw MlpError(-2, "singular basis (solver.rs:1301)");
+    if (res != ITER_OPTIMAL) throw MlpError(-3, "primal loop ended with unexpected status " + std::to_string(res));
     dual_feasible = true;
 }
 void Engine::restore_feasibility() {
-    for (;;) {
-        if (!take_budget()) return;
-        int st_ = dual_iteration(-1, 0.0);
-        if (st_ == ITER_FEASIBLE) break;
-        if (st_ == ITER_INFEASIBLE) throw LpFail{1};
-    }
+    int res = run_loop(1);
+    if (budget_exhausted) return;
+    if (res == ITER_INFEASIBLE) throw LpFail{1};
+    if (res == ITER_SINGULAR) throw MlpError(-2, "singular basis (solver.rs:1301)");
+    if (res != ITER_FEASIBLE) throw MlpError(-3, "dual loop ended with unexpected status " + std::to_string(res));
     primal_feasible = true;
-}
-
-// ------------------------------------------------------------------ one primal iteration
-int Engine::primal_iteration() {
-    DevView v = view();
-    launch_price_primal(v, enable_pse, st);   // K1
-    launch_ftran_col(v, st);                  // K2 (device-driven by it->q)
-    launch_ratio_primal(v, st);               // K5
-    launch_btran_unit(v, st);                 // K3 (device-driven by it->r; no-op unless ITER_PIVOT)
-    sync_iter();
-    int status = h_it->status;
-    if (status == ITER_OPTIMAL || status == ITER_UNBOUNDED) return status;
-    stats.iterations += 1;
-    stats.primal_iters += 1;
-    values_dirty = true;
-    if (status == ITER_FLIP) {
-        launch_update_flip(v, st);
-        stats.bound_flips += 1;
-        if (trace) trace_log.push_back({0, h_it->q, -1, h_it->entering_var, -1, 0.0, h_it->obj});
-        return status;
-    }
-    pivot_post(0, true);
-    return status;
-}
-
-// ------------------------------------------------------------------ one dual iteration
-int Engine::dual_iteration(int forced_row, double forced_val) {
-    DevView v = view();
-    if (forced_row < 0) launch_price_dual(v, enable_dse, st);  // K6
-    else set_iter(ITER_PIVOT, -1, forced_row, forced_val);     // fix_var on a basic var (solver.rs:384-391)
-    launch_btran_unit(v, st);       // K3
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (profile) {
-        e0 = get_event(); e1 = get_event();
-        HIPCHECK(hipEventRecord(e0, st));
-    }
-    launch_sweep(v, 0, 0, st);      // K4: alpha_r = rho^T N
-    if (profile) {
-        HIPCHECK(hipEventRecord(e1, st));
-        ev_pending.push_back({e0, e1, 1});
-        stats.sweep_bytes += 12.0 * (double)nnz_nonbasic + 16.0 * num_vars;
-        stats.sweep_launches += 1;
-    }
-    launch_ratio_dual(v, st);       // K7
-    launch_ftran_col(v, st);        // K2 (device-driven by it->q)
-    sync_iter();
-    int status = h_it->status;
-    if (status == ITER_FEASIBLE || status == ITER_INFEASIBLE) return status;
-    stats.iterations += 1;
-    stats.dual_iters += 1;
-    values_dirty = true;
-    pivot_post(1, true);
-    return status;
-}
-
-// ------------------------------------------------------------------ Solver::pivot (solver.rs:1023-1104)
-// Preconditions: IterState holds (q, r, pivot_coeff, ...) with status ITER_PIVOT; alpha_q, rho, rK
-// (and for the dual path alpha_r) are in HBM.
-void Engine::pivot_post(int phase, bool btran_done) {
-    const int q = h_it->q, r = h_it->r;
-    const int ev = h_nb_vars[q], lv = h_basic_vars[r];
-    const bool old_nuc = h_kslot_of_pos[r] >= 0;
-    const bool new_sing = col_nnz(ev) == 1;
-    StructUpdate u;
-    std::memset(&u, 0, sizeof(u));
-    u.r = r;
-    u.kase = old_nuc ? (new_sing ? 2 : 0) : (new_sing ? 3 : 1);
-    u.sr = old_nuc ? h_kslot_of_pos[r] : -1;
-    u.i_r = old_nuc ? -1 : h_srow_of_pos[r];
-    u.inv_diag_r = old_nuc ? 0.0 : 1.0 / h_sdiag_of_pos[r];
-    if (new_sing) {
-        u.i_q = h_crow[h_cptr[ev]];
-        u.diag_q = h_cval[h_cptr[ev]];
-        u.cq = h_kslot_of_row[u.i_q];
-        if (u.cq < 0) {
-            // the entering singleton sits on an S-row: legal only when it replaces the singleton
-            // that covers that very row (then alpha_K = 0, W is unchanged, only the diagonal moves)
-            if (!old_nuc && u.i_q == u.i_r) u.kase = 4;
-            else throw MlpError(-2, "singular basis: two singleton columns on one row");
-        }
-    }
-    if (u.kase == 1) ensure_nucleus_cap(k_ + 1);
-    DevView v = view();
-    if (!btran_done) launch_btran_unit(v, st);
-    if (enable_pse) launch_prep_v(v, st);  // alpha_sq, y_S, tK
-    // fused pass: tauK = W rK, vK = W^T tK, W -= (aK - e_r) rK^T / alpha_q[r]
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (profile && k_ > 0) {
-        e0 = get_event(); e1 = get_event();
-        HIPCHECK(hipEventRecord(e0, st));
-    }
-    launch_fused_w(v, enable_pse, 1, u.sr, st);
-    if (profile && k_ > 0) {
-        HIPCHECK(hipEventRecord(e1, st));
-        ev_pending.push_back({e0, e1, 0});
-        stats.fused_bytes += 16.0 * (double)k_ * (double)k_;
-        stats.fused_launches += 1;
-    }
-    launch_finish_tau(v, st);
-    if (enable_pse) launch_finish_v(v, st);
-    launch_structure_update(v, u, st);
-    // tableau row(s): primal computes alpha_r (+ helper) in one pass over A; dual only needs helper
-    bool need_sweep = (phase == 0) || enable_pse;
-    if (need_sweep) {
-        if (profile) {
-            e0 = get_event(); e1 = get_event();
-            HIPCHECK(hipEventRecord(e0, st));
-        }
-        if (phase == 0) launch_sweep(v, enable_pse, 0, st);
-        else launch_sweep(v, 1, 1, st);
-        if (profile) {
-            HIPCHECK(hipEventRecord(e1, st));
-            ev_pending.push_back({e0, e1, 1});
-            stats.sweep_bytes += 12.0 * (double)nnz_nonbasic + 16.0 * num_vars;
-            stats.sweep_launches += 1;
-        }
-    }
-    launch_update_pivot(v, enable_dse, enable_pse, st);  // K8
-
-    // ---- host mirror of the bookkeeping (solver.rs:1088-1091) and of the partition change
-    switch (u.kase) {
-        case 0: break;
-        case 1: {
-            int s = k_;
-            h_kslot_of_pos[r] = s; h_pos_of_kslot[s] = r;
-            h_kslot_of_row[u.i_r] = s; h_row_of_kslot[s] = u.i_r;
-            k_ += 1;
-            break;
-        }
-        case 2: {
-            int last = k_ - 1;
-            if (u.sr != last) {
-                int pl = h_pos_of_kslot[last];
-                h_pos_of_kslot[u.sr] = pl; h_kslot_of_pos[pl] = u.sr;
-            }
-            h_kslot_of_pos[r] = -1; h_srow_of_pos[r] = u.i_q; h_sdiag_of_pos[r] = u.diag_q;
-            if (u.cq != last) {
-                int il = h_row_of_kslot[last];
-                h_row_of_kslot[u.cq] = il; h_kslot_of_row[il] = u.cq;
-            }
-            h_kslot_of_row[u.i_q] = -1; h_pos_of_srow[u.i_q] = r;
-            k_ -= 1;
-            break;
-        }
-        case 3:
-            h_srow_of_pos[r] = u.i_q; h_sdiag_of_pos[r] = u.diag_q;
-            h_kslot_of_row[u.i_q] = -1; h_pos_of_srow[u.i_q] = r;
-            h_kslot_of_row[u.i_r] = u.cq; h_row_of_kslot[u.cq] = u.i_r;
-            break;
-        case 4:
-            h_sdiag_of_pos[r] = u.diag_q;
-            break;
-    }
-    h_basic_vars[r] = ev; h_var_loc[ev] = r;
-    h_nb_vars[q] = lv; h_var_loc[lv] = -1 - q;
-    nnz_nonbasic += (size_t)col_nnz(lv);
-    nnz_nonbasic -= (size_t)col_nnz(ev);
-    stats.basis_changes += 1;
-    if (trace) trace_log.push_back({phase, q, r, ev, lv, h_it->pivot_coeff, h_it->obj});
-    if (profile && ev_pending.size() >= 2048) resolve_events();
 }
 
 // ------------------------------------------------------------------ helpers used by the warm-start API
 void Engine::calc_col_coeffs(int col) {  // solver.rs:671-677
-    set_iter(ITER_PIVOT, col, -1, 0.0);
-    launch_ftran_col(view(), st);
+    sync_view();
+    const DevView& dv = hview;
+    launch_clear_work(hview, st);
+    launch_set_iter(dv, ITER_PIVOT, col, -1, 0.0, 0, st);
+    launch_ftran_col(dv, geom(), 0, st);
 }
 void Engine::calc_row_coeffs(int row, bool with_sweep) {  // solver.rs:680-693
-    set_iter(ITER_PIVOT, -1, row, 0.0);
-    DevView v = view();
-    launch_btran_unit(v, st);
-    if (with_sweep) launch_sweep(v, 0, 0, st);
+    sync_view();
+    const DevView& dv = hview;
+    launch_clear_work(hview, st);
+    launch_set_iter(dv, ITER_PIVOT, -1, row, 0.0, 0, st);
+    launch_btran_unit(dv, geom(), 0, st);
+    if (with_sweep) launch_sweep(dv, geom(), 0, st);
 }
 
 // solver.rs:1199-1231.  There is no eta file to flush: W is always current.
 void Engine::recalc_obj_coeffs() {
-    DevView v = view();
-    // c_B by position -> alpha_q buffer; y = B^-T c_B -> rho buffer
-    launch_gather_basic_obj(v, d_alpha_q.p, st);
-    launch_btran_dense(v, d_alpha_q.p, d_rho.p, st);
-    launch_recalc_d(v, d_rho.p, st);
+    sync_view();
+    const DevView& dv = hview;
+    const Geom g = geom();
+    launch_btran_dense(dv, g, st);  // y = B^-T c_B -> rv.y
+    launch_recalc_d(dv, g, st);
 }
 
 void Engine::fix_var(int var, double val) {  // solver.rs:378-415
@@ -600,14 +641,26 @@ void Engine::fix_var(int var, double val) {  // solver.rs:378-415
     if (val < h_lo[var] || val > h_hi[var]) throw LpFail{1};
     int col;
     if (h_var_loc[var] >= 0) {
+        // basic: one forced dual pivot towards `val` (solver.rs:384-391)
         int row = h_var_loc[var];
-        int st_ = dual_iteration(row, val);
-        if (st_ == ITER_INFEASIBLE) throw LpFail{1};
-        col = h_it->q;
+        ensure_nucleus_cap(k_ + 2);
+        sync_view();
+        const DevView& dv = hview;
+        launch_reset_ring(dv, st);
+        launch_set_iter(dv, ITER_PIVOT, -1, row, val, 1, st);
+        record_iteration(1, false);
+        pull_ctl();
+        int64_t keep = pivot_budget;
+        pivot_budget = -1;
+        int res = process_records(1, 1);
+        pivot_budget = keep;
+        if (res == ITER_INFEASIBLE) throw LpFail{1};
+        if (res != ITER_PIVOT) throw MlpError(-2, "fix_var: forced pivot failed");
+        col = -1 - h_var_loc[var];
     } else {
         col = -1 - h_var_loc[var];
         calc_col_coeffs(col);
-        launch_shift_nonbasic(view(), col, val, st);
+        launch_shift_nonbasic(hview, geom(), col, val, st);
         values_dirty = true;
     }
     uint8_t f = NB_AT_MIN | NB_AT_MAX | NB_FIXED;
@@ -615,6 +668,7 @@ void Engine::fix_var(int var, double val) {  // solver.rs:378-415
     HIPCHECK(hipStreamSynchronize(st));
     h_nb_fixed[col] = 1;
     primal_feasible = false;
+    budget_exhausted = false;
     restore_feasibility();
     stats.solve_wall_s += now_s() - t0;
 }
@@ -631,6 +685,7 @@ bool Engine::unfix_var(int var) {  // solver.rs:418-438
     HIPCHECK(hipStreamSynchronize(st));
     dual_feasible = false;
     double t0 = now_s();
+    budget_exhausted = false;
     try {
         optimize();
     } catch (LpFail&) {
@@ -685,7 +740,7 @@ void Engine::add_constraint(Constraint c) {
         int var = c.idx[p];
         int loc = h_var_loc[var];
         lhs += (loc >= 0 ? h_xB[loc] : h_xN[-1 - loc]) * c.val[p];
-        if (loc >= 0 && h_kslot_of_pos[loc] < 0) touches_basic_singleton = true;
+        if (loc >= 0 && col_nnz(var) == 1) touches_basic_singleton = true;  // that column stops being a singleton
     }
     double xnew = c.rhs - lhs;
     // matrix: append the CSR row (+ slack), rebuild the CSC (O(nnz), like solver.rs:597-610)
@@ -700,6 +755,7 @@ void Engine::add_constraint(Constraint c) {
     h_obj.push_back(0.0);
     h_lo.push_back(smin);
     h_hi.push_back(smax);
+    HIPCHECK(hipStreamSynchronize(st));
     alloc_row_buffers(m_ + 1);
     m_ += 1;
     N_ += 1;
@@ -710,8 +766,6 @@ void Engine::add_constraint(Constraint c) {
     // new basic position `row` holding the slack (singleton on the new row)
     h_basic_vars.push_back(slack);
     h_var_loc.push_back(row);
-    h_kslot_of_pos.push_back(-1); h_srow_of_pos.push_back(row); h_sdiag_of_pos.push_back(1.0);
-    h_kslot_of_row.push_back(-1); h_pos_of_srow.push_back(row);
     int neg1 = -1;
     double one = 1.0, beta0 = 1.0;
     HIPCHECK(hipMemcpyAsync(d_basic_vars.p + row, &slack, sizeof(int), hipMemcpyHostToDevice, st));
@@ -727,15 +781,18 @@ void Engine::add_constraint(Constraint c) {
     HIPCHECK(hipMemcpyAsync(d_pos_of_srow.p + row, &row, sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHECK(hipStreamSynchronize(st));
     values_dirty = true;
+    view_dirty = true;
+    sync_view();
+    launch_init_nb_rng(hview, geom(), st);
     if (touches_basic_singleton) rebuild_inverse();  // a singleton column just gained an entry
 
     if (enable_pse || enable_dse) {  // solver.rs:615-630: last tableau row feeds the edge norms
         calc_row_coeffs(m_ - 1, enable_pse);
-        if (enable_pse) launch_sq_norms_add_row(view(), st);
-        if (enable_dse)
-            HIPCHECK(hipMemcpyAsync(d_beta.p + row, &d_it.p->rho_sq, sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (enable_pse) launch_sq_norms_add_row(hview, geom(), st);
+        if (enable_dse) launch_copy_rho_sq_to_beta(hview, row, st);
     }
     primal_feasible = false;
+    budget_exhausted = false;
     restore_feasibility();
     stats.solve_wall_s += now_s() - t0;
 }
@@ -744,16 +801,20 @@ void Engine::add_constraint(Constraint c) {
 // Counterpart of BasisSolver::reset (solver.rs:1286-1303): classify the basic columns (singleton vs
 // nucleus), build K = B[R_K, P_K] densely from the CSC and invert it on the device.
 void Engine::rebuild_inverse() {
+    HIPCHECK(hipStreamSynchronize(st));
     std::vector<int> claimed(m_, -1);
-    k_ = 0;
     std::vector<int> nuc_pos;
+    h_kslot_of_pos.assign(m_, -1);
+    h_srow_of_pos.assign(m_, 0);
+    h_sdiag_of_pos.assign(m_, 1.0);
+    h_kslot_of_row.assign(m_, -1);
+    h_pos_of_srow.assign(m_, 0);
     for (int p = 0; p < m_; ++p) {
         int var = h_basic_vars[p];
         if (col_nnz(var) == 1) {
             int i = h_crow[h_cptr[var]];
             if (claimed[i] >= 0) throw MlpError(-2, "singular basis: two singleton columns on one row");
             claimed[i] = p;
-            h_kslot_of_pos[p] = -1;
             h_srow_of_pos[p] = i;
             h_sdiag_of_pos[p] = h_cval[h_cptr[var]];
         } else {
@@ -761,11 +822,13 @@ void Engine::rebuild_inverse() {
         }
     }
     int k = (int)nuc_pos.size();
+    k_ = 0;  // nothing to preserve while growing
     ensure_nucleus_cap(std::max(k, 1));
+    h_pos_of_kslot.assign(cap_, -1);
+    h_row_of_kslot.assign(cap_, -1);
     int s = 0;
     for (int i = 0; i < m_; ++i) {
         if (claimed[i] >= 0) {
-            h_kslot_of_row[i] = -1;
             h_pos_of_srow[i] = claimed[i];
         } else {
             if (s >= k) throw MlpError(-2, "singular basis: more uncovered rows than nucleus columns");
@@ -780,10 +843,7 @@ void Engine::rebuild_inverse() {
         h_pos_of_kslot[b] = nuc_pos[b];
     }
     k_ = k;
-    d_kslot_of_pos.upload(h_kslot_of_pos, st); d_srow_of_pos.upload(h_srow_of_pos, st);
-    d_sdiag_of_pos.upload(h_sdiag_of_pos, st);
-    d_kslot_of_row.upload(h_kslot_of_row, st); d_pos_of_srow.upload(h_pos_of_srow, st);
-    d_pos_of_kslot.upload(h_pos_of_kslot, st); d_row_of_kslot.upload(h_row_of_kslot, st);
+    push_maps();
     if (k > 0) {
         DevBuf<double> Kd, scratch;
         DevBuf<int> flag;
@@ -791,8 +851,8 @@ void Engine::rebuild_inverse() {
         scratch.ensure((size_t)k + 8, 0, st);
         flag.ensure(1, 0, st);
         HIPCHECK(hipMemsetAsync(flag.p, 0, sizeof(int), st));
-        DevView v = view();
-        launch_build_nucleus(v, Kd.p, st);
+        sync_view();
+        launch_build_nucleus(hview, geom(), Kd.p, k, st);
         launch_gauss_jordan(Kd.p, d_W.p, k, cap_, flag.p, scratch.p, st);
         int hflag = 0;
         HIPCHECK(hipMemcpyAsync(&hflag, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -803,62 +863,62 @@ void Engine::rebuild_inverse() {
 }
 
 double Engine::reinvert(bool replace) {
-    HIPCHECK(hipStreamSynchronize(st));
+    pull_maps();
     if (k_ == 0) return 0.0;
-    // keep the incremental W aside, rebuild, compare
-    DevBuf<double> oldW;
-    DevBuf<int> old_pk, old_rk;
     std::vector<int> hp = h_pos_of_kslot, hr = h_row_of_kslot, hkp = h_kslot_of_pos, hkr = h_kslot_of_row,
                      hsr = h_srow_of_pos, hps = h_pos_of_srow;
     std::vector<double> hsd = h_sdiag_of_pos;
-    int kold = k_, capold = cap_;
-    oldW.ensure((size_t)capold * capold, 0, st);
-    HIPCHECK(hipMemcpyAsync(oldW.p, d_W.p, sizeof(double) * (size_t)capold * capold, hipMemcpyDeviceToDevice, st));
+    const int kold = k_, capold = cap_;
+    std::vector<double> a((size_t)kold * kold);
+    HIPCHECK(hipMemcpy2D(a.data(), (size_t)kold * sizeof(double), d_W.p, (size_t)capold * sizeof(double),
+                         (size_t)kold * sizeof(double), (size_t)kold, hipMemcpyDeviceToHost));
+    DevBuf<double> oldW;
+    if (!replace) {
+        oldW.alloc_exact((size_t)capold * capold);
+        HIPCHECK(hipMemcpy(oldW.p, d_W.p, sizeof(double) * (size_t)capold * capold, hipMemcpyDeviceToDevice));
+    }
     rebuild_inverse();
     double diff = -1.0;
-    if (k_ == kold && cap_ == capold) {
-        // fresh slots are assigned in ascending position/row order; map the old block onto them
-        std::vector<double> a((size_t)capold * capold), b((size_t)cap_ * cap_);
-        HIPCHECK(hipMemcpy(a.data(), oldW.p, sizeof(double) * a.size(), hipMemcpyDeviceToHost));
-        HIPCHECK(hipMemcpy(b.data(), d_W.p, sizeof(double) * b.size(), hipMemcpyDeviceToHost));
+    if (k_ == kold) {
+        std::vector<double> b((size_t)kold * kold);
+        HIPCHECK(hipMemcpy2D(b.data(), (size_t)kold * sizeof(double), d_W.p, (size_t)cap_ * sizeof(double),
+                             (size_t)kold * sizeof(double), (size_t)kold, hipMemcpyDeviceToHost));
         diff = 0.0;
         for (int s1 = 0; s1 < kold; ++s1)
             for (int s2 = 0; s2 < kold; ++s2) {
                 int p = hp[s1], i = hr[s2];
-                double x = a[(size_t)s1 * capold + s2];
-                double y = b[(size_t)h_kslot_of_pos[p] * cap_ + h_kslot_of_row[i]];
+                double x = a[(size_t)s1 * kold + s2];
+                double y = b[(size_t)h_kslot_of_pos[p] * kold + h_kslot_of_row[i]];
                 double dlt = std::fabs(x - y);
                 if (!(dlt <= diff)) diff = dlt;
             }
     }
-    if (!replace) {  // restore the incremental representation
+    if (!replace && cap_ == capold) {  // restore the incremental representation
         h_pos_of_kslot = hp; h_row_of_kslot = hr; h_kslot_of_pos = hkp; h_kslot_of_row = hkr;
         h_srow_of_pos = hsr; h_pos_of_srow = hps; h_sdiag_of_pos = hsd;
         k_ = kold;
-        HIPCHECK(hipMemcpyAsync(d_W.p, oldW.p, sizeof(double) * (size_t)capold * capold, hipMemcpyDeviceToDevice, st));
-        d_kslot_of_pos.upload(h_kslot_of_pos, st); d_srow_of_pos.upload(h_srow_of_pos, st);
-        d_sdiag_of_pos.upload(h_sdiag_of_pos, st);
-        d_kslot_of_row.upload(h_kslot_of_row, st); d_pos_of_srow.upload(h_pos_of_srow, st);
-        d_pos_of_kslot.upload(h_pos_of_kslot, st); d_row_of_kslot.upload(h_row_of_kslot, st);
-        HIPCHECK(hipStreamSynchronize(st));
+        HIPCHECK(hipMemcpy(d_W.p, oldW.p, sizeof(double) * (size_t)capold * capold, hipMemcpyDeviceToDevice));
+        push_maps();
     }
     return diff;
 }
 
 // ------------------------------------------------------------------ clone (lib.rs:313 / solver.rs:14)
 Engine* Engine::clone() {
-    HIPCHECK(hipStreamSynchronize(st));
+    pull_maps();
     Engine* e = new Engine();
     e->num_vars = num_vars; e->direction = direction;
-    e->m_ = m_; e->N_ = N_; e->k_ = k_; e->cap_ = 0;
+    e->m_ = m_; e->N_ = N_;
     e->h_obj = h_obj; e->h_lo = h_lo; e->h_hi = h_hi; e->h_rhs = h_rhs;
     e->h_rptr = h_rptr; e->h_rcol = h_rcol; e->h_rval = h_rval;
     e->h_cptr = h_cptr; e->h_crow = h_crow; e->h_cval = h_cval;
     e->h_basic_vars = h_basic_vars; e->h_nb_vars = h_nb_vars; e->h_var_loc = h_var_loc;
     e->h_kslot_of_pos = h_kslot_of_pos; e->h_srow_of_pos = h_srow_of_pos; e->h_kslot_of_row = h_kslot_of_row;
     e->h_pos_of_srow = h_pos_of_srow; e->h_sdiag_of_pos = h_sdiag_of_pos; e->h_nb_fixed = h_nb_fixed;
+    e->h_pos_of_kslot = h_pos_of_kslot; e->h_row_of_kslot = h_row_of_kslot;
     e->enable_pse = enable_pse; e->enable_dse = enable_dse;
     e->primal_feasible = primal_feasible; e->dual_feasible = dual_feasible;
+    e->resume_in_optimize = resume_in_optimize;
     e->nnz_nonbasic = nnz_nonbasic;
     e->trace = trace; e->profile = profile;
     hipStream_t s2 = e->st;
@@ -874,25 +934,22 @@ Engine* Engine::clone() {
     e->d_beta.copy_from(d_beta, mm, s2);
     e->d_nb_vars.copy_from(d_nb_vars, nn, s2); e->d_d.copy_from(d_d, nn, s2); e->d_xN.copy_from(d_xN, nn, s2);
     e->d_gamma.copy_from(d_gamma, nn, s2); e->d_nbflags.copy_from(d_nbflags, nn, s2);
-    e->d_alpha_r.ensure(nn, 0, s2); e->d_helper.ensure(nn, 0, s2);
-    e->d_kslot_of_pos.copy_from(d_kslot_of_pos, mm, s2); e->d_srow_of_pos.copy_from(d_srow_of_pos, mm, s2);
-    e->d_sdiag_of_pos.copy_from(d_sdiag_of_pos, mm, s2);
-    e->d_kslot_of_row.copy_from(d_kslot_of_row, mm, s2); e->d_pos_of_srow.copy_from(d_pos_of_srow, mm, s2);
-    e->d_red_key.ensure(1024, 0, s2); e->d_red_idx.ensure(1024, 0, s2);
+    e->d_alpha_r.ensure(nn, 0, s2); e->d_helper.ensure(nn, 0, s2); e->d_nb_rng.copy_from(d_nb_rng, nn, s2);
+    e->d_red_key.ensure(1024, 0, s2); e->d_red_key2.ensure(1024, 0, s2); e->d_red_idx.ensure(1024, 0, s2);
     e->d_ticket.ensure(4, 0, s2);
     HIPCHECK(hipMemsetAsync(e->d_ticket.p, 0, 4 * sizeof(unsigned), s2));
-    e->d_it.copy_from(d_it, 1, s2);
+    e->d_ctl.copy_from(d_ctl, 1, s2);
     // nucleus: same capacity so the block copies 1:1
-    int kk = k_;
     e->k_ = 0;
-    e->ensure_nucleus_cap(cap_);
-    e->k_ = kk;
-    if (cap_ == e->cap_ && k_ > 0)
+    e->cap_ = 0;
+    e->ensure_nucleus_cap(std::min(cap_, std::max(m_, 1)));
+    if (e->cap_ != cap_) throw MlpError(-3, "clone: capacity mismatch");
+    e->k_ = k_;
+    if (k_ > 0)
         HIPCHECK(hipMemcpyAsync(e->d_W.p, d_W.p, sizeof(double) * (size_t)cap_ * cap_, hipMemcpyDeviceToDevice, s2));
-    e->h_pos_of_kslot = h_pos_of_kslot; e->h_row_of_kslot = h_row_of_kslot;
-    e->d_pos_of_kslot.upload(e->h_pos_of_kslot, s2); e->d_row_of_kslot.upload(e->h_row_of_kslot, s2);
+    e->push_maps();
     HIPCHECK(hipStreamSynchronize(s2));
-    *e->h_it = *h_it;
+    std::memcpy(e->h_ctl, h_ctl, sizeof(Ctl));
     e->values_dirty = true;
     return e;
 }
@@ -902,9 +959,9 @@ uint64_t Engine::state(const char* what, double* out, uint64_t cap) {
     HIPCHECK(hipStreamSynchronize(st));
     std::string w(what);
     std::vector<double> tmp;
-    auto from_dev_d = [&](const DevBuf<double>& b, size_t n) {
+    auto from_dev_d = [&](const double* b, size_t n) {
         tmp.resize(n);
-        if (n) HIPCHECK(hipMemcpy(tmp.data(), b.p, n * sizeof(double), hipMemcpyDeviceToHost));
+        if (n) HIPCHECK(hipMemcpy(tmp.data(), b, n * sizeof(double), hipMemcpyDeviceToHost));
     };
     auto from_dev_i = [&](const DevBuf<int>& b, size_t n) {
         std::vector<int> t(n);
@@ -913,19 +970,18 @@ uint64_t Engine::state(const char* what, double* out, uint64_t cap) {
     };
     size_t mm = m_, nn = num_vars;
     if (w == "basic_vars") from_dev_i(d_basic_vars, mm);
-    else if (w == "basic_var_vals") from_dev_d(d_xB, mm);
-    else if (w == "basic_var_mins") from_dev_d(d_loB, mm);
-    else if (w == "basic_var_maxs") from_dev_d(d_hiB, mm);
-    else if (w == "dual_edge_sq_norms") from_dev_d(d_beta, mm);
+    else if (w == "basic_var_vals") from_dev_d(d_xB.p, mm);
+    else if (w == "basic_var_mins") from_dev_d(d_loB.p, mm);
+    else if (w == "basic_var_maxs") from_dev_d(d_hiB.p, mm);
+    else if (w == "dual_edge_sq_norms") from_dev_d(d_beta.p, mm);
     else if (w == "nb_vars") from_dev_i(d_nb_vars, nn);
-    else if (w == "nb_var_obj_coeffs") from_dev_d(d_d, nn);
-    else if (w == "nb_var_vals") from_dev_d(d_xN, nn);
-    else if (w == "primal_edge_sq_norms") from_dev_d(d_gamma, nn);
+    else if (w == "nb_var_obj_coeffs") from_dev_d(d_d.p, nn);
+    else if (w == "nb_var_vals") from_dev_d(d_xN.p, nn);
+    else if (w == "primal_edge_sq_norms") from_dev_d(d_gamma.p, nn);
     else if (w == "var_loc") from_dev_i(d_var_loc, (size_t)N_);
-    else if (w == "col_coeffs") from_dev_d(d_alpha_q, mm);
-    else if (w == "inv_basis_row_coeffs") from_dev_d(d_rho, mm);
-    else if (w == "row_coeffs") from_dev_d(d_alpha_r, nn);
-    else if (w == "tau") from_dev_d(d_tau, mm);
+    else if (w == "col_coeffs") from_dev_d(d_work.p, mm);
+    else if (w == "row_coeffs") from_dev_d(d_alpha_r.p, nn);
+    else if (w == "tau") from_dev_d(d_work.p + mm, mm);
     else if (w == "nb_flags") {
         std::vector<uint8_t> t(nn);
         if (nn) HIPCHECK(hipMemcpy(t.data(), d_nbflags.p, nn, hipMemcpyDeviceToHost));

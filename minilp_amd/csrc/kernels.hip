@@ -3,6 +3,9 @@
 // Reference loops replaced (file:line in ztlpn/minilp 0.2.2) are cited per kernel.  None of this
 // is GEMM-shaped: every kernel is an HBM/L2-bound stream with wave64 shuffle reductions, so there
 // is no MFMA here (DESIGN.md §4 gives the algorithmic bytes per kernel).
+//
+// All pivot kernels take a pointer to the device-resident DevView and read the nucleus size and
+// the pivot scalars from its Ctl block, so one iteration is a fixed launch sequence (hipGraph).
 #include "kernels.h"
 
 #include <limits.h>
@@ -90,17 +93,22 @@ __device__ __forceinline__ double block_sum(double x) {  // thread 0, fixed tree
     return x;
 }
 
-// Cross-workgroup hand-off (cdna_hip_programming.md §6 G16): thread 0 has stored this block's
-// partial; agent-scope release, ticket, and the last arriver does an agent-scope acquire that
-// drops this CU's stale L1 lines before the block re-reads every partial.
+// Cross-workgroup hand-off without fences (cdna_hip_programming.md §6 G16, form "8-B agent atomics
+// both sides"): every partial is stored write-through (relaxed agent-scope atomic store = sc1), the
+// storing lane drains its stores (s_waitcnt vmcnt(0)) and takes a ticket; the last arriver re-reads
+// all partials with agent-scope (sc1, L1-bypassing) loads.  No buffer_wbl2 / buffer_inv needed.
+__device__ __forceinline__ void st_agent(double* p, double x) {
+    __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(int* p, int x) {
+    __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ bool last_block_arrives(unsigned* ticket) {
     __shared__ int s_last;
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (t == gridDim.x - 1);
-        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
     return s_last != 0;
@@ -116,8 +124,8 @@ __device__ __forceinline__ int ld_agent(const int* p) {
 __device__ __forceinline__ bool grid_best(Cand& c, const DevView& v) {
     c = block_best(c);
     if (threadIdx.x == 0) {
-        v.red_key[blockIdx.x] = c.key;
-        v.red_idx[blockIdx.x] = c.idx;
+        st_agent(&v.red_key[blockIdx.x], c.key);
+        st_agent(&v.red_idx[blockIdx.x], c.idx);
     }
     if (!last_block_arrives(v.ticket)) return false;
     Cand x = cand_none();
@@ -129,22 +137,29 @@ __device__ __forceinline__ bool grid_best(Cand& c, const DevView& v) {
     if (threadIdx.x == 0) *v.ticket = 0;
     return true;
 }
-__device__ __forceinline__ bool grid_min(double& x, const DevView& v) {
-    x = block_min(x);
-    if (threadIdx.x == 0) v.red_key[blockIdx.x] = x;
+// grid-wide (min, sum) pair in one pass
+__device__ __forceinline__ bool grid_min_sum(double& mn, double& sm, const DevView& v) {
+    mn = block_min(mn);
+    sm = block_sum(sm);
+    if (threadIdx.x == 0) {
+        st_agent(&v.red_key[blockIdx.x], mn);
+        st_agent(&v.red_key2[blockIdx.x], sm);
+    }
     if (!last_block_arrives(v.ticket)) return false;
-    double y = INFINITY;
+    double y = INFINITY, z = 0.0;
     for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) {
         double t = ld_agent(&v.red_key[i]);
         if (t < y) y = t;
+        z += ld_agent(&v.red_key2[i]);
     }
-    x = block_min(y);
+    mn = block_min(y);
+    sm = block_sum(z);
     if (threadIdx.x == 0) *v.ticket = 0;
     return true;
 }
 __device__ __forceinline__ bool grid_sum(double& x, const DevView& v) {
     x = block_sum(x);
-    if (threadIdx.x == 0) v.red_key[blockIdx.x] = x;
+    if (threadIdx.x == 0) st_agent(&v.red_key[blockIdx.x], x);
     if (!last_block_arrives(v.ticket)) return false;
     double y = 0.0;
     for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) y += ld_agent(&v.red_key[i]);
@@ -159,6 +174,7 @@ static inline int grid_for(int n, int per_thread = 4, int max_blocks = 512) {
     if (b > max_blocks) b = max_blocks;
     return (int)b;
 }
+static inline int blocks_for(long n, int per_block = BLK) { return n <= 0 ? 1 : (int)((n + per_block - 1) / per_block); }
 
 template <int G>
 __device__ __forceinline__ double group_sum(double x) {  // xor tree inside G consecutive lanes
@@ -167,25 +183,102 @@ __device__ __forceinline__ double group_sum(double x) {  // xor tree inside G co
     return x;
 }
 
+__device__ __forceinline__ void push_rec(Ctl* c, int phase) {  // single thread
+    int n = c->ring_n;
+    if (n < RING) {
+        PivotRec& r = c->ring[n];
+        r.status = c->it.status;
+        r.phase = phase;
+        r.q = c->it.q;
+        r.r = c->it.r;
+        r.entering_var = c->it.entering_var;
+        r.leaving_var = c->it.leaving_var;
+        r.kase = c->up.kase;
+        r.k_after = c->k;
+        r.pivot_coeff = c->it.pivot_coeff;
+        r.obj = c->it.obj;
+    }
+    c->ring_n = n + 1;
+}
+
+// Partition-change plan, run by ONE thread once q, r and the final alpha_q are
+// known.  The host never needs (q, r): this is what makes the iteration graph-replayable.
+__device__ void plan_update(const DevView& v, Ctl* c, int phase) {
+    StructUpdate& u = c->up;
+    u.kase = -1;
+    if (c->it.status != ITER_PIVOT) return;
+    const int r = c->it.r, ev = c->it.entering_var;
+    const int sr = v.kslot_of_pos[r];
+    const bool old_nuc = sr >= 0;
+    const int cb = v.csc_ptr[ev];
+    const bool new_sing = (v.csc_ptr[ev + 1] - cb) == 1;
+    u.r = r;
+    u.sr = sr;
+    u.kold = c->k;
+    u.i_r = -1;
+    u.i_q = -1;
+    u.cq = -1;
+    u.diag_q = 0.0;
+    u.inv_diag_r = 0.0;
+    if (!old_nuc) {
+        u.i_r = v.srow_of_pos[r];
+        u.inv_diag_r = 1.0 / v.sdiag_of_pos[r];
+    }
+    c->it.inv_alpha = 1.0 / v.alpha_q[r];
+    if (new_sing) {
+        u.i_q = v.csc_row[cb];
+        u.diag_q = v.csc_val[cb];
+        u.cq = v.kslot_of_row[u.i_q];
+        if (u.cq < 0) {
+            // an entering singleton on an S-row is legal only when it replaces the singleton
+            // covering that row (then alpha_K = 0 and only the diagonal entry changes)
+            if (!old_nuc && u.i_q == u.i_r) {
+                u.kase = 4;
+            } else {
+                c->it.status = ITER_SINGULAR;
+                c->halt = 1;
+                push_rec(c, phase);
+            }
+        } else {
+            u.kase = old_nuc ? 2 : 3;
+        }
+    } else {
+        if (!old_nuc && c->k >= v.ld) {  // no room to grow: the host failed to reserve capacity
+            c->it.status = ITER_SINGULAR;
+            c->halt = 1;
+            push_rec(c, phase);
+        } else {
+            u.kase = old_nuc ? 0 : 1;
+        }
+    }
+}
+
 // ------------------------------------------------------------------- K1: primal pricing
 // solver.rs:696-739: argmax over eligible non-basic columns of d^2/gamma (PSE) or |d| (Dantzig).
 __global__ void __launch_bounds__(BLK) k_price_primal(DevView v, int use_pse) {
+    Ctl* c = v.ctl;
+    if (c->halt) return;
     Cand best = cand_none();
-    for (int c = blockIdx.x * BLK + threadIdx.x; c < v.n; c += gridDim.x * BLK) {
-        double dd = v.d[c];
-        uint8_t f = v.nbflags[c];
+    for (int j = blockIdx.x * BLK + threadIdx.x; j < v.n; j += gridDim.x * BLK) {
+        double dd = v.d[j];
+        uint8_t f = v.nbflags[j];
         if (((f & NB_AT_MIN) && dd > -EPS) || ((f & NB_AT_MAX) && dd < EPS)) continue;  // solver.rs:705-706
-        double score = use_pse ? dd * dd / v.gamma[c] : fabs(dd);
-        Cand t{score, c};
+        double score = use_pse ? dd * dd / v.gamma[j] : fabs(dd);
+        Cand t{score, j};
         if (cand_better(t, best)) best = t;
     }
     if (!grid_best(best, v)) return;
     if (threadIdx.x == 0) {
-        IterState* it = v.it;
+        IterState* it = &c->it;
+        it->klist_n = 0;
+        it->blist_n = 0;
+        c->up.kase = -1;
         if (best.idx == NONE_IDX) {
             it->status = ITER_OPTIMAL;
             it->q = -1;
             it->r = -1;
+            c->halt = 1;
+            push_rec(c, 0);
         } else {
             int q = best.idx;
             int var = v.nb_vars[q];
@@ -194,18 +287,19 @@ __global__ void __launch_bounds__(BLK) k_price_primal(DevView v, int use_pse) {
             it->q = q;
             it->r = -1;
             it->entering_var = var;
+            it->leaving_var = -1;
             it->sign = dq < 0.0;  // solver.rs:743
             it->entering_cur = v.xN[q];
             it->entering_other = (dq < 0.0) ? v.var_hi[var] : v.var_lo[var];  // solver.rs:744-748
         }
-        it->klist_n = 0;
-        it->blist_n = 0;
     }
 }
 
 // ------------------------------------------------------------------- K6: dual pricing
 // solver.rs:855-917: argmax over infeasible rows of infeas^2/beta.
 __global__ void __launch_bounds__(BLK) k_price_dual(DevView v, int use_dse) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->forced) return;
     Cand best = cand_none();
     for (int r = blockIdx.x * BLK + threadIdx.x; r < v.m; r += gridDim.x * BLK) {
         double val = v.xB[r], mn = v.loB[r], mx = v.hiB[r];
@@ -219,22 +313,26 @@ __global__ void __launch_bounds__(BLK) k_price_dual(DevView v, int use_dse) {
     }
     if (!grid_best(best, v)) return;
     if (threadIdx.x == 0) {
-        IterState* it = v.it;
+        IterState* it = &c->it;
+        it->klist_n = 0;
+        it->blist_n = 0;
+        c->up.kase = -1;
         if (best.idx == NONE_IDX) {
             it->status = ITER_FEASIBLE;
             it->r = -1;
             it->q = -1;
+            c->halt = 1;
+            push_rec(c, 1);
         } else {
             int r = best.idx;
             double val = v.xB[r], mn = v.loB[r];
             it->status = ITER_PIVOT;
             it->r = r;
             it->q = -1;
+            it->entering_var = -1;
             it->leaving_new_val = (val < mn) ? mn : v.hiB[r];  // solver.rs:908-914
             it->leaving_var = v.basic_vars[r];
         }
-        it->klist_n = 0;
-        it->blist_n = 0;
     }
 }
 
@@ -245,10 +343,10 @@ __global__ void __launch_bounds__(BLK) k_price_dual(DevView v, int use_dse) {
 //   gather : aK = W[:, list] * coeffs  (only the touched columns of W are read)
 //            + push of -F*aK into the singleton positions (CSC columns of the nucleus basics)
 __global__ void __launch_bounds__(64) k_ftran_prep(DevView v) {
-    IterState* it = v.it;
-    if (it->status != ITER_PIVOT) return;
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
     int lane = threadIdx.x;
-    int var = it->entering_var;
+    int var = c->it.entering_var;
     int base = v.csc_ptr[var], end = v.csc_ptr[var + 1];
     int cnt = 0;
     for (int e0 = base; e0 < end; e0 += 64) {
@@ -274,18 +372,30 @@ __global__ void __launch_bounds__(64) k_ftran_prep(DevView v) {
         }
         cnt += __popcll(mask);
     }
-    if (lane == 0) it->klist_n = cnt;
+    if (lane == 0) c->it.klist_n = cnt;
 }
 
-// xK[slot] = sum_j list_a[j] * W[slot][list_s[j]]; out_pos[pos(slot)] = xK; then the F push.
+// push of -x * (column of the basic variable at `p`) into the singleton positions
+template <int G>
+__device__ __forceinline__ void push_F(const DevView& v, int p, double x, double* out_pos, int gl) {
+    int var = v.basic_vars[p];
+    int end = v.csc_ptr[var + 1];
+    for (int e = v.csc_ptr[var] + gl; e < end; e += G) {
+        int i = v.csc_row[e];
+        if (v.kslot_of_row[i] < 0) {
+            int ps = v.pos_of_srow[i];
+            unsafeAtomicAdd(&out_pos[ps], -v.csc_val[e] * x / v.sdiag_of_pos[ps]);
+        }
+    }
+}
 template <int G>
 __global__ void __launch_bounds__(BLK) k_ftran_gather(DevView v) {
-    const IterState* it = v.it;
-    if (it->status != ITER_PIVOT) return;
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
     int slot = (blockIdx.x * BLK + threadIdx.x) / G;
     int gl = threadIdx.x & (G - 1);
-    if (slot >= v.k) return;
-    int n = it->klist_n;
+    if (slot >= c->k) return;
+    int n = c->it.klist_n;
     double acc = 0.0;
     const double* wrow = v.W + (size_t)slot * v.ld;
     for (int j = gl; j < n; j += G) acc += v.klist_a[j] * wrow[v.klist_s[j]];
@@ -295,46 +405,19 @@ __global__ void __launch_bounds__(BLK) k_ftran_gather(DevView v) {
         v.aK[slot] = acc;
         v.alpha_q[p] = acc;
     }
-    if (acc != 0.0) {
-        int var = v.basic_vars[p];
-        int end = v.csc_ptr[var + 1];
-        for (int e = v.csc_ptr[var] + gl; e < end; e += G) {
-            int i = v.csc_row[e];
-            if (v.kslot_of_row[i] < 0) {
-                int ps = v.pos_of_srow[i];
-                unsafeAtomicAdd(&v.alpha_q[ps], -v.csc_val[e] * acc / v.sdiag_of_pos[ps]);
-            }
-        }
-    }
-}
-
-// Generic finish of a dense FTRAN: xK (by row slot) -> out (by position) incl. the F push.
-__global__ void __launch_bounds__(BLK) k_ftran_init_single(DevView v, const double* b_row, double* out_pos) {
-    if (v.it->status != ITER_PIVOT) return;
-    int p = blockIdx.x * BLK + threadIdx.x;
-    if (p >= v.m) return;
-    if (v.kslot_of_pos[p] < 0) out_pos[p] = b_row[v.srow_of_pos[p]] / v.sdiag_of_pos[p];
+    if (acc != 0.0) push_F<G>(v, p, acc, v.alpha_q, gl);
 }
 template <int G>
-__global__ void __launch_bounds__(BLK) k_ftran_push(DevView v, const double* xK, double* out_pos) {
-    if (v.it->status != ITER_PIVOT) return;
+__global__ void __launch_bounds__(BLK) k_tau_push(DevView v) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
     int slot = (blockIdx.x * BLK + threadIdx.x) / G;
     int gl = threadIdx.x & (G - 1);
-    if (slot >= v.k) return;
-    double x = xK[slot];
+    if (slot >= c->up.kold) return;
+    double x = v.tauK[slot];
     int p = v.pos_of_kslot[slot];
-    if (gl == 0) out_pos[p] = x;
-    if (x != 0.0) {
-        int var = v.basic_vars[p];
-        int end = v.csc_ptr[var + 1];
-        for (int e = v.csc_ptr[var] + gl; e < end; e += G) {
-            int i = v.csc_row[e];
-            if (v.kslot_of_row[i] < 0) {
-                int ps = v.pos_of_srow[i];
-                unsafeAtomicAdd(&out_pos[ps], -v.csc_val[e] * x / v.sdiag_of_pos[ps]);
-            }
-        }
-    }
+    if (gl == 0) v.tau[p] = x;
+    if (x != 0.0) push_F<G>(v, p, x, v.tau, gl);
 }
 
 // ------------------------------------------------------------------- K5: primal Harris ratio test
@@ -350,31 +433,38 @@ __device__ __forceinline__ double leaving_step(const DevView& v, int p, double c
         return val > mn ? val - mn : 0.0;
     }
 }
-// pass 1 (solver.rs:782-795)
-__global__ void __launch_bounds__(BLK) k_ratio_primal_p1(DevView v) {
-    IterState* it = v.it;
-    if (it->status != ITER_PIVOT) return;
-    int sign = it->sign;
-    double mn = INFINITY;
+// pass 1 (solver.rs:782-795); with PSE also ||alpha_q||^2 (solver.rs:1136) and the singleton part
+// y_S of v = B^-T alpha_q (solver.rs:1114), both of which need the same stream over alpha_q.
+__global__ void __launch_bounds__(BLK) k_ratio_primal_p1(DevView v, int use_pse) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    int sign = c->it.sign;
+    double mn = INFINITY, sq = 0.0;
     for (int p = blockIdx.x * BLK + threadIdx.x; p < v.m; p += gridDim.x * BLK) {
         double coeff = v.alpha_q[p];
+        if (use_pse) {
+            sq += coeff * coeff;
+            if (v.kslot_of_pos[p] < 0) v.rv[v.srow_of_pos[p]].y = coeff / v.sdiag_of_pos[p];
+        }
         double ca = fabs(coeff);
         if (ca < EPS) continue;
         bool tm;
         double cur = (leaving_step(v, p, coeff, sign, tm) + EPS) / ca;
         if (cur < mn) mn = cur;
     }
-    if (!grid_min(mn, v)) return;
+    if (!grid_min_sum(mn, sq, v)) return;
     if (threadIdx.x == 0) {
-        double max_step = fabs(it->entering_other - it->entering_cur);
+        double max_step = fabs(c->it.entering_other - c->it.entering_cur);
         if (mn < max_step) max_step = mn;
-        it->max_step = max_step;
+        c->it.max_step = max_step;
+        c->it.alpha_sq = sq + 1.0;
     }
 }
 // pass 2 (solver.rs:800-853)
 __global__ void __launch_bounds__(BLK) k_ratio_primal_p2(DevView v) {
-    IterState* it = v.it;
-    if (it->status != ITER_PIVOT) return;
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    IterState* it = &c->it;
     int sign = it->sign;
     double max_step = it->max_step;
     Cand best = cand_none();
@@ -408,17 +498,38 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_p2(DevView v) {
             it->leaving_var = v.basic_vars[r];
             it->pivot_obj = dq / coeff;  // solver.rs:1073
             it->obj += dq * diff;        // solver.rs:1027
-            it->status = ITER_PIVOT;
         } else if (isinf(it->entering_other)) {
             it->status = ITER_UNBOUNDED;  // solver.rs:842-844
+            c->halt = 1;
+            push_rec(c, 0);
         } else {
             double diff = it->entering_other - it->entering_cur;  // solver.rs:846-851
             it->r = -1;
             it->entering_new_val = it->entering_other;
             it->entering_diff = diff;
+            it->pivot_coeff = 0.0;
             it->obj += dq * diff;
             it->status = ITER_FLIP;
         }
+    }
+}
+
+// dual path, after FTRAN: the FTRAN-side pivot, ||alpha_q||^2 and y_S (PSE), then the plan
+__global__ void __launch_bounds__(BLK) k_post_ftran(DevView v, int use_pse) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    double sq = 0.0;
+    if (use_pse) {
+        for (int p = blockIdx.x * BLK + threadIdx.x; p < v.m; p += gridDim.x * BLK) {
+            double coeff = v.alpha_q[p];
+            sq += coeff * coeff;
+            if (v.kslot_of_pos[p] < 0) v.rv[v.srow_of_pos[p]].y = coeff / v.sdiag_of_pos[p];
+        }
+    }
+    if (!grid_sum(sq, v)) return;
+    if (threadIdx.x == 0) {
+        c->it.alpha_sq = sq + 1.0;
+        plan_update(v, c, 1);
     }
 }
 
@@ -426,9 +537,10 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_p2(DevView v) {
 // rho = B^-T e_r (solver.rs:680-683 -> 1322-1338).  With W explicit this is one row of W when r
 // is a nucleus position, or a short combination of rows (those nucleus columns that have an
 // entry in the leaving singleton's row, read from the CSR row) otherwise.
-__global__ void __launch_bounds__(64) k_btran_prep(DevView v) {
-    IterState* it = v.it;
-    if (it->status != ITER_PIVOT) return;
+__global__ void __launch_bounds__(64) k_btran_prep(DevView v, int plan_after) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    IterState* it = &c->it;
     int lane = threadIdx.x;
     int r = it->r;
     int sr = v.kslot_of_pos[r];
@@ -438,78 +550,116 @@ __global__ void __launch_bounds__(64) k_btran_prep(DevView v) {
             v.blist_a[0] = 1.0;
             it->blist_n = 1;
         }
-        return;
-    }
-    int i_r = v.srow_of_pos[r];
-    double inv = 1.0 / v.sdiag_of_pos[r];
-    if (lane == 0) v.rho[i_r] = inv;
-    int base = v.csr_ptr[i_r], end = v.csr_ptr[i_r + 1];
-    int cnt = 0;
-    for (int e0 = base; e0 < end; e0 += 64) {
-        int e = e0 + lane;
-        bool valid = e < end;
-        int s = -1;
-        double a = 0.0;
-        if (valid) {
-            int loc = v.var_loc[v.csr_col[e]];
-            a = v.csr_val[e];
-            if (loc >= 0) s = v.kslot_of_pos[loc];
+    } else {
+        int i_r = v.srow_of_pos[r];
+        double inv = 1.0 / v.sdiag_of_pos[r];
+        if (lane == 0) {
+            v.rv[i_r].x = inv;
+            v.tau[r] = inv * inv;  // tau_S = (rho_S - F tauK)/diag: only row i_r of rho_S is non-zero
         }
-        bool isk = valid && s >= 0;
-        unsigned long long mask = __ballot(isk);
-        if (isk) {
-            int off = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-            v.blist_s[off] = s;
-            v.blist_a[off] = -a * inv;
+        int base = v.csr_ptr[i_r], end = v.csr_ptr[i_r + 1];
+        int cnt = 0;
+        for (int e0 = base; e0 < end; e0 += 64) {
+            int e = e0 + lane;
+            bool valid = e < end;
+            int s = -1;
+            double a = 0.0;
+            if (valid) {
+                int loc = v.var_loc[v.csr_col[e]];
+                a = v.csr_val[e];
+                if (loc >= 0) s = v.kslot_of_pos[loc];
+            }
+            bool isk = valid && s >= 0;
+            unsigned long long mask = __ballot(isk);
+            if (isk) {
+                int off = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+                v.blist_s[off] = s;
+                v.blist_a[off] = -a * inv;
+            }
+            cnt += __popcll(mask);
         }
-        cnt += __popcll(mask);
+        if (lane == 0) it->blist_n = cnt;
     }
-    if (lane == 0) it->blist_n = cnt;
+    if (plan_after && lane == 0) plan_update(v, c, 0);
 }
+// rK = sum_j blist_a[j] * W[blist_s[j], :]; rho scatter; ||rho||^2
 __global__ void __launch_bounds__(BLK) k_btran_gather(DevView v) {
-    const IterState* it = v.it;
-    if (it->status != ITER_PIVOT) return;
-    int s = blockIdx.x * BLK + threadIdx.x;
-    if (s >= v.k) return;
-    int n = it->blist_n;
-    double acc = 0.0;
-    for (int j = 0; j < n; ++j) acc += v.blist_a[j] * v.W[(size_t)v.blist_s[j] * v.ld + s];
-    v.rK[s] = acc;
-    v.rho[v.row_of_kslot[s]] = acc;
-}
-// ||x||^2 over n entries -> *out (fixed reduction tree)
-__global__ void __launch_bounds__(BLK) k_sqnorm(DevView v, const double* x, int n, double* out, int add_one) {
-    if (v.it->status != ITER_PIVOT) return;
-    double s = 0.0;
-    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) s += x[i] * x[i];
-    if (!grid_sum(s, v)) return;
-    if (threadIdx.x == 0) *out = s + (add_one ? 1.0 : 0.0);
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    const int k = c->k;
+    const int n = c->it.blist_n;
+    double sq = 0.0;
+    for (int s = blockIdx.x * BLK + threadIdx.x; s < k; s += gridDim.x * BLK) {
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc += v.blist_a[j] * v.W[(size_t)v.blist_s[j] * v.ld + s];
+        v.rK[s] = acc;
+        v.rv[v.row_of_kslot[s]].x = acc;
+        sq += acc * acc;
+    }
+    if (!grid_sum(sq, v)) return;
+    if (threadIdx.x == 0) {
+        int r = c->it.r;
+        if (v.kslot_of_pos[r] < 0) {
+            double inv = 1.0 / v.sdiag_of_pos[r];
+            sq += inv * inv;
+        }
+        c->it.rho_sq = sq;
+    }
 }
 
 // ------------------------------------------------------------------- K4: tableau row  rho^T N
 // solver.rs:685-692 (and 1117-1132 for the PSE helper).  The reference pushes rows of supp(rho)
 // through the CSR; here every non-basic column PULLS its dot product from the CSC: no atomics,
 // fixed summation order, one streaming pass over A that yields alpha_r and (PSE) N^T v together.
-template <int G, int MODE>  // MODE 0: alpha_r only, 1: alpha_r + helper, 2: helper only
+// G lanes per column, 4 independent (index -> gather) chains per lane per trip; rho and v are
+// interleaved (double2) so one 16-byte gather serves both products.
+// nb_rng[c] caches the CSC range of the column at non-basic position c (one dependent hop instead
+// of three).  (Non-temporal loads on the A stream were measured: 82 us vs 57 us per sweep — worse.)
+template <int G, int U, int MODE>  // U entries per lane per trip; MODE 0: alpha_r, 1: alpha_r + helper, 2: helper
 __global__ void __launch_bounds__(BLK) k_sweep(DevView v) {
-    if (v.it->status != ITER_PIVOT) return;
-    int c = (blockIdx.x * BLK + threadIdx.x) / G;
+    const Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    int col = (blockIdx.x * BLK + threadIdx.x) / G;
     int gl = threadIdx.x & (G - 1);
-    if (c >= v.n) return;
-    int var = v.nb_vars[c];
-    int end = v.csc_ptr[var + 1];
+    if (col >= v.n) return;
+    const int2 rg = v.nb_rng[col];
+    const int beg = rg.x, end = rg.y;
     double a1 = 0.0, a2 = 0.0;
-    for (int e = v.csc_ptr[var] + gl; e < end; e += G) {
-        int i = v.csc_row[e];
-        double a = v.csc_val[e];
-        if (MODE != 2) a1 += a * v.rho[i];
-        if (MODE != 0) a2 += a * v.vvec[i];
+    for (int e0 = beg + gl; e0 < end; e0 += U * G) {
+        int idx[U];
+        double a[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            int e = e0 + j * G;
+            bool ok = e < end;
+            idx[j] = ok ? v.csc_row[e] : 0;
+            a[j] = ok ? v.csc_val[e] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            if (MODE == 1) {
+                double2 t = v.rv[idx[j]];
+                a1 += a[j] * t.x;
+                a2 += a[j] * t.y;
+            } else if (MODE == 0) {
+                a1 += a[j] * v.rv[idx[j]].x;
+            } else {
+                a2 += a[j] * v.rv[idx[j]].y;
+            }
+        }
     }
     if (MODE != 2) a1 = group_sum<G>(a1);
     if (MODE != 0) a2 = group_sum<G>(a2);
     if (gl == 0) {
-        if (MODE != 2) v.alpha_r[c] = a1;
-        if (MODE != 0) v.helper[c] = a2;
+        if (MODE != 2) v.alpha_r[col] = a1;
+        if (MODE != 0) v.helper[col] = a2;
+    }
+}
+__global__ void __launch_bounds__(BLK) k_init_nb_rng(DevView v) {
+    int j = blockIdx.x * BLK + threadIdx.x;
+    if (j < v.n) {
+        int var = v.nb_vars[j];
+        v.nb_rng[j] = make_int2(v.csc_ptr[var], v.csc_ptr[var + 1]);
     }
 }
 
@@ -527,34 +677,35 @@ __device__ __forceinline__ double clamp_obj(double d, uint8_t f) {  // solver.rs
     return d;
 }
 __global__ void __launch_bounds__(BLK) k_ratio_dual_p1(DevView v) {  // solver.rs:962-974
-    IterState* it = v.it;
-    if (it->status != ITER_PIVOT) return;
-    int lsign = it->leaving_new_val > v.xB[it->r];
-    double mn = INFINITY;
-    for (int c = blockIdx.x * BLK + threadIdx.x; c < v.n; c += gridDim.x * BLK) {
-        double coeff = v.alpha_r[c];
-        uint8_t f = v.nbflags[c];
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    int lsign = c->it.leaving_new_val > v.xB[c->it.r];
+    double mn = INFINITY, dummy = 0.0;
+    for (int j = blockIdx.x * BLK + threadIdx.x; j < v.n; j += gridDim.x * BLK) {
+        double coeff = v.alpha_r[j];
+        uint8_t f = v.nbflags[j];
         if (!dual_eligible(coeff, f, lsign)) continue;
-        double cur = (fabs(clamp_obj(v.d[c], f)) + EPS) / fabs(coeff);
+        double cur = (fabs(clamp_obj(v.d[j], f)) + EPS) / fabs(coeff);
         if (cur < mn) mn = cur;
     }
-    if (!grid_min(mn, v)) return;
-    if (threadIdx.x == 0) it->max_step = mn;
+    if (!grid_min_sum(mn, dummy, v)) return;
+    if (threadIdx.x == 0) c->it.max_step = mn;
 }
 __global__ void __launch_bounds__(BLK) k_ratio_dual_p2(DevView v) {  // solver.rs:979-1021
-    IterState* it = v.it;
-    if (it->status != ITER_PIVOT) return;
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    IterState* it = &c->it;
     int r = it->r;
     int lsign = it->leaving_new_val > v.xB[r];
     double max_step = it->max_step;
     Cand best = cand_none();
-    for (int c = blockIdx.x * BLK + threadIdx.x; c < v.n; c += gridDim.x * BLK) {
-        double coeff = v.alpha_r[c];
-        uint8_t f = v.nbflags[c];
+    for (int j = blockIdx.x * BLK + threadIdx.x; j < v.n; j += gridDim.x * BLK) {
+        double coeff = v.alpha_r[j];
+        uint8_t f = v.nbflags[j];
         if (!dual_eligible(coeff, f, lsign)) continue;
-        double cur = fabs(clamp_obj(v.d[c], f)) / fabs(coeff);
+        double cur = fabs(clamp_obj(v.d[j], f)) / fabs(coeff);
         if (cur <= max_step) {
-            Cand t{fabs(coeff), c};
+            Cand t{fabs(coeff), j};
             if (cand_better(t, best)) best = t;
         }
     }
@@ -562,6 +713,8 @@ __global__ void __launch_bounds__(BLK) k_ratio_dual_p2(DevView v) {  // solver.r
     if (threadIdx.x == 0) {
         if (best.idx == NONE_IDX) {
             it->status = ITER_INFEASIBLE;
+            c->halt = 1;
+            push_rec(c, 1);
             return;
         }
         int q = best.idx;
@@ -580,35 +733,25 @@ __global__ void __launch_bounds__(BLK) k_ratio_dual_p2(DevView v) {  // solver.r
     }
 }
 
-// ------------------------------------------------------------------- v = B^-T alpha_q, stage 1
-// (solver.rs:1114).  y_S on singleton rows, then the rhs tK of the transposed nucleus solve.
-__global__ void __launch_bounds__(BLK) k_btran_single(DevView v, const double* c_pos, double* y_row) {
-    if (v.it->status != ITER_PIVOT) return;
-    int p = blockIdx.x * BLK + threadIdx.x;
-    if (p >= v.m) return;
-    if (v.kslot_of_pos[p] < 0) y_row[v.srow_of_pos[p]] = c_pos[p] / v.sdiag_of_pos[p];
-}
+// ------------------------------------------------------------------- v = B^-T alpha_q, stage 2
+// rhs of the transposed nucleus solve: tK = c_K - F^T y_S (solver.rs:1114; y_S came from pass 1)
 template <int G>
-__global__ void __launch_bounds__(BLK) k_btran_rhs(DevView v, const double* c_pos, const double* y_row) {
-    if (v.it->status != ITER_PIVOT) return;
+__global__ void __launch_bounds__(BLK) k_btran_rhs(DevView v) {
+    const Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
     int slot = (blockIdx.x * BLK + threadIdx.x) / G;
     int gl = threadIdx.x & (G - 1);
-    if (slot >= v.k) return;
+    if (slot >= c->k) return;
     int p = v.pos_of_kslot[slot];
     int var = v.basic_vars[p];
     int end = v.csc_ptr[var + 1];
     double acc = 0.0;
     for (int e = v.csc_ptr[var] + gl; e < end; e += G) {
         int i = v.csc_row[e];
-        if (v.kslot_of_row[i] < 0) acc += v.csc_val[e] * y_row[i];
+        if (v.kslot_of_row[i] < 0) acc += v.csc_val[e] * v.rv[i].y;
     }
     acc = group_sum<G>(acc);
-    if (gl == 0) v.tK[slot] = c_pos[p] - acc;
-}
-__global__ void __launch_bounds__(BLK) k_scatter_cols(DevView v, const double* xK, double* y_row) {
-    if (v.it->status != ITER_PIVOT) return;
-    int s = blockIdx.x * BLK + threadIdx.x;
-    if (s < v.k) y_row[v.row_of_kslot[s]] = xK[s];
+    if (gl == 0) v.tK[slot] = v.alpha_q[p] - acc;
 }
 
 // ------------------------------------------------------------------- fused pass over W
@@ -620,12 +763,14 @@ __global__ void __launch_bounds__(BLK) k_scatter_cols(DevView v, const double* x
 // Block = FW_TR rows x FW_TC columns; per-block partials are reduced by k_fused_reduce in a fixed
 // order (no float atomics => bitwise reproducible).
 template <bool WITH_TAU, bool WITH_V, bool DO_UPDATE>
-__global__ void __launch_bounds__(BLK) k_fused_w(DevView v, int rslot, double inv_alpha_override) {
-    if (v.it->status != ITER_PIVOT) return;
-    __shared__ double s_tau[FW_TR][BLK / 64];
-    const int k = v.k, ld = v.ld;
+__global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
+    const Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    const int k = c->k, ld = v.ld;
     const int row0 = blockIdx.x * FW_TR;
     const int col0 = blockIdx.y * FW_TC;
+    if (row0 >= k || col0 >= k) return;
+    __shared__ double s_tau[FW_TR][BLK / 64];
     const int tid = threadIdx.x;
     int cidx[4];
     cidx[0] = col0 + 2 * tid;
@@ -635,8 +780,8 @@ __global__ void __launch_bounds__(BLK) k_fused_w(DevView v, int rslot, double in
     double rk[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) rk[j] = (cidx[j] < k) ? v.rK[cidx[j]] : 0.0;
-    double inv_alpha = 0.0;
-    if (DO_UPDATE) inv_alpha = (inv_alpha_override != 0.0) ? inv_alpha_override : 1.0 / v.alpha_q[v.it->r];
+    const double inv_alpha = DO_UPDATE ? c->it.inv_alpha : 0.0;
+    const int rslot = DO_UPDATE ? c->up.sr : -1;
     double vacc[4] = {0.0, 0.0, 0.0, 0.0};
     double tacc[FW_TR];
     const bool pair0 = cidx[1] < k, pair1 = cidx[3] < k;
@@ -702,185 +847,231 @@ __global__ void __launch_bounds__(BLK) k_fused_w(DevView v, int rslot, double in
         }
     }
 }
-__global__ void __launch_bounds__(BLK) k_fused_reduce(DevView v, int nstripes, int nchunks, int with_tau, int with_v) {
-    if (v.it->status != ITER_PIVOT) return;
-    int i = blockIdx.x * BLK + threadIdx.x;
-    if (i >= v.k) return;
-    if (with_tau) {
-        double s = 0.0;
-        for (int c = 0; c < nchunks; ++c) s += v.part_tau[(size_t)c * v.ld + i];
-        v.tauK[i] = s;
+// fixed-order reduction of the per-block partials; vK is scattered straight into v (by row).
+// Block = 32 slots x 8 stripe groups: each thread sums every 8th stripe, LDS combines the 8 partials
+// in a fixed order (deterministic), so the stripe loop is 8x shorter than one thread per slot.
+template <bool WITH_TAU, bool WITH_V>
+__global__ void __launch_bounds__(BLK) k_fused_reduce(DevView v) {
+    const Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    const int k = c->k;
+    const int lane32 = threadIdx.x & 31, grp = threadIdx.x >> 5;  // 8 groups
+    const int i = blockIdx.x * 32 + lane32;
+    if (blockIdx.x * 32 >= k) return;
+    __shared__ double s_part[8][33];
+    const int nstripes = (k + FW_TR - 1) / FW_TR, nchunks = (k + FW_TC - 1) / FW_TC;
+    if (WITH_V) {
+        double s0 = 0.0, s1 = 0.0;
+        if (i < k) {
+            int t = grp;
+            for (; t + 8 < nstripes; t += 16) {
+                s0 += v.part_v[(size_t)t * v.ld + i];
+                s1 += v.part_v[(size_t)(t + 8) * v.ld + i];
+            }
+            if (t < nstripes) s0 += v.part_v[(size_t)t * v.ld + i];
+        }
+        s_part[grp][lane32] = s0 + s1;
+        __syncthreads();
+        if (grp == 0 && i < k) {
+            double s = s_part[0][lane32];
+#pragma unroll
+            for (int g2 = 1; g2 < 8; ++g2) s += s_part[g2][lane32];
+            v.vK[i] = s;
+            v.rv[v.row_of_kslot[i]].y = s;
+        }
     }
-    if (with_v) {
+    if (WITH_TAU && grp == 1 && i < k) {
         double s = 0.0;
-        for (int t = 0; t < nstripes; ++t) s += v.part_v[(size_t)t * v.ld + i];
-        v.vK[i] = s;
+        for (int j = 0; j < nchunks; ++j) s += v.part_tau[(size_t)j * v.ld + i];
+        v.tauK[i] = s;
     }
 }
 
 // ------------------------------------------------------------------- partition change
 // B'^-1[p,i] = B^-1[p,i] - (alpha_p - [p==r]) rho_i / alpha_r, restricted to the new nucleus.
-__global__ void __launch_bounds__(BLK) k_struct_grow(DevView v, StructUpdate u) {  // case 1: sing -> nuc
-    if (v.it->status != ITER_PIVOT) return;
-    int s = blockIdx.x * BLK + threadIdx.x;
-    int kold = v.k;  // view still carries the old k
-    double inv_alpha = 1.0 / v.alpha_q[u.r];
-    if (s < kold) {
-        v.W[(size_t)kold * v.ld + s] = v.rK[s] * inv_alpha;                    // new row: rho / alpha_r
-        v.W[(size_t)s * v.ld + kold] = -v.aK[s] * u.inv_diag_r * inv_alpha;    // new column
-    } else if (s == kold) {
-        v.W[(size_t)kold * v.ld + kold] = u.inv_diag_r * inv_alpha;
-        v.kslot_of_pos[u.r] = kold;
-        v.pos_of_kslot[kold] = u.r;
-        v.kslot_of_row[u.i_r] = kold;
-        v.row_of_kslot[kold] = u.i_r;
-    }
-}
-__global__ void __launch_bounds__(BLK) k_struct_newcol(DevView v, StructUpdate u) {  // case 3: sing -> sing
-    if (v.it->status != ITER_PIVOT) return;
-    int s = blockIdx.x * BLK + threadIdx.x;
-    double inv_alpha = 1.0 / v.alpha_q[u.r];
-    if (s < v.k) v.W[(size_t)s * v.ld + u.cq] = -v.aK[s] * u.inv_diag_r * inv_alpha;
-    if (s == 0) {
-        v.srow_of_pos[u.r] = u.i_q;
-        v.sdiag_of_pos[u.r] = u.diag_q;
-        v.kslot_of_row[u.i_q] = -1;
-        v.pos_of_srow[u.i_q] = u.r;
-        v.kslot_of_row[u.i_r] = u.cq;
-        v.row_of_kslot[u.cq] = u.i_r;
-    }
-}
-// case 4: a singleton replaces the singleton of the same row: only the diagonal entry changes
-__global__ void k_struct_newdiag(DevView v, StructUpdate u) {
-    if (v.it->status != ITER_PIVOT) return;
-    v.sdiag_of_pos[u.r] = u.diag_q;
-}
-// case 2: nuc -> sing.  Drop row slot sr and col slot cq; keep slots compact by moving the last in.
-__global__ void __launch_bounds__(BLK) k_struct_shrink_row(DevView v, StructUpdate u) {
-    if (v.it->status != ITER_PIVOT) return;
-    int s = blockIdx.x * BLK + threadIdx.x;
-    int last = v.k - 1;
-    if (s < v.k && u.sr != last) v.W[(size_t)u.sr * v.ld + s] = v.W[(size_t)last * v.ld + s];
-    if (s == 0) {
-        if (u.sr != last) {
-            int pl = v.pos_of_kslot[last];
-            v.pos_of_kslot[u.sr] = pl;
-            v.kslot_of_pos[pl] = u.sr;
+// One kernel, the case comes from the device-side plan.  Shrinking keeps the slots compact:
+// W_new[a][b] = W_old[src_row(a)][src_col(b)] with src_row(sr) = last, src_col(cq) = last; all reads
+// come from row/column `last`, all writes go to row sr / column cq, so there is no hazard.
+__global__ void __launch_bounds__(BLK) k_struct_update(DevView v) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    const StructUpdate u = c->up;
+    if (u.kase <= 0) return;
+    const int s = blockIdx.x * BLK + threadIdx.x;
+    const int kold = u.kold;
+    const int ld = v.ld;
+    const double inv_alpha = c->it.inv_alpha;
+    if (u.kase == 1) {  // singleton -> nucleus: append row slot kold (position r) and col slot kold (row i_r)
+        if (s < kold) {
+            v.W[(size_t)kold * ld + s] = v.rK[s] * inv_alpha;
+            v.W[(size_t)s * ld + kold] = -v.aK[s] * u.inv_diag_r * inv_alpha;
+        } else if (s == kold) {
+            v.W[(size_t)kold * ld + kold] = u.inv_diag_r * inv_alpha;
+            v.kslot_of_pos[u.r] = kold;
+            v.pos_of_kslot[kold] = u.r;
+            v.kslot_of_row[u.i_r] = kold;
+            v.row_of_kslot[kold] = u.i_r;
+            c->k = kold + 1;
         }
-        v.kslot_of_pos[u.r] = -1;
-        v.srow_of_pos[u.r] = u.i_q;
-        v.sdiag_of_pos[u.r] = u.diag_q;
-    }
-}
-__global__ void __launch_bounds__(BLK) k_struct_shrink_col(DevView v, StructUpdate u) {
-    if (v.it->status != ITER_PIVOT) return;
-    int s = blockIdx.x * BLK + threadIdx.x;
-    int last = v.k - 1;
-    if (s < last && u.cq != last) v.W[(size_t)s * v.ld + u.cq] = v.W[(size_t)s * v.ld + last];
-    if (s == 0) {
-        if (u.cq != last) {
-            int il = v.row_of_kslot[last];
-            v.row_of_kslot[u.cq] = il;
-            v.kslot_of_row[il] = u.cq;
+    } else if (u.kase == 2) {  // nucleus -> singleton: drop row slot sr and col slot cq
+        const int last = kold - 1;
+        if (s < last) {
+            if (u.sr != last) v.W[(size_t)u.sr * ld + s] = v.W[(size_t)last * ld + (s == u.cq ? last : s)];
+            if (u.cq != last) v.W[(size_t)s * ld + u.cq] = v.W[(size_t)(s == u.sr ? last : s) * ld + last];
         }
-        v.kslot_of_row[u.i_q] = -1;
-        v.pos_of_srow[u.i_q] = u.r;
+        if (s == 0) {
+            if (u.sr != last) {
+                int pl = v.pos_of_kslot[last];
+                v.pos_of_kslot[u.sr] = pl;
+                v.kslot_of_pos[pl] = u.sr;
+            }
+            v.kslot_of_pos[u.r] = -1;
+            v.srow_of_pos[u.r] = u.i_q;
+            v.sdiag_of_pos[u.r] = u.diag_q;
+            if (u.cq != last) {
+                int il = v.row_of_kslot[last];
+                v.row_of_kslot[u.cq] = il;
+                v.kslot_of_row[il] = u.cq;
+            }
+            v.kslot_of_row[u.i_q] = -1;
+            v.pos_of_srow[u.i_q] = u.r;
+            c->k = last;
+        }
+    } else if (u.kase == 3) {  // singleton -> singleton on another row: col slot cq now stands for row i_r
+        if (s < kold) v.W[(size_t)s * ld + u.cq] = -v.aK[s] * u.inv_diag_r * inv_alpha;
+        if (s == 0) {
+            v.srow_of_pos[u.r] = u.i_q;
+            v.sdiag_of_pos[u.r] = u.diag_q;
+            v.kslot_of_row[u.i_q] = -1;
+            v.pos_of_srow[u.i_q] = u.r;
+            v.kslot_of_row[u.i_r] = u.cq;
+            v.row_of_kslot[u.cq] = u.i_r;
+        }
+    } else if (u.kase == 4) {  // singleton replaced by another singleton of the same row
+        if (s == 0) v.sdiag_of_pos[u.r] = u.diag_q;
     }
 }
 
 // ------------------------------------------------------------------- K8: updates after the pivot
 // basic side: solver.rs:1049-1058 (x_B, bounds), 1164-1173 (dual steepest-edge norms)
-__global__ void __launch_bounds__(BLK) k_update_basic(DevView v, int use_dse) {
-    const IterState* it = v.it;
-    if (it->status != ITER_PIVOT) return;
-    int p = blockIdx.x * BLK + threadIdx.x;
-    if (p >= v.m) return;
-    int r = it->r;
-    double pc = it->pivot_coeff;
-    double a = v.alpha_q[p];
-    if (p == r) {
-        int ev = it->entering_var;
-        v.xB[r] = it->entering_new_val;
-        v.loB[r] = v.var_lo[ev];
-        v.hiB[r] = v.var_hi[ev];
-        if (use_dse) v.beta[r] = it->rho_sq / (pc * pc);
-        v.basic_vars[r] = ev;
-        v.var_loc[ev] = r;
-        v.var_loc[it->leaving_var] = -1 - it->q;
-    } else if (a != 0.0) {
-        v.xB[p] -= it->entering_diff * a;
-        if (use_dse) v.beta[p] += -2.0 * a * v.tau[p] / pc + it->rho_sq * a * a / (pc * pc);
-    }
-}
 // non-basic side: solver.rs:1068-1080 (value/state of the leaving var, reduced costs), 1140-1150 (PSE)
-__global__ void __launch_bounds__(BLK) k_update_nonbasic(DevView v, int use_pse) {
-    const IterState* it = v.it;
-    if (it->status != ITER_PIVOT) return;
-    int c = blockIdx.x * BLK + threadIdx.x;
-    if (c >= v.n) return;
-    int q = it->q;
-    double pc = it->pivot_coeff;
-    if (c == q) {
-        int lv = it->leaving_var;
-        double lnv = it->leaving_new_val;
-        v.d[q] = -it->pivot_obj;
-        if (use_pse) v.gamma[q] = it->alpha_sq / (pc * pc);
-        v.nb_vars[q] = lv;
-        v.xN[q] = lnv;
-        v.nbflags[q] = (uint8_t)((lnv == v.var_lo[lv] ? NB_AT_MIN : 0) | (lnv == v.var_hi[lv] ? NB_AT_MAX : 0));
-    } else {
-        double ar = v.alpha_r[c];
-        if (ar != 0.0) {
-            v.d[c] -= it->pivot_obj * ar;
-            if (use_pse) v.gamma[c] += -2.0 * ar * v.helper[c] / pc + it->alpha_sq * ar * ar / (pc * pc);
+// bound flip: solver.rs:1031-1042
+__global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int use_dse, int use_pse) {
+    Ctl* c = v.ctl;
+    if (c->halt) return;
+    const IterState* it = &c->it;
+    const int status = it->status;
+    const int t = blockIdx.x * BLK + threadIdx.x;
+    if (status == ITER_FLIP) {
+        if (t < v.m) {
+            double a = v.alpha_q[t];
+            if (a != 0.0) v.xB[t] -= it->entering_diff * a;
+        }
+        if (t == 0) {
+            int q = it->q, ev = it->entering_var;
+            double nv = it->entering_new_val;
+            v.xN[q] = nv;
+            v.nbflags[q] = (uint8_t)((v.nbflags[q] & NB_FIXED) | (nv == v.var_lo[ev] ? NB_AT_MIN : 0) |
+                                     (nv == v.var_hi[ev] ? NB_AT_MAX : 0));
+            push_rec(c, phase);
+        }
+        return;
+    }
+    if (status != ITER_PIVOT) return;
+    const int r = it->r, q = it->q;
+    const double pc = it->pivot_coeff;
+    if (t < v.m) {
+        double a = v.alpha_q[t];
+        if (t == r) {
+            int ev = it->entering_var;
+            v.xB[r] = it->entering_new_val;
+            v.loB[r] = v.var_lo[ev];
+            v.hiB[r] = v.var_hi[ev];
+            if (use_dse) v.beta[r] = it->rho_sq / (pc * pc);
+            v.basic_vars[r] = ev;
+            v.var_loc[ev] = r;
+            v.var_loc[it->leaving_var] = -1 - q;
+        } else if (a != 0.0) {
+            v.xB[t] -= it->entering_diff * a;
+            if (use_dse) v.beta[t] += -2.0 * a * v.tau[t] / pc + it->rho_sq * a * a / (pc * pc);
         }
     }
-}
-// bound flip: solver.rs:1031-1042
-__global__ void __launch_bounds__(BLK) k_update_flip(DevView v) {
-    const IterState* it = v.it;
-    if (it->status != ITER_FLIP) return;
-    int p = blockIdx.x * BLK + threadIdx.x;
-    if (p < v.m) {
-        double a = v.alpha_q[p];
-        if (a != 0.0) v.xB[p] -= it->entering_diff * a;
+    if (t < v.n) {
+        if (t == q) {
+            int lv = it->leaving_var;
+            double lnv = it->leaving_new_val;
+            v.d[q] = -it->pivot_obj;
+            if (use_pse) v.gamma[q] = it->alpha_sq / (pc * pc);
+            v.nb_vars[q] = lv;
+            v.nb_rng[q] = make_int2(v.csc_ptr[lv], v.csc_ptr[lv + 1]);
+            v.xN[q] = lnv;
+            v.nbflags[q] = (uint8_t)((lnv == v.var_lo[lv] ? NB_AT_MIN : 0) | (lnv == v.var_hi[lv] ? NB_AT_MAX : 0));
+        } else {
+            double ar = v.alpha_r[t];
+            if (ar != 0.0) {
+                v.d[t] -= it->pivot_obj * ar;
+                if (use_pse) v.gamma[t] += -2.0 * ar * v.helper[t] / pc + it->alpha_sq * ar * ar / (pc * pc);
+            }
+        }
     }
-    if (p == 0) {
-        int q = it->q, ev = it->entering_var;
-        double nv = it->entering_new_val;
-        v.xN[q] = nv;
-        v.nbflags[q] = (uint8_t)((v.nbflags[q] & NB_FIXED) | (nv == v.var_lo[ev] ? NB_AT_MIN : 0) |
-                                 (nv == v.var_hi[ev] ? NB_AT_MAX : 0));
-    }
+    if (t == 0) push_rec(c, phase);
 }
 
-// ------------------------------------------------------------------- K9: recalc reduced costs
-// solver.rs:1216-1231: d_c = c_c - a_c . y for every non-basic c, then the objective from scratch.
+// ------------------------------------------------------------------- helpers outside the pivot graph
+__global__ void k_set_iter(DevView v, int status, int q, int r, double lnv, int forced) {
+    Ctl* c = v.ctl;
+    IterState* it = &c->it;
+    it->status = status;
+    it->q = q;
+    it->r = r;
+    it->leaving_new_val = lnv;
+    it->entering_var = q >= 0 ? v.nb_vars[q] : -1;
+    it->leaving_var = r >= 0 ? v.basic_vars[r] : -1;
+    it->klist_n = 0;
+    it->blist_n = 0;
+    c->up.kase = -1;
+    c->forced = forced;
+    c->halt = 0;
+}
+__global__ void k_reset_ring(DevView v) {
+    Ctl* c = v.ctl;
+    c->ring_n = 0;
+    c->halt = 0;
+    c->forced = 0;
+}
+// K9: recalc reduced costs (solver.rs:1216-1231): d_c = c_c - a_c . y, then the objective from scratch
+__global__ void __launch_bounds__(BLK) k_gather_basic_obj(DevView v) {
+    int p = blockIdx.x * BLK + threadIdx.x;
+    if (p < v.m) {
+        double cb = v.obj_c[v.basic_vars[p]];
+        v.alpha_q[p] = cb;
+        if (v.kslot_of_pos[p] < 0) v.rv[v.srow_of_pos[p]].y = cb / v.sdiag_of_pos[p];
+    }
+    if (p == 0) {
+        v.ctl->it.status = ITER_PIVOT;
+        v.ctl->halt = 0;
+        v.ctl->up.kase = -1;
+    }
+}
 template <int G>
-__global__ void __launch_bounds__(BLK) k_recalc_d(DevView v, const double* y_row) {
-    int c = (blockIdx.x * BLK + threadIdx.x) / G;
+__global__ void __launch_bounds__(BLK) k_recalc_d(DevView v) {
+    int col = (blockIdx.x * BLK + threadIdx.x) / G;
     int gl = threadIdx.x & (G - 1);
-    if (c >= v.n) return;
-    int var = v.nb_vars[c];
+    if (col >= v.n) return;
+    int var = v.nb_vars[col];
     int end = v.csc_ptr[var + 1];
     double acc = 0.0;
-    for (int e = v.csc_ptr[var] + gl; e < end; e += G) acc += v.csc_val[e] * y_row[v.csc_row[e]];
+    for (int e = v.csc_ptr[var] + gl; e < end; e += G) acc += v.csc_val[e] * v.rv[v.csc_row[e]].y;
     acc = group_sum<G>(acc);
-    if (gl == 0) v.d[c] = v.obj_c[var] - acc;
+    if (gl == 0) v.d[col] = v.obj_c[var] - acc;
 }
 __global__ void __launch_bounds__(BLK) k_recalc_obj(DevView v) {
     double s = 0.0;
     for (int p = blockIdx.x * BLK + threadIdx.x; p < v.m; p += gridDim.x * BLK) s += v.obj_c[v.basic_vars[p]] * v.xB[p];
-    for (int c = blockIdx.x * BLK + threadIdx.x; c < v.n; c += gridDim.x * BLK) s += v.obj_c[v.nb_vars[c]] * v.xN[c];
+    for (int j = blockIdx.x * BLK + threadIdx.x; j < v.n; j += gridDim.x * BLK) s += v.obj_c[v.nb_vars[j]] * v.xN[j];
     if (!grid_sum(s, v)) return;
-    if (threadIdx.x == 0) v.it->obj = s;
+    if (threadIdx.x == 0) v.ctl->it.obj = s;
 }
-__global__ void k_set_status(DevView v, int status) { v.it->status = status; }
-__global__ void k_gather_basic_obj(DevView v, double* c_pos) {
-    int p = blockIdx.x * BLK + threadIdx.x;
-    if (p < v.m) c_pos[p] = v.obj_c[v.basic_vars[p]];
-}
-
 // fix_var on a non-basic variable (solver.rs:393-404): x_B -= diff * alpha_q, obj += diff * d, x_N = val
 __global__ void __launch_bounds__(BLK) k_shift_nonbasic(DevView v, int col, double val) {
     int p = blockIdx.x * BLK + threadIdx.x;
@@ -889,27 +1080,27 @@ __global__ void __launch_bounds__(BLK) k_shift_nonbasic(DevView v, int col, doub
         double a = v.alpha_q[p];
         if (a != 0.0) v.xB[p] -= diff * a;
     }
-    __syncthreads();
-    if (p == 0) v.it->obj += diff * v.d[col];
+    if (p == 0) v.ctl->it.obj += diff * v.d[col];
 }
 __global__ void k_set_xn(DevView v, int col, double val) { v.xN[col] = val; }
 // add_constraint (solver.rs:620-624): gamma[c] += alpha_r[c]^2
 __global__ void __launch_bounds__(BLK) k_gamma_add_row(DevView v) {
-    int c = blockIdx.x * BLK + threadIdx.x;
-    if (c < v.n) {
-        double a = v.alpha_r[c];
-        v.gamma[c] += a * a;
+    int j = blockIdx.x * BLK + threadIdx.x;
+    if (j < v.n) {
+        double a = v.alpha_r[j];
+        v.gamma[j] += a * a;
     }
 }
+__global__ void k_copy_rho_sq_to_beta(DevView v, int row) { v.beta[row] = v.ctl->it.rho_sq; }
 
 // ------------------------------------------------------------------- from-scratch inversion
 // Counterpart of BasisSolver::reset (solver.rs:1286-1303): rebuild the nucleus K from the CSC
 // columns of the basic variables and invert it by Gauss-Jordan with partial pivoting.
 template <int G>
-__global__ void __launch_bounds__(BLK) k_build_nucleus(DevView v, double* Kd) {
+__global__ void __launch_bounds__(BLK) k_build_nucleus(DevView v, double* Kd, int k) {
     int slot = (blockIdx.x * BLK + threadIdx.x) / G;  // row slot <-> position (column of K)
     int gl = threadIdx.x & (G - 1);
-    if (slot >= v.k) return;
+    if (slot >= k) return;
     int var = v.basic_vars[v.pos_of_kslot[slot]];
     int end = v.csc_ptr[var + 1];
     for (int e = v.csc_ptr[var] + gl; e < end; e += G) {
@@ -920,11 +1111,11 @@ __global__ void __launch_bounds__(BLK) k_build_nucleus(DevView v, double* Kd) {
 __global__ void __launch_bounds__(BLK) k_set_identity(double* Wv, int k, int ld) {
     size_t i = (size_t)blockIdx.x * BLK + threadIdx.x;
     if (i < (size_t)k * k) {
-        int r = (int)(i / k), c = (int)(i % k);
-        Wv[(size_t)r * ld + c] = (r == c) ? 1.0 : 0.0;
+        int r = (int)(i / k), cc = (int)(i % k);
+        Wv[(size_t)r * ld + cc] = (r == cc) ? 1.0 : 0.0;
     }
 }
-// one block: pivot search in column j (rows >= j); scratch[0] = pivot row, flag=1 if singular
+// one block: pivot search in column j (rows >= j); flag=1 if singular
 __global__ void __launch_bounds__(BLK) k_gj_pivot(const double* Kd, int k, int ld, int j, int* piv_row, int* flag) {
     Cand best = cand_none();
     for (int a = j + threadIdx.x; a < k; a += BLK) {
@@ -952,154 +1143,149 @@ __global__ void __launch_bounds__(BLK) k_gj_factors(const double* Kd, int k, int
 // swap rows j <-> piv in both matrices and scale the new row j by 1/pivot
 __global__ void __launch_bounds__(BLK) k_gj_swap_scale(double* Kd, double* Wv, int k, int ld, int j, const int* piv_row,
                                                      const double* factors) {
-    int c = blockIdx.x * BLK + threadIdx.x;
-    if (c >= k) return;
+    int cc = blockIdx.x * BLK + threadIdx.x;
+    if (cc >= k) return;
     int pr = *piv_row;
     double inv = factors[k];
-    double a = Kd[(size_t)pr * ld + c], b = Kd[(size_t)j * ld + c];
-    double x = Wv[(size_t)pr * ld + c], y = Wv[(size_t)j * ld + c];
+    double a = Kd[(size_t)pr * ld + cc], b = Kd[(size_t)j * ld + cc];
+    double x = Wv[(size_t)pr * ld + cc], y = Wv[(size_t)j * ld + cc];
     if (pr != j) {
-        Kd[(size_t)pr * ld + c] = b;
-        Wv[(size_t)pr * ld + c] = y;
+        Kd[(size_t)pr * ld + cc] = b;
+        Wv[(size_t)pr * ld + cc] = y;
     }
-    Kd[(size_t)j * ld + c] = a * inv;
-    Wv[(size_t)j * ld + c] = x * inv;
+    Kd[(size_t)j * ld + cc] = a * inv;
+    Wv[(size_t)j * ld + cc] = x * inv;
 }
 __global__ void __launch_bounds__(BLK) k_gj_eliminate(double* Kd, double* Wv, int k, int ld, int j, const double* factors) {
-    int c = blockIdx.x * BLK + threadIdx.x;
+    int cc = blockIdx.x * BLK + threadIdx.x;
     int a = blockIdx.y;
-    if (c >= k || a == j) return;
+    if (cc >= k || a == j) return;
     double f = factors[a];
     if (f == 0.0) return;
-    Kd[(size_t)a * ld + c] -= f * Kd[(size_t)j * ld + c];
-    Wv[(size_t)a * ld + c] -= f * Wv[(size_t)j * ld + c];
-}
-__global__ void __launch_bounds__(BLK) k_max_abs_diff(const double* A, const double* B, int k, int ld, double* out) {
-    double mx = 0.0;
-    size_t tot = (size_t)k * k;
-    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < tot; i += (size_t)gridDim.x * BLK) {
-        int r = (int)(i / k), c = (int)(i % k);
-        double dlt = fabs(A[(size_t)r * ld + c] - B[(size_t)r * ld + c]);
-        if (dlt != dlt) dlt = INFINITY;
-        if (dlt > mx) mx = dlt;
-    }
-    // max via atomics on the bit pattern (non-negative doubles order like uint64)
-    mx = -wave_min(-mx);
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(mx));
+    Kd[(size_t)a * ld + cc] -= f * Kd[(size_t)j * ld + cc];
+    Wv[(size_t)a * ld + cc] -= f * Wv[(size_t)j * ld + cc];
 }
 
 // ===================================================================================== launchers
-static inline int blocks_for(int n, int per_block = BLK) { return n <= 0 ? 1 : (n + per_block - 1) / per_block; }
+#define LANES_SWITCH(L, STMT4, STMT16, STMT32) \
+    do {                                        \
+        if ((L) <= 4) { STMT4; }                \
+        else if ((L) <= 16) { STMT16; }         \
+        else { STMT32; }                        \
+    } while (0)
 
-void launch_price_primal(const DevView& v, int use_pse, hipStream_t st) {
-    hipLaunchKernelGGL(k_price_primal, dim3(grid_for(v.n)), dim3(BLK), 0, st, v, use_pse);
+void launch_clear_work(const DevView& hv, hipStream_t st) {
+    // alpha_q | tau | rv are carved from one allocation (engine): a single memset node
+    (void)hipMemsetAsync(hv.alpha_q, 0, sizeof(double) * 4 * (size_t)hv.m, st);
 }
-void launch_price_dual(const DevView& v, int use_dse, hipStream_t st) {
-    hipLaunchKernelGGL(k_price_dual, dim3(grid_for(v.m)), dim3(BLK), 0, st, v, use_dse);
+void launch_price_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st) {
+    hipLaunchKernelGGL(k_price_primal, dim3(grid_for(g.n)), dim3(BLK), 0, st, dv, use_pse);
 }
-void launch_ftran_col(const DevView& v, hipStream_t st) {
-    (void)hipMemsetAsync(v.alpha_q, 0, sizeof(double) * (size_t)v.m, st);
-    hipLaunchKernelGGL(k_ftran_prep, dim3(1), dim3(64), 0, st, v);
-    if (v.k > 0) hipLaunchKernelGGL(k_ftran_gather<16>, dim3(blocks_for(v.k * 16)), dim3(BLK), 0, st, v);
+void launch_price_dual(const DevView& dv, const Geom& g, int use_dse, hipStream_t st) {
+    hipLaunchKernelGGL(k_price_dual, dim3(grid_for(g.m)), dim3(BLK), 0, st, dv, use_dse);
 }
-void launch_ratio_primal(const DevView& v, hipStream_t st) {
-    hipLaunchKernelGGL(k_ratio_primal_p1, dim3(grid_for(v.m)), dim3(BLK), 0, st, v);
-    hipLaunchKernelGGL(k_ratio_primal_p2, dim3(grid_for(v.m)), dim3(BLK), 0, st, v);
+void launch_ftran_col(const DevView& dv, const Geom& g, int plan_after, hipStream_t st) {
+    (void)plan_after;
+    hipLaunchKernelGGL(k_ftran_prep, dim3(1), dim3(64), 0, st, dv);
+    LANES_SWITCH(g.lanes,
+                 hipLaunchKernelGGL(k_ftran_gather<4>, dim3(blocks_for((long)g.cap * 4)), dim3(BLK), 0, st, dv),
+                 hipLaunchKernelGGL(k_ftran_gather<16>, dim3(blocks_for((long)g.cap * 16)), dim3(BLK), 0, st, dv),
+                 hipLaunchKernelGGL(k_ftran_gather<64>, dim3(blocks_for((long)g.cap * 64)), dim3(BLK), 0, st, dv));
 }
-void launch_btran_unit(const DevView& v, hipStream_t st) {
-    (void)hipMemsetAsync(v.rho, 0, sizeof(double) * (size_t)v.m, st);
-    hipLaunchKernelGGL(k_btran_prep, dim3(1), dim3(64), 0, st, v);
-    if (v.k > 0) hipLaunchKernelGGL(k_btran_gather, dim3(blocks_for(v.k)), dim3(BLK), 0, st, v);
-    hipLaunchKernelGGL(k_sqnorm, dim3(grid_for(v.m)), dim3(BLK), 0, st, v, (const double*)v.rho, v.m, &v.it->rho_sq, 0);
+void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st) {
+    hipLaunchKernelGGL(k_ratio_primal_p1, dim3(grid_for(g.m)), dim3(BLK), 0, st, dv, use_pse);
+    hipLaunchKernelGGL(k_ratio_primal_p2, dim3(grid_for(g.m)), dim3(BLK), 0, st, dv);
 }
-void launch_sweep(const DevView& v, int with_helper, int only_helper, hipStream_t st) {
-    dim3 g(blocks_for(v.n * 16)), b(BLK);
-    if (only_helper) hipLaunchKernelGGL((k_sweep<16, 2>), g, b, 0, st, v);
-    else if (with_helper) hipLaunchKernelGGL((k_sweep<16, 1>), g, b, 0, st, v);
-    else hipLaunchKernelGGL((k_sweep<16, 0>), g, b, 0, st, v);
+void launch_post_ftran(const DevView& dv, const Geom& g, int use_pse, hipStream_t st) {
+    hipLaunchKernelGGL(k_post_ftran, dim3(use_pse ? grid_for(g.m) : 1), dim3(BLK), 0, st, dv, use_pse);
 }
-void launch_ratio_dual(const DevView& v, hipStream_t st) {
-    hipLaunchKernelGGL(k_ratio_dual_p1, dim3(grid_for(v.n)), dim3(BLK), 0, st, v);
-    hipLaunchKernelGGL(k_ratio_dual_p2, dim3(grid_for(v.n)), dim3(BLK), 0, st, v);
+void launch_btran_unit(const DevView& dv, const Geom& g, int plan_after, hipStream_t st) {
+    hipLaunchKernelGGL(k_btran_prep, dim3(1), dim3(64), 0, st, dv, plan_after);
+    hipLaunchKernelGGL(k_btran_gather, dim3(grid_for(g.cap, 1)), dim3(BLK), 0, st, dv);
 }
-void launch_prep_v(const DevView& v, hipStream_t st) {
-    hipLaunchKernelGGL(k_sqnorm, dim3(grid_for(v.m)), dim3(BLK), 0, st, v, (const double*)v.alpha_q, v.m, &v.it->alpha_sq, 1);
-    hipLaunchKernelGGL(k_btran_single, dim3(blocks_for(v.m)), dim3(BLK), 0, st, v, (const double*)v.alpha_q, v.vvec);
-    if (v.k > 0) hipLaunchKernelGGL(k_btran_rhs<16>, dim3(blocks_for(v.k * 16)), dim3(BLK), 0, st, v, (const double*)v.alpha_q, (const double*)v.vvec);
+void launch_sweep(const DevView& dv, const Geom& g, int mode, hipStream_t st) {
+#define SWEEP(G, U)                                                                                               \
+    do {                                                                                                          \
+        dim3 gr(blocks_for((long)g.n * G)), b(BLK);                                                               \
+        if (mode == 0) hipLaunchKernelGGL((k_sweep<G, U, 0>), gr, b, 0, st, dv);                                  \
+        else if (mode == 1) hipLaunchKernelGGL((k_sweep<G, U, 1>), gr, b, 0, st, dv);                             \
+        else hipLaunchKernelGGL((k_sweep<G, U, 2>), gr, b, 0, st, dv);                                            \
+    } while (0)
+    if (g.sweep_variant == 1) { LANES_SWITCH(g.lanes, SWEEP(4, 4), SWEEP(16, 4), SWEEP(32, 4)); }
+    else if (g.sweep_variant == 2) { LANES_SWITCH(g.lanes, SWEEP(4, 8), SWEEP(8, 8), SWEEP(32, 8)); }
+    else { LANES_SWITCH(g.lanes, SWEEP(4, 4), SWEEP(16, 4), SWEEP(16, 8)); }
+#undef SWEEP
 }
-void launch_fused_w(const DevView& v, int with_v, int do_update, int rslot, hipStream_t st) {
-    if (v.k <= 0) return;
-    int nstripes = (v.k + FW_TR - 1) / FW_TR, nchunks = (v.k + FW_TC - 1) / FW_TC;
-    dim3 g(nstripes, nchunks), b(BLK);
-    if (do_update) {
-        if (with_v) hipLaunchKernelGGL((k_fused_w<true, true, true>), g, b, 0, st, v, rslot, 0.0);
-        else hipLaunchKernelGGL((k_fused_w<true, false, true>), g, b, 0, st, v, rslot, 0.0);
+void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st) {
+    hipLaunchKernelGGL(k_init_nb_rng, dim3(blocks_for(g.n)), dim3(BLK), 0, st, dv);
+}
+void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st) {
+    hipLaunchKernelGGL(k_ratio_dual_p1, dim3(grid_for(g.n)), dim3(BLK), 0, st, dv);
+    hipLaunchKernelGGL(k_ratio_dual_p2, dim3(grid_for(g.n)), dim3(BLK), 0, st, dv);
+}
+void launch_btran_rhs(const DevView& dv, const Geom& g, hipStream_t st) {
+    LANES_SWITCH(g.lanes,
+                 hipLaunchKernelGGL(k_btran_rhs<4>, dim3(blocks_for((long)g.cap * 4)), dim3(BLK), 0, st, dv),
+                 hipLaunchKernelGGL(k_btran_rhs<16>, dim3(blocks_for((long)g.cap * 16)), dim3(BLK), 0, st, dv),
+                 hipLaunchKernelGGL(k_btran_rhs<64>, dim3(blocks_for((long)g.cap * 64)), dim3(BLK), 0, st, dv));
+}
+void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st) {
+    int nstripes = (g.cap + FW_TR - 1) / FW_TR, nchunks = (g.cap + FW_TC - 1) / FW_TC;
+    dim3 gr(nstripes, nchunks), b(BLK);
+    if (with_v) {
+        hipLaunchKernelGGL((k_fused_w<true, true, true>), gr, b, 0, st, dv);
+        hipLaunchKernelGGL((k_fused_reduce<true, true>), dim3(blocks_for(g.cap, 32)), b, 0, st, dv);
     } else {
-        if (with_v) hipLaunchKernelGGL((k_fused_w<false, true, false>), g, b, 0, st, v, rslot, 0.0);
-        else hipLaunchKernelGGL((k_fused_w<true, false, false>), g, b, 0, st, v, rslot, 0.0);
-    }
-    int with_tau = do_update || !with_v;
-    hipLaunchKernelGGL(k_fused_reduce, dim3(blocks_for(v.k)), dim3(BLK), 0, st, v, nstripes, nchunks, with_tau, with_v);
-}
-void launch_finish_tau(const DevView& v, hipStream_t st) {
-    (void)hipMemsetAsync(v.tau, 0, sizeof(double) * (size_t)v.m, st);
-    hipLaunchKernelGGL(k_ftran_init_single, dim3(blocks_for(v.m)), dim3(BLK), 0, st, v, (const double*)v.rho, v.tau);
-    if (v.k > 0) hipLaunchKernelGGL(k_ftran_push<16>, dim3(blocks_for(v.k * 16)), dim3(BLK), 0, st, v, (const double*)v.tauK, v.tau);
-}
-void launch_finish_v(const DevView& v, hipStream_t st) {
-    if (v.k > 0) hipLaunchKernelGGL(k_scatter_cols, dim3(blocks_for(v.k)), dim3(BLK), 0, st, v, (const double*)v.vK, v.vvec);
-}
-void launch_structure_update(const DevView& v, const StructUpdate& u, hipStream_t st) {
-    switch (u.kase) {
-        case 0: break;  // nuc -> nuc: the fused pass already produced the new row
-        case 1: hipLaunchKernelGGL(k_struct_grow, dim3(blocks_for(v.k + 1)), dim3(BLK), 0, st, v, u); break;
-        case 2:
-            hipLaunchKernelGGL(k_struct_shrink_row, dim3(blocks_for(v.k)), dim3(BLK), 0, st, v, u);
-            hipLaunchKernelGGL(k_struct_shrink_col, dim3(blocks_for(v.k)), dim3(BLK), 0, st, v, u);
-            break;
-        case 3: hipLaunchKernelGGL(k_struct_newcol, dim3(blocks_for(v.k > 0 ? v.k : 1)), dim3(BLK), 0, st, v, u); break;
-        case 4: hipLaunchKernelGGL(k_struct_newdiag, dim3(1), dim3(1), 0, st, v, u); break;
+        hipLaunchKernelGGL((k_fused_w<true, false, true>), gr, b, 0, st, dv);
+        hipLaunchKernelGGL((k_fused_reduce<true, false>), dim3(blocks_for(g.cap, 32)), b, 0, st, dv);
     }
 }
-void launch_update_pivot(const DevView& v, int use_dse, int use_pse, hipStream_t st) {
-    hipLaunchKernelGGL(k_update_basic, dim3(blocks_for(v.m)), dim3(BLK), 0, st, v, use_dse);
-    hipLaunchKernelGGL(k_update_nonbasic, dim3(blocks_for(v.n)), dim3(BLK), 0, st, v, use_pse);
+void launch_tau_push(const DevView& dv, const Geom& g, hipStream_t st) {
+    LANES_SWITCH(g.lanes,
+                 hipLaunchKernelGGL(k_tau_push<4>, dim3(blocks_for((long)g.cap * 4)), dim3(BLK), 0, st, dv),
+                 hipLaunchKernelGGL(k_tau_push<16>, dim3(blocks_for((long)g.cap * 16)), dim3(BLK), 0, st, dv),
+                 hipLaunchKernelGGL(k_tau_push<64>, dim3(blocks_for((long)g.cap * 64)), dim3(BLK), 0, st, dv));
 }
-void launch_update_flip(const DevView& v, hipStream_t st) {
-    hipLaunchKernelGGL(k_update_flip, dim3(blocks_for(v.m)), dim3(BLK), 0, st, v);
+void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st) {
+    hipLaunchKernelGGL(k_struct_update, dim3(blocks_for(g.cap)), dim3(BLK), 0, st, dv);
 }
-void launch_btran_dense(const DevView& v, const double* c_pos, double* y_row, hipStream_t st) {
-    hipLaunchKernelGGL(k_set_status, dim3(1), dim3(1), 0, st, v, (int)ITER_PIVOT);
-    (void)hipMemsetAsync(y_row, 0, sizeof(double) * (size_t)v.m, st);
-    hipLaunchKernelGGL(k_btran_single, dim3(blocks_for(v.m)), dim3(BLK), 0, st, v, c_pos, y_row);
-    if (v.k > 0) {
-        hipLaunchKernelGGL(k_btran_rhs<16>, dim3(blocks_for(v.k * 16)), dim3(BLK), 0, st, v, c_pos, (const double*)y_row);
-        launch_fused_w(v, 1, 0, -1, st);
-        hipLaunchKernelGGL(k_scatter_cols, dim3(blocks_for(v.k)), dim3(BLK), 0, st, v, (const double*)v.vK, y_row);
-    }
+void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_dse, int use_pse, hipStream_t st) {
+    int t = g.m > g.n ? g.m : g.n;
+    hipLaunchKernelGGL(k_update_pivot, dim3(blocks_for(t)), dim3(BLK), 0, st, dv, phase, use_dse, use_pse);
 }
-void launch_ftran_dense(const DevView& v, const double* b_row, double* x_pos, hipStream_t st) {
-    // gather rK = b[R_K] is the caller's job when needed; not on the pivot path (kept for refresh).
-    (void)v; (void)b_row; (void)x_pos; (void)st;
+void launch_set_iter(const DevView& dv, int status, int q, int r, double lnv, int forced, hipStream_t st) {
+    hipLaunchKernelGGL(k_set_iter, dim3(1), dim3(1), 0, st, dv, status, q, r, lnv, forced);
 }
-void launch_gather_basic_obj(const DevView& v, double* c_pos, hipStream_t st) {
-    hipLaunchKernelGGL(k_gather_basic_obj, dim3(blocks_for(v.m)), dim3(BLK), 0, st, v, c_pos);
+void launch_reset_ring(const DevView& dv, hipStream_t st) { hipLaunchKernelGGL(k_reset_ring, dim3(1), dim3(1), 0, st, dv); }
+void launch_btran_dense(const DevView& dv, const Geom& g, hipStream_t st) {
+    // c_B by position -> alpha_q, y_S -> rv.y; then tK, vK = W^T tK, scatter into rv.y
+    hipLaunchKernelGGL(k_gather_basic_obj, dim3(blocks_for(g.m)), dim3(BLK), 0, st, dv);
+    launch_btran_rhs(dv, g, st);
+    int nstripes = (g.cap + FW_TR - 1) / FW_TR, nchunks = (g.cap + FW_TC - 1) / FW_TC;
+    hipLaunchKernelGGL((k_fused_w<false, true, false>), dim3(nstripes, nchunks), dim3(BLK), 0, st, dv);
+    hipLaunchKernelGGL((k_fused_reduce<false, true>), dim3(blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv);
 }
-void launch_recalc_d(const DevView& v, const double* y_row, hipStream_t st) {
-    hipLaunchKernelGGL(k_recalc_d<16>, dim3(blocks_for(v.n * 16)), dim3(BLK), 0, st, v, y_row);
-    hipLaunchKernelGGL(k_recalc_obj, dim3(grid_for(v.m + v.n)), dim3(BLK), 0, st, v);
+void launch_recalc_d(const DevView& dv, const Geom& g, hipStream_t st) {
+    LANES_SWITCH(g.lanes,
+                 hipLaunchKernelGGL(k_recalc_d<4>, dim3(blocks_for((long)g.n * 4)), dim3(BLK), 0, st, dv),
+                 hipLaunchKernelGGL(k_recalc_d<16>, dim3(blocks_for((long)g.n * 16)), dim3(BLK), 0, st, dv),
+                 hipLaunchKernelGGL(k_recalc_d<64>, dim3(blocks_for((long)g.n * 64)), dim3(BLK), 0, st, dv));
+    hipLaunchKernelGGL(k_recalc_obj, dim3(grid_for(g.m + g.n)), dim3(BLK), 0, st, dv);
 }
-void launch_shift_nonbasic(const DevView& v, int col, double val, hipStream_t st) {
-    hipLaunchKernelGGL(k_shift_nonbasic, dim3(blocks_for(v.m)), dim3(BLK), 0, st, v, col, val);
-    hipLaunchKernelGGL(k_set_xn, dim3(1), dim3(1), 0, st, v, col, val);
+void launch_shift_nonbasic(const DevView& dv, const Geom& g, int col, double val, hipStream_t st) {
+    hipLaunchKernelGGL(k_shift_nonbasic, dim3(blocks_for(g.m)), dim3(BLK), 0, st, dv, col, val);
+    hipLaunchKernelGGL(k_set_xn, dim3(1), dim3(1), 0, st, dv, col, val);
 }
-void launch_sq_norms_add_row(const DevView& v, hipStream_t st) {
-    hipLaunchKernelGGL(k_gamma_add_row, dim3(blocks_for(v.n)), dim3(BLK), 0, st, v);
+void launch_sq_norms_add_row(const DevView& dv, const Geom& g, hipStream_t st) {
+    hipLaunchKernelGGL(k_gamma_add_row, dim3(blocks_for(g.n)), dim3(BLK), 0, st, dv);
 }
-void launch_build_nucleus(const DevView& v, double* Kd, hipStream_t st) {
-    if (v.k <= 0) return;
-    (void)hipMemsetAsync(Kd, 0, sizeof(double) * (size_t)v.k * v.ld, st);
-    hipLaunchKernelGGL(k_build_nucleus<16>, dim3(blocks_for(v.k * 16)), dim3(BLK), 0, st, v, Kd);
+void launch_copy_rho_sq_to_beta(const DevView& dv, int row, hipStream_t st) {
+    hipLaunchKernelGGL(k_copy_rho_sq_to_beta, dim3(1), dim3(1), 0, st, dv, row);
+}
+void launch_build_nucleus(const DevView& dv, const Geom& g, double* Kd, int k, hipStream_t st) {
+    if (k <= 0) return;
+    (void)hipMemsetAsync(Kd, 0, sizeof(double) * (size_t)k * g.cap, st);
+    hipLaunchKernelGGL(k_build_nucleus<16>, dim3(blocks_for((long)k * 16)), dim3(BLK), 0, st, dv, Kd, k);
 }
 void launch_gauss_jordan(double* Kd, double* Winv, int k, int ld, int* d_flag, double* d_scratch, hipStream_t st) {
     if (k <= 0) return;
@@ -1113,14 +1299,6 @@ void launch_gauss_jordan(double* Kd, double* Winv, int k, int ld, int* d_flag, d
         hipLaunchKernelGGL(k_gj_swap_scale, dim3(blocks_for(k)), dim3(BLK), 0, st, Kd, Winv, k, ld, j, (const int*)piv, (const double*)factors);
         hipLaunchKernelGGL(k_gj_eliminate, dim3(blocks_for(k), k), dim3(BLK), 0, st, Kd, Winv, k, ld, j, (const double*)factors);
     }
-}
-void launch_max_abs_diff(const double* A, const double* B, int k, int ld, double* d_out, hipStream_t st) {
-    (void)hipMemsetAsync(d_out, 0, sizeof(double), st);
-    if (k <= 0) return;
-    size_t tot = (size_t)k * k;
-    int g = (int)((tot + BLK * 4 - 1) / (BLK * 4));
-    if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(k_max_abs_diff, dim3(g), dim3(BLK), 0, st, A, B, k, ld, d_out);
 }
 
 }  // namespace mlp

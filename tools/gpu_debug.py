@@ -6,7 +6,8 @@ import traceback
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import minilp_amd as M
 from minilp_amd import lpgen
 from oracle import minilp_oracle as O

@@ -4,7 +4,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import minilp_amd as M
 from minilp_amd import lpgen
 
