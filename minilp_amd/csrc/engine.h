@@ -195,6 +195,7 @@ private:
     void upload_matrix();
     void alloc_row_buffers(int m_new);
     void ensure_nucleus_cap(int need);
+    void ensure_red();
     void pull_ctl();
     void pull_maps();
     void push_maps();

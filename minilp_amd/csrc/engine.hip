@@ -200,6 +200,11 @@ void Engine::ensure_nucleus_cap(int need) {
     view_dirty = true;
 }
 
+void Engine::ensure_red() {
+    size_t need = std::max<size_t>(1024, (size_t)(std::max(m_, num_vars) + 255) / 256 + 8);
+    d_red_key.ensure(need, 0, st); d_red_key2.ensure(need, 0, st); d_red_idx.ensure(need, 0, st);
+    view_dirty = true;
+}
 void Engine::pull_ctl() {
     HIPCHECK(hipMemcpyAsync(h_ctl, d_ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
@@ -364,7 +369,7 @@ void Engine::try_new(const ProblemData& pd) {
     d_nb_vars.upload(h_nb_vars, st);
     d_d.upload(d, st); d_xN.upload(xN, st); d_gamma.upload(gamma, st); d_nbflags.upload(flags, st);
     d_alpha_r.ensure(n, 0, st); d_helper.ensure(n, 0, st); d_nb_rng.ensure(n, 0, st);
-    d_red_key.ensure(1024, 0, st); d_red_key2.ensure(1024, 0, st); d_red_idx.ensure(1024, 0, st);
+    ensure_red();
     d_ticket.ensure(4, 0, st);
     HIPCHECK(hipMemsetAsync(d_ticket.p, 0, 4 * sizeof(unsigned), st));
     d_ctl.ensure(1, 0, st);
@@ -414,56 +419,38 @@ void Engine::record_iteration(int phase, bool with_events) {
     const DevView& dv = hview;
     const Geom g = geom();
     const int pse = enable_pse ? 1 : 0, dse = enable_dse ? 1 : 0;
-    // fork/join: work that is off the critical path runs on the side stream st2 (a parallel
-    // branch of the captured graph; real concurrency in eager mode too)
-    // (measured: graph branches cost more in cross-queue signalling than they hide at these kernel
-    //  sizes — 4.6-4.9k vs 5.4k pivots/s on config 4 — so the default is a linear chain)
-    hipStream_t st2 = use_branches ? this->st2 : st;
-    auto fork = [&](int i) {
-        if (!use_branches) return;
-        HIPCHECK(hipEventRecord(evFork[i], st));
-        HIPCHECK(hipStreamWaitEvent(st2, evFork[i], 0));
-    };
-    auto join = [&](int i) {
-        if (!use_branches) return;
-        HIPCHECK(hipEventRecord(evJoin[i], st2));
-        HIPCHECK(hipStreamWaitEvent(st, evJoin[i], 0));
-    };
-    fork(0);
-    launch_clear_work(hview, st2);             // alpha_q, tau, rho|v := 0   (branch)
+    // The pricing decision (q for primal, r for dual) is already in Ctl: it was taken by the
+    // previous iteration's update kernel, or by the standalone pricing kernel at batch start.
     if (phase == 0) {
-        launch_price_primal(dv, g, pse, st);   // K1
-        join(0);
-        launch_ftran_col(dv, g, 0, st);        // K2 (device-driven by it.q)
-        launch_ratio_primal(dv, g, pse, st);   // K5 (+ ||alpha||^2, y_S); p2 ends the decision
-        launch_btran_unit(dv, g, 1, st);       // K3 (device-driven by it.r) + partition plan
+        launch_ftran_prep(dv, 1, st);          // K2 head: entering column scalars, singleton rows, list
+        launch_ftran_gather(dv, g, st);        // K2: alpha_q = B^-1 a_q
+        launch_ratio_primal(dv, g, pse, st);   // K5 p1 (+ ||alpha||^2, y_S), p2 (+ K3 head + partition plan)
+        launch_btran(dv, g, pse, st);          // K3: rho, rK, ||rho||^2  |  tK = alpha_K - F^T y_S
     } else {
-        launch_price_dual(dv, g, dse, st);     // K6
-        join(0);
-        launch_btran_unit(dv, g, 0, st);       // K3
+        launch_btran_prep(dv, 1, 0, st);       // K3 head (device-driven by it.r)
+        launch_btran(dv, g, 0, st);            // K3
         if (with_events) HIPCHECK(hipEventRecord(ev[0], st));
-        launch_sweep(dv, g, 0, st);            // K4: alpha_r = rho^T N
+        launch_sweep(dv, g, 0, 0, st);         // K4: alpha_r = rho^T N
         if (with_events) HIPCHECK(hipEventRecord(ev[1], st));
-        launch_ratio_dual(dv, g, st);          // K7
-        launch_ftran_col(dv, g, 0, st);        // K2
+        launch_ratio_dual(dv, g, st);          // K7 p1, p2 (+ K2 head)
+        launch_ftran_gather(dv, g, st);        // K2
         launch_post_ftran(dv, g, pse, st);     // alpha_sq, y_S, partition plan
+        if (pse) launch_btran_rhs(dv, g, st);  // tK
     }
-    if (pse) launch_btran_rhs(dv, g, st);      // tK = alpha_K - F^T y_S
     if (with_events) HIPCHECK(hipEventRecord(ev[2], st));
-    launch_fused_w(dv, g, pse, st);            // tauK, vK, eta update of W (+ scatter of v)
+    launch_fused_w(dv, g, pse, st);            // tauK / vK partials + eta update of W
     if (with_events) HIPCHECK(hipEventRecord(ev[3], st));
-    fork(1);
-    launch_tau_push(dv, g, st2);               // tau by position (F push)        (branch)
-    launch_structure_update(dv, g, st2);       // new / dropped nucleus slots      (branch)
+    launch_post_fused(dv, g, pse, st);         // tau by position (F push)  |  v reduce + scatter
     if (phase == 0) {
         if (with_events) HIPCHECK(hipEventRecord(ev[0], st));
-        launch_sweep(dv, g, pse ? 1 : 0, st);  // K4 (+ PSE helper in the same pass over A)
+        launch_sweep(dv, g, pse ? 1 : 0, 1, st);  // K4 (+ PSE helper in the same pass)  |  partition change
         if (with_events) HIPCHECK(hipEventRecord(ev[1], st));
     } else if (pse) {
-        launch_sweep(dv, g, 2, st);
+        launch_sweep(dv, g, 2, 1, st);
+    } else {
+        launch_structure_update(dv, g, st);
     }
-    join(1);
-    launch_update_pivot(dv, g, phase, dse, pse, st);  // K8 + per-pivot record
+    launch_update_pivot(dv, g, phase, dse, pse, st);  // K8 + zero the work vectors + price the next iteration
 }
 
 hipGraphExec_t Engine::get_graph(int phase) {
@@ -503,6 +490,7 @@ int Engine::process_records(int phase, int launched) {
     int result = ITER_PIVOT;
     for (int i = 0; i < n; ++i) {
         const PivotRec& r = h_ctl->ring[i];
+        if (pivot_budget == 0) break;  // a decision taken beyond the budget (next-iteration pricing) does not count
         if (pivot_budget > 0) pivot_budget -= 1;
         if (r.status == ITER_PIVOT || r.status == ITER_FLIP) {
             stats.iterations += 1;
@@ -547,6 +535,9 @@ int Engine::run_loop(int phase) {
         sync_view();
         const DevView& dv = hview;
         launch_reset_ring(dv, st);
+        launch_clear_work(dv, st);
+        if (phase == 0) launch_price_primal(dv, geom(), enable_pse ? 1 : 0, st);  // opens the first iteration
+        else launch_price_dual(dv, geom(), enable_dse ? 1 : 0, st);
         if (use_graph && !sample) {
             hipGraphExec_t ge = get_graph(phase);
             for (int i = 0; i < B; ++i) HIPCHECK(hipGraphLaunch(ge, st));
@@ -616,15 +607,17 @@ void Engine::calc_col_coeffs(int col) {  // solver.rs:671-677
     const DevView& dv = hview;
     launch_clear_work(hview, st);
     launch_set_iter(dv, ITER_PIVOT, col, -1, 0.0, 0, st);
-    launch_ftran_col(dv, geom(), 0, st);
+    launch_ftran_prep(dv, 0, st);
+    launch_ftran_gather(dv, geom(), st);
 }
 void Engine::calc_row_coeffs(int row, bool with_sweep) {  // solver.rs:680-693
     sync_view();
     const DevView& dv = hview;
     launch_clear_work(hview, st);
     launch_set_iter(dv, ITER_PIVOT, -1, row, 0.0, 0, st);
-    launch_btran_unit(dv, geom(), 0, st);
-    if (with_sweep) launch_sweep(dv, geom(), 0, st);
+    launch_btran_prep(dv, 0, 0, st);
+    launch_btran(dv, geom(), 0, st);
+    if (with_sweep) launch_sweep(dv, geom(), 0, 0, st);
 }
 
 // solver.rs:1199-1231.  There is no eta file to flush: W is always current.
@@ -647,6 +640,7 @@ void Engine::fix_var(int var, double val) {  // solver.rs:378-415
         sync_view();
         const DevView& dv = hview;
         launch_reset_ring(dv, st);
+        launch_clear_work(dv, st);
         launch_set_iter(dv, ITER_PIVOT, -1, row, val, 1, st);
         record_iteration(1, false);
         pull_ctl();
@@ -759,6 +753,7 @@ void Engine::add_constraint(Constraint c) {
     alloc_row_buffers(m_ + 1);
     m_ += 1;
     N_ += 1;
+    ensure_red();
     build_csc();
     upload_matrix();
     for (size_t p = 0; p < c.idx.size(); ++p)
@@ -935,7 +930,7 @@ Engine* Engine::clone() {
     e->d_nb_vars.copy_from(d_nb_vars, nn, s2); e->d_d.copy_from(d_d, nn, s2); e->d_xN.copy_from(d_xN, nn, s2);
     e->d_gamma.copy_from(d_gamma, nn, s2); e->d_nbflags.copy_from(d_nbflags, nn, s2);
     e->d_alpha_r.ensure(nn, 0, s2); e->d_helper.ensure(nn, 0, s2); e->d_nb_rng.copy_from(d_nb_rng, nn, s2);
-    e->d_red_key.ensure(1024, 0, s2); e->d_red_key2.ensure(1024, 0, s2); e->d_red_idx.ensure(1024, 0, s2);
+    e->ensure_red();
     e->d_ticket.ensure(4, 0, s2);
     HIPCHECK(hipMemsetAsync(e->d_ticket.p, 0, 4 * sizeof(unsigned), s2));
     e->d_ctl.copy_from(d_ctl, 1, s2);

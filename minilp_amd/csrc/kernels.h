@@ -132,22 +132,24 @@ struct Geom {
     int sweep_variant;  // tuning knob (MLP_SWEEP): 0 default
 };
 
-// ---- launch wrappers (all asynchronous on `st`; `dv` is the DEVICE pointer to the DevView) ----
+// ---- launch wrappers (all asynchronous on `st`; the DevView is passed to the kernels by value) ----
 void launch_clear_work(const DevView& dv, hipStream_t st);  // alpha_q, tau, rv := 0 (one memset)
-void launch_price_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st);
-void launch_price_dual(const DevView& dv, const Geom& g, int use_dse, hipStream_t st);
-void launch_ftran_col(const DevView& dv, const Geom& g, int plan_after, hipStream_t st);  // alpha_q = B^-1 a_q [+ plan]
-void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st);   // -> r / flip / unbounded (+ alpha_sq, y_S)
-void launch_post_ftran(const DevView& dv, const Geom& g, int use_pse, hipStream_t st);     // dual path: inv_alpha, alpha_sq, y_S
-void launch_btran_unit(const DevView& dv, const Geom& g, int plan_after, hipStream_t st);  // rho, rK, rho_sq [+ plan]
-void launch_sweep(const DevView& dv, const Geom& g, int mode, hipStream_t st);             // 0 alpha_r, 1 both, 2 helper
+void launch_price_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st);  // standalone K1 (first iteration of a batch)
+void launch_price_dual(const DevView& dv, const Geom& g, int use_dse, hipStream_t st);    // standalone K6
+void launch_ftran_prep(const DevView& dv, int derive_primal, hipStream_t st);             // FTRAN head (one wave)
+void launch_ftran_gather(const DevView& dv, const Geom& g, hipStream_t st);               // alpha_q = B^-1 a_q
+void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st);  // K5 p1 (+alpha_sq, y_S), p2 (+BTRAN head, plan)
+void launch_post_ftran(const DevView& dv, const Geom& g, int use_pse, hipStream_t st);    // dual path: alpha_sq, y_S, plan
+void launch_btran_prep(const DevView& dv, int derive_dual, int plan_after, hipStream_t st);  // BTRAN head (one wave)
+void launch_btran(const DevView& dv, const Geom& g, int with_rhs, hipStream_t st);        // rho, rK, rho_sq [| tK]
+void launch_btran_rhs(const DevView& dv, const Geom& g, hipStream_t st);                  // tK alone
+void launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, hipStream_t st);  // K4 [| partition change]
 void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st);
-void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st);
-void launch_btran_rhs(const DevView& dv, const Geom& g, hipStream_t st);                   // tK (PSE)
-void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st);         // tauK, vK, W update, scatter
-void launch_tau_push(const DevView& dv, const Geom& g, hipStream_t st);
+void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st);                 // K7 p1, p2 (+FTRAN head)
+void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st);        // tauK/vK partials + eta update of W
+void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st);     // tau push | v reduce+scatter
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st);
-void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_dse, int use_pse, hipStream_t st);
+void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_dse, int use_pse, hipStream_t st);  // K8 + clear + next pricing
 // non-graph helpers
 void launch_set_iter(const DevView& dv, int status, int q, int r, double lnv, int forced, hipStream_t st);
 void launch_reset_ring(const DevView& dv, hipStream_t st);

@@ -103,12 +103,12 @@ __device__ __forceinline__ void st_agent(double* p, double x) {
 __device__ __forceinline__ void st_agent(int* p, int x) {
     __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ bool last_block_arrives(unsigned* ticket) {
+__device__ __forceinline__ bool last_block_arrives(unsigned* ticket, unsigned nblocks) {
     __shared__ int s_last;
     if (threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == gridDim.x - 1);
+        s_last = (t == nblocks - 1);
     }
     __syncthreads();
     return s_last != 0;
@@ -127,7 +127,7 @@ __device__ __forceinline__ bool grid_best(Cand& c, const DevView& v) {
         st_agent(&v.red_key[blockIdx.x], c.key);
         st_agent(&v.red_idx[blockIdx.x], c.idx);
     }
-    if (!last_block_arrives(v.ticket)) return false;
+    if (!last_block_arrives(v.ticket, gridDim.x)) return false;
     Cand x = cand_none();
     for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) {
         Cand t{ld_agent(&v.red_key[i]), ld_agent(&v.red_idx[i])};
@@ -145,7 +145,7 @@ __device__ __forceinline__ bool grid_min_sum(double& mn, double& sm, const DevVi
         st_agent(&v.red_key[blockIdx.x], mn);
         st_agent(&v.red_key2[blockIdx.x], sm);
     }
-    if (!last_block_arrives(v.ticket)) return false;
+    if (!last_block_arrives(v.ticket, gridDim.x)) return false;
     double y = INFINITY, z = 0.0;
     for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) {
         double t = ld_agent(&v.red_key[i]);
@@ -157,12 +157,13 @@ __device__ __forceinline__ bool grid_min_sum(double& mn, double& sm, const DevVi
     if (threadIdx.x == 0) *v.ticket = 0;
     return true;
 }
-__device__ __forceinline__ bool grid_sum(double& x, const DevView& v) {
+__device__ __forceinline__ bool grid_sum(double& x, const DevView& v, int nblocks = -1) {
+    if (nblocks < 0) nblocks = (int)gridDim.x;
     x = block_sum(x);
     if (threadIdx.x == 0) st_agent(&v.red_key[blockIdx.x], x);
-    if (!last_block_arrives(v.ticket)) return false;
+    if (!last_block_arrives(v.ticket, (unsigned)nblocks)) return false;
     double y = 0.0;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) y += ld_agent(&v.red_key[i]);
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) y += ld_agent(&v.red_key[i]);
     x = block_sum(y);
     if (threadIdx.x == 0) *v.ticket = 0;
     return true;
@@ -253,100 +254,24 @@ __device__ void plan_update(const DevView& v, Ctl* c, int phase) {
     }
 }
 
-// ------------------------------------------------------------------- K1: primal pricing
-// solver.rs:696-739: argmax over eligible non-basic columns of d^2/gamma (PSE) or |d| (Dantzig).
-__global__ void __launch_bounds__(BLK) k_price_primal(DevView v, int use_pse) {
-    Ctl* c = v.ctl;
-    if (c->halt) return;
-    Cand best = cand_none();
-    for (int j = blockIdx.x * BLK + threadIdx.x; j < v.n; j += gridDim.x * BLK) {
-        double dd = v.d[j];
-        uint8_t f = v.nbflags[j];
-        if (((f & NB_AT_MIN) && dd > -EPS) || ((f & NB_AT_MAX) && dd < EPS)) continue;  // solver.rs:705-706
-        double score = use_pse ? dd * dd / v.gamma[j] : fabs(dd);
-        Cand t{score, j};
-        if (cand_better(t, best)) best = t;
-    }
-    if (!grid_best(best, v)) return;
-    if (threadIdx.x == 0) {
-        IterState* it = &c->it;
-        it->klist_n = 0;
-        it->blist_n = 0;
-        c->up.kase = -1;
-        if (best.idx == NONE_IDX) {
-            it->status = ITER_OPTIMAL;
-            it->q = -1;
-            it->r = -1;
-            c->halt = 1;
-            push_rec(c, 0);
-        } else {
-            int q = best.idx;
-            int var = v.nb_vars[q];
+// ------------------------------------------------------------------- wave-level stage heads
+// FTRAN head (one wave): derive the entering column's scalars, land its singleton-row entries in
+// alpha_q and list its entries on nucleus rows.  alpha_q = B^-1 a_q  (solver.rs:671-677).
+__device__ void ftran_prep_wave(const DevView& v, Ctl* c, int lane, int derive_primal) {
+    IterState* it = &c->it;
+    const int q = it->q;
+    const int var = v.nb_vars[q];
+    if (lane == 0) {
+        it->entering_var = var;
+        if (derive_primal) {  // solver.rs:741-748
             double dq = v.d[q];
-            it->status = ITER_PIVOT;
-            it->q = q;
-            it->r = -1;
-            it->entering_var = var;
-            it->leaving_var = -1;
-            it->sign = dq < 0.0;  // solver.rs:743
+            it->sign = dq < 0.0;
             it->entering_cur = v.xN[q];
-            it->entering_other = (dq < 0.0) ? v.var_hi[var] : v.var_lo[var];  // solver.rs:744-748
-        }
-    }
-}
-
-// ------------------------------------------------------------------- K6: dual pricing
-// solver.rs:855-917: argmax over infeasible rows of infeas^2/beta.
-__global__ void __launch_bounds__(BLK) k_price_dual(DevView v, int use_dse) {
-    Ctl* c = v.ctl;
-    if (c->halt || c->forced) return;
-    Cand best = cand_none();
-    for (int r = blockIdx.x * BLK + threadIdx.x; r < v.m; r += gridDim.x * BLK) {
-        double val = v.xB[r], mn = v.loB[r], mx = v.hiB[r];
-        double infeas;
-        if (val < mn - EPS) infeas = mn - val;
-        else if (val > mx + EPS) infeas = val - mx;
-        else continue;
-        double score = use_dse ? infeas * infeas / v.beta[r] : infeas;
-        Cand t{score, r};
-        if (cand_better(t, best)) best = t;
-    }
-    if (!grid_best(best, v)) return;
-    if (threadIdx.x == 0) {
-        IterState* it = &c->it;
-        it->klist_n = 0;
-        it->blist_n = 0;
-        c->up.kase = -1;
-        if (best.idx == NONE_IDX) {
-            it->status = ITER_FEASIBLE;
+            it->entering_other = (dq < 0.0) ? v.var_hi[var] : v.var_lo[var];
             it->r = -1;
-            it->q = -1;
-            c->halt = 1;
-            push_rec(c, 1);
-        } else {
-            int r = best.idx;
-            double val = v.xB[r], mn = v.loB[r];
-            it->status = ITER_PIVOT;
-            it->r = r;
-            it->q = -1;
-            it->entering_var = -1;
-            it->leaving_new_val = (val < mn) ? mn : v.hiB[r];  // solver.rs:908-914
-            it->leaving_var = v.basic_vars[r];
+            it->leaving_var = -1;
         }
     }
-}
-
-// ------------------------------------------------------------------- K2: FTRAN of one column
-// alpha_q = B^-1 a_q  (solver.rs:671-677 -> 1305-1319 -> lu.rs:79-106).  B^-1 is held as a
-// singleton split + dense nucleus inverse W (DESIGN.md §3.2), so the solve is:
-//   prep   : singleton rows of a_q land directly; entries on nucleus rows become a short list
-//   gather : aK = W[:, list] * coeffs  (only the touched columns of W are read)
-//            + push of -F*aK into the singleton positions (CSC columns of the nucleus basics)
-__global__ void __launch_bounds__(64) k_ftran_prep(DevView v) {
-    Ctl* c = v.ctl;
-    if (c->halt || c->it.status != ITER_PIVOT) return;
-    int lane = threadIdx.x;
-    int var = c->it.entering_var;
     int base = v.csc_ptr[var], end = v.csc_ptr[var + 1];
     int cnt = 0;
     for (int e0 = base; e0 < end; e0 += 64) {
@@ -372,9 +297,130 @@ __global__ void __launch_bounds__(64) k_ftran_prep(DevView v) {
         }
         cnt += __popcll(mask);
     }
-    if (lane == 0) c->it.klist_n = cnt;
+    if (lane == 0) it->klist_n = cnt;
+}
+// BTRAN head (one wave): rho = B^-T e_r (solver.rs:680-683) as a short list of rows of W.
+__device__ void btran_prep_wave(const DevView& v, Ctl* c, int lane, int r, int derive_dual, int plan_after, int phase) {
+    IterState* it = &c->it;
+    if (derive_dual && !c->forced && lane == 0) {  // solver.rs:892-916 (a host-forced row keeps the host's value)
+        double val = v.xB[r], mn = v.loB[r];
+        it->leaving_new_val = (val < mn) ? mn : v.hiB[r];
+        it->leaving_var = v.basic_vars[r];
+        it->q = -1;
+        it->entering_var = -1;
+    }
+    int sr = v.kslot_of_pos[r];
+    if (sr >= 0) {
+        if (lane == 0) {
+            v.blist_s[0] = sr;
+            v.blist_a[0] = 1.0;
+            it->blist_n = 1;
+        }
+    } else {
+        int i_r = v.srow_of_pos[r];
+        double inv = 1.0 / v.sdiag_of_pos[r];
+        if (lane == 0) {
+            v.rv[i_r].x = inv;
+            v.tau[r] = inv * inv;  // tau_S = (rho_S - F tauK)/diag: only row i_r of rho_S is non-zero
+        }
+        int base = v.csr_ptr[i_r], end = v.csr_ptr[i_r + 1];
+        int cnt = 0;
+        for (int e0 = base; e0 < end; e0 += 64) {
+            int e = e0 + lane;
+            bool valid = e < end;
+            int s = -1;
+            double a = 0.0;
+            if (valid) {
+                int loc = v.var_loc[v.csr_col[e]];
+                a = v.csr_val[e];
+                if (loc >= 0) s = v.kslot_of_pos[loc];
+            }
+            bool isk = valid && s >= 0;
+            unsigned long long mask = __ballot(isk);
+            if (isk) {
+                int off = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+                v.blist_s[off] = s;
+                v.blist_a[off] = -a * inv;
+            }
+            cnt += __popcll(mask);
+        }
+        if (lane == 0) it->blist_n = cnt;
+    }
+    if (plan_after && lane == 0) plan_update(v, c, phase);
 }
 
+// ------------------------------------------------------------------- K1 / K6: pricing
+// K1 solver.rs:696-739: argmax over eligible non-basic columns of d^2/gamma (PSE) or |d| (Dantzig).
+// K6 solver.rs:855-917: argmax over infeasible rows of infeas^2/beta.
+__device__ __forceinline__ Cand price_primal_one(double dd, double gm, uint8_t f, int j, int use_pse) {
+    if (((f & NB_AT_MIN) && dd > -EPS) || ((f & NB_AT_MAX) && dd < EPS)) return cand_none();  // solver.rs:705-706
+    return Cand{use_pse ? dd * dd / gm : fabs(dd), j};
+}
+__device__ __forceinline__ Cand price_dual_one(double val, double mn, double mx, double bt, int r, int use_dse) {
+    double infeas;
+    if (val < mn - EPS) infeas = mn - val;
+    else if (val > mx + EPS) infeas = val - mx;
+    else return cand_none();
+    return Cand{use_dse ? infeas * infeas / bt : infeas, r};
+}
+// single thread: open the next iteration with the pricing decision (derived scalars are filled by
+// the head wave of the next kernel, after the kernel boundary has made this launch's stores visible)
+__device__ __forceinline__ void open_iteration(Ctl* c, int phase, Cand best) {
+    IterState* it = &c->it;
+    it->klist_n = 0;
+    it->blist_n = 0;
+    c->up.kase = -1;
+    if (best.idx == NONE_IDX) {
+        it->status = phase == 0 ? ITER_OPTIMAL : ITER_FEASIBLE;
+        it->q = -1;
+        it->r = -1;
+        c->halt = 1;
+        push_rec(c, phase);
+    } else {
+        it->status = ITER_PIVOT;
+        if (phase == 0) {
+            it->q = best.idx;
+            it->r = -1;
+        } else {
+            it->r = best.idx;
+            it->q = -1;
+        }
+    }
+}
+__global__ void __launch_bounds__(BLK) k_price_primal(DevView v, int use_pse) {
+    Ctl* c = v.ctl;
+    if (c->halt) return;
+    Cand best = cand_none();
+    for (int j = blockIdx.x * BLK + threadIdx.x; j < v.n; j += gridDim.x * BLK) {
+        Cand t = price_primal_one(v.d[j], use_pse ? v.gamma[j] : 1.0, v.nbflags[j], j, use_pse);
+        if (cand_better(t, best)) best = t;
+    }
+    if (!grid_best(best, v)) return;
+    if (threadIdx.x == 0) open_iteration(c, 0, best);
+}
+__global__ void __launch_bounds__(BLK) k_price_dual(DevView v, int use_dse) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->forced) return;
+    Cand best = cand_none();
+    for (int r = blockIdx.x * BLK + threadIdx.x; r < v.m; r += gridDim.x * BLK) {
+        Cand t = price_dual_one(v.xB[r], v.loB[r], v.hiB[r], use_dse ? v.beta[r] : 1.0, r, use_dse);
+        if (cand_better(t, best)) best = t;
+    }
+    if (!grid_best(best, v)) return;
+    if (threadIdx.x == 0) open_iteration(c, 1, best);
+}
+
+// ------------------------------------------------------------------- K2: FTRAN of one column
+// alpha_q = B^-1 a_q  (solver.rs:671-677 -> 1305-1319 -> lu.rs:79-106).  B^-1 is held as a
+// singleton split + dense nucleus inverse W (DESIGN.md §3.2), so the solve is:
+//   head   : singleton rows of a_q land directly; entries on nucleus rows become a short list
+//   gather : aK = W[:, list] * coeffs  (only the touched columns of W are read)
+//            + push of -F*aK into the singleton positions (CSC columns of the nucleus basics)
+__global__ void __launch_bounds__(64) k_ftran_prep(DevView v, int derive_primal) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    ftran_prep_wave(v, c, threadIdx.x, derive_primal);
+}
 // push of -x * (column of the basic variable at `p`) into the singleton positions
 template <int G>
 __device__ __forceinline__ void push_F(const DevView& v, int p, double x, double* out_pos, int gl) {
@@ -406,18 +452,6 @@ __global__ void __launch_bounds__(BLK) k_ftran_gather(DevView v) {
         v.alpha_q[p] = acc;
     }
     if (acc != 0.0) push_F<G>(v, p, acc, v.alpha_q, gl);
-}
-template <int G>
-__global__ void __launch_bounds__(BLK) k_tau_push(DevView v) {
-    Ctl* c = v.ctl;
-    if (c->halt || c->it.status != ITER_PIVOT) return;
-    int slot = (blockIdx.x * BLK + threadIdx.x) / G;
-    int gl = threadIdx.x & (G - 1);
-    if (slot >= c->up.kold) return;
-    double x = v.tauK[slot];
-    int p = v.pos_of_kslot[slot];
-    if (gl == 0) v.tau[p] = x;
-    if (x != 0.0) push_F<G>(v, p, x, v.tau, gl);
 }
 
 // ------------------------------------------------------------------- K5: primal Harris ratio test
@@ -460,7 +494,7 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_p1(DevView v, int use_pse)
         c->it.alpha_sq = sq + 1.0;
     }
 }
-// pass 2 (solver.rs:800-853)
+// pass 2 (solver.rs:800-853); the finalising block goes straight on with the BTRAN head + plan
 __global__ void __launch_bounds__(BLK) k_ratio_primal_p2(DevView v) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
@@ -480,9 +514,11 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_p2(DevView v) {
         }
     }
     if (!grid_best(best, v)) return;
+    __shared__ int s_r;
     if (threadIdx.x == 0) {
         int q = it->q;
         double dq = v.d[q];
+        s_r = -1;
         if (best.idx != NONE_IDX) {
             int r = best.idx;
             double coeff = v.alpha_q[r];
@@ -498,6 +534,7 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_p2(DevView v) {
             it->leaving_var = v.basic_vars[r];
             it->pivot_obj = dq / coeff;  // solver.rs:1073
             it->obj += dq * diff;        // solver.rs:1027
+            s_r = r;
         } else if (isinf(it->entering_other)) {
             it->status = ITER_UNBOUNDED;  // solver.rs:842-844
             c->halt = 1;
@@ -512,6 +549,8 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_p2(DevView v) {
             it->status = ITER_FLIP;
         }
     }
+    __syncthreads();
+    if (s_r >= 0 && threadIdx.x < 64) btran_prep_wave(v, c, threadIdx.x, s_r, 0, 1, 0);
 }
 
 // dual path, after FTRAN: the FTRAN-side pivot, ||alpha_q||^2 and y_S (PSE), then the plan
@@ -537,88 +576,140 @@ __global__ void __launch_bounds__(BLK) k_post_ftran(DevView v, int use_pse) {
 // rho = B^-T e_r (solver.rs:680-683 -> 1322-1338).  With W explicit this is one row of W when r
 // is a nucleus position, or a short combination of rows (those nucleus columns that have an
 // entry in the leaving singleton's row, read from the CSR row) otherwise.
-__global__ void __launch_bounds__(64) k_btran_prep(DevView v, int plan_after) {
+__global__ void __launch_bounds__(64) k_btran_prep(DevView v, int derive_dual, int plan_after) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
-    IterState* it = &c->it;
-    int lane = threadIdx.x;
-    int r = it->r;
-    int sr = v.kslot_of_pos[r];
-    if (sr >= 0) {
-        if (lane == 0) {
-            v.blist_s[0] = sr;
-            v.blist_a[0] = 1.0;
-            it->blist_n = 1;
-        }
-    } else {
-        int i_r = v.srow_of_pos[r];
-        double inv = 1.0 / v.sdiag_of_pos[r];
-        if (lane == 0) {
-            v.rv[i_r].x = inv;
-            v.tau[r] = inv * inv;  // tau_S = (rho_S - F tauK)/diag: only row i_r of rho_S is non-zero
-        }
-        int base = v.csr_ptr[i_r], end = v.csr_ptr[i_r + 1];
-        int cnt = 0;
-        for (int e0 = base; e0 < end; e0 += 64) {
-            int e = e0 + lane;
-            bool valid = e < end;
-            int s = -1;
-            double a = 0.0;
-            if (valid) {
-                int loc = v.var_loc[v.csr_col[e]];
-                a = v.csr_val[e];
-                if (loc >= 0) s = v.kslot_of_pos[loc];
-            }
-            bool isk = valid && s >= 0;
-            unsigned long long mask = __ballot(isk);
-            if (isk) {
-                int off = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-                v.blist_s[off] = s;
-                v.blist_a[off] = -a * inv;
-            }
-            cnt += __popcll(mask);
-        }
-        if (lane == 0) it->blist_n = cnt;
-    }
-    if (plan_after && lane == 0) plan_update(v, c, 0);
+    btran_prep_wave(v, c, threadIdx.x, c->it.r, derive_dual, plan_after, 1);
 }
-// rK = sum_j blist_a[j] * W[blist_s[j], :]; rho scatter; ||rho||^2
-__global__ void __launch_bounds__(BLK) k_btran_gather(DevView v) {
+// Horizontally fused: blocks [0, n_gather) do rK = sum_j blist_a[j] * W[blist_s[j], :], the rho
+// scatter and ||rho||^2; the remaining blocks (PSE) build tK = alpha_K - F^T y_S (solver.rs:1114).
+template <int G>
+__global__ void __launch_bounds__(BLK) k_btran(DevView v, int n_gather) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     const int k = c->k;
-    const int n = c->it.blist_n;
-    double sq = 0.0;
-    for (int s = blockIdx.x * BLK + threadIdx.x; s < k; s += gridDim.x * BLK) {
-        double acc = 0.0;
-        for (int j = 0; j < n; ++j) acc += v.blist_a[j] * v.W[(size_t)v.blist_s[j] * v.ld + s];
-        v.rK[s] = acc;
-        v.rv[v.row_of_kslot[s]].x = acc;
-        sq += acc * acc;
-    }
-    if (!grid_sum(sq, v)) return;
-    if (threadIdx.x == 0) {
-        int r = c->it.r;
-        if (v.kslot_of_pos[r] < 0) {
-            double inv = 1.0 / v.sdiag_of_pos[r];
-            sq += inv * inv;
+    if ((int)blockIdx.x < n_gather) {
+        const int n = c->it.blist_n;
+        double sq = 0.0;
+        for (int s = blockIdx.x * BLK + threadIdx.x; s < k; s += n_gather * BLK) {
+            double acc = 0.0;
+            for (int j = 0; j < n; ++j) acc += v.blist_a[j] * v.W[(size_t)v.blist_s[j] * v.ld + s];
+            v.rK[s] = acc;
+            v.rv[v.row_of_kslot[s]].x = acc;
+            sq += acc * acc;
         }
-        c->it.rho_sq = sq;
+        if (!grid_sum(sq, v, n_gather)) return;
+        if (threadIdx.x == 0) {
+            int r = c->it.r;
+            if (v.kslot_of_pos[r] < 0) {
+                double inv = 1.0 / v.sdiag_of_pos[r];
+                sq += inv * inv;
+            }
+            c->it.rho_sq = sq;
+        }
+    } else {
+        int slot = (((int)blockIdx.x - n_gather) * BLK + threadIdx.x) / G;
+        int gl = threadIdx.x & (G - 1);
+        if (slot >= k) return;
+        int p = v.pos_of_kslot[slot];
+        int var = v.basic_vars[p];
+        int end = v.csc_ptr[var + 1];
+        double acc = 0.0;
+        for (int e = v.csc_ptr[var] + gl; e < end; e += G) {
+            int i = v.csc_row[e];
+            if (v.kslot_of_row[i] < 0) acc += v.csc_val[e] * v.rv[i].y;
+        }
+        acc = group_sum<G>(acc);
+        if (gl == 0) v.tK[slot] = v.alpha_q[p] - acc;
     }
+}
+
+// ------------------------------------------------------------------- partition change (DESIGN §3.3)
+// B'^-1[p,i] = B^-1[p,i] - (alpha_p - [p==r]) rho_i / alpha_r, restricted to the new nucleus.
+// The case comes from the device-side plan.  Shrinking keeps the slots compact:
+// W_new[a][b] = W_old[src_row(a)][src_col(b)] with src_row(sr) = last, src_col(cq) = last; all reads
+// come from row/column `last`, all writes go to row sr / column cq, so there is no hazard.
+__device__ __forceinline__ void struct_update_body(const DevView& v, Ctl* c, int s) {
+    const StructUpdate u = c->up;
+    if (u.kase <= 0) return;
+    const int kold = u.kold;
+    const int ld = v.ld;
+    const double inv_alpha = c->it.inv_alpha;
+    if (u.kase == 1) {  // singleton -> nucleus: append row slot kold (position r) and col slot kold (row i_r)
+        if (s < kold) {
+            v.W[(size_t)kold * ld + s] = v.rK[s] * inv_alpha;
+            v.W[(size_t)s * ld + kold] = -v.aK[s] * u.inv_diag_r * inv_alpha;
+        } else if (s == kold) {
+            v.W[(size_t)kold * ld + kold] = u.inv_diag_r * inv_alpha;
+            v.kslot_of_pos[u.r] = kold;
+            v.pos_of_kslot[kold] = u.r;
+            v.kslot_of_row[u.i_r] = kold;
+            v.row_of_kslot[kold] = u.i_r;
+            c->k = kold + 1;
+        }
+    } else if (u.kase == 2) {  // nucleus -> singleton: drop row slot sr and col slot cq
+        const int last = kold - 1;
+        if (s < last) {
+            if (u.sr != last) v.W[(size_t)u.sr * ld + s] = v.W[(size_t)last * ld + (s == u.cq ? last : s)];
+            if (u.cq != last) v.W[(size_t)s * ld + u.cq] = v.W[(size_t)(s == u.sr ? last : s) * ld + last];
+        }
+        if (s == 0) {
+            if (u.sr != last) {
+                int pl = v.pos_of_kslot[last];
+                v.pos_of_kslot[u.sr] = pl;
+                v.kslot_of_pos[pl] = u.sr;
+            }
+            v.kslot_of_pos[u.r] = -1;
+            v.srow_of_pos[u.r] = u.i_q;
+            v.sdiag_of_pos[u.r] = u.diag_q;
+            if (u.cq != last) {
+                int il = v.row_of_kslot[last];
+                v.row_of_kslot[u.cq] = il;
+                v.kslot_of_row[il] = u.cq;
+            }
+            v.kslot_of_row[u.i_q] = -1;
+            v.pos_of_srow[u.i_q] = u.r;
+            c->k = last;
+        }
+    } else if (u.kase == 3) {  // singleton -> singleton on another row: col slot cq now stands for row i_r
+        if (s < kold) v.W[(size_t)s * ld + u.cq] = -v.aK[s] * u.inv_diag_r * inv_alpha;
+        if (s == 0) {
+            v.srow_of_pos[u.r] = u.i_q;
+            v.sdiag_of_pos[u.r] = u.diag_q;
+            v.kslot_of_row[u.i_q] = -1;
+            v.pos_of_srow[u.i_q] = u.r;
+            v.kslot_of_row[u.i_r] = u.cq;
+            v.row_of_kslot[u.cq] = u.i_r;
+        }
+    } else if (u.kase == 4) {  // singleton replaced by another singleton of the same row
+        if (s == 0) v.sdiag_of_pos[u.r] = u.diag_q;
+    }
+}
+__global__ void __launch_bounds__(BLK) k_struct_update(DevView v) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    struct_update_body(v, c, blockIdx.x * BLK + threadIdx.x);
 }
 
 // ------------------------------------------------------------------- K4: tableau row  rho^T N
 // solver.rs:685-692 (and 1117-1132 for the PSE helper).  The reference pushes rows of supp(rho)
 // through the CSR; here every non-basic column PULLS its dot product from the CSC: no atomics,
 // fixed summation order, one streaming pass over A that yields alpha_r and (PSE) N^T v together.
-// G lanes per column, 4 independent (index -> gather) chains per lane per trip; rho and v are
-// interleaved (double2) so one 16-byte gather serves both products.
-// nb_rng[c] caches the CSC range of the column at non-basic position c (one dependent hop instead
-// of three).  (Non-temporal loads on the A stream were measured: 82 us vs 57 us per sweep — worse.)
-template <int G, int U, int MODE>  // U entries per lane per trip; MODE 0: alpha_r, 1: alpha_r + helper, 2: helper
-__global__ void __launch_bounds__(BLK) k_sweep(DevView v) {
-    const Ctl* c = v.ctl;
+// G lanes per column, U independent (index -> gather) chains per lane per trip; rho and v are
+// interleaved (double2) so one 16-byte gather serves both products.  nb_rng[c] caches the CSC
+// range of the column at non-basic position c.  Blocks beyond n_sweep apply the partition change
+// (it touches W and the slot maps only, nothing the sweep reads).
+// Measured (PMC, config 4): 11.9 M L2 requests per launch, 90 % L2 hits, FETCH_SIZE 76 MB — A lives
+// in the 256 MB Infinity Cache and the kernel is bound by the L2 request rate of the 10^7 gathers.
+// Non-temporal loads on the A stream were tried: 82 us vs 57 us (worse).
+template <int G, int U, int MODE>  // MODE 0: alpha_r, 1: alpha_r + helper, 2: helper
+__global__ void __launch_bounds__(BLK) k_sweep(DevView v, int n_sweep) {
+    Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
+    if ((int)blockIdx.x >= n_sweep) {
+        struct_update_body(v, c, ((int)blockIdx.x - n_sweep) * BLK + threadIdx.x);
+        return;
+    }
     int col = (blockIdx.x * BLK + threadIdx.x) / G;
     int gl = threadIdx.x & (G - 1);
     if (col >= v.n) return;
@@ -691,7 +782,8 @@ __global__ void __launch_bounds__(BLK) k_ratio_dual_p1(DevView v) {  // solver.r
     if (!grid_min_sum(mn, dummy, v)) return;
     if (threadIdx.x == 0) c->it.max_step = mn;
 }
-__global__ void __launch_bounds__(BLK) k_ratio_dual_p2(DevView v) {  // solver.rs:979-1021
+// solver.rs:979-1021; the finalising block goes straight on with the FTRAN head
+__global__ void __launch_bounds__(BLK) k_ratio_dual_p2(DevView v) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     IterState* it = &c->it;
@@ -710,34 +802,36 @@ __global__ void __launch_bounds__(BLK) k_ratio_dual_p2(DevView v) {  // solver.r
         }
     }
     if (!grid_best(best, v)) return;
+    __shared__ int s_ok;
     if (threadIdx.x == 0) {
+        s_ok = 0;
         if (best.idx == NONE_IDX) {
             it->status = ITER_INFEASIBLE;
             c->halt = 1;
             push_rec(c, 1);
-            return;
+        } else {
+            int q = best.idx;
+            double coeff = v.alpha_r[q];
+            double dq = v.d[q];
+            double diff = (v.xB[r] - it->leaving_new_val) / coeff;  // solver.rs:1005
+            it->q = q;
+            it->pivot_coeff = coeff;
+            it->entering_diff = diff;
+            it->entering_cur = v.xN[q];
+            it->entering_new_val = v.xN[q] + diff;
+            it->pivot_obj = dq / coeff;
+            it->obj += dq * diff;
+            it->leaving_var = v.basic_vars[r];
+            s_ok = 1;
         }
-        int q = best.idx;
-        double coeff = v.alpha_r[q];
-        double dq = v.d[q];
-        double diff = (v.xB[r] - it->leaving_new_val) / coeff;  // solver.rs:1005
-        it->q = q;
-        it->entering_var = v.nb_vars[q];
-        it->pivot_coeff = coeff;
-        it->entering_diff = diff;
-        it->entering_cur = v.xN[q];
-        it->entering_new_val = v.xN[q] + diff;
-        it->pivot_obj = dq / coeff;
-        it->obj += dq * diff;
-        it->leaving_var = v.basic_vars[r];
     }
+    __syncthreads();
+    if (s_ok && threadIdx.x < 64) ftran_prep_wave(v, c, threadIdx.x, 0);
 }
-
-// ------------------------------------------------------------------- v = B^-T alpha_q, stage 2
-// rhs of the transposed nucleus solve: tK = c_K - F^T y_S (solver.rs:1114; y_S came from pass 1)
+// tK = alpha_K - F^T y_S on its own (dual path with PSE, where it cannot ride on k_btran)
 template <int G>
 __global__ void __launch_bounds__(BLK) k_btran_rhs(DevView v) {
-    const Ctl* c = v.ctl;
+    Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     int slot = (blockIdx.x * BLK + threadIdx.x) / G;
     int gl = threadIdx.x & (G - 1);
@@ -760,7 +854,7 @@ __global__ void __launch_bounds__(BLK) k_btran_rhs(DevView v) {
 //   vK   = W^T * tK        (BTRAN #2 for primal steepest edge, solver.rs:1114)
 //   W   -= (aK - e_r) rK^T / alpha_r   (the eta transformation of solver.rs:1274-1284 applied
 //                                       eagerly: B'^-1 = E B^-1)
-// Block = FW_TR rows x FW_TC columns; per-block partials are reduced by k_fused_reduce in a fixed
+// Block = FW_TR rows x FW_TC columns; per-block partials are reduced by k_post_fused in a fixed
 // order (no float atomics => bitwise reproducible).
 template <bool WITH_TAU, bool WITH_V, bool DO_UPDATE>
 __global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
@@ -847,174 +941,168 @@ __global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
         }
     }
 }
-// fixed-order reduction of the per-block partials; vK is scattered straight into v (by row).
-// Block = 32 slots x 8 stripe groups: each thread sums every 8th stripe, LDS combines the 8 partials
-// in a fixed order (deterministic), so the stripe loop is 8x shorter than one thread per slot.
-template <bool WITH_TAU, bool WITH_V>
-__global__ void __launch_bounds__(BLK) k_fused_reduce(DevView v) {
-    const Ctl* c = v.ctl;
-    if (c->halt || c->it.status != ITER_PIVOT) return;
-    const int k = c->k;
-    const int lane32 = threadIdx.x & 31, grp = threadIdx.x >> 5;  // 8 groups
-    const int i = blockIdx.x * 32 + lane32;
-    if (blockIdx.x * 32 >= k) return;
-    __shared__ double s_part[8][33];
-    const int nstripes = (k + FW_TR - 1) / FW_TR, nchunks = (k + FW_TC - 1) / FW_TC;
-    if (WITH_V) {
-        double s0 = 0.0, s1 = 0.0;
-        if (i < k) {
-            int t = grp;
-            for (; t + 8 < nstripes; t += 16) {
-                s0 += v.part_v[(size_t)t * v.ld + i];
-                s1 += v.part_v[(size_t)(t + 8) * v.ld + i];
-            }
-            if (t < nstripes) s0 += v.part_v[(size_t)t * v.ld + i];
-        }
-        s_part[grp][lane32] = s0 + s1;
-        __syncthreads();
-        if (grp == 0 && i < k) {
-            double s = s_part[0][lane32];
-#pragma unroll
-            for (int g2 = 1; g2 < 8; ++g2) s += s_part[g2][lane32];
-            v.vK[i] = s;
-            v.rv[v.row_of_kslot[i]].y = s;
-        }
-    }
-    if (WITH_TAU && grp == 1 && i < k) {
-        double s = 0.0;
-        for (int j = 0; j < nchunks; ++j) s += v.part_tau[(size_t)j * v.ld + i];
-        v.tauK[i] = s;
-    }
-}
-
-// ------------------------------------------------------------------- partition change (DESIGN §3.3)
-// B'^-1[p,i] = B^-1[p,i] - (alpha_p - [p==r]) rho_i / alpha_r, restricted to the new nucleus.
-// One kernel, the case comes from the device-side plan.  Shrinking keeps the slots compact:
-// W_new[a][b] = W_old[src_row(a)][src_col(b)] with src_row(sr) = last, src_col(cq) = last; all reads
-// come from row/column `last`, all writes go to row sr / column cq, so there is no hazard.
-__global__ void __launch_bounds__(BLK) k_struct_update(DevView v) {
+// After the fused pass (horizontally fused): blocks [0, n_push) finish tau = B^-1 rho by position
+// (tau_K from the per-chunk partials in a fixed order, then the push of -F tau_K, solver.rs:1157);
+// the remaining blocks reduce the v partials in a fixed order and scatter v_K by row (solver.rs:1114).
+template <int G, bool WITH_V>
+__global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
-    const StructUpdate u = c->up;
-    if (u.kase <= 0) return;
-    const int s = blockIdx.x * BLK + threadIdx.x;
-    const int kold = u.kold;
-    const int ld = v.ld;
-    const double inv_alpha = c->it.inv_alpha;
-    if (u.kase == 1) {  // singleton -> nucleus: append row slot kold (position r) and col slot kold (row i_r)
-        if (s < kold) {
-            v.W[(size_t)kold * ld + s] = v.rK[s] * inv_alpha;
-            v.W[(size_t)s * ld + kold] = -v.aK[s] * u.inv_diag_r * inv_alpha;
-        } else if (s == kold) {
-            v.W[(size_t)kold * ld + kold] = u.inv_diag_r * inv_alpha;
-            v.kslot_of_pos[u.r] = kold;
-            v.pos_of_kslot[kold] = u.r;
-            v.kslot_of_row[u.i_r] = kold;
-            v.row_of_kslot[kold] = u.i_r;
-            c->k = kold + 1;
+    const int k = c->k;
+    if ((int)blockIdx.x < n_push) {
+        int slot = (blockIdx.x * BLK + threadIdx.x) / G;
+        int gl = threadIdx.x & (G - 1);
+        if (slot >= k) return;
+        const int nchunks = (k + FW_TC - 1) / FW_TC;
+        double x = 0.0;
+        for (int j = 0; j < nchunks; ++j) x += v.part_tau[(size_t)j * v.ld + slot];
+        int p = v.pos_of_kslot[slot];
+        if (gl == 0) {
+            v.tauK[slot] = x;
+            v.tau[p] = x;
         }
-    } else if (u.kase == 2) {  // nucleus -> singleton: drop row slot sr and col slot cq
-        const int last = kold - 1;
-        if (s < last) {
-            if (u.sr != last) v.W[(size_t)u.sr * ld + s] = v.W[(size_t)last * ld + (s == u.cq ? last : s)];
-            if (u.cq != last) v.W[(size_t)s * ld + u.cq] = v.W[(size_t)(s == u.sr ? last : s) * ld + last];
-        }
-        if (s == 0) {
-            if (u.sr != last) {
-                int pl = v.pos_of_kslot[last];
-                v.pos_of_kslot[u.sr] = pl;
-                v.kslot_of_pos[pl] = u.sr;
-            }
-            v.kslot_of_pos[u.r] = -1;
-            v.srow_of_pos[u.r] = u.i_q;
-            v.sdiag_of_pos[u.r] = u.diag_q;
-            if (u.cq != last) {
-                int il = v.row_of_kslot[last];
-                v.row_of_kslot[u.cq] = il;
-                v.kslot_of_row[il] = u.cq;
-            }
-            v.kslot_of_row[u.i_q] = -1;
-            v.pos_of_srow[u.i_q] = u.r;
-            c->k = last;
-        }
-    } else if (u.kase == 3) {  // singleton -> singleton on another row: col slot cq now stands for row i_r
-        if (s < kold) v.W[(size_t)s * ld + u.cq] = -v.aK[s] * u.inv_diag_r * inv_alpha;
-        if (s == 0) {
-            v.srow_of_pos[u.r] = u.i_q;
-            v.sdiag_of_pos[u.r] = u.diag_q;
-            v.kslot_of_row[u.i_q] = -1;
-            v.pos_of_srow[u.i_q] = u.r;
-            v.kslot_of_row[u.i_r] = u.cq;
-            v.row_of_kslot[u.cq] = u.i_r;
-        }
-    } else if (u.kase == 4) {  // singleton replaced by another singleton of the same row
-        if (s == 0) v.sdiag_of_pos[u.r] = u.diag_q;
+        if (x != 0.0) push_F<G>(v, p, x, v.tau, gl);
+        return;
     }
+    if (!WITH_V) return;
+    // 32 slots x 8 stripe groups per block; LDS combines the 8 partial sums in a fixed order
+    const int b = (int)blockIdx.x - n_push;
+    const int lane32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int i = b * 32 + lane32;
+    if (b * 32 >= k) return;
+    __shared__ double s_part[8][33];
+    const int nstripes = (k + FW_TR - 1) / FW_TR;
+    double s0 = 0.0, s1 = 0.0;
+    if (i < k) {
+        int t = grp;
+        for (; t + 8 < nstripes; t += 16) {
+            s0 += v.part_v[(size_t)t * v.ld + i];
+            s1 += v.part_v[(size_t)(t + 8) * v.ld + i];
+        }
+        if (t < nstripes) s0 += v.part_v[(size_t)t * v.ld + i];
+    }
+    s_part[grp][lane32] = s0 + s1;
+    __syncthreads();
+    if (grp == 0 && i < k) {
+        double sv = s_part[0][lane32];
+#pragma unroll
+        for (int g2 = 1; g2 < 8; ++g2) sv += s_part[g2][lane32];
+        v.vK[i] = sv;
+        v.rv[v.row_of_kslot[i]].y = sv;
+    }
+}
+// v-only reduction for the dense transposed solve of recalc_obj_coeffs
+__global__ void __launch_bounds__(BLK) k_reduce_v(DevView v) {
+    Ctl* c = v.ctl;
+    const int k = c->k;
+    int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= k) return;
+    const int nstripes = (k + FW_TR - 1) / FW_TR;
+    double s = 0.0;
+    for (int t = 0; t < nstripes; ++t) s += v.part_v[(size_t)t * v.ld + i];
+    v.vK[i] = s;
+    v.rv[v.row_of_kslot[i]].y = s;
 }
 
 // ------------------------------------------------------------------- K8: updates after the pivot
 // basic side: solver.rs:1049-1058 (x_B, bounds), 1164-1173 (dual steepest-edge norms)
 // non-basic side: solver.rs:1068-1080 (value/state of the leaving var, reduced costs), 1140-1150 (PSE)
 // bound flip: solver.rs:1031-1042
+// The same pass (a) zeroes this iteration's work vectors behind itself (alpha_q, tau, rho|v are each
+// read for the last time here), and (b) prices the NEXT iteration from the values it has just
+// written (K1 when next_phase = 0, K6 when 1), so neither a memset nor a pricing kernel is needed
+// inside the replayed graph.
 __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int use_dse, int use_pse) {
     Ctl* c = v.ctl;
     if (c->halt) return;
     const IterState* it = &c->it;
     const int status = it->status;
+    if (status != ITER_PIVOT && status != ITER_FLIP) return;
     const int t = blockIdx.x * BLK + threadIdx.x;
-    if (status == ITER_FLIP) {
-        if (t < v.m) {
-            double a = v.alpha_q[t];
-            if (a != 0.0) v.xB[t] -= it->entering_diff * a;
-        }
-        if (t == 0) {
-            int q = it->q, ev = it->entering_var;
-            double nv = it->entering_new_val;
-            v.xN[q] = nv;
-            v.nbflags[q] = (uint8_t)((v.nbflags[q] & NB_FIXED) | (nv == v.var_lo[ev] ? NB_AT_MIN : 0) |
-                                     (nv == v.var_hi[ev] ? NB_AT_MAX : 0));
-            push_rec(c, phase);
-        }
-        return;
-    }
-    if (status != ITER_PIVOT) return;
-    const int r = it->r, q = it->q;
+    const bool flip = status == ITER_FLIP;
+    const int r = flip ? -1 : it->r, q = it->q;
     const double pc = it->pivot_coeff;
+    Cand cand = cand_none();
     if (t < v.m) {
         double a = v.alpha_q[t];
+        double xb = v.xB[t], lo = v.loB[t], hi = v.hiB[t], bt = use_dse ? v.beta[t] : 1.0;
         if (t == r) {
             int ev = it->entering_var;
-            v.xB[r] = it->entering_new_val;
-            v.loB[r] = v.var_lo[ev];
-            v.hiB[r] = v.var_hi[ev];
-            if (use_dse) v.beta[r] = it->rho_sq / (pc * pc);
+            xb = it->entering_new_val;
+            lo = v.var_lo[ev];
+            hi = v.var_hi[ev];
+            v.xB[r] = xb;
+            v.loB[r] = lo;
+            v.hiB[r] = hi;
+            if (use_dse) {
+                bt = it->rho_sq / (pc * pc);
+                v.beta[r] = bt;
+            }
             v.basic_vars[r] = ev;
             v.var_loc[ev] = r;
             v.var_loc[it->leaving_var] = -1 - q;
         } else if (a != 0.0) {
-            v.xB[t] -= it->entering_diff * a;
-            if (use_dse) v.beta[t] += -2.0 * a * v.tau[t] / pc + it->rho_sq * a * a / (pc * pc);
-        }
-    }
-    if (t < v.n) {
-        if (t == q) {
-            int lv = it->leaving_var;
-            double lnv = it->leaving_new_val;
-            v.d[q] = -it->pivot_obj;
-            if (use_pse) v.gamma[q] = it->alpha_sq / (pc * pc);
-            v.nb_vars[q] = lv;
-            v.nb_rng[q] = make_int2(v.csc_ptr[lv], v.csc_ptr[lv + 1]);
-            v.xN[q] = lnv;
-            v.nbflags[q] = (uint8_t)((lnv == v.var_lo[lv] ? NB_AT_MIN : 0) | (lnv == v.var_hi[lv] ? NB_AT_MAX : 0));
-        } else {
-            double ar = v.alpha_r[t];
-            if (ar != 0.0) {
-                v.d[t] -= it->pivot_obj * ar;
-                if (use_pse) v.gamma[t] += -2.0 * ar * v.helper[t] / pc + it->alpha_sq * ar * ar / (pc * pc);
+            xb -= it->entering_diff * a;
+            v.xB[t] = xb;
+            if (use_dse && !flip) {
+                bt += -2.0 * a * v.tau[t] / pc + it->rho_sq * a * a / (pc * pc);
+                v.beta[t] = bt;
             }
         }
+        v.alpha_q[t] = 0.0;
+        v.tau[t] = 0.0;
+        v.rv[t] = make_double2(0.0, 0.0);
+        if (phase == 1 && !c->forced) cand = price_dual_one(xb, lo, hi, bt, t, use_dse);
     }
-    if (t == 0) push_rec(c, phase);
+    if (t < v.n) {
+        double dd = v.d[t], gm = use_pse ? v.gamma[t] : 1.0;
+        uint8_t f = v.nbflags[t];
+        if (t == q) {
+            if (flip) {
+                int ev = it->entering_var;
+                double nv = it->entering_new_val;
+                v.xN[q] = nv;
+                f = (uint8_t)((f & NB_FIXED) | (nv == v.var_lo[ev] ? NB_AT_MIN : 0) | (nv == v.var_hi[ev] ? NB_AT_MAX : 0));
+                v.nbflags[q] = f;
+            } else {
+                int lv = it->leaving_var;
+                double lnv = it->leaving_new_val;
+                dd = -it->pivot_obj;
+                v.d[q] = dd;
+                if (use_pse) {
+                    gm = it->alpha_sq / (pc * pc);
+                    v.gamma[q] = gm;
+                }
+                v.nb_vars[q] = lv;
+                v.nb_rng[q] = make_int2(v.csc_ptr[lv], v.csc_ptr[lv + 1]);
+                v.xN[q] = lnv;
+                f = (uint8_t)((lnv == v.var_lo[lv] ? NB_AT_MIN : 0) | (lnv == v.var_hi[lv] ? NB_AT_MAX : 0));
+                v.nbflags[q] = f;
+            }
+        } else if (!flip) {
+            double ar = v.alpha_r[t];
+            if (ar != 0.0) {
+                dd -= it->pivot_obj * ar;
+                v.d[t] = dd;
+                if (use_pse) {
+                    gm += -2.0 * ar * v.helper[t] / pc + it->alpha_sq * ar * ar / (pc * pc);
+                    v.gamma[t] = gm;
+                }
+            }
+        }
+        if (phase == 0) cand = price_primal_one(dd, gm, f, t, use_pse);
+    }
+    // every block arrives here only after its own updates; the last arriver closes this iteration
+    // (record) and opens the next one with the pricing decision
+    if (!grid_best(cand, v)) return;
+    if (threadIdx.x == 0) {
+        push_rec(c, phase);
+        if (c->forced) {
+            c->halt = 1;  // a host-forced iteration (fix_var) is a single step
+        } else {
+            open_iteration(c, phase, cand);
+        }
+    }
 }
 
 // ------------------------------------------------------------------- helpers outside the pivot graph
@@ -1175,7 +1263,7 @@ __global__ void __launch_bounds__(BLK) k_gj_eliminate(double* Kd, double* Wv, in
     } while (0)
 
 void launch_clear_work(const DevView& hv, hipStream_t st) {
-    // alpha_q | tau | rv are carved from one allocation (engine): a single memset node
+    // alpha_q | tau | rv are carved from one allocation (engine): a single memset
     (void)hipMemsetAsync(hv.alpha_q, 0, sizeof(double) * 4 * (size_t)hv.m, st);
 }
 void launch_price_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st) {
@@ -1184,9 +1272,10 @@ void launch_price_primal(const DevView& dv, const Geom& g, int use_pse, hipStrea
 void launch_price_dual(const DevView& dv, const Geom& g, int use_dse, hipStream_t st) {
     hipLaunchKernelGGL(k_price_dual, dim3(grid_for(g.m)), dim3(BLK), 0, st, dv, use_dse);
 }
-void launch_ftran_col(const DevView& dv, const Geom& g, int plan_after, hipStream_t st) {
-    (void)plan_after;
-    hipLaunchKernelGGL(k_ftran_prep, dim3(1), dim3(64), 0, st, dv);
+void launch_ftran_prep(const DevView& dv, int derive_primal, hipStream_t st) {
+    hipLaunchKernelGGL(k_ftran_prep, dim3(1), dim3(64), 0, st, dv, derive_primal);
+}
+void launch_ftran_gather(const DevView& dv, const Geom& g, hipStream_t st) {
     LANES_SWITCH(g.lanes,
                  hipLaunchKernelGGL(k_ftran_gather<4>, dim3(blocks_for((long)g.cap * 4)), dim3(BLK), 0, st, dv),
                  hipLaunchKernelGGL(k_ftran_gather<16>, dim3(blocks_for((long)g.cap * 16)), dim3(BLK), 0, st, dv),
@@ -1194,22 +1283,39 @@ void launch_ftran_col(const DevView& dv, const Geom& g, int plan_after, hipStrea
 }
 void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st) {
     hipLaunchKernelGGL(k_ratio_primal_p1, dim3(grid_for(g.m)), dim3(BLK), 0, st, dv, use_pse);
-    hipLaunchKernelGGL(k_ratio_primal_p2, dim3(grid_for(g.m)), dim3(BLK), 0, st, dv);
+    hipLaunchKernelGGL(k_ratio_primal_p2, dim3(grid_for(g.m)), dim3(BLK), 0, st, dv);  // + BTRAN head + plan
 }
 void launch_post_ftran(const DevView& dv, const Geom& g, int use_pse, hipStream_t st) {
     hipLaunchKernelGGL(k_post_ftran, dim3(use_pse ? grid_for(g.m) : 1), dim3(BLK), 0, st, dv, use_pse);
 }
-void launch_btran_unit(const DevView& dv, const Geom& g, int plan_after, hipStream_t st) {
-    hipLaunchKernelGGL(k_btran_prep, dim3(1), dim3(64), 0, st, dv, plan_after);
-    hipLaunchKernelGGL(k_btran_gather, dim3(grid_for(g.cap, 1)), dim3(BLK), 0, st, dv);
+void launch_btran_prep(const DevView& dv, int derive_dual, int plan_after, hipStream_t st) {
+    hipLaunchKernelGGL(k_btran_prep, dim3(1), dim3(64), 0, st, dv, derive_dual, plan_after);
 }
-void launch_sweep(const DevView& dv, const Geom& g, int mode, hipStream_t st) {
+void launch_btran(const DevView& dv, const Geom& g, int with_rhs, hipStream_t st) {
+    int n_gather = blocks_for(g.cap);
+    if (n_gather > 512) n_gather = 512;
+#define BTRAN(G)                                                                                           \
+    do {                                                                                                   \
+        int n_rhs = with_rhs ? blocks_for((long)g.cap * G) : 0;                                            \
+        hipLaunchKernelGGL(k_btran<G>, dim3(n_gather + n_rhs), dim3(BLK), 0, st, dv, n_gather);            \
+    } while (0)
+    LANES_SWITCH(g.lanes, BTRAN(4), BTRAN(16), BTRAN(64));
+#undef BTRAN
+}
+void launch_btran_rhs(const DevView& dv, const Geom& g, hipStream_t st) {
+    LANES_SWITCH(g.lanes,
+                 hipLaunchKernelGGL(k_btran_rhs<4>, dim3(blocks_for((long)g.cap * 4)), dim3(BLK), 0, st, dv),
+                 hipLaunchKernelGGL(k_btran_rhs<16>, dim3(blocks_for((long)g.cap * 16)), dim3(BLK), 0, st, dv),
+                 hipLaunchKernelGGL(k_btran_rhs<64>, dim3(blocks_for((long)g.cap * 64)), dim3(BLK), 0, st, dv));
+}
+void launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, hipStream_t st) {
 #define SWEEP(G, U)                                                                                               \
     do {                                                                                                          \
-        dim3 gr(blocks_for((long)g.n * G)), b(BLK);                                                               \
-        if (mode == 0) hipLaunchKernelGGL((k_sweep<G, U, 0>), gr, b, 0, st, dv);                                  \
-        else if (mode == 1) hipLaunchKernelGGL((k_sweep<G, U, 1>), gr, b, 0, st, dv);                             \
-        else hipLaunchKernelGGL((k_sweep<G, U, 2>), gr, b, 0, st, dv);                                            \
+        int n_sweep = blocks_for((long)g.n * G);                                                                  \
+        dim3 gr(n_sweep + (with_struct ? blocks_for(g.cap) : 0)), b(BLK);                                         \
+        if (mode == 0) hipLaunchKernelGGL((k_sweep<G, U, 0>), gr, b, 0, st, dv, n_sweep);                         \
+        else if (mode == 1) hipLaunchKernelGGL((k_sweep<G, U, 1>), gr, b, 0, st, dv, n_sweep);                    \
+        else hipLaunchKernelGGL((k_sweep<G, U, 2>), gr, b, 0, st, dv, n_sweep);                                   \
     } while (0)
     if (g.sweep_variant == 1) { LANES_SWITCH(g.lanes, SWEEP(4, 4), SWEEP(16, 4), SWEEP(32, 4)); }
     else if (g.sweep_variant == 2) { LANES_SWITCH(g.lanes, SWEEP(4, 8), SWEEP(8, 8), SWEEP(32, 8)); }
@@ -1221,30 +1327,23 @@ void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st) {
 }
 void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st) {
     hipLaunchKernelGGL(k_ratio_dual_p1, dim3(grid_for(g.n)), dim3(BLK), 0, st, dv);
-    hipLaunchKernelGGL(k_ratio_dual_p2, dim3(grid_for(g.n)), dim3(BLK), 0, st, dv);
-}
-void launch_btran_rhs(const DevView& dv, const Geom& g, hipStream_t st) {
-    LANES_SWITCH(g.lanes,
-                 hipLaunchKernelGGL(k_btran_rhs<4>, dim3(blocks_for((long)g.cap * 4)), dim3(BLK), 0, st, dv),
-                 hipLaunchKernelGGL(k_btran_rhs<16>, dim3(blocks_for((long)g.cap * 16)), dim3(BLK), 0, st, dv),
-                 hipLaunchKernelGGL(k_btran_rhs<64>, dim3(blocks_for((long)g.cap * 64)), dim3(BLK), 0, st, dv));
+    hipLaunchKernelGGL(k_ratio_dual_p2, dim3(grid_for(g.n)), dim3(BLK), 0, st, dv);  // + FTRAN head
 }
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st) {
     int nstripes = (g.cap + FW_TR - 1) / FW_TR, nchunks = (g.cap + FW_TC - 1) / FW_TC;
     dim3 gr(nstripes, nchunks), b(BLK);
-    if (with_v) {
-        hipLaunchKernelGGL((k_fused_w<true, true, true>), gr, b, 0, st, dv);
-        hipLaunchKernelGGL((k_fused_reduce<true, true>), dim3(blocks_for(g.cap, 32)), b, 0, st, dv);
-    } else {
-        hipLaunchKernelGGL((k_fused_w<true, false, true>), gr, b, 0, st, dv);
-        hipLaunchKernelGGL((k_fused_reduce<true, false>), dim3(blocks_for(g.cap, 32)), b, 0, st, dv);
-    }
+    if (with_v) hipLaunchKernelGGL((k_fused_w<true, true, true>), gr, b, 0, st, dv);
+    else hipLaunchKernelGGL((k_fused_w<true, false, true>), gr, b, 0, st, dv);
 }
-void launch_tau_push(const DevView& dv, const Geom& g, hipStream_t st) {
-    LANES_SWITCH(g.lanes,
-                 hipLaunchKernelGGL(k_tau_push<4>, dim3(blocks_for((long)g.cap * 4)), dim3(BLK), 0, st, dv),
-                 hipLaunchKernelGGL(k_tau_push<16>, dim3(blocks_for((long)g.cap * 16)), dim3(BLK), 0, st, dv),
-                 hipLaunchKernelGGL(k_tau_push<64>, dim3(blocks_for((long)g.cap * 64)), dim3(BLK), 0, st, dv));
+void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st) {
+#define POSTF(G)                                                                                                  \
+    do {                                                                                                          \
+        int n_push = blocks_for((long)g.cap * G);                                                                 \
+        if (with_v) hipLaunchKernelGGL((k_post_fused<G, true>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push); \
+        else hipLaunchKernelGGL((k_post_fused<G, false>), dim3(n_push), dim3(BLK), 0, st, dv, n_push);            \
+    } while (0)
+    LANES_SWITCH(g.lanes, POSTF(4), POSTF(16), POSTF(64));
+#undef POSTF
 }
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st) {
     hipLaunchKernelGGL(k_struct_update, dim3(blocks_for(g.cap)), dim3(BLK), 0, st, dv);
@@ -1263,7 +1362,7 @@ void launch_btran_dense(const DevView& dv, const Geom& g, hipStream_t st) {
     launch_btran_rhs(dv, g, st);
     int nstripes = (g.cap + FW_TR - 1) / FW_TR, nchunks = (g.cap + FW_TC - 1) / FW_TC;
     hipLaunchKernelGGL((k_fused_w<false, true, false>), dim3(nstripes, nchunks), dim3(BLK), 0, st, dv);
-    hipLaunchKernelGGL((k_fused_reduce<false, true>), dim3(blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv);
+    hipLaunchKernelGGL(k_reduce_v, dim3(blocks_for(g.cap)), dim3(BLK), 0, st, dv);
 }
 void launch_recalc_d(const DevView& dv, const Geom& g, hipStream_t st) {
     LANES_SWITCH(g.lanes,
