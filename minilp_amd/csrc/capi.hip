@@ -171,6 +171,7 @@ void mlp_solution_stats(const mlp_solution* s, mlp_stats* o) {
     o->fused_bytes = t.fused_bytes; o->fused_ms = t.fused_ms; o->sweep_bytes = t.sweep_bytes; o->sweep_ms = t.sweep_ms;
     o->fused_launches = t.fused_launches; o->sweep_launches = t.sweep_launches;
     o->solve_wall_s = t.solve_wall_s;
+    o->max_pivot_err = t.max_pivot_err;
 }
 void mlp_solution_reset_stats(mlp_solution* s) {
     guarded([&] { s->eng->resolve_events(); });

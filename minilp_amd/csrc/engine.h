@@ -95,6 +95,7 @@ struct Stats {
     double fused_bytes = 0, fused_ms = 0, sweep_bytes = 0, sweep_ms = 0;
     uint64_t fused_launches = 0, sweep_launches = 0;
     double solve_wall_s = 0;
+    double max_pivot_err = 0;
 };
 
 class Engine {
@@ -163,6 +164,7 @@ private:
     DevBuf<double> d_alpha_r, d_helper;
     DevBuf<int2> d_nb_rng;
     int sweep_variant = 0;
+    double refresh_tol = 1e-7;  // re-invert W when the two-way pivot check disagrees by more than this
     DevBuf<double> d_aK, d_rK, d_tK, d_tauK, d_vK, d_klist_a, d_blist_a, d_part_tau, d_part_v;
     DevBuf<int> d_klist_s, d_blist_s;
     DevBuf<double> d_red_key, d_red_key2;

@@ -69,6 +69,8 @@ Engine::Engine() {
     use_graph = !(ng && ng[0] == '1');
     const char* br = std::getenv("MLP_BRANCH");
     use_branches = br && br[0] == '1';
+    const char* rt = std::getenv("MLP_REFRESH_TOL");
+    if (rt) refresh_tol = std::atof(rt);
     const char* sv = std::getenv("MLP_SWEEP");
     if (sv) sweep_variant = std::atoi(sv);
     const char* bs = std::getenv("MLP_BATCH");
@@ -564,6 +566,9 @@ int Engine::run_loop(int phase) {
                 stats.fused_launches += 1;
             }
         }
+        // drift monitor: the pivot element from FTRAN and from the tableau row must agree
+        if (h_ctl->max_pivot_err > stats.max_pivot_err) stats.max_pivot_err = h_ctl->max_pivot_err;
+        if (res == ITER_PIVOT && !(h_ctl->max_pivot_err <= refresh_tol) && k_ > 0) rebuild_inverse();
         if (res != ITER_PIVOT) return res;
     }
 }

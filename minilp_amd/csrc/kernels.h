@@ -69,6 +69,7 @@ struct Ctl {
     int halt;    // set when an iteration ends the loop (optimal / unbounded / ...): later replays no-op
     int ring_n;  // records written since the host last reset it
     int forced;  // dual iteration with a host-forced row (fix_var): skip dual pricing
+    double max_pivot_err;  // max over the batch of |alpha_q[r] - alpha_r[q]| / max(1,|alpha_q[r]|): drift monitor of W
     PivotRec ring[RING];
 };
 

@@ -1067,6 +1067,12 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
             } else {
                 int lv = it->leaving_var;
                 double lnv = it->leaving_new_val;
+                // the pivot element computed two ways (FTRAN side / BTRAN side) measures the drift of W
+                {
+                    double fa = 1.0 / it->inv_alpha, ba = v.alpha_r[q];
+                    double err = fabs(fa - ba) / fmax(1.0, fabs(fa));
+                    if (err > c->max_pivot_err || err != err) c->max_pivot_err = err;
+                }
                 dd = -it->pivot_obj;
                 v.d[q] = dd;
                 if (use_pse) {
@@ -1126,6 +1132,7 @@ __global__ void k_reset_ring(DevView v) {
     c->ring_n = 0;
     c->halt = 0;
     c->forced = 0;
+    c->max_pivot_err = 0.0;
 }
 // K9: recalc reduced costs (solver.rs:1216-1231): d_c = c_c - a_c . y, then the objective from scratch
 __global__ void __launch_bounds__(BLK) k_gather_basic_obj(DevView v) {
