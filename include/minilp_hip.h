@@ -49,6 +49,12 @@ uint32_t mlp_problem_num_vars(const mlp_problem* p);
 int mlp_problem_add_constraint(mlp_problem* p, const uint32_t* vars, const double* coeffs, uint64_t k,
                                int cmp_op, double rhs);                        /* add_constraint lib.rs:276 */
 int mlp_problem_solve(const mlp_problem* p, mlp_solution** out);               /* solve lib.rs:291 */
+/* read-back of the model data (Problem is plain data in the reference too, lib.rs:194-200) */
+uint64_t mlp_problem_num_constraints(const mlp_problem* p);
+int mlp_problem_var(const mlp_problem* p, uint32_t var, double* obj_coeff, double* min, double* max);
+/* returns the number of terms; copies min(terms, cap) of them (sorted by variable) */
+uint64_t mlp_problem_constraint(const mlp_problem* p, uint64_t c, uint32_t* vars, double* coeffs, uint64_t cap,
+                                int* cmp_op, double* rhs);
 
 /* ---- Solution (lib.rs:332-424) ----------------------------------------------------------- */
 mlp_solution* mlp_solution_clone(const mlp_solution* s);  /* #[derive(Clone)] lib.rs:313: deep copy of device state */

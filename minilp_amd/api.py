@@ -69,6 +69,9 @@ def lib():
     sig("mlp_problem_num_vars", u32, vp)
     sig("mlp_problem_add_constraint", i32, vp, pu32, pdbl, u64, i32, dbl)
     sig("mlp_problem_solve", i32, vp, C.POINTER(vp))
+    sig("mlp_problem_num_constraints", u64, vp)
+    sig("mlp_problem_var", i32, vp, u32, pdbl, pdbl, pdbl)
+    sig("mlp_problem_constraint", u64, vp, u64, pu32, pdbl, u64, C.POINTER(i32), pdbl)
     sig("mlp_problem_solve_ex", i32, vp, C.POINTER(vp), i64, u32)
     sig("mlp_solution_continue", i32, vp, i64)
     sig("mlp_solution_budget_exhausted", i32, vp)
@@ -160,6 +163,27 @@ class Problem:
         idx = np.ascontiguousarray(idx, dtype=np.uint32)
         val = np.ascontiguousarray(val, dtype=np.float64)
         _raise(lib().mlp_problem_add_constraint(self._h, _p(idx, C.c_uint32), _p(val, C.c_double), len(idx), cmp_op, rhs))
+
+    def variables(self):
+        """[(obj_coeff, min, max)] as given to add_var."""
+        o, a, b = C.c_double(), C.c_double(), C.c_double()
+        res = []
+        for v in range(self.num_vars):
+            _raise(lib().mlp_problem_var(self._h, v, C.byref(o), C.byref(a), C.byref(b)))
+            res.append((o.value, a.value, b.value))
+        return res
+
+    def constraints(self):
+        """[(vars, coeffs, cmp_op, rhs)] with terms sorted by variable (sprs CsVec order, lib.rs:279)."""
+        res = []
+        op, rhs = C.c_int(), C.c_double()
+        for c in range(lib().mlp_problem_num_constraints(self._h)):
+            k = lib().mlp_problem_constraint(self._h, c, None, None, 0, C.byref(op), C.byref(rhs))
+            idx = np.zeros(k, dtype=np.uint32)
+            val = np.zeros(k, dtype=np.float64)
+            lib().mlp_problem_constraint(self._h, c, _p(idx, C.c_uint32), _p(val, C.c_double), k, C.byref(op), C.byref(rhs))
+            res.append((idx, val, op.value, rhs.value))
+        return res
 
     def solve(self, budget=-1, trace=False, profile=False):
         out = C.c_void_p()

@@ -69,6 +69,26 @@ uint32_t mlp_problem_num_vars(const mlp_problem* p) { return (uint32_t)p->pd.obj
 int mlp_problem_add_constraint(mlp_problem* p, const uint32_t* vars, const double* coeffs, uint64_t k, int op, double rhs) {
     return guarded([&] { p->pd.add_constraint(vars, coeffs, k, op, rhs); });
 }
+uint64_t mlp_problem_num_constraints(const mlp_problem* p) { return p->pd.cons.size(); }
+int mlp_problem_var(const mlp_problem* p, uint32_t var, double* obj, double* mn, double* mx) {
+    return guarded([&] {
+        if (var >= p->pd.obj.size()) throw MlpError(MLP_EINVAL, "variable out of range");
+        *obj = p->pd.direction == 1 ? -p->pd.obj[var] : p->pd.obj[var];
+        *mn = p->pd.lo[var];
+        *mx = p->pd.hi[var];
+    });
+}
+uint64_t mlp_problem_constraint(const mlp_problem* p, uint64_t ci, uint32_t* vars, double* coeffs, uint64_t cap, int* op, double* rhs) {
+    if (ci >= p->pd.cons.size()) return 0;
+    const Constraint& c = p->pd.cons[ci];
+    if (op) *op = c.op;
+    if (rhs) *rhs = c.rhs;
+    for (size_t i = 0; i < c.idx.size() && i < cap; ++i) {
+        vars[i] = (uint32_t)c.idx[i];
+        coeffs[i] = c.val[i];
+    }
+    return c.idx.size();
+}
 int mlp_problem_solve_ex(const mlp_problem* p, mlp_solution** out, int64_t budget, uint32_t flags) {
     *out = nullptr;
     mlp_solution* s = new mlp_solution();

@@ -153,6 +153,7 @@ private:
     hipStream_t st = nullptr, st2 = nullptr;  // st2: side branch of the iteration graph
     hipEvent_t evFork[3] = {nullptr, nullptr, nullptr}, evJoin[3] = {nullptr, nullptr, nullptr};
     uint64_t batches_run = 0;
+    int eager_iters_in_geom = 0;
     DevBuf<int> d_cptr, d_crow, d_rptr, d_rcol;
     DevBuf<double> d_cval, d_rval, d_lo, d_hi, d_obj;
     DevBuf<int> d_var_loc, d_basic_vars, d_nb_vars;

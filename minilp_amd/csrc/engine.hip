@@ -137,6 +137,7 @@ DevView* Engine::sync_view() {
     if (std::memcmp(&old, &hview, sizeof(DevView)) != 0) {
         HIPCHECK(hipStreamSynchronize(st));
         drop_graphs();  // kernel arguments (the view, by value) are baked into the captured graphs
+        eager_iters_in_geom = 0;
     }
     view_dirty = false;
     return &hview;
@@ -531,7 +532,14 @@ int Engine::run_loop(int phase) {
         // launch stream (sweep and fused pass), the others are graph replays as usual
         const bool sample = profile && (batches_run % 8 == 0);
         batches_run += 1;
-        int B = (use_graph && !sample) ? batch : 1;
+        // Capturing a graph costs milliseconds and is invalidated by every add_constraint (m changes),
+        // so short warm-start re-solves run eagerly; the graph is captured once the same geometry has
+        // survived a few iterations.
+        sync_view();
+        const bool have_graph = gexec[phase][enable_pse ? 1 : 0] != nullptr;
+        const bool graph_now = use_graph && !sample && (have_graph || eager_iters_in_geom >= 4);
+        if (!have_graph) eager_iters_in_geom += 1;
+        int B = graph_now ? batch : 1;
         if (pivot_budget > 0 && (int64_t)B > pivot_budget) B = (int)pivot_budget;
         ensure_nucleus_cap(k_ + B + 1);
         sync_view();
@@ -540,7 +548,7 @@ int Engine::run_loop(int phase) {
         launch_clear_work(dv, st);
         if (phase == 0) launch_price_primal(dv, geom(), enable_pse ? 1 : 0, st);  // opens the first iteration
         else launch_price_dual(dv, geom(), enable_dse ? 1 : 0, st);
-        if (use_graph && !sample) {
+        if (graph_now) {
             hipGraphExec_t ge = get_graph(phase);
             for (int i = 0; i < B; ++i) HIPCHECK(hipGraphLaunch(ge, st));
         } else {

@@ -112,9 +112,11 @@ def build_problem(problem_cls, lp):
     return p
 
 
-def to_mps(lp):
-    """Free-format MPS text of an instance (mps.rs reader; always the Minimize convention of
-    examples/solve_mps.rs:32 is up to the caller — the objective row is written as given)."""
+def to_mps(lp, ranges=None):
+    """Free-format MPS text of an instance (mps.rs reader).  `ranges`: optional {row: R} entries
+    written to a RANGES section (mps.rs:306-321 turns each into a >= row and a <= row).
+    Bounds that free-format MPS as read by the reference cannot express (-inf lower with a
+    non-negative finite upper) are rejected."""
     m, n = lp["m"], lp["n"]
     out = [f"NAME {lp['name']}", "ROWS", " N COST"]
     tag = {EQ: "E", LE: "L", GE: "G"}
@@ -129,12 +131,20 @@ def to_mps(lp):
     for j in range(n):
         if lp["obj"][j] != 0.0 or not rows_of[j]:
             out.append(f"    X{j} COST {float(lp['obj'][j])!r}")
-        for i, a in rows_of[j]:
-            out.append(f"    X{j} R{i} {a!r}")
+        pairs = rows_of[j]
+        for t in range(0, len(pairs), 2):  # one or two (row, value) pairs per line
+            line = f"    X{j} R{pairs[t][0]} {pairs[t][1]!r}"
+            if t + 1 < len(pairs):
+                line += f" R{pairs[t + 1][0]} {pairs[t + 1][1]!r}"
+            out.append(line)
     out.append("RHS")
     for i in range(m):
         if lp["rhs"][i] != 0.0:
             out.append(f"    RHS R{i} {float(lp['rhs'][i])!r}")
+    if ranges:
+        out.append("RANGES")
+        for i, r in sorted(ranges.items()):
+            out.append(f"    RNG R{i} {float(r)!r}")
     out.append("BOUNDS")
     for j in range(n):
         lo, hi = float(lp["lo"][j]), float(lp["hi"][j])
@@ -142,9 +152,13 @@ def to_mps(lp):
             out.append(f" FR BND X{j}")
         elif lo == hi:
             out.append(f" FX BND X{j} {lo!r}")
+        elif lo == -np.inf:
+            if hi >= 0.0:
+                raise ValueError("(-inf, ub>=0] is not expressible for the reference's MPS reader")
+            out.append(f" UP BND X{j} {hi!r}")
         else:
             if lo != 0.0:
-                out.append(f" LO BND X{j} {lo!r}" if lo != -np.inf else f" LO BND X{j} -1e30")
+                out.append(f" LO BND X{j} {lo!r}")
             if hi != np.inf:
                 out.append(f" UP BND X{j} {hi!r}")
     out.append("ENDATA")

@@ -26,6 +26,7 @@ CASES = [
     ("mixed", dict(m=100, n=150, k=6, seed=3)),
     ("mixed", dict(m=300, n=400, k=8, seed=4)),
     ("mixed", dict(m=1000, n=1500, k=6, seed=5)),
+    ("mixed", dict(m=6000, n=10000, k=4, seed=3)),   # BASELINE config 3 stand-in: ~10k vars, sparse, via MPS
 ]
 GEN = {"sparse": lpgen.gen_sparse_lp, "dense": lpgen.gen_dense_lp, "mixed": lpgen.gen_mixed_lp}
 
