@@ -32,6 +32,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=4)
     ap.add_argument("--cpu-pivots", type=int, default=300, help="bounded CPU-baseline sample (pivots after warm-up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--independent", action="store_true",
+                    help="N > 1: one independent LP per rank (weak scaling) instead of column-block sharded pricing of ONE LP")
     return ap.parse_args()
 
 
@@ -62,23 +64,44 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
+    oversub = world > 1 and torch.cuda.device_count() < world  # test rigs with fewer GPUs than ranks
+    dev_index = 0 if oversub else (local_rank if world > 1 else 0)
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if oversub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+    red_dev = "cpu" if oversub else "cuda"
     import minilp_amd as M
     from minilp_amd import lpgen
-    M.set_device(local_rank if world > 1 else 0)
+    M.set_device(dev_index)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # N > 1: every rank pivots its own instance of the same family (independent LPs, no data-path
-    # collective) => weak scaling.  Rank 0 solves the BASELINE seed.
-    lp = lpgen.gen_sparse_lp(a.rows, a.cols, a.nnz_per_row, a.seed + rank)
+    # N > 1 (default): ONE LP, its pricing path (tableau-row sweep K4, d/gamma update K8, pricing scan
+    # K1) sharded over disjoint blocks of non-basic positions, candidates exchanged once per pivot
+    #  => strong scaling.  --independent: one LP per rank, no data-path exchange => weak.
+    from minilp_amd import dist as mdist
+    sharded = world > 1 and not a.independent
+    lp = lpgen.gen_sparse_lp(a.rows, a.cols, a.nnz_per_row, a.seed + (0 if sharded or world == 1 else rank))
     p = lpgen.build_problem(M.Problem, lp)
     s = p.solve(budget=0, profile=True)
+    mailbox = None
+    if sharded:
+        ok = 1
+        try:
+            mailbox = mdist.setup_sharding(s, dist)
+        except Exception as e:  # every rank must take the same branch
+            print(f"[rank {rank}] sharding unavailable: {e}", file=sys.stderr, flush=True)
+            ok = 0
+        t_ok = torch.tensor([ok], dtype=torch.int32, device=red_dev)
+        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        if int(t_ok.item()) == 0:
+            raise SystemExit("sharded pricing could not be set up on every rank; rerun with --independent")
     s.continue_solve(a.warmup)           # W untimed warm-up pivots
     s.reset_stats()
     barrier()
@@ -89,12 +112,12 @@ def main():
     st = s.stats()
     done = st["iterations"]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        c = torch.tensor([float(done)], dtype=torch.float64, device="cuda")
+        c = torch.tensor([float(done)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        total = float(c.item())
+        total = float(c.item()) / world if sharded else float(c.item())   # sharded: every rank counts the same pivots
     else:
         total = float(done)
     if rank == 0:
@@ -117,13 +140,17 @@ def main():
                             algorithmic_bytes_per_launch=kern[dom]["algorithmic_bytes_per_launch"],
                             other_kernels={k: v for k, v in kern.items() if k != dom})
         out = dict(metric="simplex pivots/sec", value=total / dt, unit="pivots/s", n_gpus=world, steps=a.steps,
-                   warmup=a.warmup, ms_per_step=dt * 1e3 / max(done, 1), higher_is_better=True, scaling="weak",
+                   warmup=a.warmup, ms_per_step=dt * 1e3 / max(done, 1), higher_is_better=True,
+                   scaling=("strong" if sharded else "weak"),
                    vs_baseline=None, dtype="f64", data="synthetic",
                    config=dict(workload=f"config 4: random LP {a.rows} vars x {a.cols} constraints, {a.nnz_per_row} nnz/row "
                                         f"(0.1% fill), Max c'x, Ax<=b, x>=0; primal simplex with PSE+DSE from the slack basis; "
                                         f"timed pivots {a.warmup}..{a.warmup + a.steps}",
                                rows=a.rows, cols=a.cols, nnz=int(st["nnz"]), seed=a.seed,
-                               parallelism=("1 GPU" if world == 1 else f"{world} GPUs, one independent LP of the family per rank"),
+                               parallelism=("1 GPU" if world == 1 else
+                                            (f"{world} GPUs: one LP, pricing path sharded over {world} column blocks, "
+                                             f"per-pivot candidate exchange through a host-mapped mailbox; FTRAN/BTRAN/W replicated"
+                                             if sharded else f"{world} GPUs, one independent LP of the family per rank")) + (" [oversubscribed test rig: all ranks on one GPU]" if oversub else ""),
                                nucleus_size_at_end=int(st["nucleus_size"]), objective_at_end=s.objective(),
                                completed_steps=int(done), bound_flips=int(st["bound_flips"])),
                    roofline=roofline)
@@ -132,6 +159,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        if mailbox and rank == 0:
+            mdist.remove_mailbox(mailbox)
         dist.destroy_process_group()
 
 

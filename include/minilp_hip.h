@@ -80,6 +80,15 @@ int mlp_solution_budget_exhausted(const mlp_solution* s);
  * solver.rs:1286-1303); returns max |W_incremental - W_fresh| through *max_diff when non-NULL. */
 int mlp_solution_reinvert(mlp_solution* s, double* max_diff);
 
+/* Column-block sharding of the pricing path across the GPUs of one node (one process per GPU,
+ * DESIGN.md §6).  Every rank builds the SAME problem, calls mlp_problem_solve_ex(budget = 0), then
+ * this function with its rank, the world size and the name of a POSIX shared-memory mailbox of
+ * 256 * world zeroed bytes created by the launcher, and then the same sequence of
+ * mlp_solution_continue calls.  Rank r owns non-basic positions [n*r/world, n*(r+1)/world): its
+ * tableau-row sweep, d/gamma update and pricing scan cover only that block; candidates are exchanged
+ * through the mailbox once per pivot.  Primal simplex loop only; the Solution mutators are refused. */
+int mlp_solution_enable_sharding(mlp_solution* s, int rank, int world, const char* shm_name);
+
 typedef struct mlp_stats {
     uint64_t iterations, basis_changes, bound_flips, primal_iters, dual_iters, reinversions;
     uint64_t num_constraints, num_total_vars, nucleus_size, nucleus_capacity, nnz;

@@ -76,6 +76,7 @@ def lib():
     sig("mlp_solution_continue", i32, vp, i64)
     sig("mlp_solution_budget_exhausted", i32, vp)
     sig("mlp_solution_reinvert", i32, vp, pdbl)
+    sig("mlp_solution_enable_sharding", i32, vp, i32, i32, C.c_char_p)
     sig("mlp_solution_clone", vp, vp)
     sig("mlp_solution_free", None, vp)
     sig("mlp_solution_objective", dbl, vp)
@@ -265,6 +266,10 @@ class Solution:
     @property
     def budget_exhausted(self):
         return bool(lib().mlp_solution_budget_exhausted(self._h))
+
+    def enable_sharding(self, rank, world, shm_name):
+        """Column-block sharding of the pricing path (include/minilp_hip.h); see minilp_amd.dist."""
+        _raise(lib().mlp_solution_enable_sharding(self._h, int(rank), int(world), shm_name.encode()))
 
     def reinvert(self):
         d = C.c_double()

@@ -36,6 +36,9 @@ static int guarded(F f) {
         return MLP_EINVAL;
     }
 }
+static void refuse_if_sharded(mlp_solution* s) {
+    if (s->eng->sharded()) throw MlpError(MLP_EINVAL, "not available on a sharded solution");
+}
 static int consume_on_error(mlp_solution** s, int st) {  // lib.rs:359, 385
     if (st != 0) {
         delete *s;
@@ -120,6 +123,10 @@ int mlp_solution_reinvert(mlp_solution* s, double* max_diff) {
     });
 }
 
+int mlp_solution_enable_sharding(mlp_solution* s, int rank, int world, const char* shm_name) {
+    return guarded([&] { s->eng->enable_sharding(rank, world, shm_name); });
+}
+
 mlp_solution* mlp_solution_clone(const mlp_solution* s) {
     mlp_solution* c = new mlp_solution();
     int st = guarded([&] { c->eng = s->eng->clone(); });
@@ -153,6 +160,7 @@ int mlp_solution_add_constraint(mlp_solution** s, const uint32_t* vars, const do
         ProblemData tmp;
         tmp.obj.resize((*s)->eng->num_vars);  // lib.rs:376: dimension = num_vars
         tmp.add_constraint(vars, coeffs, k, op, rhs);
+        refuse_if_sharded(*s);
         (*s)->eng->pivot_budget = -1;
         (*s)->eng->add_constraint(tmp.cons[0]);
     }));
@@ -160,6 +168,7 @@ int mlp_solution_add_constraint(mlp_solution** s, const uint32_t* vars, const do
 int mlp_solution_fix_var(mlp_solution** s, uint32_t var, double val) {
     return consume_on_error(s, guarded([&] {
         if ((int)var >= (*s)->eng->num_vars) throw MlpError(MLP_EINVAL, "variable out of range (lib.rs:391)");
+        refuse_if_sharded(*s);
         (*s)->eng->pivot_budget = -1;
         (*s)->eng->fix_var((int)var, val);
     }));
@@ -167,6 +176,7 @@ int mlp_solution_fix_var(mlp_solution** s, uint32_t var, double val) {
 int mlp_solution_unfix_var(mlp_solution** s, uint32_t var, int* was_fixed) {
     return consume_on_error(s, guarded([&] {
         if ((int)var >= (*s)->eng->num_vars) throw MlpError(MLP_EINVAL, "variable out of range (lib.rs:400)");
+        refuse_if_sharded(*s);
         (*s)->eng->pivot_budget = -1;
         *was_fixed = (*s)->eng->unfix_var((int)var) ? 1 : 0;
     }));
@@ -174,6 +184,7 @@ int mlp_solution_unfix_var(mlp_solution** s, uint32_t var, int* was_fixed) {
 int mlp_solution_add_gomory_cut(mlp_solution** s, uint32_t var) {
     return consume_on_error(s, guarded([&] {
         if ((int)var >= (*s)->eng->num_vars) throw MlpError(MLP_EINVAL, "variable out of range (lib.rs:420)");
+        refuse_if_sharded(*s);
         (*s)->eng->pivot_budget = -1;
         (*s)->eng->add_gomory_cut((int)var);
     }));

@@ -116,6 +116,8 @@ public:
     double cur_obj_val();                                                   // solver.rs:51
     Engine* clone();                                                        // #[derive(Clone)] solver.rs:14
     double reinvert(bool replace);  // from-scratch nucleus inversion; returns max |W - W_fresh|
+    void enable_sharding(int rank, int world, const char* shm_name);  // column-block pricing across ranks
+    bool sharded() const { return shard_world > 1; }
 
     int num_vars = 0;
     int direction = 0;
@@ -165,6 +167,10 @@ private:
     DevBuf<double> d_alpha_r, d_helper;
     DevBuf<int2> d_nb_rng;
     int sweep_variant = 0;
+    int shard_rank = 0, shard_world = 1;
+    MailRec* d_mail = nullptr;
+    void* mail_host = nullptr;
+    size_t mail_bytes = 0;
     double refresh_tol = 1e-7;  // re-invert W when the two-way pivot check disagrees by more than this
     DevBuf<double> d_aK, d_rK, d_tK, d_tauK, d_vK, d_klist_a, d_blist_a, d_part_tau, d_part_v;
     DevBuf<int> d_klist_s, d_blist_s;

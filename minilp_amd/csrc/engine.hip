@@ -12,6 +12,11 @@
 #include <cstring>
 #include <limits>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 namespace mlp {
 
 static const double INF = std::numeric_limits<double>::infinity();
@@ -82,6 +87,10 @@ Engine::~Engine() {
     for (auto& e : ev)
         if (e) (void)hipEventDestroy(e);
     if (h_ctl) (void)hipHostFree(h_ctl);
+    if (mail_host) {
+        (void)hipHostUnregister(mail_host);
+        (void)munmap(mail_host, mail_bytes);
+    }
     for (int i = 0; i < 3; ++i) {
         if (evFork[i]) (void)hipEventDestroy(evFork[i]);
         if (evJoin[i]) (void)hipEventDestroy(evJoin[i]);
@@ -134,6 +143,9 @@ DevView* Engine::sync_view() {
     v.red_key = d_red_key.p; v.red_key2 = d_red_key2.p; v.red_idx = d_red_idx.p; v.ticket = d_ticket.p;
     v.ctl = d_ctl.p;
     v.nb_rng = d_nb_rng.p;
+    v.rank = shard_rank; v.world = shard_world; v.mail = d_mail;
+    v.nb_lo = shard_world > 1 ? (int)((long)num_vars * shard_rank / shard_world) : 0;
+    v.nb_hi = shard_world > 1 ? (int)((long)num_vars * (shard_rank + 1) / shard_world) : num_vars;
     if (std::memcmp(&old, &hview, sizeof(DevView)) != 0) {
         HIPCHECK(hipStreamSynchronize(st));
         drop_graphs();  // kernel arguments (the view, by value) are baked into the captured graphs
@@ -237,6 +249,37 @@ void Engine::push_maps() {
     d_pos_of_kslot.upload(h_pos_of_kslot, st); d_row_of_kslot.upload(h_row_of_kslot, st);
     HIPCHECK(hipMemcpyAsync(&d_ctl.p->k, &k_, sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHECK(hipStreamSynchronize(st));
+    view_dirty = true;
+}
+
+// ------------------------------------------------------------------ column-block sharding
+// The mailbox is a POSIX shared-memory object created (zeroed) by the launcher; every rank maps it
+// and registers it with HIP so that kernels on every GPU read and write the same host pages.
+void Engine::enable_sharding(int rank, int world, const char* shm_name) {
+    if (world < 1 || rank < 0 || rank >= world) throw MlpError(-1, "enable_sharding: bad rank/world");
+    HIPCHECK(hipStreamSynchronize(st));
+    if (world == 1) {
+        shard_rank = 0; shard_world = 1; d_mail = nullptr;
+        view_dirty = true;
+        return;
+    }
+    size_t bytes = sizeof(MailRec) * 4 * (size_t)world;
+    int fd = shm_open(shm_name, O_RDWR, 0600);
+    if (fd < 0) throw MlpError(-1, std::string("enable_sharding: shm_open failed for ") + shm_name);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < bytes) {
+        close(fd);
+        throw MlpError(-1, "enable_sharding: mailbox object too small");
+    }
+    void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) throw MlpError(-1, "enable_sharding: mmap failed");
+    HIPCHECK(hipHostRegister(p, bytes, hipHostRegisterMapped));
+    void* dp = nullptr;
+    HIPCHECK(hipHostGetDevicePointer(&dp, p, 0));
+    mail_host = p; mail_bytes = bytes;
+    d_mail = reinterpret_cast<MailRec*>(dp);
+    shard_rank = rank; shard_world = world;
     view_dirty = true;
 }
 
@@ -523,6 +566,8 @@ int Engine::process_records(int phase, int launched) {
 }
 
 int Engine::run_loop(int phase) {
+    if (shard_world > 1 && phase != 0)
+        throw MlpError(-1, "sharded pricing covers the primal simplex loop only (DESIGN.md §6)");
     for (;;) {
         if (pivot_budget == 0) {
             budget_exhausted = true;
@@ -602,6 +647,7 @@ void Engine::optimize() {
     if (budget_exhausted) return;
     if (res == ITER_UNBOUNDED) throw LpFail{2};
     if (res == ITER_SINGULAR) throw MlpError(-2, "singular basis (solver.rs:1301)");
+    if (res == ITER_COMM) throw MlpError(-3, "sharded pricing: a peer rank did not answer (mailbox spin bound)");
     if (res != ITER_OPTIMAL) throw MlpError(-3, "primal loop ended with unexpected status " + std::to_string(res));
     dual_feasible = true;
 }

@@ -22,6 +22,7 @@ enum IterStatus : int {
     ITER_INFEASIBLE = 5,  // dual: no entering column (solver.rs:1019)
     ITER_SINGULAR = 6,    // partition plan found two singleton columns on one row
     ITER_NONE = 7,        // nothing recorded (halted replay)
+    ITER_COMM = 8,        // sharded mode: a peer did not answer within the spin bound
 };
 
 // Per-iteration scalars, written by kernels.
@@ -69,8 +70,16 @@ struct Ctl {
     int halt;    // set when an iteration ends the loop (optimal / unbounded / ...): later replays no-op
     int ring_n;  // records written since the host last reset it
     int forced;  // dual iteration with a host-forced row (fix_var): skip dual pricing
+    unsigned long long xepoch[2];  // sharded mode: exchange counters (kind 0: pricing, kind 1: ratio decision)
     double max_pivot_err;  // max over the batch of |alpha_q[r] - alpha_r[q]| / max(1,|alpha_q[r]|): drift monitor of W
     PivotRec ring[RING];
+};
+
+// Sharded pricing: one 64-byte mailbox record per (kind, parity, rank) in host
+// memory mapped into every rank's GPU; a rank writes only its own slot and polls the others.
+struct alignas(64) MailRec {
+    unsigned long long epoch;
+    double f[7];
 };
 
 // Non-basic flags (solver.rs:66-70 NonBasicVarState + nb_var_is_fixed)
@@ -120,6 +129,9 @@ struct DevView {
     // reductions
     double* red_key; double* red_key2; int* red_idx; unsigned* ticket;
     Ctl* ctl;
+    // column-block sharding of the pricing path: this rank owns non-basic positions [nb_lo, nb_hi)
+    int nb_lo, nb_hi, rank, world;
+    MailRec* mail;  // [2 kinds][2 parities][world], null when world == 1
 };
 
 // fused pass tiling

@@ -137,6 +137,66 @@ __device__ __forceinline__ bool grid_best(Cand& c, const DevView& v) {
     if (threadIdx.x == 0) *v.ticket = 0;
     return true;
 }
+// arg-best with a payload travelling with the winner (used by pricing: the winner's reduced cost
+// must come through the reduction, not through a re-read of memory another block has just written)
+__device__ __forceinline__ void wave_best_p(Cand& c, double& pay) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Cand t;
+        t.key = __shfl_down(c.key, o, 64);
+        t.idx = __shfl_down(c.idx, o, 64);
+        double tp = __shfl_down(pay, o, 64);
+        if (cand_better(t, c)) {
+            c = t;
+            pay = tp;
+        }
+    }
+}
+__device__ __forceinline__ void block_best_p(Cand& c, double& pay) {  // result valid in thread 0
+    __shared__ double s_key[BLK / 64], s_pay[BLK / 64];
+    __shared__ int s_idx[BLK / 64];
+    wave_best_p(c, pay);
+    int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) {
+        s_key[w] = c.key;
+        s_idx[w] = c.idx;
+        s_pay[w] = pay;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < BLK / 64; ++i) {
+            Cand t{s_key[i], s_idx[i]};
+            if (cand_better(t, c)) {
+                c = t;
+                pay = s_pay[i];
+            }
+        }
+    }
+}
+__device__ __forceinline__ bool grid_best_p(Cand& c, double& pay, const DevView& v) {
+    block_best_p(c, pay);
+    if (threadIdx.x == 0) {
+        st_agent(&v.red_key[blockIdx.x], c.key);
+        st_agent(&v.red_idx[blockIdx.x], c.idx);
+        st_agent(&v.red_key2[blockIdx.x], pay);
+    }
+    if (!last_block_arrives(v.ticket, gridDim.x)) return false;
+    Cand x = cand_none();
+    double xp = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) {
+        Cand t{ld_agent(&v.red_key[i]), ld_agent(&v.red_idx[i])};
+        if (cand_better(t, x)) {
+            x = t;
+            xp = ld_agent(&v.red_key2[i]);
+        }
+    }
+    block_best_p(x, xp);
+    c = x;
+    pay = xp;
+    if (threadIdx.x == 0) *v.ticket = 0;
+    return true;
+}
 // grid-wide (min, sum) pair in one pass
 __device__ __forceinline__ bool grid_min_sum(double& mn, double& sm, const DevView& v) {
     mn = block_min(mn);
@@ -200,6 +260,89 @@ __device__ __forceinline__ void push_rec(Ctl* c, int phase) {  // single thread
         r.obj = c->it.obj;
     }
     c->ring_n = n + 1;
+}
+
+// ---- sharded pricing: mailbox exchange between the ranks of one solve (one thread) ------------
+// Records live in host memory mapped into every GPU (fine-grained, system-scope coherent).  A rank
+// writes only its own slot (payload, then the epoch with system-scope release) and polls the other
+// slots for the same epoch; two parity buffers per kind keep a fast rank from overwriting a record
+// a slow rank has not read yet.  Spins are bounded: a missing peer ends the solve with ITER_COMM.
+__device__ __forceinline__ MailRec* mail_slot(const DevView& v, int kind, unsigned long long epoch, int rank) {
+    return v.mail + ((size_t)(kind * 2 + (int)(epoch & 1ull)) * v.world + rank);
+}
+__device__ __forceinline__ void mail_post(MailRec* slot, unsigned long long epoch, const double* f) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) __hip_atomic_store(&slot->f[i], f[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&slot->epoch, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ bool mail_wait(MailRec* slot, unsigned long long epoch, double* f) {
+    for (long spins = 0;; ++spins) {
+        if (__hip_atomic_load(&slot->epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == epoch) break;
+        if (spins > 60000000L) return false;  // ~10+ s
+        __builtin_amdgcn_s_sleep(4);
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) f[i] = __hip_atomic_load(&slot->f[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return true;
+}
+__device__ __forceinline__ void comm_fail(Ctl* c, int phase) {
+    c->it.status = ITER_COMM;
+    c->halt = 1;
+    push_rec(c, phase);
+}
+// all-gather of the per-shard pricing candidates, run by ONE WAVE: lane r polls rank r's slot (one
+// PCIe round trip for all peers), then the wave reduces them identically on every rank
+// (score desc, position asc) and adopts the winner's reduced cost d_q.  Result valid in lane 0.
+__device__ bool exchange_best_wave(const DevView& v, Ctl* c, int phase, Cand& best, double dq_local, int lane) {
+    if (v.world <= 1) return true;
+    unsigned long long ep = c->xepoch[0] + 1ull;
+    if (lane == 0) {
+        double f[7] = {best.key, (double)best.idx, dq_local, 0.0, 0.0, 0.0, 0.0};
+        mail_post(mail_slot(v, 0, ep, v.rank), ep, f);
+    }
+    Cand g = cand_none();
+    double dq = 0.0;
+    int owner = -1;
+    bool ok = true;
+    for (int r2 = lane; r2 < v.world; r2 += 64) {
+        Cand t = best;
+        double td = dq_local;
+        if (r2 != v.rank) {
+            double h[7];
+            if (!mail_wait(mail_slot(v, 0, ep, r2), ep, h)) ok = false;
+            t = Cand{h[0], (int)h[1]};
+            td = h[2];
+        }
+        if (owner < 0 || cand_better(t, g)) {
+            g = t;
+            dq = td;
+            owner = r2;
+        }
+    }
+    ok = __all(ok);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Cand t;
+        t.key = __shfl_down(g.key, o, 64);
+        t.idx = __shfl_down(g.idx, o, 64);
+        double td = __shfl_down(dq, o, 64);
+        int to = __shfl_down(owner, o, 64);
+        if (to >= 0 && (owner < 0 || cand_better(t, g))) {
+            g = t;
+            dq = td;
+            owner = to;
+        }
+    }
+    if (lane == 0) {
+        c->xepoch[0] = ep;
+        if (!ok) {
+            comm_fail(c, phase);
+        } else {
+            if (g.idx != NONE_IDX && owner != v.rank) v.d[g.idx] = dq;  // non-owners hold no valid d outside their block
+            best = g;
+        }
+    }
+    return ok;
 }
 
 // Partition-change plan, run by ONE thread once q, r and the final alpha_q are
@@ -387,16 +530,44 @@ __device__ __forceinline__ void open_iteration(Ctl* c, int phase, Cand best) {
         }
     }
 }
+// Finalising block of a pricing reduction: optionally close the current iteration (record), then
+// open the next one with the (sharded: globally exchanged) pricing decision.
+__device__ __forceinline__ void close_and_open(const DevView& v, Ctl* c, int phase, Cand best, double pay, bool close_current) {
+    __shared__ double s_key, s_pay;
+    __shared__ int s_idx, s_go;
+    if (threadIdx.x == 0) {
+        if (close_current) push_rec(c, phase);
+        s_go = 1;
+        if (close_current && c->forced) {
+            c->halt = 1;  // a host-forced iteration (fix_var) is a single step
+            s_go = 0;
+        }
+        s_key = best.key;
+        s_idx = best.idx;
+        s_pay = pay;
+    }
+    __syncthreads();
+    if (!s_go || threadIdx.x >= 64) return;
+    Cand b{s_key, s_idx};
+    bool ok = true;
+    if (phase == 0) ok = exchange_best_wave(v, c, phase, b, s_pay, threadIdx.x);
+    if (threadIdx.x == 0 && ok) open_iteration(c, phase, b);
+}
 __global__ void __launch_bounds__(BLK) k_price_primal(DevView v, int use_pse) {
     Ctl* c = v.ctl;
     if (c->halt) return;
     Cand best = cand_none();
-    for (int j = blockIdx.x * BLK + threadIdx.x; j < v.n; j += gridDim.x * BLK) {
-        Cand t = price_primal_one(v.d[j], use_pse ? v.gamma[j] : 1.0, v.nbflags[j], j, use_pse);
-        if (cand_better(t, best)) best = t;
+    double pay = 0.0;
+    for (int j = v.nb_lo + blockIdx.x * BLK + threadIdx.x; j < v.nb_hi; j += gridDim.x * BLK) {
+        double dj = v.d[j];
+        Cand t = price_primal_one(dj, use_pse ? v.gamma[j] : 1.0, v.nbflags[j], j, use_pse);
+        if (cand_better(t, best)) {
+            best = t;
+            pay = dj;
+        }
     }
-    if (!grid_best(best, v)) return;
-    if (threadIdx.x == 0) open_iteration(c, 0, best);
+    if (!grid_best_p(best, pay, v)) return;
+    close_and_open(v, c, 0, best, pay, false);
 }
 __global__ void __launch_bounds__(BLK) k_price_dual(DevView v, int use_dse) {
     Ctl* c = v.ctl;
@@ -516,37 +687,64 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_p2(DevView v) {
     if (!grid_best(best, v)) return;
     __shared__ int s_r;
     if (threadIdx.x == 0) {
-        int q = it->q;
-        double dq = v.d[q];
-        s_r = -1;
+        const int q = it->q;
+        const double dq = v.d[q];
+        // decide locally without side effects ...
+        int status = ITER_PIVOT, r = -1;
+        double coeff = 0.0, lnv = 0.0, diff = 0.0, enew = 0.0, pobj = 0.0;
         if (best.idx != NONE_IDX) {
-            int r = best.idx;
-            double coeff = v.alpha_q[r];
+            r = best.idx;
+            coeff = v.alpha_q[r];
             bool tm;
             leaving_step(v, r, coeff, sign, tm);
-            double lnv = tm ? v.hiB[r] : v.loB[r];
-            double diff = (v.xB[r] - lnv) / coeff;  // solver.rs:828
+            lnv = tm ? v.hiB[r] : v.loB[r];
+            diff = (v.xB[r] - lnv) / coeff;  // solver.rs:828
+            enew = it->entering_cur + diff;
+            pobj = dq / coeff;               // solver.rs:1073
+        } else if (isinf(it->entering_other)) {
+            status = ITER_UNBOUNDED;         // solver.rs:842-844
+        } else {
+            status = ITER_FLIP;              // solver.rs:846-851
+            diff = it->entering_other - it->entering_cur;
+            enew = it->entering_other;
+        }
+        // ... in sharded mode every rank adopts rank 0's decision (alpha_q is replicated, but its
+        // float atomics make it reproducible only to rounding; the decision must be identical)
+        bool ok = true;
+        if (v.world > 1) {
+            const unsigned long long ep = ++c->xepoch[1];
+            if (v.rank == 0) {
+                double f[7] = {(double)status, (double)r, coeff, lnv, diff, enew, pobj};
+                mail_post(mail_slot(v, 1, ep, 0), ep, f);
+            } else {
+                double h[7];
+                ok = mail_wait(mail_slot(v, 1, ep, 0), ep, h);
+                if (ok) {
+                    status = (int)h[0]; r = (int)h[1]; coeff = h[2]; lnv = h[3]; diff = h[4]; enew = h[5]; pobj = h[6];
+                } else {
+                    comm_fail(c, 0);
+                }
+            }
+        }
+        s_r = -1;
+        if (ok) {
+            it->status = status;
             it->r = r;
             it->pivot_coeff = coeff;
             it->leaving_new_val = lnv;
             it->entering_diff = diff;
-            it->entering_new_val = it->entering_cur + diff;
-            it->leaving_var = v.basic_vars[r];
-            it->pivot_obj = dq / coeff;  // solver.rs:1073
-            it->obj += dq * diff;        // solver.rs:1027
-            s_r = r;
-        } else if (isinf(it->entering_other)) {
-            it->status = ITER_UNBOUNDED;  // solver.rs:842-844
-            c->halt = 1;
-            push_rec(c, 0);
-        } else {
-            double diff = it->entering_other - it->entering_cur;  // solver.rs:846-851
-            it->r = -1;
-            it->entering_new_val = it->entering_other;
-            it->entering_diff = diff;
-            it->pivot_coeff = 0.0;
-            it->obj += dq * diff;
-            it->status = ITER_FLIP;
+            it->entering_new_val = enew;
+            it->pivot_obj = pobj;
+            if (status == ITER_UNBOUNDED) {
+                c->halt = 1;
+                push_rec(c, 0);
+            } else {
+                it->obj += dq * diff;  // solver.rs:1027
+                if (status == ITER_PIVOT) {
+                    it->leaving_var = v.basic_vars[r];
+                    s_r = r;
+                }
+            }
         }
     }
     __syncthreads();
@@ -710,9 +908,9 @@ __global__ void __launch_bounds__(BLK) k_sweep(DevView v, int n_sweep) {
         struct_update_body(v, c, ((int)blockIdx.x - n_sweep) * BLK + threadIdx.x);
         return;
     }
-    int col = (blockIdx.x * BLK + threadIdx.x) / G;
+    int col = v.nb_lo + (blockIdx.x * BLK + threadIdx.x) / G;
     int gl = threadIdx.x & (G - 1);
-    if (col >= v.n) return;
+    if (col >= v.nb_hi) return;
     const int2 rg = v.nb_rng[col];
     const int beg = rg.x, end = rg.y;
     double a1 = 0.0, a2 = 0.0;
@@ -1023,6 +1221,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
     const int r = flip ? -1 : it->r, q = it->q;
     const double pc = it->pivot_coeff;
     Cand cand = cand_none();
+    double cand_d = 0.0;
     if (t < v.m) {
         double a = v.alpha_q[t];
         double xb = v.xB[t], lo = v.loB[t], hi = v.hiB[t], bt = use_dse ? v.beta[t] : 1.0;
@@ -1068,7 +1267,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                 int lv = it->leaving_var;
                 double lnv = it->leaving_new_val;
                 // the pivot element computed two ways (FTRAN side / BTRAN side) measures the drift of W
-                {
+                if (q >= v.nb_lo && q < v.nb_hi) {
                     double fa = 1.0 / it->inv_alpha, ba = v.alpha_r[q];
                     double err = fabs(fa - ba) / fmax(1.0, fabs(fa));
                     if (err > c->max_pivot_err || err != err) c->max_pivot_err = err;
@@ -1085,7 +1284,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                 f = (uint8_t)((lnv == v.var_lo[lv] ? NB_AT_MIN : 0) | (lnv == v.var_hi[lv] ? NB_AT_MAX : 0));
                 v.nbflags[q] = f;
             }
-        } else if (!flip) {
+        } else if (!flip && t >= v.nb_lo && t < v.nb_hi) {
             double ar = v.alpha_r[t];
             if (ar != 0.0) {
                 dd -= it->pivot_obj * ar;
@@ -1096,19 +1295,15 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                 }
             }
         }
-        if (phase == 0) cand = price_primal_one(dd, gm, f, t, use_pse);
+        if (phase == 0 && t >= v.nb_lo && t < v.nb_hi) {
+            cand = price_primal_one(dd, gm, f, t, use_pse);
+            cand_d = dd;
+        }
     }
     // every block arrives here only after its own updates; the last arriver closes this iteration
     // (record) and opens the next one with the pricing decision
-    if (!grid_best(cand, v)) return;
-    if (threadIdx.x == 0) {
-        push_rec(c, phase);
-        if (c->forced) {
-            c->halt = 1;  // a host-forced iteration (fix_var) is a single step
-        } else {
-            open_iteration(c, phase, cand);
-        }
-    }
+    if (!grid_best_p(cand, cand_d, v)) return;
+    close_and_open(v, c, phase, cand, cand_d, true);
 }
 
 // ------------------------------------------------------------------- helpers outside the pivot graph
@@ -1274,7 +1469,7 @@ void launch_clear_work(const DevView& hv, hipStream_t st) {
     (void)hipMemsetAsync(hv.alpha_q, 0, sizeof(double) * 4 * (size_t)hv.m, st);
 }
 void launch_price_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st) {
-    hipLaunchKernelGGL(k_price_primal, dim3(grid_for(g.n)), dim3(BLK), 0, st, dv, use_pse);
+    hipLaunchKernelGGL(k_price_primal, dim3(grid_for(dv.nb_hi - dv.nb_lo)), dim3(BLK), 0, st, dv, use_pse);
 }
 void launch_price_dual(const DevView& dv, const Geom& g, int use_dse, hipStream_t st) {
     hipLaunchKernelGGL(k_price_dual, dim3(grid_for(g.m)), dim3(BLK), 0, st, dv, use_dse);
@@ -1318,7 +1513,7 @@ void launch_btran_rhs(const DevView& dv, const Geom& g, hipStream_t st) {
 void launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, hipStream_t st) {
 #define SWEEP(G, U)                                                                                               \
     do {                                                                                                          \
-        int n_sweep = blocks_for((long)g.n * G);                                                                  \
+        int n_sweep = blocks_for((long)(dv.nb_hi - dv.nb_lo) * G);                                                \
         dim3 gr(n_sweep + (with_struct ? blocks_for(g.cap) : 0)), b(BLK);                                         \
         if (mode == 0) hipLaunchKernelGGL((k_sweep<G, U, 0>), gr, b, 0, st, dv, n_sweep);                         \
         else if (mode == 1) hipLaunchKernelGGL((k_sweep<G, U, 1>), gr, b, 0, st, dv, n_sweep);                    \

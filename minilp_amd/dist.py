@@ -1,0 +1,62 @@
+"""One-process-per-GPU helpers for the sharded pricing path.
+
+Control plane only (no arithmetic): the mailbox that the pivot kernels use is a POSIX shared-memory
+object, created and zeroed by rank 0; `torch.distributed` (RCCL on GPUs, gloo in the CPU tests)
+carries its name, the barriers and the timing reductions.
+"""
+import os
+import uuid
+
+MAILREC_BYTES = 64
+KINDS, PARITIES = 2, 2
+
+
+def mailbox_bytes(world):
+    return MAILREC_BYTES * KINDS * PARITIES * world
+
+
+def shard_range(n, rank, world):
+    """Non-basic positions [lo, hi) owned by `rank` — must match Engine::sync_view."""
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def create_mailbox(world, name=None):
+    """Rank 0: create a zero-filled shared-memory object; returns its shm name ('/mlp_<uuid>')."""
+    name = name or "/mlp_" + uuid.uuid4().hex[:16]
+    path = "/dev/shm" + name
+    with open(path, "wb") as f:
+        f.write(b"\0" * mailbox_bytes(world))
+    return name
+
+
+def remove_mailbox(name):
+    try:
+        os.unlink("/dev/shm" + name)
+    except OSError:
+        pass
+
+
+def setup_sharding(solution, dist=None):
+    """Call on every rank after `Problem.solve(budget=0)`: agree on a mailbox and enable sharding.
+    `dist` is torch.distributed (initialised) or None for a single process.  Returns the mailbox name
+    (rank 0 should remove it at the end)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return None
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [create_mailbox(world) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    solution.enable_sharding(rank, world, box[0])
+    dist.barrier()
+    return box[0]
+
+
+def combine_candidates(cands):
+    """Reference implementation of the on-device candidate reduction (score desc, position asc;
+    position -1 = no candidate) — used by the CPU tests to pin the tie-break rule."""
+    best = (-float("inf"), -1)
+    for score, pos in cands:
+        if pos < 0:
+            continue
+        if best[1] < 0 or score > best[0] or (score == best[0] and pos < best[1]):
+            best = (score, pos)
+    return best

@@ -1,0 +1,79 @@
+"""CPU (gloo, world_size 2): the control plane of the sharded pricing path — mailbox creation and
+name broadcast, block partition, and the mailbox protocol itself (post own slot, poll peers, reduce
+with the device's tie-break rule) emulated on the mapped shared-memory object the kernels use."""
+import os
+import struct
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from minilp_amd import dist as md
+
+
+def test_shard_ranges_partition_positions():
+    for n in (1, 7, 100000, 100003):
+        for world in (1, 2, 3, 8):
+            rs = [md.shard_range(n, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+            assert max(hi - lo for lo, hi in rs) - min(hi - lo for lo, hi in rs) <= 1
+
+
+def test_combine_candidates_tie_break():
+    assert md.combine_candidates([(1.0, 5), (2.0, 9), (2.0, 3), (0.5, -1)]) == (2.0, 3)   # score desc, position asc
+    assert md.combine_candidates([(-1.0, -1), (-1.0, -1)])[1] == -1
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    box = [md.create_mailbox(world) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    name = box[0]
+    path = "/dev/shm" + name
+    assert os.path.getsize(path) == md.mailbox_bytes(world)
+    mm = np.memmap(path, dtype=np.uint8, mode="r+")
+    rec = md.MAILREC_BYTES
+
+    def slot(kind, epoch, r):
+        return (kind * 2 + (epoch & 1)) * world * rec + r * rec
+
+    results = []
+    for epoch in range(1, 6):  # five pricing exchanges with the device protocol
+        score, pos = float((rank * 7 + epoch * 3) % 5), rank * 10 + epoch
+        off = slot(0, epoch, rank)
+        mm[off + 8: off + 24] = np.frombuffer(struct.pack("<dd", score, float(pos)), dtype=np.uint8)  # payload first
+        mm[off: off + 8] = np.frombuffer(struct.pack("<Q", epoch), dtype=np.uint8)                      # epoch last
+        cands = []
+        for r2 in range(world):
+            o2 = slot(0, epoch, r2)
+            t0 = time.time()
+            while struct.unpack("<Q", bytes(mm[o2: o2 + 8]))[0] != epoch:
+                assert time.time() - t0 < 20
+            sc, ps = struct.unpack("<dd", bytes(mm[o2 + 8: o2 + 24]))
+            cands.append((sc, int(ps)))
+        results.append(md.combine_candidates(cands))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, results)
+    if rank == 0:
+        q.put(all(g == gathered[0] for g in gathered) and len(results) == 5)
+        md.remove_mailbox(name)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_mailbox_protocol_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, 29641, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
