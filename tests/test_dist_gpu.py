@@ -1,0 +1,20 @@
+"""GPU: the sharded pricing path with 2 and 3 ranks (processes) sharing the one visible GPU — the
+mailbox lives in host memory, so the full device-side exchange protocol runs.  Gate:
+the sharded run picks the identical pivot sequence to the unsharded run."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.common import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world,pivots", [(2, 600), (3, 400)])
+def test_sharded_pricing_matches_unsharded_pivot_for_pivot(world, pivots):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_test.py"), str(world), "4000", "3500", "12", str(pivots)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "traces identical: True" in r.stdout

@@ -55,7 +55,7 @@ if __name__ == "__main__":
     m, n, k, pivots = (int(x) for x in (sys.argv[2:6] if len(sys.argv) > 5 else (3000, 3000, 12, 400)))
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, world, 29533, m, n, k, pivots, out)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, 29533 + world, m, n, k, pivots, out)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
