@@ -135,7 +135,7 @@ struct DevView {
 };
 
 // fused pass tiling
-constexpr int FW_TR = 16;    // rows per block
+constexpr int FW_TR = 8;     // minimum rows per block (sizes the partial buffers; kernels use 8 or 16)
 constexpr int FW_TC = 1024;  // columns per block (256 threads x 4)
 
 // Launch geometry that is baked into a captured graph.

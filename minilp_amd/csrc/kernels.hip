@@ -1054,15 +1054,15 @@ __global__ void __launch_bounds__(BLK) k_btran_rhs(DevView v) {
 //                                       eagerly: B'^-1 = E B^-1)
 // Block = FW_TR rows x FW_TC columns; per-block partials are reduced by k_post_fused in a fixed
 // order (no float atomics => bitwise reproducible).
-template <bool WITH_TAU, bool WITH_V, bool DO_UPDATE>
+template <int TR, bool WITH_TAU, bool WITH_V, bool DO_UPDATE>
 __global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
     const Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     const int k = c->k, ld = v.ld;
-    const int row0 = blockIdx.x * FW_TR;
+    const int row0 = blockIdx.x * TR;
     const int col0 = blockIdx.y * FW_TC;
     if (row0 >= k || col0 >= k) return;
-    __shared__ double s_tau[FW_TR][BLK / 64];
+    __shared__ double s_tau[TR][BLK / 64];
     const int tid = threadIdx.x;
     int cidx[4];
     cidx[0] = col0 + 2 * tid;
@@ -1075,11 +1075,11 @@ __global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
     const double inv_alpha = DO_UPDATE ? c->it.inv_alpha : 0.0;
     const int rslot = DO_UPDATE ? c->up.sr : -1;
     double vacc[4] = {0.0, 0.0, 0.0, 0.0};
-    double tacc[FW_TR];
+    double tacc[TR];
     const bool pair0 = cidx[1] < k, pair1 = cidx[3] < k;
     const bool one0 = cidx[0] < k, one1 = cidx[2] < k;
 #pragma unroll
-    for (int a = 0; a < FW_TR; ++a) {
+    for (int a = 0; a < TR; ++a) {
         int row = row0 + a;
         tacc[a] = 0.0;
         if (row >= k) continue;
@@ -1124,12 +1124,12 @@ __global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
     if (WITH_TAU) {
         int wv = tid >> 6, l = tid & 63;
 #pragma unroll
-        for (int a = 0; a < FW_TR; ++a) {
+        for (int a = 0; a < TR; ++a) {
             double s = wave_sum(tacc[a]);
             if (l == 0) s_tau[a][wv] = s;
         }
         __syncthreads();
-        if (tid < FW_TR) {
+        if (tid < TR) {
             int row = row0 + tid;
             if (row < k) {
                 double s = s_tau[tid][0];
@@ -1142,7 +1142,7 @@ __global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
 // After the fused pass (horizontally fused): blocks [0, n_push) finish tau = B^-1 rho by position
 // (tau_K from the per-chunk partials in a fixed order, then the push of -F tau_K, solver.rs:1157);
 // the remaining blocks reduce the v partials in a fixed order and scatter v_K by row (solver.rs:1114).
-template <int G, bool WITH_V>
+template <int G, bool WITH_V, int TR>
 __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
@@ -1169,7 +1169,7 @@ __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push) {
     const int i = b * 32 + lane32;
     if (b * 32 >= k) return;
     __shared__ double s_part[8][33];
-    const int nstripes = (k + FW_TR - 1) / FW_TR;
+    const int nstripes = (k + TR - 1) / TR;
     double s0 = 0.0, s1 = 0.0;
     if (i < k) {
         int t = grp;
@@ -1190,12 +1190,13 @@ __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push) {
     }
 }
 // v-only reduction for the dense transposed solve of recalc_obj_coeffs
+template <int TR>
 __global__ void __launch_bounds__(BLK) k_reduce_v(DevView v) {
     Ctl* c = v.ctl;
     const int k = c->k;
     int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= k) return;
-    const int nstripes = (k + FW_TR - 1) / FW_TR;
+    const int nstripes = (k + TR - 1) / TR;
     double s = 0.0;
     for (int t = 0; t < nstripes; ++t) s += v.part_v[(size_t)t * v.ld + i];
     v.vK[i] = s;
@@ -1531,18 +1532,28 @@ void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st) {
     hipLaunchKernelGGL(k_ratio_dual_p1, dim3(grid_for(g.n)), dim3(BLK), 0, st, dv);
     hipLaunchKernelGGL(k_ratio_dual_p2, dim3(grid_for(g.n)), dim3(BLK), 0, st, dv);  // + FTRAN head
 }
+// rows per tile of the fused pass: 8 while W is small (more blocks in flight, 14 vs 20 us at
+// k = 1 800), 16 from cap 8192 on (half the v partials; measured 5.0-5.2 TB/s at k = 6 500 either way)
+static inline int fw_tr(const Geom& g) { return g.cap <= 4096 ? 8 : 16; }
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st) {
-    int nstripes = (g.cap + FW_TR - 1) / FW_TR, nchunks = (g.cap + FW_TC - 1) / FW_TC;
+    const int tr = fw_tr(g);
+    int nstripes = (g.cap + tr - 1) / tr, nchunks = (g.cap + FW_TC - 1) / FW_TC;
     dim3 gr(nstripes, nchunks), b(BLK);
-    if (with_v) hipLaunchKernelGGL((k_fused_w<true, true, true>), gr, b, 0, st, dv);
-    else hipLaunchKernelGGL((k_fused_w<true, false, true>), gr, b, 0, st, dv);
+    if (tr == 8) {
+        if (with_v) hipLaunchKernelGGL((k_fused_w<8, true, true, true>), gr, b, 0, st, dv);
+        else hipLaunchKernelGGL((k_fused_w<8, true, false, true>), gr, b, 0, st, dv);
+    } else {
+        if (with_v) hipLaunchKernelGGL((k_fused_w<16, true, true, true>), gr, b, 0, st, dv);
+        else hipLaunchKernelGGL((k_fused_w<16, true, false, true>), gr, b, 0, st, dv);
+    }
 }
 void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st) {
 #define POSTF(G)                                                                                                  \
     do {                                                                                                          \
         int n_push = blocks_for((long)g.cap * G);                                                                 \
-        if (with_v) hipLaunchKernelGGL((k_post_fused<G, true>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push); \
-        else hipLaunchKernelGGL((k_post_fused<G, false>), dim3(n_push), dim3(BLK), 0, st, dv, n_push);            \
+        if (with_v && fw_tr(g) == 8) hipLaunchKernelGGL((k_post_fused<G, true, 8>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push); \
+        else if (with_v) hipLaunchKernelGGL((k_post_fused<G, true, 16>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push); \
+        else hipLaunchKernelGGL((k_post_fused<G, false, 16>), dim3(n_push), dim3(BLK), 0, st, dv, n_push);        \
     } while (0)
     LANES_SWITCH(g.lanes, POSTF(4), POSTF(16), POSTF(64));
 #undef POSTF
@@ -1562,9 +1573,9 @@ void launch_btran_dense(const DevView& dv, const Geom& g, hipStream_t st) {
     // c_B by position -> alpha_q, y_S -> rv.y; then tK, vK = W^T tK, scatter into rv.y
     hipLaunchKernelGGL(k_gather_basic_obj, dim3(blocks_for(g.m)), dim3(BLK), 0, st, dv);
     launch_btran_rhs(dv, g, st);
-    int nstripes = (g.cap + FW_TR - 1) / FW_TR, nchunks = (g.cap + FW_TC - 1) / FW_TC;
-    hipLaunchKernelGGL((k_fused_w<false, true, false>), dim3(nstripes, nchunks), dim3(BLK), 0, st, dv);
-    hipLaunchKernelGGL(k_reduce_v, dim3(blocks_for(g.cap)), dim3(BLK), 0, st, dv);
+    int nstripes = (g.cap + 16 - 1) / 16, nchunks = (g.cap + FW_TC - 1) / FW_TC;
+    hipLaunchKernelGGL((k_fused_w<16, false, true, false>), dim3(nstripes, nchunks), dim3(BLK), 0, st, dv);
+    hipLaunchKernelGGL(k_reduce_v<16>, dim3(blocks_for(g.cap)), dim3(BLK), 0, st, dv);
 }
 void launch_recalc_d(const DevView& dv, const Geom& g, hipStream_t st) {
     LANES_SWITCH(g.lanes,
