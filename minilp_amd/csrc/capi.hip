@@ -1,6 +1,7 @@
 // capi.hip — extern "C" boundary (include/minilp_hip.h).  No C++ exception crosses the ABI.
 #include "../../include/minilp_hip.h"
 
+#include <cmath>
 #include <cstring>
 #include <string>
 
@@ -39,8 +40,11 @@ static int guarded(F f) {
 static void refuse_if_sharded(mlp_solution* s) {
     if (s->eng->sharded()) throw MlpError(MLP_EINVAL, "not available on a sharded solution");
 }
+static void require(mlp_solution** s) {
+    if (!s || !*s) throw MlpError(MLP_EINVAL, "NULL solution (consumed by a failed mutator?)");
+}
 static int consume_on_error(mlp_solution** s, int st) {  // lib.rs:359, 385
-    if (st != 0) {
+    if (st != 0 && s && *s) {
         delete *s;
         *s = nullptr;
     }
@@ -138,25 +142,29 @@ mlp_solution* mlp_solution_clone(const mlp_solution* s) {
 }
 void mlp_solution_free(mlp_solution* s) { delete s; }
 double mlp_solution_objective(const mlp_solution* s) {  // lib.rs:334-339
+    if (!s) return std::nan("");
     double v = 0.0;
     guarded([&] { v = s->eng->cur_obj_val(); });
     return s->eng->direction == 1 ? -v : v;
 }
-uint32_t mlp_solution_num_vars(const mlp_solution* s) { return (uint32_t)s->eng->num_vars; }
+uint32_t mlp_solution_num_vars(const mlp_solution* s) { return s ? (uint32_t)s->eng->num_vars : 0; }
 int mlp_solution_var_value(const mlp_solution* s, uint32_t var, double* out) {
     return guarded([&] {
+        if (!s) throw MlpError(MLP_EINVAL, "NULL solution (consumed by a failed mutator?)");
         if ((int)var >= s->eng->num_vars) throw MlpError(MLP_EINVAL, "variable out of range (lib.rs:345)");
         *out = s->eng->get_value((int)var);
     });
 }
 int mlp_solution_values(const mlp_solution* s, double* out, uint32_t n) {
     return guarded([&] {
+        if (!s) throw MlpError(MLP_EINVAL, "NULL solution (consumed by a failed mutator?)");
         if ((int)n > s->eng->num_vars) throw MlpError(MLP_EINVAL, "too many values requested");
         s->eng->get_values(out, (int)n);
     });
 }
 int mlp_solution_add_constraint(mlp_solution** s, const uint32_t* vars, const double* coeffs, uint64_t k, int op, double rhs) {
     return consume_on_error(s, guarded([&] {
+        require(s);
         ProblemData tmp;
         tmp.obj.resize((*s)->eng->num_vars);  // lib.rs:376: dimension = num_vars
         tmp.add_constraint(vars, coeffs, k, op, rhs);
@@ -167,6 +175,7 @@ int mlp_solution_add_constraint(mlp_solution** s, const uint32_t* vars, const do
 }
 int mlp_solution_fix_var(mlp_solution** s, uint32_t var, double val) {
     return consume_on_error(s, guarded([&] {
+        require(s);
         if ((int)var >= (*s)->eng->num_vars) throw MlpError(MLP_EINVAL, "variable out of range (lib.rs:391)");
         refuse_if_sharded(*s);
         (*s)->eng->pivot_budget = -1;
@@ -175,6 +184,7 @@ int mlp_solution_fix_var(mlp_solution** s, uint32_t var, double val) {
 }
 int mlp_solution_unfix_var(mlp_solution** s, uint32_t var, int* was_fixed) {
     return consume_on_error(s, guarded([&] {
+        require(s);
         if ((int)var >= (*s)->eng->num_vars) throw MlpError(MLP_EINVAL, "variable out of range (lib.rs:400)");
         refuse_if_sharded(*s);
         (*s)->eng->pivot_budget = -1;
@@ -183,6 +193,7 @@ int mlp_solution_unfix_var(mlp_solution** s, uint32_t var, int* was_fixed) {
 }
 int mlp_solution_add_gomory_cut(mlp_solution** s, uint32_t var) {
     return consume_on_error(s, guarded([&] {
+        require(s);
         if ((int)var >= (*s)->eng->num_vars) throw MlpError(MLP_EINVAL, "variable out of range (lib.rs:420)");
         refuse_if_sharded(*s);
         (*s)->eng->pivot_budget = -1;

@@ -363,3 +363,15 @@ def test_config4_100k_budget_properties():
         prev = sg.objective()
     assert sg.stats()["iterations"] == 2400
     assert sg.reinvert() < 1e-6
+
+
+def test_differential_fuzz_small_lps():
+    """1 500 random small LPs (every bound kind, E/L/G rows, empty rows, both directions): status and
+    objective vs the oracle, plus a warm-started extra row on every third optimal case."""
+    import importlib.util
+    import os
+    from tests.common import ROOT
+    spec = importlib.util.spec_from_file_location("fuzz_tool", os.path.join(ROOT, "tools", "fuzz.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    assert fz.main(1500, 11) == 0
