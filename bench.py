@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--cols", type=int, default=100000)
     ap.add_argument("--nnz-per-row", type=int, default=100)
     ap.add_argument("--seed", type=int, default=4)
-    ap.add_argument("--cpu-pivots", type=int, default=300, help="bounded CPU-baseline sample (pivots after warm-up)")
+    ap.add_argument("--cpu-pivots", type=int, default=500, help="bounded CPU-baseline sample (pivots after warm-up; ~20 s of CPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--independent", action="store_true",
                     help="N > 1: one independent LP per rank (weak scaling) instead of column-block sharded pricing of ONE LP")

@@ -178,7 +178,6 @@ private:
     DevBuf<int> d_red_idx;
     DevBuf<unsigned> d_ticket;
     DevBuf<Ctl> d_ctl;
-    DevBuf<DevView> d_view;
     DevView hview;
     bool view_dirty = true;
     Ctl* h_ctl = nullptr;  // pinned
@@ -193,7 +192,6 @@ private:
     hipGraphExec_t gexec[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipGraph_t ggraph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     Geom ggeom[2][2];
-    bool gprof[2][2] = {{false, false}, {false, false}};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // sweep0, sweep1, fused0, fused1
     void drop_graphs();
     hipGraphExec_t get_graph(int phase);

@@ -524,7 +524,6 @@ hipGraphExec_t Engine::get_graph(int phase) {
     HIPCHECK(hipStreamEndCapture(st, &ggraph[phase][pse]));
     HIPCHECK(hipGraphInstantiate(&gexec[phase][pse], ggraph[phase][pse], nullptr, nullptr, 0));
     ggeom[phase][pse] = g;
-    gprof[phase][pse] = profile;
     return gexec[phase][pse];
 }
 

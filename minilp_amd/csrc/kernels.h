@@ -1,10 +1,11 @@
 // kernels.h — device-side data layout and launch wrappers of the pivot hot path.
 // All arrays live in HBM for the lifetime of a Solution; see DESIGN.md §3 for the layout.
 //
-// Every kernel takes ONE argument: a pointer to the device-resident DevView.  Nothing a kernel
-// needs changes its launch arguments from pivot to pivot (the nucleus size, the pivot scalars and
-// the partition-change plan live in the device-resident Ctl block), so a whole simplex iteration
-// is a fixed kernel sequence that is captured once into a hipGraph and replayed.
+// Every kernel takes the DevView BY VALUE (pointers and sizes only: it sits in the kernarg segment,
+// so reaching it costs no dependent load).  Nothing a kernel needs changes its launch arguments
+// from pivot to pivot — the nucleus size, the pivot scalars and the partition-change plan live in
+// the device-resident Ctl block — so a whole simplex iteration is a fixed kernel sequence that is
+// captured once into a hipGraph and replayed.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -85,8 +86,8 @@ struct alignas(64) MailRec {
 // Non-basic flags (solver.rs:66-70 NonBasicVarState + nb_var_is_fixed)
 constexpr uint8_t NB_AT_MIN = 1, NB_AT_MAX = 2, NB_FIXED = 4;
 
-// Everything the kernels need; lives in device memory, re-uploaded by the host only when a
-// buffer is re-allocated (growth of W, add_constraint).
+// Everything the kernels need (passed by value); it changes only when a buffer is re-allocated
+// (growth of W, add_constraint), which also invalidates the captured graphs.
 struct DevView {
     int m, n;  // constraints (= basic positions), non-basic positions (= num_vars)
     int ld;    // leading dimension (= capacity) of W
