@@ -170,6 +170,7 @@ private:
     int shard_rank = 0, shard_world = 1;
     MailRec* d_mail = nullptr;
     void* mail_host = nullptr;
+    void* blas = nullptr;  // rocblas_handle for the blocked re-inversion
     size_t mail_bytes = 0;
     double refresh_tol = 1e-7;  // re-invert W when the two-way pivot check disagrees by more than this
     DevBuf<double> d_aK, d_rK, d_tK, d_tauK, d_vK, d_klist_a, d_blist_a, d_part_tau, d_part_v;

@@ -5,6 +5,9 @@
 // reads back one small record per pivot, once per batch.
 #include "engine.h"
 
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -87,6 +90,7 @@ Engine::~Engine() {
     for (auto& e : ev)
         if (e) (void)hipEventDestroy(e);
     if (h_ctl) (void)hipHostFree(h_ctl);
+    if (blas) (void)rocblas_destroy_handle(reinterpret_cast<rocblas_handle>(blas));
     if (mail_host) {
         (void)hipHostUnregister(mail_host);
         (void)munmap(mail_host, mail_bytes);
@@ -898,18 +902,42 @@ void Engine::rebuild_inverse() {
     k_ = k;
     push_maps();
     if (k > 0) {
-        DevBuf<double> Kd, scratch;
-        DevBuf<int> flag;
-        Kd.ensure((size_t)k * cap_, 0, st);
-        scratch.ensure((size_t)k + 8, 0, st);
-        flag.ensure(1, 0, st);
-        HIPCHECK(hipMemsetAsync(flag.p, 0, sizeof(int), st));
         sync_view();
-        launch_build_nucleus(hview, geom(), Kd.p, k, st);
-        launch_gauss_jordan(Kd.p, d_W.p, k, cap_, flag.p, scratch.p, st);
+        DevBuf<int> flag;
+        flag.ensure(2, 0, st);
+        HIPCHECK(hipMemsetAsync(flag.p, 0, 2 * sizeof(int), st));
         int hflag = 0;
-        HIPCHECK(hipMemcpyAsync(&hflag, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipStreamSynchronize(st));
+        if (k >= 384) {
+            // Large nucleus: blocked LU + inverse from rocSOLVER (GEMM-based, O(k^3) flops at library
+            // speed).  K is assembled row-major straight into W; a row-major matrix handed over as
+            // column-major is its transpose, and (K^T)^-1 read back row-major is K^-1, so no transposes.
+            launch_build_nucleus(hview, geom(), d_W.p, k, st);
+            if (!blas) {
+                if (rocblas_create_handle(reinterpret_cast<rocblas_handle*>(&blas)) != rocblas_status_success)
+                    throw MlpError(-3, "rocblas_create_handle failed");
+            }
+            rocblas_handle h = reinterpret_cast<rocblas_handle>(blas);
+            rocblas_set_stream(h, st);
+            DevBuf<int> ipiv;
+            ipiv.ensure((size_t)k, 0, st);
+            if (rocsolver_dgetrf(h, k, k, d_W.p, cap_, ipiv.p, flag.p) != rocblas_status_success)
+                throw MlpError(-3, "rocsolver_dgetrf failed");
+            if (rocsolver_dgetri(h, k, d_W.p, cap_, ipiv.p, flag.p + 1) != rocblas_status_success)
+                throw MlpError(-3, "rocsolver_dgetri failed");
+            int hf[2] = {0, 0};
+            HIPCHECK(hipMemcpyAsync(hf, flag.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipStreamSynchronize(st));
+            hflag = hf[0] | hf[1];
+        } else {
+            // Small nucleus: hand-written Gauss-Jordan with partial pivoting
+            DevBuf<double> Kd, scratch;
+            Kd.ensure((size_t)k * cap_, 0, st);
+            scratch.ensure((size_t)k + 8, 0, st);
+            launch_build_nucleus(hview, geom(), Kd.p, k, st);
+            launch_gauss_jordan(Kd.p, d_W.p, k, cap_, flag.p, scratch.p, st);
+            HIPCHECK(hipMemcpyAsync(&hflag, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipStreamSynchronize(st));
+        }
         if (hflag) throw MlpError(-2, "singular basis matrix (solver.rs:1301)");
     }
     stats.reinversions += 1;
