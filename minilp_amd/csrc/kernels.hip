@@ -1054,7 +1054,29 @@ __global__ void __launch_bounds__(BLK) k_btran_rhs(DevView v) {
 //                                       eagerly: B'^-1 = E B^-1)
 // Block = FW_TR rows x FW_TC columns; per-block partials are reduced by k_post_fused in a fixed
 // order (no float atomics => bitwise reproducible).
-template <int TR, bool WITH_TAU, bool WITH_V, bool DO_UPDATE>
+// W accesses of the fused pass.  NT = true: non-temporal loads and stores.  Measured on config 4 at
+// k = 6 500 (W = 340 MB > the 256 MB Infinity Cache): the pass itself is a little slower (138 vs 125 us)
+// but it stops evicting A, so the tableau-row sweep stays at 59 us instead of 90 us: +9 % pivots/s.
+// While W fits the cache (cap <= 4096) plain accesses are faster.
+typedef double dbl2_t __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ double2 fw_load2(const double* p) {
+    if (NT) {
+        dbl2_t t = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t*>(p));
+        return make_double2(t.x, t.y);
+    }
+    return *reinterpret_cast<const double2*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void fw_store2(double* p, double a, double b) {
+    if (NT) {
+        dbl2_t t = {a, b};
+        __builtin_nontemporal_store(t, reinterpret_cast<dbl2_t*>(p));
+    } else {
+        *reinterpret_cast<double2*>(p) = make_double2(a, b);
+    }
+}
+template <int TR, bool WITH_TAU, bool WITH_V, bool DO_UPDATE, bool NT = false>
 __global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
     const Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
@@ -1086,14 +1108,14 @@ __global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
         double* wp = v.W + (size_t)row * ld;
         double w[4] = {0.0, 0.0, 0.0, 0.0};
         if (pair0) {
-            double2 t = *reinterpret_cast<const double2*>(wp + cidx[0]);
+            double2 t = fw_load2<NT>(wp + cidx[0]);
             w[0] = t.x;
             w[1] = t.y;
         } else if (one0) {
             w[0] = wp[cidx[0]];
         }
         if (pair1) {
-            double2 t = *reinterpret_cast<const double2*>(wp + cidx[2]);
+            double2 t = fw_load2<NT>(wp + cidx[2]);
             w[2] = t.x;
             w[3] = t.y;
         } else if (one1) {
@@ -1109,9 +1131,9 @@ __global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
             double u = (v.aK[row] - (row == rslot ? 1.0 : 0.0)) * inv_alpha;
 #pragma unroll
             for (int j = 0; j < 4; ++j) w[j] -= u * rk[j];
-            if (pair0) *reinterpret_cast<double2*>(wp + cidx[0]) = make_double2(w[0], w[1]);
+            if (pair0) fw_store2<NT>(wp + cidx[0], w[0], w[1]);
             else if (one0) wp[cidx[0]] = w[0];
-            if (pair1) *reinterpret_cast<double2*>(wp + cidx[2]) = make_double2(w[2], w[3]);
+            if (pair1) fw_store2<NT>(wp + cidx[2], w[2], w[3]);
             else if (one1) wp[cidx[2]] = w[2];
         }
     }
@@ -1543,8 +1565,8 @@ void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st
         if (with_v) hipLaunchKernelGGL((k_fused_w<8, true, true, true>), gr, b, 0, st, dv);
         else hipLaunchKernelGGL((k_fused_w<8, true, false, true>), gr, b, 0, st, dv);
     } else {
-        if (with_v) hipLaunchKernelGGL((k_fused_w<16, true, true, true>), gr, b, 0, st, dv);
-        else hipLaunchKernelGGL((k_fused_w<16, true, false, true>), gr, b, 0, st, dv);
+        if (with_v) hipLaunchKernelGGL((k_fused_w<16, true, true, true, true>), gr, b, 0, st, dv);
+        else hipLaunchKernelGGL((k_fused_w<16, true, false, true, true>), gr, b, 0, st, dv);
     }
 }
 void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st) {
