@@ -96,6 +96,8 @@ typedef struct mlp_stats {
     double fused_bytes, fused_ms, sweep_bytes, sweep_ms;
     uint64_t fused_launches, sweep_launches;
     double solve_wall_s; /* host wall time spent inside the pivot loops */
+    uint64_t kase[5]; /* basis changes by partition case: nucleus->nucleus, singleton->nucleus (grow), nucleus->singleton
+                         (shrink), singleton->singleton (column swap), same-row singleton swap */
     double max_pivot_err; /* drift monitor: max |alpha_q[r] - alpha_r[q]| / max(1,|alpha_q[r]|) seen so far */
 } mlp_stats;
 void mlp_solution_stats(const mlp_solution* s, mlp_stats* out);

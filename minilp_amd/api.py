@@ -32,7 +32,7 @@ class MlpStats(C.Structure):
                                             "nucleus_capacity", "nnz")]
                 + [(n, C.c_double) for n in ("fused_bytes", "fused_ms", "sweep_bytes", "sweep_ms")]
                 + [(n, C.c_uint64) for n in ("fused_launches", "sweep_launches")]
-                + [("solve_wall_s", C.c_double), ("max_pivot_err", C.c_double)])
+                + [("solve_wall_s", C.c_double), ("kase", C.c_uint64 * 5), ("max_pivot_err", C.c_double)])
 
 
 _lib = None
@@ -279,7 +279,9 @@ class Solution:
     def stats(self):
         s = MlpStats()
         lib().mlp_solution_stats(self._h, C.byref(s))
-        return {n: getattr(s, n) for n, _ in MlpStats._fields_}
+        d = {n: getattr(s, n) for n, _ in MlpStats._fields_}
+        d["kase"] = list(d["kase"])
+        return d
 
     def reset_stats(self):
         lib().mlp_solution_reset_stats(self._h)

@@ -214,6 +214,7 @@ void mlp_solution_stats(const mlp_solution* s, mlp_stats* o) {
     o->fused_launches = t.fused_launches; o->sweep_launches = t.sweep_launches;
     o->solve_wall_s = t.solve_wall_s;
     o->max_pivot_err = t.max_pivot_err;
+    for (int i = 0; i < 5; ++i) o->kase[i] = t.kase[i];
 }
 void mlp_solution_reset_stats(mlp_solution* s) {
     guarded([&] { s->eng->resolve_events(); });

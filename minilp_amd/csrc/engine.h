@@ -96,6 +96,7 @@ struct Stats {
     uint64_t fused_launches = 0, sweep_launches = 0;
     double solve_wall_s = 0;
     double max_pivot_err = 0;
+    uint64_t kase[5] = {0, 0, 0, 0, 0};  // partition-change cases: nuc->nuc, grow, shrink, col swap, same-row
 };
 
 class Engine {

@@ -558,6 +558,7 @@ int Engine::process_records(int phase, int launched) {
                 nnz_nonbasic += (size_t)col_nnz(lv);
                 nnz_nonbasic -= (size_t)col_nnz(ev_);
                 stats.basis_changes += 1;
+                if (r.kase >= 0 && r.kase < 5) stats.kase[r.kase] += 1;
                 if (trace) trace_log.push_back({r.phase, r.q, r.r, ev_, lv, r.pivot_coeff, r.obj});
             }
         } else {

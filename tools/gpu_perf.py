@@ -25,7 +25,7 @@ for c in range(nchunks):
         line += f" fused: {st['fused_ms']/st['fused_launches']*1e3:.1f}us/launch {st['fused_bytes']/st['fused_ms']/1e6:.1f}GB/s"
     if profile and st["sweep_launches"]:
         line += f" sweep: {st['sweep_ms']/st['sweep_launches']*1e3:.1f}us/launch {st['sweep_bytes']/st['sweep_ms']/1e6:.1f}GB/s"
-    line += f" piverr={st['max_pivot_err']:.2e} reinv={st['reinversions']}"
+    line += f" kase={st['kase']} piverr={st['max_pivot_err']:.2e} reinv={st['reinversions']}"
     print(line, flush=True)
     if not s.budget_exhausted:
         break
