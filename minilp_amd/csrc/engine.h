@@ -163,7 +163,8 @@ private:
     DevBuf<double> d_xB, d_loB, d_hiB, d_beta, d_d, d_xN, d_gamma;
     DevBuf<uint8_t> d_nbflags;
     DevBuf<int> d_kslot_of_pos, d_srow_of_pos, d_kslot_of_row, d_pos_of_srow, d_pos_of_kslot, d_row_of_kslot;
-    DevBuf<double> d_sdiag_of_pos, d_W;
+    DevBuf<double> d_sdiag_of_pos, d_W, d_U, d_V;
+    int lr_force = -1;  // MLP_LOWRANK: force the delayed-update period (0 = off); default: 16 from cap 8192 on
     DevBuf<double> d_work;  // alpha_q | tau | rv (2m)  — one memset per pivot
     DevBuf<double> d_alpha_r, d_helper;
     DevBuf<int2> d_nb_rng;
@@ -205,6 +206,7 @@ private:
     void alloc_row_buffers(int m_new);
     void ensure_nucleus_cap(int need);
     void ensure_red();
+    void flush_lowrank();
     void pull_ctl();
     void pull_maps();
     void push_maps();

@@ -79,6 +79,8 @@ Engine::Engine() {
     use_branches = br && br[0] == '1';
     const char* rt = std::getenv("MLP_REFRESH_TOL");
     if (rt) refresh_tol = std::atof(rt);
+    const char* lr = std::getenv("MLP_LOWRANK");
+    if (lr) lr_force = std::max(0, std::min(LR_MAX, std::atoi(lr)));
     const char* sv = std::getenv("MLP_SWEEP");
     if (sv) sweep_variant = std::atoi(sv);
     const char* bs = std::getenv("MLP_BATCH");
@@ -137,6 +139,8 @@ DevView* Engine::sync_view() {
     v.kslot_of_pos = d_kslot_of_pos.p; v.srow_of_pos = d_srow_of_pos.p; v.sdiag_of_pos = d_sdiag_of_pos.p;
     v.kslot_of_row = d_kslot_of_row.p; v.pos_of_srow = d_pos_of_srow.p;
     v.pos_of_kslot = d_pos_of_kslot.p; v.row_of_kslot = d_row_of_kslot.p; v.W = d_W.p;
+    v.U = d_U.p; v.V = d_V.p; v.pad1 = 0;
+    v.lrJ = lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 16 : 0);
     v.alpha_q = d_work.p;
     v.tau = d_work.p + (size_t)m_;
     v.rv = reinterpret_cast<double2*>(d_work.p + 2 * (size_t)m_);
@@ -197,6 +201,7 @@ void Engine::alloc_row_buffers(int m_new) {
 void Engine::ensure_nucleus_cap(int need) {
     if (need > m_) need = m_;  // the nucleus can never exceed the number of rows
     if (need <= cap_) return;
+    flush_lowrank();  // pending rank-1 terms are folded before the buffers move
     HIPCHECK(hipStreamSynchronize(st));
     int ncap = std::max(256, cap_ * 2);
     while (ncap < need) ncap *= 2;
@@ -215,6 +220,8 @@ void Engine::ensure_nucleus_cap(int need) {
     int nstripes = (ncap + FW_TR - 1) / FW_TR + 1, nchunks = (ncap + FW_TC - 1) / FW_TC + 1;
     d_part_v.ensure((size_t)nstripes * ncap, 0, st);
     d_part_tau.ensure((size_t)nchunks * ncap, 0, st);
+    d_U.ensure((size_t)LR_MAX * ncap, 0, st);
+    d_V.ensure((size_t)LR_MAX * ncap, 0, st);
     cap_ = ncap;
     view_dirty = true;
 }
@@ -223,6 +230,14 @@ void Engine::ensure_red() {
     size_t need = std::max<size_t>(1024, (size_t)(std::max(m_, num_vars) + 255) / 256 + 8);
     d_red_key.ensure(need, 0, st); d_red_key2.ensure(need, 0, st); d_red_idx.ensure(need, 0, st);
     view_dirty = true;
+}
+// delayed-update mode: fold the pending rank-1 terms into W0 (host-requested, outside the pivot graph)
+void Engine::flush_lowrank() {
+    if (cap_ == 0 || !d_ctl.p) return;
+    sync_view();
+    if (!hview.lrJ) return;
+    launch_fold_lowrank(hview, geom(), st);
+    HIPCHECK(hipStreamSynchronize(st));
 }
 void Engine::pull_ctl() {
     HIPCHECK(hipMemcpyAsync(h_ctl, d_ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
@@ -685,6 +700,7 @@ void Engine::calc_row_coeffs(int row, bool with_sweep) {  // solver.rs:680-693
 
 // solver.rs:1199-1231.  There is no eta file to flush: W is always current.
 void Engine::recalc_obj_coeffs() {
+    flush_lowrank();  // the dense transposed solve reads W0 as the whole inverse
     sync_view();
     const DevView& dv = hview;
     const Geom g = geom();
@@ -860,6 +876,7 @@ void Engine::add_constraint(Constraint c) {
 // nucleus), build K = B[R_K, P_K] densely from the CSC and invert it on the device.
 void Engine::rebuild_inverse() {
     HIPCHECK(hipStreamSynchronize(st));
+    HIPCHECK(hipMemsetAsync(&d_ctl.p->nlow, 0, 2 * sizeof(int), st));  // a fresh inverse has no pending terms
     std::vector<int> claimed(m_, -1);
     std::vector<int> nuc_pos;
     h_kslot_of_pos.assign(m_, -1);
@@ -945,6 +962,7 @@ void Engine::rebuild_inverse() {
 }
 
 double Engine::reinvert(bool replace) {
+    flush_lowrank();
     pull_maps();
     if (k_ == 0) return 0.0;
     std::vector<int> hp = h_pos_of_kslot, hr = h_row_of_kslot, hkp = h_kslot_of_pos, hkr = h_kslot_of_row,
@@ -987,6 +1005,7 @@ double Engine::reinvert(bool replace) {
 
 // ------------------------------------------------------------------ clone (lib.rs:313 / solver.rs:14)
 Engine* Engine::clone() {
+    flush_lowrank();
     pull_maps();
     Engine* e = new Engine();
     e->num_vars = num_vars; e->direction = direction;

@@ -52,7 +52,7 @@ struct StructUpdate {  // how the (P_K, R_K) partition changes 
     int i_q;   // row of the entering singleton (cases 2, 3, 4)
     int cq;    // col slot of i_q (cases 2, 3)
     int kold;  // nucleus size before the change
-    int pad;
+    int jn;    // delayed-update mode: index the new rank-1 term gets (0 after a fold)
     double diag_q;      // value of the entering singleton's entry
     double inv_diag_r;  // rho[i_r] = 1/diag of the leaving singleton
 };
@@ -62,6 +62,7 @@ struct PivotRec {  // one per executed iteration, host reads them back in batche
     double pivot_coeff, obj;
 };
 constexpr int RING = 64;
+constexpr int LR_MAX = 32;  // capacity of the pending rank-1 list of the delayed-update mode
 
 // Mutable control block (device memory; copied to the host once per batch of replays).
 struct Ctl {
@@ -71,6 +72,10 @@ struct Ctl {
     int halt;    // set when an iteration ends the loop (optimal / unbounded / ...): later replays no-op
     int ring_n;  // records written since the host last reset it
     int forced;  // dual iteration with a host-forced row (fix_var): skip dual pricing
+    // delayed-update mode: W = W0 + sum_{j<nlow} U[j] V[j]^T
+    int nlow;   // number of pending rank-1 terms
+    int fold;   // this pivot's fused pass folds the pending terms into W0 (set by the plan)
+    double lr_c[LR_MAX], lr_e[LR_MAX], lr_g[LR_MAX], lr_h[LR_MAX];  // V[j].a_list, U[j].b_list, V[j].rho_K, U[j].t_K
     unsigned long long xepoch[2];  // sharded mode: exchange counters (kind 0: pricing, kind 1: ratio decision)
     double max_pivot_err;  // max over the batch of |alpha_q[r] - alpha_r[q]| / max(1,|alpha_q[r]|): drift monitor of W
     PivotRec ring[RING];
@@ -110,7 +115,11 @@ struct DevView {
     int* pos_of_srow;      // m: position of the singleton covering that row
     int* pos_of_kslot;     // cap: row slot -> position
     int* row_of_kslot;     // cap: col slot -> row
-    double* W;             // cap x ld, row-major: W[rowslot(p)][colslot(i)] = (B^-1)[p, i]
+    double* W;             // cap x ld, row-major: W[rowslot(p)][colslot(i)] = (B^-1)[p, i]  (W0 in delayed-update mode)
+    double* U;             // LR_MAX x ld: pending rank-1 terms, row-slot side   (delayed-update mode)
+    double* V;             // LR_MAX x ld: pending rank-1 terms, col-slot side
+    int lrJ;               // 0: every pivot updates W in place; J > 0: fold every J pivots
+    int pad1;
     // per-pivot vectors
     double* alpha_q;  // m by position  (col_coeffs,            solver.rs:54)
     double* tau;      // m by position  (B^-1 rho,              solver.rs:1157)
@@ -173,6 +182,7 @@ void launch_shift_nonbasic(const DevView& dv, const Geom& g, int col, double val
 void launch_sq_norms_add_row(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_copy_rho_sq_to_beta(const DevView& dv, int row, hipStream_t st);
 void launch_build_nucleus(const DevView& dv, const Geom& g, double* Kd, int k, hipStream_t st);
+void launch_fold_lowrank(const DevView& dv, const Geom& g, hipStream_t st);  // W0 += U^T V, nlow := 0 (host-requested flush)
 void launch_gauss_jordan(double* Kd, double* Winv, int k, int ld, int* d_flag, double* d_scratch, hipStream_t st);
 
 }  // namespace mlp

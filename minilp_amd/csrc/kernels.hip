@@ -369,6 +369,8 @@ __device__ void plan_update(const DevView& v, Ctl* c, int phase) {
         u.inv_diag_r = 1.0 / v.sdiag_of_pos[r];
     }
     c->it.inv_alpha = 1.0 / v.alpha_q[r];
+    c->fold = (v.lrJ > 0 && c->nlow >= v.lrJ) ? 1 : 0;
+    u.jn = c->fold ? 0 : c->nlow;
     if (new_sing) {
         u.i_q = v.csc_row[cb];
         u.diag_q = v.csc_val[cb];
@@ -441,6 +443,15 @@ __device__ void ftran_prep_wave(const DevView& v, Ctl* c, int lane, int derive_p
         cnt += __popcll(mask);
     }
     if (lane == 0) it->klist_n = cnt;
+    if (v.lrJ) {  // delayed-update mode: c_j = V[j] . (listed entries of a_q), one lane per pending term
+        const int nlow = c->nlow;
+        for (int j = lane; j < nlow; j += 64) {
+            const double* Vj = v.V + (size_t)j * v.ld;
+            double sacc = 0.0;
+            for (int l = 0; l < cnt; ++l) sacc += ld_agent(&v.klist_a[l]) * Vj[ld_agent(&v.klist_s[l])];
+            c->lr_c[j] = sacc;
+        }
+    }
 }
 // BTRAN head (one wave): rho = B^-T e_r (solver.rs:680-683) as a short list of rows of W.
 __device__ void btran_prep_wave(const DevView& v, Ctl* c, int lane, int r, int derive_dual, int plan_after, int phase) {
@@ -488,6 +499,17 @@ __device__ void btran_prep_wave(const DevView& v, Ctl* c, int lane, int r, int d
             cnt += __popcll(mask);
         }
         if (lane == 0) it->blist_n = cnt;
+    }
+    if (v.lrJ) {  // delayed-update mode: e_j = U[j] . (listed rows), one lane per pending term
+        const int nlow = c->nlow;
+        const int nb = (sr >= 0) ? 1 : __shfl(it->blist_n, 0, 64);
+        for (int j = lane; j < nlow; j += 64) {
+            const double* Uj = v.U + (size_t)j * v.ld;
+            double sacc = 0.0;
+            if (sr >= 0) sacc = Uj[sr];
+            else for (int b = 0; b < nb; ++b) sacc += ld_agent(&v.blist_a[b]) * Uj[ld_agent(&v.blist_s[b])];
+            c->lr_e[j] = sacc;
+        }
     }
     if (plan_after && lane == 0) plan_update(v, c, phase);
 }
@@ -616,6 +638,10 @@ __global__ void __launch_bounds__(BLK) k_ftran_gather(DevView v) {
     double acc = 0.0;
     const double* wrow = v.W + (size_t)slot * v.ld;
     for (int j = gl; j < n; j += G) acc += v.klist_a[j] * wrow[v.klist_s[j]];
+    if (v.lrJ) {
+        const int nlow = c->nlow;
+        for (int j = gl; j < nlow; j += G) acc += v.U[(size_t)j * v.ld + slot] * c->lr_c[j];
+    }
     acc = group_sum<G>(acc);
     int p = v.pos_of_kslot[slot];
     if (gl == 0) {
@@ -792,6 +818,10 @@ __global__ void __launch_bounds__(BLK) k_btran(DevView v, int n_gather) {
         for (int s = blockIdx.x * BLK + threadIdx.x; s < k; s += n_gather * BLK) {
             double acc = 0.0;
             for (int j = 0; j < n; ++j) acc += v.blist_a[j] * v.W[(size_t)v.blist_s[j] * v.ld + s];
+            if (v.lrJ) {
+                const int nlow = c->nlow;
+                for (int j = 0; j < nlow; ++j) acc += c->lr_e[j] * v.V[(size_t)j * v.ld + s];
+            }
             v.rK[s] = acc;
             v.rv[v.row_of_kslot[s]].x = acc;
             sq += acc * acc;
@@ -827,9 +857,59 @@ __global__ void __launch_bounds__(BLK) k_btran(DevView v, int n_gather) {
 // The case comes from the device-side plan.  Shrinking keeps the slots compact:
 // W_new[a][b] = W_old[src_row(a)][src_col(b)] with src_row(sr) = last, src_col(cq) = last; all reads
 // come from row/column `last`, all writes go to row sr / column cq, so there is no hazard.
+// Delayed-update mode: instead of touching W0, append this pivot's rank-1 term to (U, V) and keep the
+// pending terms consistent with the slot changes (new slot: zeros in the old terms; dropped slot: the
+// last slot's entries move in; replaced column: zeros in every term's V).
+__device__ __forceinline__ void lowrank_append(const DevView& v, Ctl* c, const StructUpdate& u, int s) {
+    const int kold = u.kold, ld = v.ld, last = kold - 1;
+    const double inv_alpha = c->it.inv_alpha;
+    const int jn = u.jn;  // index of the new term (0 when this pivot's fused pass folded the pending ones)
+    if (u.kase == 4) {
+        if (s == 0) c->nlow = jn;
+        return;
+    }
+    double* Un = v.U + (size_t)jn * ld;
+    double* Vn = v.V + (size_t)jn * ld;
+    if (u.kase == 0 || u.kase == 2) {
+        const int lim = (u.kase == 2) ? last : kold;
+        if (s < lim) {
+            int sr_src = (u.kase == 2 && s == u.sr) ? last : s;   // row slot whose term value lands in slot s
+            int sc_src = (u.kase == 2 && s == u.cq) ? last : s;   // col slot whose term value lands in slot s
+            Un[s] = -(v.aK[sr_src] - (sr_src == u.sr ? 1.0 : 0.0)) * inv_alpha;
+            Vn[s] = v.rK[sc_src];
+        }
+        if (u.kase == 2 && s < jn) {  // pending terms follow the move of the last slot
+            double* Uj = v.U + (size_t)s * ld;
+            double* Vj = v.V + (size_t)s * ld;
+            if (u.sr != last) Uj[u.sr] = Uj[last];
+            if (u.cq != last) Vj[u.cq] = Vj[last];
+        }
+    } else if (u.kase == 1) {
+        if (s < kold) {
+            Un[s] = -v.aK[s] * inv_alpha;
+            Vn[s] = v.rK[s];
+        } else if (s == kold) {
+            Un[kold] = 0.0;
+            Vn[kold] = 0.0;
+        }
+        if (s < jn) {  // the new slot does not exist in the pending terms
+            v.U[(size_t)s * ld + kold] = 0.0;
+            v.V[(size_t)s * ld + kold] = 0.0;
+        }
+    } else if (u.kase == 3) {
+        if (s < kold) {
+            Un[s] = -v.aK[s] * inv_alpha;
+            Vn[s] = (s == u.cq) ? 0.0 : v.rK[s];
+        }
+        if (s < jn) v.V[(size_t)s * ld + u.cq] = 0.0;
+    }
+    if (s == 0) c->nlow = jn + 1;
+}
 __device__ __forceinline__ void struct_update_body(const DevView& v, Ctl* c, int s) {
     const StructUpdate u = c->up;
-    if (u.kase <= 0) return;
+    if (u.kase < 0) return;
+    if (v.lrJ) lowrank_append(v, c, u, s);
+    if (u.kase == 0) return;
     const int kold = u.kold;
     const int ld = v.ld;
     const double inv_alpha = c->it.inv_alpha;
@@ -1161,6 +1241,144 @@ __global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
         }
     }
 }
+// Delayed-update mode: W = W0 + sum_j U[j] V[j]^T with at most J pending rank-1
+// terms.  A normal pivot only READS W0 here (tau/v partials; the low-rank part of the two products is
+// added in k_post_fused from the dots g_j = V[j].rho_K, h_j = U[j].t_K computed by the extra block
+// row of this launch); every J-th pivot FOLDS: w = w0 + sum_j U[j][row] V[j][col] is formed in
+// registers, used for the partials and written back.  W traffic per pivot: 8 k^2 (+ 16 k^2 / J)
+// instead of 16 k^2.
+template <int TR, bool WITH_V, bool NT>
+__global__ void __launch_bounds__(BLK) k_fused_lr(DevView v, int fold_only) {
+    Ctl* c = v.ctl;
+    if (!fold_only && (c->halt || c->it.status != ITER_PIVOT)) return;
+    const int k = c->k, ld = v.ld;
+    const int nlow = c->nlow;
+    const bool fold = fold_only || c->fold;
+    const int tid = threadIdx.x;
+    if (blockIdx.y == gridDim.y - 1) {  // extra block row: the low-rank dots of this pivot
+        const int j = blockIdx.x;
+        if (fold || j >= nlow) return;
+        const double* Vj = v.V + (size_t)j * ld;
+        const double* Uj = v.U + (size_t)j * ld;
+        double g = 0.0, h = 0.0;
+        for (int s = tid; s < k; s += BLK) {
+            g += Vj[s] * v.rK[s];
+            if (WITH_V) h += Uj[s] * v.tK[s];
+        }
+        g = block_sum(g);
+        h = block_sum(h);
+        if (tid == 0) {
+            c->lr_g[j] = g;
+            c->lr_h[j] = h;
+        }
+        return;
+    }
+    const int row0 = blockIdx.x * TR;
+    const int col0 = blockIdx.y * FW_TC;
+    if (row0 >= k || col0 >= k) return;
+    __shared__ double s_tau[TR][BLK / 64];
+    __shared__ double s_u[LR_MAX][TR];
+    int cidx[4];
+    cidx[0] = col0 + 2 * tid;
+    cidx[1] = cidx[0] + 1;
+    cidx[2] = col0 + 512 + 2 * tid;
+    cidx[3] = cidx[2] + 1;
+    const bool pair0 = cidx[1] < k, pair1 = cidx[3] < k;
+    const bool one0 = cidx[0] < k, one1 = cidx[2] < k;
+    double w[TR][4];
+#pragma unroll
+    for (int a = 0; a < TR; ++a) {
+        int row = row0 + a;
+        w[a][0] = w[a][1] = w[a][2] = w[a][3] = 0.0;
+        if (row >= k) continue;
+        const double* wp = v.W + (size_t)row * ld;
+        if (pair0) {
+            double2 t = fw_load2<NT>(wp + cidx[0]);
+            w[a][0] = t.x;
+            w[a][1] = t.y;
+        } else if (one0) {
+            w[a][0] = wp[cidx[0]];
+        }
+        if (pair1) {
+            double2 t = fw_load2<NT>(wp + cidx[2]);
+            w[a][2] = t.x;
+            w[a][3] = t.y;
+        } else if (one1) {
+            w[a][2] = wp[cidx[2]];
+        }
+    }
+    if (fold && nlow > 0) {
+        for (int i = tid; i < nlow * TR; i += BLK) {
+            int j = i / TR, a = i % TR;
+            int row = row0 + a;
+            s_u[j][a] = row < k ? v.U[(size_t)j * ld + row] : 0.0;
+        }
+        __syncthreads();
+        for (int j = 0; j < nlow; ++j) {
+            const double* Vj = v.V + (size_t)j * ld;
+            double vj[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vj[q] = (cidx[q] < k) ? Vj[cidx[q]] : 0.0;
+#pragma unroll
+            for (int a = 0; a < TR; ++a) {
+                double u = s_u[j][a];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[a][q] += u * vj[q];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < TR; ++a) {
+            int row = row0 + a;
+            if (row >= k) continue;
+            double* wp = v.W + (size_t)row * ld;
+            if (pair0) fw_store2<NT>(wp + cidx[0], w[a][0], w[a][1]);
+            else if (one0) wp[cidx[0]] = w[a][0];
+            if (pair1) fw_store2<NT>(wp + cidx[2], w[a][2], w[a][3]);
+            else if (one1) wp[cidx[2]] = w[a][2];
+        }
+    }
+    if (fold_only) return;
+    double rk[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rk[q] = (cidx[q] < k) ? v.rK[cidx[q]] : 0.0;
+    double vacc[4] = {0.0, 0.0, 0.0, 0.0};
+    double tacc[TR];
+#pragma unroll
+    for (int a = 0; a < TR; ++a) {
+        int row = row0 + a;
+        tacc[a] = w[a][0] * rk[0] + w[a][1] * rk[1] + w[a][2] * rk[2] + w[a][3] * rk[3];
+        if (WITH_V && row < k) {
+            double t = v.tK[row];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vacc[q] += w[a][q] * t;
+        }
+    }
+    if (WITH_V) {
+        double* pv = v.part_v + (size_t)blockIdx.x * ld;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (cidx[q] < k) pv[cidx[q]] = vacc[q];
+    }
+    int wv = tid >> 6, l = tid & 63;
+#pragma unroll
+    for (int a = 0; a < TR; ++a) {
+        double sacc = wave_sum(tacc[a]);
+        if (l == 0) s_tau[a][wv] = sacc;
+    }
+    __syncthreads();
+    if (tid < TR) {
+        int row = row0 + tid;
+        if (row < k) {
+            double sacc = s_tau[tid][0];
+            for (int i = 1; i < BLK / 64; ++i) sacc += s_tau[tid][i];
+            v.part_tau[(size_t)blockIdx.y * ld + row] = sacc;
+        }
+    }
+}
+__global__ void k_reset_nlow(DevView v) {
+    v.ctl->nlow = 0;
+    v.ctl->fold = 0;
+}
 // After the fused pass (horizontally fused): blocks [0, n_push) finish tau = B^-1 rho by position
 // (tau_K from the per-chunk partials in a fixed order, then the push of -F tau_K, solver.rs:1157);
 // the remaining blocks reduce the v partials in a fixed order and scatter v_K by row (solver.rs:1114).
@@ -1176,6 +1394,10 @@ __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push) {
         const int nchunks = (k + FW_TC - 1) / FW_TC;
         double x = 0.0;
         for (int j = 0; j < nchunks; ++j) x += v.part_tau[(size_t)j * v.ld + slot];
+        if (v.lrJ && !c->fold) {  // low-rank part of W_eff * rho_K
+            const int nlow = c->nlow;
+            for (int j = 0; j < nlow; ++j) x += v.U[(size_t)j * v.ld + slot] * c->lr_g[j];
+        }
         int p = v.pos_of_kslot[slot];
         if (gl == 0) {
             v.tauK[slot] = x;
@@ -1207,6 +1429,10 @@ __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push) {
         double sv = s_part[0][lane32];
 #pragma unroll
         for (int g2 = 1; g2 < 8; ++g2) sv += s_part[g2][lane32];
+        if (v.lrJ && !c->fold) {  // low-rank part of W_eff^T * t_K
+            const int nlow = c->nlow;
+            for (int j = 0; j < nlow; ++j) sv += v.V[(size_t)j * v.ld + i] * c->lr_h[j];
+        }
         v.vK[i] = sv;
         v.rv[v.row_of_kslot[i]].y = sv;
     }
@@ -1557,7 +1783,29 @@ void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st) {
 // rows per tile of the fused pass: 8 while W is small (more blocks in flight, 14 vs 20 us at
 // k = 1 800), 16 from cap 8192 on (half the v partials; measured 5.0-5.2 TB/s at k = 6 500 either way)
 static inline int fw_tr(const Geom& g) { return g.cap <= 4096 ? 8 : 16; }
+static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fold_only, hipStream_t st) {
+    const int tr = fw_tr(g);
+    int nstripes = (g.cap + tr - 1) / tr, nchunks = (g.cap + FW_TC - 1) / FW_TC;
+    if (nstripes < LR_MAX) nstripes = LR_MAX;  // the extra block row needs one block per pending term
+    dim3 gr(nstripes, nchunks + 1), b(BLK);
+    if (tr == 8) {
+        if (with_v) hipLaunchKernelGGL((k_fused_lr<8, true, false>), gr, b, 0, st, dv, fold_only);
+        else hipLaunchKernelGGL((k_fused_lr<8, false, false>), gr, b, 0, st, dv, fold_only);
+    } else {
+        if (with_v) hipLaunchKernelGGL((k_fused_lr<16, true, true>), gr, b, 0, st, dv, fold_only);
+        else hipLaunchKernelGGL((k_fused_lr<16, false, true>), gr, b, 0, st, dv, fold_only);
+    }
+}
+void launch_fold_lowrank(const DevView& dv, const Geom& g, hipStream_t st) {
+    if (!dv.lrJ) return;
+    launch_fused_lr(dv, g, 0, 1, st);
+    hipLaunchKernelGGL(k_reset_nlow, dim3(1), dim3(1), 0, st, dv);
+}
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st) {
+    if (dv.lrJ) {
+        launch_fused_lr(dv, g, with_v, 0, st);
+        return;
+    }
     const int tr = fw_tr(g);
     int nstripes = (g.cap + tr - 1) / tr, nchunks = (g.cap + FW_TC - 1) / FW_TC;
     dim3 gr(nstripes, nchunks), b(BLK);

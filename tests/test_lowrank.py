@@ -1,0 +1,74 @@
+"""GPU: the delayed-update mode of the nucleus inverse (W = W0 + sum_j U_j V_j^T, folded every J
+pivots).  It is switched on automatically from capacity 8192; here it is forced on
+small instances (MLP_LOWRANK=J is read when a Solution is created) and must reproduce the oracle's
+pivot sequence exactly like the in-place mode, through every partition case."""
+import os
+
+import numpy as np
+import pytest
+
+import minilp_amd as M
+from minilp_amd import lpgen
+from oracle import minilp_oracle as O
+from tests.common import GEN, X_ATOL, check_feasible, obj_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=[1, 3, 16])
+def lowrank(request):
+    os.environ["MLP_LOWRANK"] = str(request.param)
+    yield request.param
+    os.environ.pop("MLP_LOWRANK", None)
+
+
+CASES = [("sparse", dict(m=200, n=200, k=10, seed=4)), ("sparse", dict(m=700, n=600, k=12, seed=6)),
+         ("dense", dict(m=150, n=100, seed=3)), ("dense", dict(m=64, n=257, seed=4))]
+
+
+@pytest.mark.parametrize("fam,kw", CASES, ids=lambda v: str(v))
+def test_lowrank_mode_matches_oracle_pivot_for_pivot(lowrank, fam, kw):
+    lp = GEN[fam](**kw)
+    so = lpgen.build_problem(O.Problem, lp).solve(trace=True)
+    sg = lpgen.build_problem(M.Problem, lp).solve(trace=True)
+    assert obj_close(sg.objective(), so.objective())
+    assert np.abs(so.values() - sg.values()).max() <= X_ATOL
+    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+    assert sum(sg.stats()["kase"]) == sg.stats()["basis_changes"]
+    assert sg.reinvert() < 1e-8  # fold + compare with a from-scratch inverse
+
+
+def test_lowrank_mode_dual_and_warm_start(lowrank):
+    lp = lpgen.gen_mixed_lp(300, 400, 8, 4)   # dual simplex, every partition case incl. singleton swaps
+    so = lpgen.build_problem(O.Problem, lp).solve()
+    sg = lpgen.build_problem(M.Problem, lp).solve()
+    assert obj_close(sg.objective(), so.objective())
+    check_feasible(lp, sg.values())
+    st = sg.stats()
+    assert st["kase"][2] + st["kase"][3] > 0
+    lp2 = lpgen.gen_sparse_lp(120, 90, 9, 21)
+    so, sg = lpgen.build_problem(O.Problem, lp2).solve(), lpgen.build_problem(M.Problem, lp2).solve()
+    x = so.values()
+    for step in range(6):
+        vars_ = [(3 * step + j) % 90 for j in range(4)]
+        lhs = float(sum(x[v] for v in vars_))
+        expr = [(v, 1.0) for v in vars_]
+        so, sg = so.add_constraint(expr, O.LE, 0.9 * lhs + 0.01), sg.add_constraint(expr, M.LE, 0.9 * lhs + 0.01)
+        assert obj_close(sg.objective(), so.objective())
+        x = so.values()
+    c = sg.clone()
+    assert obj_close(c.objective(), sg.objective())
+
+
+def test_lowrank_mode_config4_budget():
+    os.environ["MLP_LOWRANK"] = "8"
+    try:
+        lp = lpgen.gen_sparse_lp(100000, 100000, 100, 4)
+        sg = lpgen.build_problem(M.Problem, lp).solve(budget=300, trace=True)
+        so = lpgen.build_problem(O.Problem, lp).solve(budget=300, trace=True)
+        assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+        assert obj_close(sg.objective(), so.objective())
+        sg.continue_solve(1500)
+        assert sg.reinvert() < 1e-6
+    finally:
+        os.environ.pop("MLP_LOWRANK", None)
