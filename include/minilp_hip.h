@@ -48,6 +48,10 @@ uint32_t mlp_problem_num_vars(const mlp_problem* p);
 /* duplicate or out-of-range variable => MLP_EINVAL (the reference panics, lib.rs:247-249) */
 int mlp_problem_add_constraint(mlp_problem* p, const uint32_t* vars, const double* coeffs, uint64_t k,
                                int cmp_op, double rhs);                        /* add_constraint lib.rs:276 */
+/* bulk forms of add_var / add_constraint (same semantics, one call): n variables; m rows in CSR */
+int mlp_problem_add_vars(mlp_problem* p, uint64_t n, const double* obj_coeffs, const double* mins, const double* maxs);
+int mlp_problem_add_constraints_csr(mlp_problem* p, uint64_t m, const uint64_t* indptr, const uint32_t* vars,
+                                    const double* coeffs, const int32_t* cmp_ops, const double* rhs);
 int mlp_problem_solve(const mlp_problem* p, mlp_solution** out);               /* solve lib.rs:291 */
 /* read-back of the model data (Problem is plain data in the reference too, lib.rs:194-200) */
 uint64_t mlp_problem_num_constraints(const mlp_problem* p);

@@ -68,6 +68,8 @@ def lib():
     sig("mlp_problem_add_var", u32, vp, dbl, dbl, dbl)
     sig("mlp_problem_num_vars", u32, vp)
     sig("mlp_problem_add_constraint", i32, vp, pu32, pdbl, u64, i32, dbl)
+    sig("mlp_problem_add_vars", i32, vp, u64, pdbl, pdbl, pdbl)
+    sig("mlp_problem_add_constraints_csr", i32, vp, u64, C.POINTER(C.c_uint64), pu32, pdbl, C.POINTER(C.c_int32), pdbl)
     sig("mlp_problem_solve", i32, vp, C.POINTER(vp))
     sig("mlp_problem_num_constraints", u64, vp)
     sig("mlp_problem_var", i32, vp, u32, pdbl, pdbl, pdbl)
@@ -164,6 +166,25 @@ class Problem:
         idx = np.ascontiguousarray(idx, dtype=np.uint32)
         val = np.ascontiguousarray(val, dtype=np.float64)
         _raise(lib().mlp_problem_add_constraint(self._h, _p(idx, C.c_uint32), _p(val, C.c_double), len(idx), cmp_op, rhs))
+
+    def add_vars_bulk(self, obj_coeffs, mins, maxs):
+        """n x add_var in one call; returns the index of the first new variable."""
+        first = self.num_vars
+        o = np.ascontiguousarray(obj_coeffs, dtype=np.float64)
+        a = np.ascontiguousarray(mins, dtype=np.float64)
+        b = np.ascontiguousarray(maxs, dtype=np.float64)
+        _raise(lib().mlp_problem_add_vars(self._h, len(o), _p(o, C.c_double), _p(a, C.c_double), _p(b, C.c_double)))
+        return first
+
+    def add_constraints_csr(self, indptr, indices, data, cmp_ops, rhs):
+        """m x add_constraint in one call (rows in CSR form)."""
+        ip = np.ascontiguousarray(indptr, dtype=np.uint64)
+        ix = np.ascontiguousarray(indices, dtype=np.uint32)
+        dv = np.ascontiguousarray(data, dtype=np.float64)
+        ops = np.ascontiguousarray(cmp_ops, dtype=np.int32)
+        rh = np.ascontiguousarray(rhs, dtype=np.float64)
+        _raise(lib().mlp_problem_add_constraints_csr(self._h, len(rh), _p(ip, C.c_uint64), _p(ix, C.c_uint32), _p(dv, C.c_double),
+                                                     _p(ops, C.c_int32), _p(rh, C.c_double)))
 
     def variables(self):
         """[(obj_coeff, min, max)] as given to add_var."""

@@ -76,6 +76,18 @@ uint32_t mlp_problem_num_vars(const mlp_problem* p) { return (uint32_t)p->pd.obj
 int mlp_problem_add_constraint(mlp_problem* p, const uint32_t* vars, const double* coeffs, uint64_t k, int op, double rhs) {
     return guarded([&] { p->pd.add_constraint(vars, coeffs, k, op, rhs); });
 }
+int mlp_problem_add_vars(mlp_problem* p, uint64_t n, const double* obj, const double* mins, const double* maxs) {
+    return guarded([&] {
+        for (uint64_t i = 0; i < n; ++i) p->pd.add_var(obj[i], mins[i], maxs[i]);
+    });
+}
+int mlp_problem_add_constraints_csr(mlp_problem* p, uint64_t m, const uint64_t* indptr, const uint32_t* vars,
+                                    const double* coeffs, const int32_t* ops, const double* rhs) {
+    return guarded([&] {
+        for (uint64_t i = 0; i < m; ++i)
+            p->pd.add_constraint(vars + indptr[i], coeffs + indptr[i], indptr[i + 1] - indptr[i], ops[i], rhs[i]);
+    });
+}
 uint64_t mlp_problem_num_constraints(const mlp_problem* p) { return p->pd.cons.size(); }
 int mlp_problem_var(const mlp_problem* p, uint32_t var, double* obj, double* mn, double* mx) {
     return guarded([&] {

@@ -103,6 +103,10 @@ def gen_mixed_lp(m, n, k, seed=3):
 def build_problem(problem_cls, lp):
     """Replay an instance through the reference's Problem API (any backend)."""
     p = problem_cls(lp["direction"])
+    if hasattr(p, "add_vars_bulk"):  # same calls, one FFI crossing
+        p.add_vars_bulk(lp["obj"], lp["lo"], lp["hi"])
+        p.add_constraints_csr(lp["indptr"], lp["indices"], lp["data"], lp["ops"], lp["rhs"])
+        return p
     for j in range(lp["n"]):
         p.add_var(float(lp["obj"][j]), (float(lp["lo"][j]), float(lp["hi"][j])))
     ip, ix, dv = lp["indptr"], lp["indices"], lp["data"]

@@ -101,3 +101,28 @@ def test_no_gpu_fails_loudly():
     with pytest.raises(M.InternalError) as e:
         p.solve()
     assert e.value.code == -4 and "no CPU fallback" in str(e.value)
+
+
+def test_bulk_model_building_equals_per_call():
+    from minilp_amd import lpgen
+    lp = lpgen.gen_mixed_lp(40, 60, 4, 9)
+    bulk = lpgen.build_problem(M.Problem, lp)
+    one = M.Problem(lp["direction"])
+    for j in range(lp["n"]):
+        one.add_var(float(lp["obj"][j]), (float(lp["lo"][j]), float(lp["hi"][j])))
+    for i in range(lp["m"]):
+        b, e = int(lp["indptr"][i]), int(lp["indptr"][i + 1])
+        one.add_constraint_arrays(lp["indices"][b:e], lp["data"][b:e], int(lp["ops"][i]), float(lp["rhs"][i]))
+    assert bulk.variables() == one.variables()
+    for x, y in zip(bulk.constraints(), one.constraints()):
+        assert (x[0] == y[0]).all() and (x[1] == y[1]).all() and x[2:] == y[2:]
+
+
+def test_null_solution_handle_is_an_error_not_a_crash():
+    import ctypes as C
+    lib = M.lib()
+    out = C.c_double()
+    assert lib.mlp_solution_var_value(None, 0, C.byref(out)) == -1
+    assert lib.mlp_solution_num_vars(None) == 0
+    h = C.c_void_p()
+    assert lib.mlp_solution_fix_var(C.byref(h), 0, 1.0) == -1
