@@ -130,6 +130,10 @@ def main():
                 kern[name] = dict(launches=n_l, avg_us=us, algorithmic_bytes_per_launch=st[name + "_bytes"] / n_l, gbs=gbs,
                                   total_ms=st[name + "_ms"])
         dom = max(kern, key=lambda k: kern[k]["total_ms"]) if kern else None
+        # the pricing path that shards over column blocks = tableau-row sweep + d/gamma update + pricing scan
+        pricing_us = None
+        if st["update_launches"] and "sweep" in kern:
+            pricing_us = kern["sweep"]["avg_us"] + st["update_ms"] * 1e3 / st["update_launches"]
         roofline = None
         if dom:
             kname = {"fused": "k_fused_w (tau=W*rho, v=W^T*t, eta update of the nucleus inverse)",
@@ -152,7 +156,8 @@ def main():
                                              f"per-pivot candidate exchange through a host-mapped mailbox; FTRAN/BTRAN/W replicated"
                                              if sharded else f"{world} GPUs, one independent LP of the family per rank")) + (" [oversubscribed test rig: all ranks on one GPU]" if oversub else ""),
                                nucleus_size_at_end=int(st["nucleus_size"]), objective_at_end=s.objective(),
-                               completed_steps=int(done), bound_flips=int(st["bound_flips"])),
+                               completed_steps=int(done), bound_flips=int(st["bound_flips"]),
+                               pricing_path_us_per_pivot=pricing_us),
                    roofline=roofline)
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lp, a.warmup, a.cpu_pivots)

@@ -32,7 +32,8 @@ class MlpStats(C.Structure):
                                             "nucleus_capacity", "nnz")]
                 + [(n, C.c_double) for n in ("fused_bytes", "fused_ms", "sweep_bytes", "sweep_ms")]
                 + [(n, C.c_uint64) for n in ("fused_launches", "sweep_launches")]
-                + [("solve_wall_s", C.c_double), ("kase", C.c_uint64 * 5), ("max_pivot_err", C.c_double)])
+                + [("solve_wall_s", C.c_double), ("kase", C.c_uint64 * 5), ("update_ms", C.c_double),
+                   ("update_launches", C.c_uint64), ("max_pivot_err", C.c_double)])
 
 
 _lib = None

@@ -94,6 +94,8 @@ struct Stats {
     uint64_t iterations = 0, basis_changes = 0, bound_flips = 0, primal_iters = 0, dual_iters = 0, reinversions = 0;
     double fused_bytes = 0, fused_ms = 0, sweep_bytes = 0, sweep_ms = 0;
     uint64_t fused_launches = 0, sweep_launches = 0;
+    double update_ms = 0;
+    uint64_t update_launches = 0;
     double solve_wall_s = 0;
     double max_pivot_err = 0;
     uint64_t kase[5] = {0, 0, 0, 0, 0};  // partition-change cases: nuc->nuc, grow, shrink, col swap, same-row
@@ -195,7 +197,7 @@ private:
     hipGraphExec_t gexec[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipGraph_t ggraph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     Geom ggeom[2][2];
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // sweep0, sweep1, fused0, fused1
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // sweep0/1, fused0/1, update0/1
     void drop_graphs();
     hipGraphExec_t get_graph(int phase);
 

@@ -515,7 +515,9 @@ void Engine::record_iteration(int phase, bool with_events) {
     } else {
         launch_structure_update(dv, g, st);
     }
+    if (with_events) HIPCHECK(hipEventRecord(ev[4], st));
     launch_update_pivot(dv, g, phase, dse, pse, st);  // K8 + zero the work vectors + price the next iteration
+    if (with_events) HIPCHECK(hipEventRecord(ev[5], st));
 }
 
 hipGraphExec_t Engine::get_graph(int phase) {
@@ -629,13 +631,20 @@ int Engine::run_loop(int phase) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) {
                 stats.sweep_ms += ms;
-                stats.sweep_bytes += 12.0 * (double)nnz_before + 16.0 * num_vars + 16.0 * m_;
+                const double sh = shard_world > 1 ? 1.0 / shard_world : 1.0;  // a rank sweeps its own column block
+                stats.sweep_bytes += sh * (12.0 * (double)nnz_before + 16.0 * num_vars) + 16.0 * m_;
                 stats.sweep_launches += 1;
             }
             if (k_before > 1 && hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) {
                 stats.fused_ms += ms;
-                stats.fused_bytes += 16.0 * (double)k_before * (double)k_before;
+                // read + write of W; a non-folding pivot of the delayed-update mode only reads it
+                const bool read_only = hview.lrJ > 0 && !h_ctl->fold;
+                stats.fused_bytes += (read_only ? 8.0 : 16.0) * (double)k_before * (double)k_before;
                 stats.fused_launches += 1;
+            }
+            if (hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) {
+                stats.update_ms += ms;
+                stats.update_launches += 1;
             }
         }
         // drift monitor: the pivot element from FTRAN and from the tableau row must agree
