@@ -7,6 +7,7 @@ timeout 900 python -m pytest tests/test_lowrank.py -x -q -m gpu > gpurun_out/v_l
 tail -3 gpurun_out/v_lowrank.log
 timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/v_gpu.log 2>&1; echo "gpu suite rc=$?"
 tail -3 gpurun_out/v_gpu.log
+timeout 300 python tools/gpu_perf.py 100000 100000 100 250 10 prof > gpurun_out/v_early.log 2>&1; grep chunk gpurun_out/v_early.log | cut -c1-250
 MLP_LOWRANK=0 timeout 600 python tools/gpu_perf.py 100000 100000 100 4000 12 prof > gpurun_out/v_late_inplace.log 2>&1
 timeout 600 python tools/gpu_perf.py 100000 100000 100 4000 12 prof > gpurun_out/v_late_lowrank.log 2>&1
 grep chunk gpurun_out/v_late_inplace.log | tail -4
