@@ -86,29 +86,46 @@ def main():
     # K1) sharded over disjoint blocks of non-basic positions, candidates exchanged once per pivot
     #  => strong scaling.  --independent: one LP per rank, no data-path exchange => weak.
     from minilp_amd import dist as mdist
-    sharded = world > 1 and not a.independent
-    lp = lpgen.gen_sparse_lp(a.rows, a.cols, a.nnz_per_row, a.seed + (0 if sharded or world == 1 else rank))
-    p = lpgen.build_problem(M.Problem, lp)
-    s = p.solve(budget=0, profile=True)
-    mailbox = None
-    if sharded:
-        ok = 1
-        try:
-            mailbox = mdist.setup_sharding(s, dist)
-        except Exception as e:  # every rank must take the same branch
-            print(f"[rank {rank}] sharding unavailable: {e}", file=sys.stderr, flush=True)
-            ok = 0
-        t_ok = torch.tensor([ok], dtype=torch.int32, device=red_dev)
+
+    def all_ok(ok):  # every rank must take the same branch
+        if world == 1:
+            return bool(ok)
+        t_ok = torch.tensor([1 if ok else 0], dtype=torch.int32, device=red_dev)
         dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
-        if int(t_ok.item()) == 0:
-            raise SystemExit("sharded pricing could not be set up on every rank; rerun with --independent")
-    s.continue_solve(a.warmup)           # W untimed warm-up pivots
-    s.reset_stats()
-    barrier()
-    t0 = time.perf_counter()
-    s.continue_solve(a.steps)            # exactly K timed pivots
-    barrier()
-    dt = time.perf_counter() - t0
+        return int(t_ok.item()) == 1
+
+    def run(sharded):
+        lp = lpgen.gen_sparse_lp(a.rows, a.cols, a.nnz_per_row, a.seed + (0 if sharded or world == 1 else rank))
+        s = lpgen.build_problem(M.Problem, lp).solve(budget=0, profile=True)
+        mailbox = None
+        try:
+            if sharded:
+                mailbox = mdist.setup_sharding(s, dist)
+            s.continue_solve(a.warmup)       # W untimed warm-up pivots
+            s.reset_stats()
+            barrier()
+            t0 = time.perf_counter()
+            s.continue_solve(a.steps)        # exactly K timed pivots
+            barrier()
+            return lp, s, mailbox, time.perf_counter() - t0, None
+        except Exception as e:               # sharded mode: a failed exchange fails on every rank (bounded waits)
+            if not sharded:
+                raise
+            return lp, s, mailbox, 0.0, e
+
+    sharded = world > 1 and not a.independent
+    note = None
+    lp, s, mailbox, dt, err = run(sharded)
+    if sharded and not all_ok(err is None):
+        # the per-pivot exchange could not be set up / timed out on this node: report the same
+        # workload as independent replicas (one LP of the family per rank) instead of nothing
+        print(f"[rank {rank}] sharded pricing failed ({err}); falling back to independent LPs", file=sys.stderr, flush=True)
+        note = f"sharded pricing failed on this node ({err if err else 'on a peer'}); independent LPs reported"
+        if mailbox and rank == 0:
+            mdist.remove_mailbox(mailbox)
+        del s
+        sharded = False
+        lp, s, mailbox, dt, err = run(False)
     st = s.stats()
     done = st["iterations"]
     if world > 1:
@@ -157,7 +174,7 @@ def main():
                                              if sharded else f"{world} GPUs, one independent LP of the family per rank")) + (" [oversubscribed test rig: all ranks on one GPU]" if oversub else ""),
                                nucleus_size_at_end=int(st["nucleus_size"]), objective_at_end=s.objective(),
                                completed_steps=int(done), bound_flips=int(st["bound_flips"]),
-                               pricing_path_us_per_pivot=pricing_us),
+                               pricing_path_us_per_pivot=pricing_us, note=note),
                    roofline=roofline)
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lp, a.warmup, a.cpu_pivots)

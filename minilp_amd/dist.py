@@ -45,8 +45,18 @@ def setup_sharding(solution, dist=None):
     rank, world = dist.get_rank(), dist.get_world_size()
     box = [create_mailbox(world) if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
-    solution.enable_sharding(rank, world, box[0])
-    dist.barrier()
+    err = None
+    try:
+        solution.enable_sharding(rank, world, box[0])
+    except Exception as e:  # every rank must leave through the same door
+        err = f"rank {rank}: {e}"
+    errs = [None] * world
+    dist.all_gather_object(errs, err)  # doubles as the barrier after which every slot is mapped
+    bad = [e for e in errs if e]
+    if bad:
+        if rank == 0:
+            remove_mailbox(box[0])
+        raise RuntimeError("sharding could not be enabled on every rank: " + "; ".join(bad))
     return box[0]
 
 
