@@ -165,12 +165,17 @@ private:
     DevBuf<double> d_xB, d_loB, d_hiB, d_beta, d_d, d_xN, d_gamma;
     DevBuf<uint8_t> d_nbflags;
     DevBuf<int> d_kslot_of_pos, d_srow_of_pos, d_kslot_of_row, d_pos_of_srow, d_pos_of_kslot, d_row_of_kslot;
+    DevBuf<RowInfo> d_rowinfo;
     DevBuf<double> d_sdiag_of_pos, d_W, d_U, d_V;
+    int ld_pad = 16;    // MLP_LDPAD: extra doubles per row of a large W (row pitch = cap + pad): breaks the power-of-two stride
+    int pad_for(int cap) const { return (cap >= 8192 || force_big_tiles) ? ld_pad : 0; }
+    int ld() const { return cap_ + pad_for(cap_); }
     int lr_force = -1;  // MLP_LOWRANK: force the delayed-update period (0 = off); default: 16 from cap 8192 on
     DevBuf<double> d_work;  // alpha_q | tau | rv (2m)  — one memset per pivot
     DevBuf<double> d_alpha_r, d_helper;
     DevBuf<int2> d_nb_rng;
     int sweep_variant = 0;
+    bool force_big_tiles = false;  // MLP_BIGTILE: use the large-nucleus tiling of the fused W pass at any size (tests)
     int shard_rank = 0, shard_world = 1;
     MailRec* d_mail = nullptr;
     void* mail_host = nullptr;

@@ -81,8 +81,12 @@ Engine::Engine() {
     if (rt) refresh_tol = std::atof(rt);
     const char* lr = std::getenv("MLP_LOWRANK");
     if (lr) lr_force = std::max(0, std::min(LR_MAX, std::atoi(lr)));
+    const char* lp = std::getenv("MLP_LDPAD");
+    if (lp) ld_pad = std::max(0, std::min(4096, std::atoi(lp))) & ~1;
     const char* sv = std::getenv("MLP_SWEEP");
     if (sv) sweep_variant = std::atoi(sv);
+    const char* bt = std::getenv("MLP_BIGTILE");
+    force_big_tiles = bt && std::atoi(bt) != 0;
     const char* bs = std::getenv("MLP_BATCH");
     if (bs) batch = std::max(1, std::min(RING, std::atoi(bs)));
 }
@@ -122,6 +126,7 @@ Geom Engine::geom() const {
     double avg = num_vars > 0 ? (double)(h_rcol.size() - (size_t)m_) / (double)num_vars : 1.0;  // structural columns
     g.lanes = avg >= 40.0 ? 64 : (avg >= 6.0 ? 16 : 4);
     g.sweep_variant = sweep_variant;
+    g.big = (cap_ > 4096 || force_big_tiles) ? 1 : 0;
     return g;
 }
 
@@ -129,7 +134,7 @@ DevView* Engine::sync_view() {
     if (!view_dirty) return &hview;
     DevView old = hview;
     DevView& v = hview;
-    v.m = m_; v.n = num_vars; v.ld = cap_; v.pad0 = 0;
+    v.m = m_; v.n = num_vars; v.ld = ld(); v.pad0 = 0;
     v.csc_ptr = d_cptr.p; v.csc_row = d_crow.p; v.csc_val = d_cval.p;
     v.csr_ptr = d_rptr.p; v.csr_col = d_rcol.p; v.csr_val = d_rval.p;
     v.var_lo = d_lo.p; v.var_hi = d_hi.p; v.obj_c = d_obj.p;
@@ -137,7 +142,7 @@ DevView* Engine::sync_view() {
     v.basic_vars = d_basic_vars.p; v.xB = d_xB.p; v.loB = d_loB.p; v.hiB = d_hiB.p; v.beta = d_beta.p;
     v.nb_vars = d_nb_vars.p; v.d = d_d.p; v.xN = d_xN.p; v.gamma = d_gamma.p; v.nbflags = d_nbflags.p;
     v.kslot_of_pos = d_kslot_of_pos.p; v.srow_of_pos = d_srow_of_pos.p; v.sdiag_of_pos = d_sdiag_of_pos.p;
-    v.kslot_of_row = d_kslot_of_row.p; v.pos_of_srow = d_pos_of_srow.p;
+    v.kslot_of_row = d_kslot_of_row.p; v.pos_of_srow = d_pos_of_srow.p; v.rowinfo = d_rowinfo.p;
     v.pos_of_kslot = d_pos_of_kslot.p; v.row_of_kslot = d_row_of_kslot.p; v.W = d_W.p;
     v.U = d_U.p; v.V = d_V.p; v.pad1 = 0;
     v.lrJ = lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 16 : 0);
@@ -190,7 +195,7 @@ void Engine::alloc_row_buffers(int m_new) {
     d_basic_vars.ensure(mm, keep, st); d_xB.ensure(mm, keep, st); d_loB.ensure(mm, keep, st);
     d_hiB.ensure(mm, keep, st); d_beta.ensure(mm, keep, st);
     d_kslot_of_pos.ensure(mm, keep, st); d_srow_of_pos.ensure(mm, keep, st); d_sdiag_of_pos.ensure(mm, keep, st);
-    d_kslot_of_row.ensure(mm, keep, st); d_pos_of_srow.ensure(mm, keep, st);
+    d_kslot_of_row.ensure(mm, keep, st); d_pos_of_srow.ensure(mm, keep, st); d_rowinfo.ensure(mm, keep, st);
     d_work.ensure(4 * mm + 8, 0, st);
     d_klist_s.ensure(mm, 0, st); d_klist_a.ensure(mm, 0, st);
     d_blist_s.ensure(mm + num_vars + 64, 0, st); d_blist_a.ensure(mm + num_vars + 64, 0, st);
@@ -206,9 +211,11 @@ void Engine::ensure_nucleus_cap(int need) {
     int ncap = std::max(256, cap_ * 2);
     while (ncap < need) ncap *= 2;
     DevBuf<double> nW;
-    nW.alloc_exact((size_t)ncap * ncap);
+    const int old_ld = ld();
+    const int nld = ncap + pad_for(ncap);
+    nW.alloc_exact((size_t)ncap * nld);
     if (k_ > 0)
-        HIPCHECK(hipMemcpy2DAsync(nW.p, (size_t)ncap * sizeof(double), d_W.p, (size_t)cap_ * sizeof(double),
+        HIPCHECK(hipMemcpy2DAsync(nW.p, (size_t)nld * sizeof(double), d_W.p, (size_t)old_ld * sizeof(double),
                                   (size_t)k_ * sizeof(double), (size_t)k_, hipMemcpyDeviceToDevice, st));
     HIPCHECK(hipStreamSynchronize(st));
     d_W.release();
@@ -218,10 +225,10 @@ void Engine::ensure_nucleus_cap(int need) {
     d_aK.ensure(ncap, keep, st); d_rK.ensure(ncap, keep, st); d_tK.ensure(ncap, keep, st);
     d_tauK.ensure(ncap, keep, st); d_vK.ensure(ncap, keep, st);
     int nstripes = (ncap + FW_TR - 1) / FW_TR + 1, nchunks = (ncap + FW_TC - 1) / FW_TC + 1;
-    d_part_v.ensure((size_t)nstripes * ncap, 0, st);
-    d_part_tau.ensure((size_t)nchunks * ncap, 0, st);
-    d_U.ensure((size_t)LR_MAX * ncap, 0, st);
-    d_V.ensure((size_t)LR_MAX * ncap, 0, st);
+    d_part_v.ensure((size_t)nstripes * nld, 0, st);
+    d_part_tau.ensure((size_t)nchunks * nld, 0, st);
+    d_U.ensure((size_t)LR_MAX * nld, 0, st);
+    d_V.ensure((size_t)LR_MAX * nld, 0, st);
     cap_ = ncap;
     view_dirty = true;
 }
@@ -263,6 +270,13 @@ void Engine::push_maps() {
     d_kslot_of_pos.upload(h_kslot_of_pos, st); d_srow_of_pos.upload(h_srow_of_pos, st);
     d_sdiag_of_pos.upload(h_sdiag_of_pos, st);
     d_kslot_of_row.upload(h_kslot_of_row, st); d_pos_of_srow.upload(h_pos_of_srow, st);
+    std::vector<RowInfo> ri(h_kslot_of_row.size());
+    for (size_t i = 0; i < ri.size(); ++i) {
+        if (h_kslot_of_row[i] >= 0) ri[i] = RowInfo{0.0, -1, h_kslot_of_row[i]};
+        else ri[i] = RowInfo{h_sdiag_of_pos[h_pos_of_srow[i]], h_pos_of_srow[i], -1};
+    }
+    d_rowinfo.upload(ri, st);
+    HIPCHECK(hipStreamSynchronize(st));  // `ri` is a local staging buffer
     h_pos_of_kslot.resize(cap_, -1);
     h_row_of_kslot.resize(cap_, -1);
     d_pos_of_kslot.upload(h_pos_of_kslot, st); d_row_of_kslot.upload(h_row_of_kslot, st);
@@ -862,6 +876,8 @@ void Engine::add_constraint(Constraint c) {
     HIPCHECK(hipMemcpyAsync(d_sdiag_of_pos.p + row, &one, sizeof(double), hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(d_kslot_of_row.p + row, &neg1, sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(d_pos_of_srow.p + row, &row, sizeof(int), hipMemcpyHostToDevice, st));
+    const RowInfo ri_new{1.0, row, -1};
+    HIPCHECK(hipMemcpyAsync(d_rowinfo.p + row, &ri_new, sizeof(RowInfo), hipMemcpyHostToDevice, st));
     HIPCHECK(hipStreamSynchronize(st));
     values_dirty = true;
     view_dirty = true;
@@ -947,9 +963,9 @@ void Engine::rebuild_inverse() {
             rocblas_set_stream(h, st);
             DevBuf<int> ipiv;
             ipiv.ensure((size_t)k, 0, st);
-            if (rocsolver_dgetrf(h, k, k, d_W.p, cap_, ipiv.p, flag.p) != rocblas_status_success)
+            if (rocsolver_dgetrf(h, k, k, d_W.p, ld(), ipiv.p, flag.p) != rocblas_status_success)
                 throw MlpError(-3, "rocsolver_dgetrf failed");
-            if (rocsolver_dgetri(h, k, d_W.p, cap_, ipiv.p, flag.p + 1) != rocblas_status_success)
+            if (rocsolver_dgetri(h, k, d_W.p, ld(), ipiv.p, flag.p + 1) != rocblas_status_success)
                 throw MlpError(-3, "rocsolver_dgetri failed");
             int hf[2] = {0, 0};
             HIPCHECK(hipMemcpyAsync(hf, flag.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -958,10 +974,10 @@ void Engine::rebuild_inverse() {
         } else {
             // Small nucleus: hand-written Gauss-Jordan with partial pivoting
             DevBuf<double> Kd, scratch;
-            Kd.ensure((size_t)k * cap_, 0, st);
+            Kd.ensure((size_t)k * ld(), 0, st);
             scratch.ensure((size_t)k + 8, 0, st);
             launch_build_nucleus(hview, geom(), Kd.p, k, st);
-            launch_gauss_jordan(Kd.p, d_W.p, k, cap_, flag.p, scratch.p, st);
+            launch_gauss_jordan(Kd.p, d_W.p, k, ld(), flag.p, scratch.p, st);
             HIPCHECK(hipMemcpyAsync(&hflag, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHECK(hipStreamSynchronize(st));
         }
@@ -977,20 +993,20 @@ double Engine::reinvert(bool replace) {
     std::vector<int> hp = h_pos_of_kslot, hr = h_row_of_kslot, hkp = h_kslot_of_pos, hkr = h_kslot_of_row,
                      hsr = h_srow_of_pos, hps = h_pos_of_srow;
     std::vector<double> hsd = h_sdiag_of_pos;
-    const int kold = k_, capold = cap_;
+    const int kold = k_, capold = cap_, ldold = ld();
     std::vector<double> a((size_t)kold * kold);
-    HIPCHECK(hipMemcpy2D(a.data(), (size_t)kold * sizeof(double), d_W.p, (size_t)capold * sizeof(double),
+    HIPCHECK(hipMemcpy2D(a.data(), (size_t)kold * sizeof(double), d_W.p, (size_t)ldold * sizeof(double),
                          (size_t)kold * sizeof(double), (size_t)kold, hipMemcpyDeviceToHost));
     DevBuf<double> oldW;
     if (!replace) {
-        oldW.alloc_exact((size_t)capold * capold);
-        HIPCHECK(hipMemcpy(oldW.p, d_W.p, sizeof(double) * (size_t)capold * capold, hipMemcpyDeviceToDevice));
+        oldW.alloc_exact((size_t)capold * ldold);
+        HIPCHECK(hipMemcpy(oldW.p, d_W.p, sizeof(double) * (size_t)capold * ldold, hipMemcpyDeviceToDevice));
     }
     rebuild_inverse();
     double diff = -1.0;
     if (k_ == kold) {
         std::vector<double> b((size_t)kold * kold);
-        HIPCHECK(hipMemcpy2D(b.data(), (size_t)kold * sizeof(double), d_W.p, (size_t)cap_ * sizeof(double),
+        HIPCHECK(hipMemcpy2D(b.data(), (size_t)kold * sizeof(double), d_W.p, (size_t)ld() * sizeof(double),
                              (size_t)kold * sizeof(double), (size_t)kold, hipMemcpyDeviceToHost));
         diff = 0.0;
         for (int s1 = 0; s1 < kold; ++s1)
@@ -1006,7 +1022,7 @@ double Engine::reinvert(bool replace) {
         h_pos_of_kslot = hp; h_row_of_kslot = hr; h_kslot_of_pos = hkp; h_kslot_of_row = hkr;
         h_srow_of_pos = hsr; h_pos_of_srow = hps; h_sdiag_of_pos = hsd;
         k_ = kold;
-        HIPCHECK(hipMemcpy(d_W.p, oldW.p, sizeof(double) * (size_t)capold * capold, hipMemcpyDeviceToDevice));
+        HIPCHECK(hipMemcpy(d_W.p, oldW.p, sizeof(double) * (size_t)capold * ldold, hipMemcpyDeviceToDevice));
         push_maps();
     }
     return diff;
@@ -1031,6 +1047,7 @@ Engine* Engine::clone() {
     e->resume_in_optimize = resume_in_optimize;
     e->nnz_nonbasic = nnz_nonbasic;
     e->trace = trace; e->profile = profile;
+    e->ld_pad = ld_pad; e->lr_force = lr_force; e->force_big_tiles = force_big_tiles;
     hipStream_t s2 = e->st;
     e->upload_matrix();
     int mk = m_;
@@ -1056,7 +1073,7 @@ Engine* Engine::clone() {
     if (e->cap_ != cap_) throw MlpError(-3, "clone: capacity mismatch");
     e->k_ = k_;
     if (k_ > 0)
-        HIPCHECK(hipMemcpyAsync(e->d_W.p, d_W.p, sizeof(double) * (size_t)cap_ * cap_, hipMemcpyDeviceToDevice, s2));
+        HIPCHECK(hipMemcpyAsync(e->d_W.p, d_W.p, sizeof(double) * (size_t)cap_ * ld(), hipMemcpyDeviceToDevice, s2));
     e->push_maps();
     HIPCHECK(hipStreamSynchronize(s2));
     std::memcpy(e->h_ctl, h_ctl, sizeof(Ctl));

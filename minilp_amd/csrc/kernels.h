@@ -93,6 +93,14 @@ constexpr uint8_t NB_AT_MIN = 1, NB_AT_MAX = 2, NB_FIXED = 4;
 
 // Everything the kernels need (passed by value); it changes only when a buffer is re-allocated
 // (growth of W, add_constraint), which also invalidates the captured graphs.
+// Row-indexed copy of (sdiag_of_pos[pos_of_srow[i]], pos_of_srow[i], kslot_of_row[i]): a singleton row has
+// kslot = -1 and (pos, diag) of its covering column; a nucleus row has kslot >= 0, pos = -1, diag = 0.
+struct alignas(16) RowInfo {
+    double diag;
+    int pos;
+    int kslot;
+};
+
 struct DevView {
     int m, n;  // constraints (= basic positions), non-basic positions (= num_vars)
     int ld;    // leading dimension (= capacity) of W
@@ -113,6 +121,7 @@ struct DevView {
     double* sdiag_of_pos;  // m: its value
     int* kslot_of_row;     // m: col slot of W for a nucleus row, -1 for a row covered by a singleton
     int* pos_of_srow;      // m: position of the singleton covering that row
+    RowInfo* rowinfo;      // m: the three row maps packed for the F pushes (one 16-byte gather per matrix entry)
     int* pos_of_kslot;     // cap: row slot -> position
     int* row_of_kslot;     // cap: col slot -> row
     double* W;             // cap x ld, row-major: W[rowslot(p)][colslot(i)] = (B^-1)[p, i]  (W0 in delayed-update mode)
@@ -153,6 +162,7 @@ struct Geom {
     int m, n, cap;
     int lanes;  // lanes per CSC column in the pull kernels (4, 16 or 64; from the average column length)
     int sweep_variant;  // tuning knob (MLP_SWEEP): 0 default
+    int big;            // fused W pass: 64-row x 1024-column blocks, non-temporal (cap > 4096, or forced by MLP_BIGTILE)
 };
 
 // ---- launch wrappers (all asynchronous on `st`; the DevView is passed to the kernels by value) ----

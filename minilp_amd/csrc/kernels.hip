@@ -620,11 +620,8 @@ __device__ __forceinline__ void push_F(const DevView& v, int p, double x, double
     int var = v.basic_vars[p];
     int end = v.csc_ptr[var + 1];
     for (int e = v.csc_ptr[var] + gl; e < end; e += G) {
-        int i = v.csc_row[e];
-        if (v.kslot_of_row[i] < 0) {
-            int ps = v.pos_of_srow[i];
-            unsafeAtomicAdd(&out_pos[ps], -v.csc_val[e] * x / v.sdiag_of_pos[ps]);
-        }
+        const RowInfo ri = v.rowinfo[v.csc_row[e]];
+        if (ri.kslot < 0) unsafeAtomicAdd(&out_pos[ri.pos], -v.csc_val[e] * x / ri.diag);
     }
 }
 template <int G>
@@ -922,6 +919,7 @@ __device__ __forceinline__ void struct_update_body(const DevView& v, Ctl* c, int
             v.kslot_of_pos[u.r] = kold;
             v.pos_of_kslot[kold] = u.r;
             v.kslot_of_row[u.i_r] = kold;
+            v.rowinfo[u.i_r] = RowInfo{0.0, -1, kold};
             v.row_of_kslot[kold] = u.i_r;
             c->k = kold + 1;
         }
@@ -944,9 +942,11 @@ __device__ __forceinline__ void struct_update_body(const DevView& v, Ctl* c, int
                 int il = v.row_of_kslot[last];
                 v.row_of_kslot[u.cq] = il;
                 v.kslot_of_row[il] = u.cq;
+                v.rowinfo[il] = RowInfo{0.0, -1, u.cq};
             }
             v.kslot_of_row[u.i_q] = -1;
             v.pos_of_srow[u.i_q] = u.r;
+            v.rowinfo[u.i_q] = RowInfo{u.diag_q, u.r, -1};
             c->k = last;
         }
     } else if (u.kase == 3) {  // singleton -> singleton on another row: col slot cq now stands for row i_r
@@ -956,11 +956,16 @@ __device__ __forceinline__ void struct_update_body(const DevView& v, Ctl* c, int
             v.sdiag_of_pos[u.r] = u.diag_q;
             v.kslot_of_row[u.i_q] = -1;
             v.pos_of_srow[u.i_q] = u.r;
+            v.rowinfo[u.i_q] = RowInfo{u.diag_q, u.r, -1};
             v.kslot_of_row[u.i_r] = u.cq;
+            v.rowinfo[u.i_r] = RowInfo{0.0, -1, u.cq};
             v.row_of_kslot[u.cq] = u.i_r;
         }
     } else if (u.kase == 4) {  // singleton replaced by another singleton of the same row
-        if (s == 0) v.sdiag_of_pos[u.r] = u.diag_q;
+        if (s == 0) {
+            v.sdiag_of_pos[u.r] = u.diag_q;
+            v.rowinfo[v.srow_of_pos[u.r]] = RowInfo{u.diag_q, u.r, -1};
+        }
     }
 }
 __global__ void __launch_bounds__(BLK) k_struct_update(DevView v) {
@@ -1156,15 +1161,39 @@ __device__ __forceinline__ void fw_store2(double* p, double a, double b) {
         *reinterpret_cast<double2*>(p) = make_double2(a, b);
     }
 }
-template <int TR, bool WITH_TAU, bool WITH_V, bool DO_UPDATE, bool NT = false>
+// LR = delayed-update mode, normal (non-folding) pivot: the same streaming pass with DO_UPDATE off;
+// it leaves folding pivots to k_fused_lr, and one extra block row computes the low-rank dots
+// g_j = V[j].rho_K, h_j = U[j].t_K that k_post_fused adds to the two products.
+template <int TR, bool WITH_TAU, bool WITH_V, bool DO_UPDATE, bool NT = false, bool LR = false, int RL = 1>
 __global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
-    const Ctl* c = v.ctl;
+    Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
+    if (LR && c->fold) return;
     const int k = c->k, ld = v.ld;
-    const int row0 = blockIdx.x * TR;
+    if (LR && blockIdx.y == gridDim.y - 1) {
+        const int j = blockIdx.x;
+        if (j >= c->nlow) return;
+        const double* Vj = v.V + (size_t)j * ld;
+        const double* Uj = v.U + (size_t)j * ld;
+        double g = 0.0, h = 0.0;
+        for (int s = threadIdx.x; s < k; s += BLK) {
+            g += Vj[s] * v.rK[s];
+            if (WITH_V) h += Uj[s] * v.tK[s];
+        }
+        g = block_sum(g);
+        h = block_sum(h);
+        if (threadIdx.x == 0) {
+            c->lr_g[j] = g;
+            c->lr_h[j] = h;
+        }
+        return;
+    }
+    // a block owns RL consecutive row tiles of TR rows (RL > 1 for a large nucleus: RL times fewer
+    // v partials to write here and to reduce in k_post_fused) and one chunk of FW_TC columns
+    const int row0 = blockIdx.x * (TR * RL);
     const int col0 = blockIdx.y * FW_TC;
     if (row0 >= k || col0 >= k) return;
-    __shared__ double s_tau[TR][BLK / 64];
+    __shared__ double s_tau[TR * RL][BLK / 64];
     const int tid = threadIdx.x;
     int cidx[4];
     cidx[0] = col0 + 2 * tid;
@@ -1177,44 +1206,55 @@ __global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
     const double inv_alpha = DO_UPDATE ? c->it.inv_alpha : 0.0;
     const int rslot = DO_UPDATE ? c->up.sr : -1;
     double vacc[4] = {0.0, 0.0, 0.0, 0.0};
-    double tacc[TR];
     const bool pair0 = cidx[1] < k, pair1 = cidx[3] < k;
     const bool one0 = cidx[0] < k, one1 = cidx[2] < k;
+    const int wv = tid >> 6, l = tid & 63;
+#pragma unroll 1
+    for (int sub = 0; sub < RL; ++sub) {
+        double tacc[TR];
 #pragma unroll
-    for (int a = 0; a < TR; ++a) {
-        int row = row0 + a;
-        tacc[a] = 0.0;
-        if (row >= k) continue;
-        double* wp = v.W + (size_t)row * ld;
-        double w[4] = {0.0, 0.0, 0.0, 0.0};
-        if (pair0) {
-            double2 t = fw_load2<NT>(wp + cidx[0]);
-            w[0] = t.x;
-            w[1] = t.y;
-        } else if (one0) {
-            w[0] = wp[cidx[0]];
-        }
-        if (pair1) {
-            double2 t = fw_load2<NT>(wp + cidx[2]);
-            w[2] = t.x;
-            w[3] = t.y;
-        } else if (one1) {
-            w[2] = wp[cidx[2]];
-        }
-        if (WITH_TAU) tacc[a] = w[0] * rk[0] + w[1] * rk[1] + w[2] * rk[2] + w[3] * rk[3];
-        if (WITH_V) {
-            double t = v.tK[row];
+        for (int a = 0; a < TR; ++a) {
+            int row = row0 + sub * TR + a;
+            tacc[a] = 0.0;
+            if (row >= k) continue;
+            double* wp = v.W + (size_t)row * ld;
+            double w[4] = {0.0, 0.0, 0.0, 0.0};
+            if (pair0) {
+                double2 t = fw_load2<NT>(wp + cidx[0]);
+                w[0] = t.x;
+                w[1] = t.y;
+            } else if (one0) {
+                w[0] = wp[cidx[0]];
+            }
+            if (pair1) {
+                double2 t = fw_load2<NT>(wp + cidx[2]);
+                w[2] = t.x;
+                w[3] = t.y;
+            } else if (one1) {
+                w[2] = wp[cidx[2]];
+            }
+            if (WITH_TAU) tacc[a] = w[0] * rk[0] + w[1] * rk[1] + w[2] * rk[2] + w[3] * rk[3];
+            if (WITH_V) {
+                double t = v.tK[row];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) vacc[j] += w[j] * t;
-        }
-        if (DO_UPDATE) {
-            double u = (v.aK[row] - (row == rslot ? 1.0 : 0.0)) * inv_alpha;
+                for (int j = 0; j < 4; ++j) vacc[j] += w[j] * t;
+            }
+            if (DO_UPDATE) {
+                double u = (v.aK[row] - (row == rslot ? 1.0 : 0.0)) * inv_alpha;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) w[j] -= u * rk[j];
-            if (pair0) fw_store2<NT>(wp + cidx[0], w[0], w[1]);
-            else if (one0) wp[cidx[0]] = w[0];
-            if (pair1) fw_store2<NT>(wp + cidx[2], w[2], w[3]);
-            else if (one1) wp[cidx[2]] = w[2];
+                for (int j = 0; j < 4; ++j) w[j] -= u * rk[j];
+                if (pair0) fw_store2<NT>(wp + cidx[0], w[0], w[1]);
+                else if (one0) wp[cidx[0]] = w[0];
+                if (pair1) fw_store2<NT>(wp + cidx[2], w[2], w[3]);
+                else if (one1) wp[cidx[2]] = w[2];
+            }
+        }
+        if (WITH_TAU) {
+#pragma unroll
+            for (int a = 0; a < TR; ++a) {
+                double sacc = wave_sum(tacc[a]);
+                if (l == 0) s_tau[sub * TR + a][wv] = sacc;
+            }
         }
     }
     if (WITH_V) {
@@ -1224,19 +1264,13 @@ __global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
             if (cidx[j] < k) pv[cidx[j]] = vacc[j];
     }
     if (WITH_TAU) {
-        int wv = tid >> 6, l = tid & 63;
-#pragma unroll
-        for (int a = 0; a < TR; ++a) {
-            double s = wave_sum(tacc[a]);
-            if (l == 0) s_tau[a][wv] = s;
-        }
         __syncthreads();
-        if (tid < TR) {
-            int row = row0 + tid;
+        for (int t = tid; t < TR * RL; t += BLK) {
+            int row = row0 + t;
             if (row < k) {
-                double s = s_tau[tid][0];
-                for (int i = 1; i < BLK / 64; ++i) s += s_tau[tid][i];
-                v.part_tau[(size_t)blockIdx.y * ld + row] = s;
+                double sacc = s_tau[t][0];
+                for (int i = 1; i < BLK / 64; ++i) sacc += s_tau[t][i];
+                v.part_tau[(size_t)blockIdx.y * ld + row] = sacc;
             }
         }
     }
@@ -1247,36 +1281,19 @@ __global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
 // row of this launch); every J-th pivot FOLDS: w = w0 + sum_j U[j][row] V[j][col] is formed in
 // registers, used for the partials and written back.  W traffic per pivot: 8 k^2 (+ 16 k^2 / J)
 // instead of 16 k^2.
-template <int TR, bool WITH_V, bool NT>
+template <int TR, bool WITH_V, bool NT, int RL = 1>
 __global__ void __launch_bounds__(BLK) k_fused_lr(DevView v, int fold_only) {
     Ctl* c = v.ctl;
     if (!fold_only && (c->halt || c->it.status != ITER_PIVOT)) return;
     const int k = c->k, ld = v.ld;
     const int nlow = c->nlow;
     const bool fold = fold_only || c->fold;
+    if (!fold) return;  // normal pivots are served by k_fused_w<.., LR = true>
     const int tid = threadIdx.x;
-    if (blockIdx.y == gridDim.y - 1) {  // extra block row: the low-rank dots of this pivot
-        const int j = blockIdx.x;
-        if (fold || j >= nlow) return;
-        const double* Vj = v.V + (size_t)j * ld;
-        const double* Uj = v.U + (size_t)j * ld;
-        double g = 0.0, h = 0.0;
-        for (int s = tid; s < k; s += BLK) {
-            g += Vj[s] * v.rK[s];
-            if (WITH_V) h += Uj[s] * v.tK[s];
-        }
-        g = block_sum(g);
-        h = block_sum(h);
-        if (tid == 0) {
-            c->lr_g[j] = g;
-            c->lr_h[j] = h;
-        }
-        return;
-    }
-    const int row0 = blockIdx.x * TR;
+    const int row0 = blockIdx.x * (TR * RL);
     const int col0 = blockIdx.y * FW_TC;
     if (row0 >= k || col0 >= k) return;
-    __shared__ double s_tau[TR][BLK / 64];
+    __shared__ double s_tau[TR * RL][BLK / 64];
     __shared__ double s_u[LR_MAX][TR];
     int cidx[4];
     cidx[0] = col0 + 2 * tid;
@@ -1285,92 +1302,95 @@ __global__ void __launch_bounds__(BLK) k_fused_lr(DevView v, int fold_only) {
     cidx[3] = cidx[2] + 1;
     const bool pair0 = cidx[1] < k, pair1 = cidx[3] < k;
     const bool one0 = cidx[0] < k, one1 = cidx[2] < k;
-    double w[TR][4];
+    double rk[4];
 #pragma unroll
-    for (int a = 0; a < TR; ++a) {
-        int row = row0 + a;
-        w[a][0] = w[a][1] = w[a][2] = w[a][3] = 0.0;
-        if (row >= k) continue;
-        const double* wp = v.W + (size_t)row * ld;
-        if (pair0) {
-            double2 t = fw_load2<NT>(wp + cidx[0]);
-            w[a][0] = t.x;
-            w[a][1] = t.y;
-        } else if (one0) {
-            w[a][0] = wp[cidx[0]];
-        }
-        if (pair1) {
-            double2 t = fw_load2<NT>(wp + cidx[2]);
-            w[a][2] = t.x;
-            w[a][3] = t.y;
-        } else if (one1) {
-            w[a][2] = wp[cidx[2]];
-        }
-    }
-    if (fold && nlow > 0) {
-        for (int i = tid; i < nlow * TR; i += BLK) {
-            int j = i / TR, a = i % TR;
-            int row = row0 + a;
-            s_u[j][a] = row < k ? v.U[(size_t)j * ld + row] : 0.0;
-        }
-        __syncthreads();
-        for (int j = 0; j < nlow; ++j) {
-            const double* Vj = v.V + (size_t)j * ld;
-            double vj[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) vj[q] = (cidx[q] < k) ? Vj[cidx[q]] : 0.0;
-#pragma unroll
-            for (int a = 0; a < TR; ++a) {
-                double u = s_u[j][a];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) w[a][q] += u * vj[q];
-            }
-        }
+    for (int q = 0; q < 4; ++q) rk[q] = (!fold_only && cidx[q] < k) ? v.rK[cidx[q]] : 0.0;
+    double vacc[4] = {0.0, 0.0, 0.0, 0.0};
+    const int wv = tid >> 6, l = tid & 63;
+#pragma unroll 1
+    for (int sub = 0; sub < RL; ++sub) {
+        const int rbase = row0 + sub * TR;
+        if (rbase >= k) break;
+        double w[TR][4];
 #pragma unroll
         for (int a = 0; a < TR; ++a) {
-            int row = row0 + a;
+            int row = rbase + a;
+            w[a][0] = w[a][1] = w[a][2] = w[a][3] = 0.0;
             if (row >= k) continue;
-            double* wp = v.W + (size_t)row * ld;
-            if (pair0) fw_store2<NT>(wp + cidx[0], w[a][0], w[a][1]);
-            else if (one0) wp[cidx[0]] = w[a][0];
-            if (pair1) fw_store2<NT>(wp + cidx[2], w[a][2], w[a][3]);
-            else if (one1) wp[cidx[2]] = w[a][2];
+            const double* wp = v.W + (size_t)row * ld;
+            if (pair0) {
+                double2 t = fw_load2<NT>(wp + cidx[0]);
+                w[a][0] = t.x;
+                w[a][1] = t.y;
+            } else if (one0) {
+                w[a][0] = wp[cidx[0]];
+            }
+            if (pair1) {
+                double2 t = fw_load2<NT>(wp + cidx[2]);
+                w[a][2] = t.x;
+                w[a][3] = t.y;
+            } else if (one1) {
+                w[a][2] = wp[cidx[2]];
+            }
+        }
+        if (nlow > 0) {
+            __syncthreads();  // the previous sub-tile's readers of s_u are done
+            for (int i = tid; i < nlow * TR; i += BLK) {
+                int j = i / TR, a = i % TR;
+                int row = rbase + a;
+                s_u[j][a] = row < k ? v.U[(size_t)j * ld + row] : 0.0;
+            }
+            __syncthreads();
+            for (int j = 0; j < nlow; ++j) {
+                const double* Vj = v.V + (size_t)j * ld;
+                double vj[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vj[q] = (cidx[q] < k) ? Vj[cidx[q]] : 0.0;
+#pragma unroll
+                for (int a = 0; a < TR; ++a) {
+                    double u = s_u[j][a];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w[a][q] += u * vj[q];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < TR; ++a) {
+                int row = rbase + a;
+                if (row >= k) continue;
+                double* wp = v.W + (size_t)row * ld;
+                if (pair0) fw_store2<NT>(wp + cidx[0], w[a][0], w[a][1]);
+                else if (one0) wp[cidx[0]] = w[a][0];
+                if (pair1) fw_store2<NT>(wp + cidx[2], w[a][2], w[a][3]);
+                else if (one1) wp[cidx[2]] = w[a][2];
+            }
+        }
+        if (fold_only) continue;
+#pragma unroll
+        for (int a = 0; a < TR; ++a) {
+            int row = rbase + a;
+            double tacc = w[a][0] * rk[0] + w[a][1] * rk[1] + w[a][2] * rk[2] + w[a][3] * rk[3];
+            if (WITH_V && row < k) {
+                double t = v.tK[row];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vacc[q] += w[a][q] * t;
+            }
+            double sacc = wave_sum(tacc);
+            if (l == 0) s_tau[sub * TR + a][wv] = sacc;
         }
     }
     if (fold_only) return;
-    double rk[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) rk[q] = (cidx[q] < k) ? v.rK[cidx[q]] : 0.0;
-    double vacc[4] = {0.0, 0.0, 0.0, 0.0};
-    double tacc[TR];
-#pragma unroll
-    for (int a = 0; a < TR; ++a) {
-        int row = row0 + a;
-        tacc[a] = w[a][0] * rk[0] + w[a][1] * rk[1] + w[a][2] * rk[2] + w[a][3] * rk[3];
-        if (WITH_V && row < k) {
-            double t = v.tK[row];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) vacc[q] += w[a][q] * t;
-        }
-    }
     if (WITH_V) {
         double* pv = v.part_v + (size_t)blockIdx.x * ld;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (cidx[q] < k) pv[cidx[q]] = vacc[q];
     }
-    int wv = tid >> 6, l = tid & 63;
-#pragma unroll
-    for (int a = 0; a < TR; ++a) {
-        double sacc = wave_sum(tacc[a]);
-        if (l == 0) s_tau[a][wv] = sacc;
-    }
     __syncthreads();
-    if (tid < TR) {
-        int row = row0 + tid;
+    for (int t = tid; t < TR * RL; t += BLK) {
+        int row = row0 + t;
         if (row < k) {
-            double sacc = s_tau[tid][0];
-            for (int i = 1; i < BLK / 64; ++i) sacc += s_tau[tid][i];
+            double sacc = s_tau[t][0];
+            for (int i = 1; i < BLK / 64; ++i) sacc += s_tau[t][i];
             v.part_tau[(size_t)blockIdx.y * ld + row] = sacc;
         }
     }
@@ -1414,16 +1434,18 @@ __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push) {
     if (b * 32 >= k) return;
     __shared__ double s_part[8][33];
     const int nstripes = (k + TR - 1) / TR;
-    double s0 = 0.0, s1 = 0.0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (i < k) {
         int t = grp;
-        for (; t + 8 < nstripes; t += 16) {
+        for (; t + 24 < nstripes; t += 32) {  // four independent loads in flight per lane
             s0 += v.part_v[(size_t)t * v.ld + i];
             s1 += v.part_v[(size_t)(t + 8) * v.ld + i];
+            s2 += v.part_v[(size_t)(t + 16) * v.ld + i];
+            s3 += v.part_v[(size_t)(t + 24) * v.ld + i];
         }
-        if (t < nstripes) s0 += v.part_v[(size_t)t * v.ld + i];
+        for (; t < nstripes; t += 8) s0 += v.part_v[(size_t)t * v.ld + i];
     }
-    s_part[grp][lane32] = s0 + s1;
+    s_part[grp][lane32] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (grp == 0 && i < k) {
         double sv = s_part[0][lane32];
@@ -1782,18 +1804,28 @@ void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st) {
 }
 // rows per tile of the fused pass: 8 while W is small (more blocks in flight, 14 vs 20 us at
 // k = 1 800), 16 from cap 8192 on (half the v partials; measured 5.0-5.2 TB/s at k = 6 500 either way)
-static inline int fw_tr(const Geom& g) { return g.cap <= 4096 ? 8 : 16; }
+// row tiles per block of the large-nucleus tiling
+constexpr int FW_RL = 1;  // measured: 4 row tiles per block slow the stream down (251 vs 163 us at k = 10 000) and the v reduce is not the bottleneck
+static inline int fw_rows(const Geom& g) { return g.big ? 16 * FW_RL : 8; }
 static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fold_only, hipStream_t st) {
-    const int tr = fw_tr(g);
-    int nstripes = (g.cap + tr - 1) / tr, nchunks = (g.cap + FW_TC - 1) / FW_TC;
-    if (nstripes < LR_MAX) nstripes = LR_MAX;  // the extra block row needs one block per pending term
-    dim3 gr(nstripes, nchunks + 1), b(BLK);
-    if (tr == 8) {
-        if (with_v) hipLaunchKernelGGL((k_fused_lr<8, true, false>), gr, b, 0, st, dv, fold_only);
-        else hipLaunchKernelGGL((k_fused_lr<8, false, false>), gr, b, 0, st, dv, fold_only);
+    const int rows = fw_rows(g);
+    int nstripes = (g.cap + rows - 1) / rows, nchunks = (g.cap + FW_TC - 1) / FW_TC;
+    // the streaming pass carries one extra block row: one block per pending term (its low-rank dots)
+    dim3 gr(nstripes < LR_MAX ? LR_MAX : nstripes, nchunks + 1), gf(nstripes, nchunks), b(BLK);
+    if (rows == 8) {
+        if (!fold_only) {  // normal pivot: read-only streaming pass (exits at once on a folding pivot)
+            if (with_v) hipLaunchKernelGGL((k_fused_w<8, true, true, false, false, true>), gr, b, 0, st, dv);
+            else hipLaunchKernelGGL((k_fused_w<8, true, false, false, false, true>), gr, b, 0, st, dv);
+        }
+        if (with_v) hipLaunchKernelGGL((k_fused_lr<8, true, false>), gf, b, 0, st, dv, fold_only);
+        else hipLaunchKernelGGL((k_fused_lr<8, false, false>), gf, b, 0, st, dv, fold_only);
     } else {
-        if (with_v) hipLaunchKernelGGL((k_fused_lr<16, true, true>), gr, b, 0, st, dv, fold_only);
-        else hipLaunchKernelGGL((k_fused_lr<16, false, true>), gr, b, 0, st, dv, fold_only);
+        if (!fold_only) {
+            if (with_v) hipLaunchKernelGGL((k_fused_w<16, true, true, false, true, true, FW_RL>), gr, b, 0, st, dv);
+            else hipLaunchKernelGGL((k_fused_w<16, true, false, false, true, true, FW_RL>), gr, b, 0, st, dv);
+        }
+        if (with_v) hipLaunchKernelGGL((k_fused_lr<16, true, true, FW_RL>), gf, b, 0, st, dv, fold_only);
+        else hipLaunchKernelGGL((k_fused_lr<16, false, true, FW_RL>), gf, b, 0, st, dv, fold_only);
     }
 }
 void launch_fold_lowrank(const DevView& dv, const Geom& g, hipStream_t st) {
@@ -1806,23 +1838,23 @@ void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st
         launch_fused_lr(dv, g, with_v, 0, st);
         return;
     }
-    const int tr = fw_tr(g);
-    int nstripes = (g.cap + tr - 1) / tr, nchunks = (g.cap + FW_TC - 1) / FW_TC;
+    const int rows = fw_rows(g);
+    int nstripes = (g.cap + rows - 1) / rows, nchunks = (g.cap + FW_TC - 1) / FW_TC;
     dim3 gr(nstripes, nchunks), b(BLK);
-    if (tr == 8) {
+    if (rows == 8) {
         if (with_v) hipLaunchKernelGGL((k_fused_w<8, true, true, true>), gr, b, 0, st, dv);
         else hipLaunchKernelGGL((k_fused_w<8, true, false, true>), gr, b, 0, st, dv);
     } else {
-        if (with_v) hipLaunchKernelGGL((k_fused_w<16, true, true, true, true>), gr, b, 0, st, dv);
-        else hipLaunchKernelGGL((k_fused_w<16, true, false, true, true>), gr, b, 0, st, dv);
+        if (with_v) hipLaunchKernelGGL((k_fused_w<16, true, true, true, true, false, FW_RL>), gr, b, 0, st, dv);
+        else hipLaunchKernelGGL((k_fused_w<16, true, false, true, true, false, FW_RL>), gr, b, 0, st, dv);
     }
 }
 void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st) {
 #define POSTF(G)                                                                                                  \
     do {                                                                                                          \
         int n_push = blocks_for((long)g.cap * G);                                                                 \
-        if (with_v && fw_tr(g) == 8) hipLaunchKernelGGL((k_post_fused<G, true, 8>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push); \
-        else if (with_v) hipLaunchKernelGGL((k_post_fused<G, true, 16>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push); \
+        if (with_v && fw_rows(g) == 8) hipLaunchKernelGGL((k_post_fused<G, true, 8>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push); \
+        else if (with_v) hipLaunchKernelGGL((k_post_fused<G, true, 16 * FW_RL>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push); \
         else hipLaunchKernelGGL((k_post_fused<G, false, 16>), dim3(n_push), dim3(BLK), 0, st, dv, n_push);        \
     } while (0)
     LANES_SWITCH(g.lanes, POSTF(4), POSTF(16), POSTF(64));
@@ -1866,7 +1898,7 @@ void launch_copy_rho_sq_to_beta(const DevView& dv, int row, hipStream_t st) {
 }
 void launch_build_nucleus(const DevView& dv, const Geom& g, double* Kd, int k, hipStream_t st) {
     if (k <= 0) return;
-    (void)hipMemsetAsync(Kd, 0, sizeof(double) * (size_t)k * g.cap, st);
+    (void)hipMemsetAsync(Kd, 0, sizeof(double) * (size_t)k * dv.ld, st);
     hipLaunchKernelGGL(k_build_nucleus<16>, dim3(blocks_for((long)k * 16)), dim3(BLK), 0, st, dv, Kd, k);
 }
 void launch_gauss_jordan(double* Kd, double* Winv, int k, int ld, int* d_flag, double* d_scratch, hipStream_t st) {

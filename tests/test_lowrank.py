@@ -15,11 +15,18 @@ from tests.common import GEN, X_ATOL, check_feasible, obj_close
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[1, 3, 16])
+# (J, large-nucleus tiling forced): J = 0 is the in-place mode; the second flag selects the 64-row
+# non-temporal tiles and a padded row pitch of W that are otherwise used from capacity 8192 on
+@pytest.fixture(params=[(1, 0), (3, 0), (16, 0), (3, 1), (16, 1), (0, 1)], ids=lambda p: f"J{p[0]}-big{p[1]}")
 def lowrank(request):
-    os.environ["MLP_LOWRANK"] = str(request.param)
-    yield request.param
-    os.environ.pop("MLP_LOWRANK", None)
+    j, big = request.param
+    os.environ["MLP_LOWRANK"] = str(j)
+    if big:
+        os.environ["MLP_BIGTILE"] = "1"
+        os.environ["MLP_LDPAD"] = "16"
+    yield j
+    for k in ("MLP_LOWRANK", "MLP_BIGTILE", "MLP_LDPAD"):
+        os.environ.pop(k, None)
 
 
 CASES = [("sparse", dict(m=200, n=200, k=10, seed=4)), ("sparse", dict(m=700, n=600, k=12, seed=6)),

@@ -5,6 +5,8 @@ import time
 import numpy as np
 
 import os
+if os.environ.get("MLP_IMPORT_TORCH"):  # rocprofv3 crashes inside graph capture with the system HIP runtime; torch's bundled one works
+    import torch  # noqa: F401
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import minilp_amd as M
 from minilp_amd import lpgen
@@ -29,4 +31,5 @@ for c in range(nchunks):
     print(line, flush=True)
     if not s.budget_exhausted:
         break
-print("reinvert diff", s.reinvert())
+if not os.environ.get("MLP_NO_REINV"):
+    print("reinvert diff", s.reinvert())
