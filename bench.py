@@ -37,6 +37,24 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(a, which):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
+    (tools/pmc_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes of this workload, corrected as
+    MI355X_MICROARCH.md prescribes and as tools/pmc_calib.sh confirms).  PMC counters cannot be
+    collected from inside the timed run, so the figure is the committed per-launch average; null when
+    the workload differs from the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        doc = json.load(open(path))
+    except OSError:
+        return None
+    w = doc.get("workload", {})
+    if (w.get("rows"), w.get("cols"), w.get("nnz_per_row"), w.get("seed")) != (a.rows, a.cols, a.nnz_per_row, a.seed):
+        return None
+    k = doc.get("kernels", {}).get(which)
+    return k["hbm_bytes_per_launch"] if k else None
+
+
 def cpu_baseline(lp, warmup, sample):
     """The oracle (single-threaded C++ restatement of minilp 0.2.2) timed on this box's host cores:
     same instance, same warm-up, then `sample` timed pivots.  kind = "port" (the Rust reference
@@ -156,7 +174,8 @@ def main():
             kname = {"fused": "k_fused_w (tau=W*rho, v=W^T*t, eta update of the nucleus inverse)",
                      "sweep": "k_sweep (tableau row rho^T N [+ PSE helper] as a CSC pull over A)"}[dom]
             roofline = dict(bound="hbm", kernel=kname, achieved=kern[dom]["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=kern[dom]["gbs"] / HBM_PEAK_GBS, traffic=None,
+                            frac=kern[dom]["gbs"] / HBM_PEAK_GBS, traffic=pmc_traffic(a, dom),
+                            traffic_unit="HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
                             avg_launch_us=kern[dom]["avg_us"], launches=kern[dom]["launches"],
                             algorithmic_bytes_per_launch=kern[dom]["algorithmic_bytes_per_launch"],
                             other_kernels={k: v for k, v in kern.items() if k != dom})
