@@ -37,7 +37,14 @@ def read_tsplib(path, limit=None):
 
 
 def stoer_wagner(w):
-    """Global min cut of a dense symmetric weight matrix.  Returns (weight, boolean side mask)."""
+    """Global min cut of a dense symmetric weight matrix.  Returns (weight, boolean side mask).
+    Native implementation (libminilp_hip.so: mlp_util_min_cut); `stoer_wagner_py` below is the
+    same algorithm in numpy, kept as its executable specification (tests compare the two)."""
+    import minilp_amd
+    return minilp_amd.min_cut(w)
+
+
+def stoer_wagner_py(w):
     n = w.shape[0]
     w = w.copy()
     groups = [[i] for i in range(n)]

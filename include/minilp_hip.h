@@ -126,6 +126,12 @@ const char* mlp_mps_var_name(const mlp_mps* f, uint32_t i); /* MpsFile::variable
 int64_t mlp_mps_var_index(const mlp_mps* f, const char* name);
 mlp_problem* mlp_mps_problem(const mlp_mps* f);             /* MpsFile::problem mps.rs:15 (a clone) */
 
+/* ---- driver helper (host only; examples/tsp.rs:437-539) -------------------------------------------
+ * Stoer-Wagner global minimum cut of a dense symmetric n x n weight matrix (row-major, zero diagonal):
+ * returns the cut weight and marks one side of the cut in side_out[n] (0/1).  Used by the TSP
+ * cutting-plane driver to separate subtour-elimination constraints. */
+double mlp_util_min_cut(uint32_t n, const double* weights, uint8_t* side_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,7 @@ Python mirror of the reference's public interface (lib.rs:61-464).  There is no 
 the built extension or without a GPU every solve raises.
 """
 from .api import (EQ, GE, LE, MAXIMIZE, MINIMIZE, Infeasible, InternalError, MpsFile, Problem, Solution,
-                  Unbounded, device_count, lib, lib_path, set_device)
+                  Unbounded, device_count, lib, lib_path, min_cut, set_device)
 
 __all__ = ["Problem", "Solution", "MpsFile", "MINIMIZE", "MAXIMIZE", "EQ", "LE", "GE", "Infeasible", "Unbounded",
-           "InternalError", "device_count", "set_device", "lib", "lib_path"]
+           "InternalError", "device_count", "set_device", "lib", "lib_path", "min_cut"]

@@ -103,6 +103,7 @@ def lib():
     sig("mlp_mps_var_name", C.c_char_p, vp, u32)
     sig("mlp_mps_var_index", i64, vp, C.c_char_p)
     sig("mlp_mps_problem", vp, vp)
+    sig("mlp_util_min_cut", C.c_double, u32, pdbl, C.POINTER(C.c_uint8))
     _lib = L
     return L
 
@@ -134,6 +135,16 @@ def _terms(expr):
 
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
+
+
+def min_cut(weights):
+    """Stoer-Wagner global minimum cut of a dense symmetric weight matrix (host helper of the TSP
+    driver, include/minilp_hip.h).  Returns (cut weight, boolean side mask)."""
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    n = w.shape[0]
+    side = np.zeros(n, dtype=np.uint8)
+    val = lib().mlp_util_min_cut(n, _p(w, C.c_double), _p(side, C.c_uint8))
+    return float(val), side.astype(bool)
 
 
 class Problem:

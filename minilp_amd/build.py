@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libminilp_hip.so")
-SOURCES = ["kernels.hip", "engine.hip", "capi.hip", "mps.cpp"]
+SOURCES = ["kernels.hip", "engine.hip", "capi.hip", "mps.cpp", "util.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]
 

@@ -42,36 +42,53 @@ struct ProblemData {  // lib.rs:193-200
     void add_constraint(const uint32_t* vars, const double* coeffs, uint64_t k, int op, double rhs);
 };
 
+// Process-wide cache of small device blocks.  A Solution owns ~50 device arrays; `Solution::clone`
+// (one per branch-and-bound node in the TSP driver, lib.rs:313) and `drop` would otherwise pay one
+// hipMalloc / hipFree each (hipFree synchronises the device).  Blocks are rounded up to a power of two
+// and recycled; large blocks (W) go straight to the runtime.  A block is returned only after the
+// owning stream has been synchronised, so the next owner may use it on any stream.
+struct DevPool {
+    static constexpr size_t kMaxBlock = (size_t)64 << 20;   // larger blocks are not cached
+    static constexpr size_t kMaxCached = (size_t)4 << 30;   // total bytes kept in the cache
+    static void* get(size_t bytes, size_t* got_bytes);
+    static void put(void* p, size_t bytes);
+    static void trim();  // hipFree everything cached
+};
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
-    size_t cap = 0;
+    size_t cap = 0;        // elements
+    size_t bytes = 0;      // size of the block as obtained from the pool
     DevBuf() {}
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) DevPool::put(p, bytes);
         p = nullptr;
         cap = 0;
+        bytes = 0;
     }
     // grow to hold n elements, preserving the first `keep` ones
     void ensure(size_t n, size_t keep, hipStream_t st) {
         if (n <= cap) return;
-        size_t ncap = n + n / 2 + 64;
-        T* np = nullptr;
-        HIPCHECK(hipMalloc(&np, ncap * sizeof(T)));
+        size_t want = n + n / 2 + 64, got = 0;
+        T* np = static_cast<T*>(DevPool::get(want * sizeof(T), &got));
         if (p && keep) HIPCHECK(hipMemcpyAsync(np, p, keep * sizeof(T), hipMemcpyDeviceToDevice, st));
         if (p) {
             HIPCHECK(hipStreamSynchronize(st));
-            (void)hipFree(p);
+            DevPool::put(p, bytes);
         }
         p = np;
-        cap = ncap;
+        bytes = got;
+        cap = got / sizeof(T);
     }
-    void alloc_exact(size_t n) {  // fresh allocation of exactly n elements (contents undefined)
+    void alloc_exact(size_t n) {  // fresh allocation of (at least) n elements (contents undefined)
         release();
-        HIPCHECK(hipMalloc(&p, n * sizeof(T)));
+        size_t got = 0;
+        p = static_cast<T*>(DevPool::get(n * sizeof(T), &got));
+        bytes = got;
         cap = n;
     }
     void upload(const std::vector<T>& h, hipStream_t st) {
@@ -175,6 +192,9 @@ private:
     DevBuf<double> d_alpha_r, d_helper;
     DevBuf<int2> d_nb_rng;
     int sweep_variant = 0;
+    int rt_device = 0;
+    void acquire_runtime();  // streams, events, pinned Ctl mirror: recycled across Solutions
+    void release_runtime();
     bool force_big_tiles = false;  // MLP_BIGTILE: use the large-nucleus tiling of the fused W pass at any size (tests)
     int shard_rank = 0, shard_world = 1;
     MailRec* d_mail = nullptr;

@@ -11,9 +11,12 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -64,13 +67,7 @@ Engine::Engine() {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         throw MlpError(-4, "no HIP device visible: the simplex hot path has no CPU fallback");
-    HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    HIPCHECK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
-    for (int i = 0; i < 3; ++i) {
-        HIPCHECK(hipEventCreateWithFlags(&evFork[i], hipEventDisableTiming));
-        HIPCHECK(hipEventCreateWithFlags(&evJoin[i], hipEventDisableTiming));
-    }
-    HIPCHECK(hipHostMalloc((void**)&h_ctl, sizeof(Ctl), hipHostMallocDefault));
+    acquire_runtime();
     std::memset(h_ctl, 0, sizeof(Ctl));
     std::memset(&hview, 0, sizeof(hview));
     const char* ng = std::getenv("MLP_NO_GRAPH");
@@ -90,23 +87,160 @@ Engine::Engine() {
     const char* bs = std::getenv("MLP_BATCH");
     if (bs) batch = std::max(1, std::min(RING, std::atoi(bs)));
 }
+// ------------------------------------------------------------------ per-Solution runtime objects
+// Two streams, six events and the pinned Ctl mirror cost 4-5 ms to create and 3 ms to destroy; the
+// TSP driver clones and drops a Solution per branch-and-bound node, so idle sets are recycled.
+namespace {
+struct RtBundle {
+    int device = 0;
+    hipStream_t st = nullptr, st2 = nullptr;
+    hipEvent_t evFork[3] = {nullptr, nullptr, nullptr}, evJoin[3] = {nullptr, nullptr, nullptr};
+    Ctl* h_ctl = nullptr;
+};
+struct RtPool {
+    std::mutex mu;
+    std::vector<RtBundle> idle;
+};
+RtPool& rt_pool() {
+    static RtPool* p = new RtPool();
+    return *p;
+}
+constexpr size_t kMaxIdleRuntimes = 64;
+}  // namespace
+void Engine::acquire_runtime() {
+    int dev = 0;
+    HIPCHECK(hipGetDevice(&dev));
+    rt_device = dev;
+    {
+        RtPool& p = rt_pool();
+        std::lock_guard<std::mutex> lk(p.mu);
+        for (size_t i = 0; i < p.idle.size(); ++i)
+            if (p.idle[i].device == dev) {
+                RtBundle b = p.idle[i];
+                p.idle.erase(p.idle.begin() + (long)i);
+                st = b.st; st2 = b.st2; h_ctl = b.h_ctl;
+                for (int j = 0; j < 3; ++j) { evFork[j] = b.evFork[j]; evJoin[j] = b.evJoin[j]; }
+                return;
+            }
+    }
+    HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIPCHECK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+    for (int i = 0; i < 3; ++i) {
+        HIPCHECK(hipEventCreateWithFlags(&evFork[i], hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&evJoin[i], hipEventDisableTiming));
+    }
+    HIPCHECK(hipHostMalloc((void**)&h_ctl, sizeof(Ctl), hipHostMallocDefault));
+}
+void Engine::release_runtime() {  // both streams are idle (synchronised by the destructor)
+    RtBundle b;
+    b.device = rt_device; b.st = st; b.st2 = st2; b.h_ctl = h_ctl;
+    for (int j = 0; j < 3; ++j) { b.evFork[j] = evFork[j]; b.evJoin[j] = evJoin[j]; }
+    st = st2 = nullptr; h_ctl = nullptr;
+    if (!b.st || !b.st2 || !b.h_ctl) {  // partially constructed: destroy what exists
+        if (b.h_ctl) (void)hipHostFree(b.h_ctl);
+        for (int j = 0; j < 3; ++j) {
+            if (b.evFork[j]) (void)hipEventDestroy(b.evFork[j]);
+            if (b.evJoin[j]) (void)hipEventDestroy(b.evJoin[j]);
+        }
+        if (b.st2) (void)hipStreamDestroy(b.st2);
+        if (b.st) (void)hipStreamDestroy(b.st);
+        return;
+    }
+    RtPool& p = rt_pool();
+    std::lock_guard<std::mutex> lk(p.mu);
+    if (p.idle.size() < kMaxIdleRuntimes) {
+        p.idle.push_back(b);
+        return;
+    }
+    (void)hipHostFree(b.h_ctl);
+    for (int j = 0; j < 3; ++j) {
+        (void)hipEventDestroy(b.evFork[j]);
+        (void)hipEventDestroy(b.evJoin[j]);
+    }
+    (void)hipStreamDestroy(b.st2);
+    (void)hipStreamDestroy(b.st);
+}
+
+// ------------------------------------------------------------------ device block cache
+namespace {
+struct PoolState {
+    std::mutex mu;
+    std::map<size_t, std::vector<void*>> free_blocks;  // by block size
+    size_t cached = 0;
+};
+PoolState& pool() {
+    static PoolState* s = new PoolState();  // never destroyed: blocks may be returned during process exit
+    return *s;
+}
+size_t round_block(size_t bytes) {
+    size_t b = 256;
+    while (b < bytes) b <<= 1;
+    return b;
+}
+}  // namespace
+void* DevPool::get(size_t bytes, size_t* got_bytes) {
+    if (bytes == 0) bytes = 1;
+    if (bytes <= kMaxBlock) {
+        const size_t b = round_block(bytes);
+        {
+            PoolState& s = pool();
+            std::lock_guard<std::mutex> lk(s.mu);
+            auto it = s.free_blocks.find(b);
+            if (it != s.free_blocks.end() && !it->second.empty()) {
+                void* p = it->second.back();
+                it->second.pop_back();
+                s.cached -= b;
+                *got_bytes = b;
+                return p;
+            }
+        }
+        bytes = b;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {  // give the cache back to the runtime and retry once
+        trim();
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess)
+        throw MlpError(-3, std::string("hipMalloc(") + std::to_string(bytes) + " bytes) failed: " + hipGetErrorString(e));
+    *got_bytes = bytes;
+    return p;
+}
+void DevPool::put(void* p, size_t bytes) {
+    if (!p) return;
+    if (bytes <= kMaxBlock && bytes == round_block(bytes)) {
+        PoolState& s = pool();
+        std::lock_guard<std::mutex> lk(s.mu);
+        if (s.cached + bytes <= kMaxCached) {
+            s.free_blocks[bytes].push_back(p);
+            s.cached += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+void DevPool::trim() {
+    PoolState& s = pool();
+    std::lock_guard<std::mutex> lk(s.mu);
+    for (auto& kv : s.free_blocks)
+        for (void* p : kv.second) (void)hipFree(p);
+    s.free_blocks.clear();
+    s.cached = 0;
+}
+
 Engine::~Engine() {
-    if (st) (void)hipStreamSynchronize(st);
+    if (st) (void)hipStreamSynchronize(st);   // the buffers go back to the pool: nothing may still use them
+    if (st2) (void)hipStreamSynchronize(st2);
     drop_graphs();
     for (auto& e : ev)
         if (e) (void)hipEventDestroy(e);
-    if (h_ctl) (void)hipHostFree(h_ctl);
     if (blas) (void)rocblas_destroy_handle(reinterpret_cast<rocblas_handle>(blas));
     if (mail_host) {
         (void)hipHostUnregister(mail_host);
         (void)munmap(mail_host, mail_bytes);
     }
-    for (int i = 0; i < 3; ++i) {
-        if (evFork[i]) (void)hipEventDestroy(evFork[i]);
-        if (evJoin[i]) (void)hipEventDestroy(evJoin[i]);
-    }
-    if (st2) (void)hipStreamDestroy(st2);
-    if (st) (void)hipStreamDestroy(st);
+    release_runtime();
 }
 void Engine::drop_graphs() {
     for (int a = 0; a < 2; ++a)
@@ -219,7 +353,7 @@ void Engine::ensure_nucleus_cap(int need) {
                                   (size_t)k_ * sizeof(double), (size_t)k_, hipMemcpyDeviceToDevice, st));
     HIPCHECK(hipStreamSynchronize(st));
     d_W.release();
-    d_W.p = nW.p; d_W.cap = nW.cap; nW.p = nullptr; nW.cap = 0;
+    d_W.p = nW.p; d_W.cap = nW.cap; d_W.bytes = nW.bytes; nW.p = nullptr; nW.cap = 0; nW.bytes = 0;
     size_t keep = (size_t)k_;
     d_pos_of_kslot.ensure(ncap, keep, st); d_row_of_kslot.ensure(ncap, keep, st);
     d_aK.ensure(ncap, keep, st); d_rK.ensure(ncap, keep, st); d_tK.ensure(ncap, keep, st);

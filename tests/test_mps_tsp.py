@@ -91,6 +91,20 @@ def test_min_cut_kat():  # examples/tsp.rs:541-564
     assert weight == 4.0
     side = set(np.nonzero(mask)[0].tolist())
     assert side in ({2, 3, 6, 7}, {0, 1, 4, 5})
+    weight_py, mask_py = tsp.stoer_wagner_py(w)
+    assert weight_py == 4.0 and (mask_py == mask).all()
+
+
+def test_min_cut_native_equals_numpy_specification():
+    rng = np.random.default_rng(7)
+    for n in (2, 3, 9, 40):
+        for _ in range(5):
+            a = rng.random((n, n)) * (rng.random((n, n)) < 0.4)
+            w = np.triu(a, 1)
+            w = w + w.T
+            wn, mn = tsp.stoer_wagner(w)
+            wp, mp = tsp.stoer_wagner_py(w)
+            assert wn == wp and (mn == mp).all()
 
 
 def test_tsp_oracle_small():
