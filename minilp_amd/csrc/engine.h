@@ -183,6 +183,11 @@ private:
     DevBuf<uint8_t> d_nbflags;
     DevBuf<int> d_kslot_of_pos, d_srow_of_pos, d_kslot_of_row, d_pos_of_srow, d_pos_of_kslot, d_row_of_kslot;
     DevBuf<RowInfo> d_rowinfo;
+    DevBuf<int> d_colblk;        // blocked F push (large nucleus): row-block offsets per column
+    DevBuf<double> d_push_part;  // ... and its PB_CHUNKS x m partial sums
+    bool colblk_dirty = true;
+    bool pb_disable = false;     // MLP_NO_BLOCKED_PUSH
+    void ensure_colblk();
     DevBuf<double> d_sdiag_of_pos, d_W, d_U, d_V;
     int ld_pad = 16;    // MLP_LDPAD: extra doubles per row of a large W (row pitch = cap + pad): breaks the power-of-two stride
     int pad_for(int cap) const { return (cap >= 8192 || force_big_tiles) ? ld_pad : 0; }

@@ -84,6 +84,8 @@ Engine::Engine() {
     if (sv) sweep_variant = std::atoi(sv);
     const char* bt = std::getenv("MLP_BIGTILE");
     force_big_tiles = bt && std::atoi(bt) != 0;
+    const char* nbp = std::getenv("MLP_NO_BLOCKED_PUSH");
+    pb_disable = nbp && std::atoi(nbp) != 0;
     const char* bs = std::getenv("MLP_BATCH");
     if (bs) batch = std::max(1, std::min(RING, std::atoi(bs)));
 }
@@ -264,6 +266,29 @@ Geom Engine::geom() const {
     return g;
 }
 
+// Row-block offsets of every column for the blocked F push: colblk[var][b] = first CSC index of column
+// var whose row is >= b * PB_ROWS (columns hold ascending rows), colblk[var][RB] = end of the column.
+void Engine::ensure_colblk() {
+    if (!colblk_dirty) return;
+    const int rb = (m_ + PB_ROWS - 1) / PB_ROWS;
+    std::vector<int> t((size_t)N_ * (rb + 1));
+    for (int var = 0; var < N_; ++var) {
+        int e = h_cptr[var];
+        const int end = h_cptr[var + 1];
+        int* dst = &t[(size_t)var * (rb + 1)];
+        for (int b = 0; b <= rb; ++b) {
+            const long lim = (long)b * PB_ROWS;
+            while (e < end && h_crow[e] < lim) ++e;
+            dst[b] = e;
+        }
+        dst[rb] = end;
+    }
+    d_colblk.upload(t, st);
+    d_push_part.ensure((size_t)PB_CHUNKS * (size_t)m_, 0, st);
+    HIPCHECK(hipStreamSynchronize(st));  // `t` is a local staging buffer
+    colblk_dirty = false;
+}
+
 DevView* Engine::sync_view() {
     if (!view_dirty) return &hview;
     DevView old = hview;
@@ -277,6 +302,11 @@ DevView* Engine::sync_view() {
     v.nb_vars = d_nb_vars.p; v.d = d_d.p; v.xN = d_xN.p; v.gamma = d_gamma.p; v.nbflags = d_nbflags.p;
     v.kslot_of_pos = d_kslot_of_pos.p; v.srow_of_pos = d_srow_of_pos.p; v.sdiag_of_pos = d_sdiag_of_pos.p;
     v.kslot_of_row = d_kslot_of_row.p; v.pos_of_srow = d_pos_of_srow.p; v.rowinfo = d_rowinfo.p;
+    v.pb_on = ((cap_ > 4096 || force_big_tiles) && !pb_disable) ? 1 : 0;
+    if (v.pb_on) ensure_colblk();
+    v.colblk = v.pb_on ? d_colblk.p : nullptr;
+    v.push_part = v.pb_on ? d_push_part.p : nullptr;
+    v.pb_rb = (m_ + PB_ROWS - 1) / PB_ROWS;
     v.pos_of_kslot = d_pos_of_kslot.p; v.row_of_kslot = d_row_of_kslot.p; v.W = d_W.p;
     v.U = d_U.p; v.V = d_V.p; v.pad1 = 0;
     v.lrJ = lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 16 : 0);
@@ -320,6 +350,7 @@ void Engine::upload_matrix() {
     d_cptr.upload(h_cptr, st); d_crow.upload(h_crow, st); d_cval.upload(h_cval, st);
     d_rptr.upload(h_rptr, st); d_rcol.upload(h_rcol, st); d_rval.upload(h_rval, st);
     d_lo.upload(h_lo, st); d_hi.upload(h_hi, st); d_obj.upload(h_obj, st);
+    colblk_dirty = true;
     view_dirty = true;
 }
 
@@ -1181,7 +1212,7 @@ Engine* Engine::clone() {
     e->resume_in_optimize = resume_in_optimize;
     e->nnz_nonbasic = nnz_nonbasic;
     e->trace = trace; e->profile = profile;
-    e->ld_pad = ld_pad; e->lr_force = lr_force; e->force_big_tiles = force_big_tiles;
+    e->ld_pad = ld_pad; e->lr_force = lr_force; e->force_big_tiles = force_big_tiles; e->pb_disable = pb_disable;
     hipStream_t s2 = e->st;
     e->upload_matrix();
     int mk = m_;

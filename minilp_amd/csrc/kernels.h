@@ -122,6 +122,11 @@ struct DevView {
     int* kslot_of_row;     // m: col slot of W for a nucleus row, -1 for a row covered by a singleton
     int* pos_of_srow;      // m: position of the singleton covering that row
     RowInfo* rowinfo;      // m: the three row maps packed for the F pushes (one 16-byte gather per matrix entry)
+    // blocked F push of the large-nucleus regime (pb_on): per column, the CSC offset at which each block of
+    // PB_ROWS rows starts (N x (pb_rb + 1)), and PB_CHUNKS x m partial sums
+    int* colblk;
+    double* push_part;
+    int pb_rb, pb_on;
     int* pos_of_kslot;     // cap: row slot -> position
     int* row_of_kslot;     // cap: col slot -> row
     double* W;             // cap x ld, row-major: W[rowslot(p)][colslot(i)] = (B^-1)[p, i]  (W0 in delayed-update mode)
@@ -158,6 +163,9 @@ constexpr int FW_TR = 8;     // minimum rows per block (sizes the partial buffer
 constexpr int FW_TC = 1024;  // columns per block (256 threads x 4)
 
 // Launch geometry that is baked into a captured graph.
+constexpr int PB_ROWS = 4096;   // rows per LDS block of the blocked F push (32 KB of doubles)
+constexpr int PB_CHUNKS = 24;   // column chunks (slot ranges) of the blocked F push
+
 struct Geom {
     int m, n, cap;
     int lanes;  // lanes per CSC column in the pull kernels (4, 16 or 64; from the average column length)

@@ -645,7 +645,98 @@ __global__ void __launch_bounds__(BLK) k_ftran_gather(DevView v) {
         v.aK[slot] = acc;
         v.alpha_q[p] = acc;
     }
-    if (acc != 0.0) push_F<G>(v, p, acc, v.alpha_q, gl);
+    if (acc != 0.0 && !v.pb_on) push_F<G>(v, p, acc, v.alpha_q, gl);
+}
+
+// Blocked F push of the large-nucleus regime.  y_S -= D^-1 F x_K through device-scope f64 atomics costs
+// ~10^6 memory-side atomics per call at k = 10^4 (~25 G/s: 45-55 us).  Here block (b, c) accumulates the
+// entries of its slot range c that fall into row block b in LDS (ds_add_f64), the per-chunk sums go to
+// push_part[c][row] with plain stores, and k_push_combine adds them up per singleton row: no global
+// atomics, and the global summation order is fixed (only the LDS order within a block is not).
+constexpr int PB_TILE = 512;  // slot descriptors staged in LDS per round
+__global__ void __launch_bounds__(BLK) k_push_stage1(DevView v, int which) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    __shared__ double acc[PB_ROWS];
+    __shared__ double s_x[PB_TILE];
+    __shared__ int s_beg[PB_TILE], s_len[PB_TILE];
+    const int b = blockIdx.x, cc = blockIdx.y, tid = threadIdx.x;
+    const int row0 = b * PB_ROWS;
+    const int nrows = min(PB_ROWS, v.m - row0);
+    for (int t = tid; t < nrows; t += BLK) acc[t] = 0.0;
+    const int k = c->k;
+    const int per = (k + PB_CHUNKS - 1) / PB_CHUNKS;
+    const int s_lo = cc * per, s_hi = min(k, s_lo + per);
+    const double* xK = which ? v.tauK : v.aK;
+    const int lane = tid & 7, grp = tid >> 3;  // 8 lanes per slot, 32 slots side by side
+    const int stride = v.pb_rb + 1;
+    for (int tile0 = s_lo; tile0 < s_hi; tile0 += PB_TILE) {
+        const int nt = min(PB_TILE, s_hi - tile0);
+        __syncthreads();  // acc zeroed / the previous tile's descriptors are no longer read
+        // phase A: one thread per slot fetches (x, segment of the column inside this row block); the
+        // three-deep dependent chain slot -> position -> variable -> offsets is paid once, in parallel
+        for (int t = tid; t < nt; t += BLK) {
+            const int slot = tile0 + t;
+            const double x = xK[slot];
+            const int var = v.basic_vars[v.pos_of_kslot[slot]];
+            const int beg = v.colblk[(size_t)var * stride + b], end = v.colblk[(size_t)var * stride + b + 1];
+            s_x[t] = x;
+            s_beg[t] = beg;
+            s_len[t] = (x != 0.0) ? end - beg : 0;
+        }
+        __syncthreads();
+        // phase B: four slots per 8-lane group in flight (independent loads), then the LDS atomics
+        for (int base = grp * 4; base < nt; base += (BLK / 8) * 4) {
+            int r[4];
+            double a[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = base + j;
+                const int len = t < nt ? s_len[t] : 0;
+                r[j] = -1;
+                a[j] = 0.0;
+                if (lane < len) {
+                    const int e = s_beg[t] + lane;
+                    r[j] = v.csc_row[e] - row0;
+                    a[j] = v.csc_val[e] * s_x[t];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (r[j] >= 0) unsafeAtomicAdd(&acc[r[j]], a[j]);
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {  // segments longer than 8 entries (rare)
+                const int t = base + j;
+                const int len = t < nt ? s_len[t] : 0;
+                for (int o = 8 + lane; o < len; o += 8) {
+                    const int e = s_beg[t] + o;
+                    unsafeAtomicAdd(&acc[v.csc_row[e] - row0], v.csc_val[e] * s_x[t]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    double* dst = v.push_part + (size_t)cc * v.m + row0;
+    for (int t = tid; t < nrows; t += BLK) dst[t] = acc[t];
+}
+__global__ void __launch_bounds__(BLK) k_push_combine(DevView v, int which) {
+    const Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    const int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= v.m) return;
+    const RowInfo ri = v.rowinfo[i];
+    if (ri.kslot >= 0) return;
+    double s = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < PB_CHUNKS; ++cc) s += v.push_part[(size_t)cc * v.m + i];
+    if (s != 0.0) {
+        double* out = which ? v.tau : v.alpha_q;
+        out[ri.pos] -= s / ri.diag;
+    }
+}
+static void launch_blocked_push(const DevView& dv, int which, hipStream_t st) {
+    hipLaunchKernelGGL(k_push_stage1, dim3(dv.pb_rb, PB_CHUNKS), dim3(BLK), 0, st, dv, which);
+    hipLaunchKernelGGL(k_push_combine, dim3((dv.m + BLK - 1) / BLK), dim3(BLK), 0, st, dv, which);
 }
 
 // ------------------------------------------------------------------- K5: primal Harris ratio test
@@ -1164,14 +1255,17 @@ __device__ __forceinline__ void fw_store2(double* p, double a, double b) {
 // LR = delayed-update mode, normal (non-folding) pivot: the same streaming pass with DO_UPDATE off;
 // it leaves folding pivots to k_fused_lr, and one extra block row computes the low-rank dots
 // g_j = V[j].rho_K, h_j = U[j].t_K that k_post_fused adds to the two products.
-template <int TR, bool WITH_TAU, bool WITH_V, bool DO_UPDATE, bool NT = false, bool LR = false, int RL = 1>
+// TILED: 1-D grid; the tile blocks stride over the (stripe, chunk) tiles of the CURRENT k, so neither a
+// pass nor an early exit pays for dispatching the cap-sized grid (16 384 blocks at cap 16 384: ~20 us).
+template <int TR, bool WITH_TAU, bool WITH_V, bool DO_UPDATE, bool NT = false, bool LR = false, int RL = 1, bool TILED = false>
 __global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     if (LR && c->fold) return;
     const int k = c->k, ld = v.ld;
-    if (LR && blockIdx.y == gridDim.y - 1) {
-        const int j = blockIdx.x;
+    const int n_tile_blocks = TILED ? (int)gridDim.x - (LR ? LR_MAX : 0) : 0;
+    if (LR && (TILED ? (int)blockIdx.x >= n_tile_blocks : blockIdx.y == gridDim.y - 1)) {
+        const int j = TILED ? (int)blockIdx.x - n_tile_blocks : (int)blockIdx.x;
         if (j >= c->nlow) return;
         const double* Vj = v.V + (size_t)j * ld;
         const double* Uj = v.U + (size_t)j * ld;
@@ -1190,11 +1284,16 @@ __global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
     }
     // a block owns RL consecutive row tiles of TR rows (RL > 1 for a large nucleus: RL times fewer
     // v partials to write here and to reduce in k_post_fused) and one chunk of FW_TC columns
-    const int row0 = blockIdx.x * (TR * RL);
-    const int col0 = blockIdx.y * FW_TC;
-    if (row0 >= k || col0 >= k) return;
     __shared__ double s_tau[TR * RL][BLK / 64];
     const int tid = threadIdx.x;
+    const int nchunks_k = (k + FW_TC - 1) / FW_TC;
+    const int ntiles = TILED ? ((k + TR * RL - 1) / (TR * RL)) * nchunks_k : 1;
+    for (int tile = TILED ? (int)blockIdx.x : 0; tile < ntiles; tile += TILED ? n_tile_blocks : 1) {
+    const int stripe = TILED ? tile / nchunks_k : (int)blockIdx.x;
+    const int chunk = TILED ? tile % nchunks_k : (int)blockIdx.y;
+    const int row0 = stripe * (TR * RL);
+    const int col0 = chunk * FW_TC;
+    if (row0 >= k || col0 >= k) return;  // untiled grids are sized by the capacity
     int cidx[4];
     cidx[0] = col0 + 2 * tid;
     cidx[1] = cidx[0] + 1;
@@ -1258,7 +1357,7 @@ __global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
         }
     }
     if (WITH_V) {
-        double* pv = v.part_v + (size_t)blockIdx.x * ld;
+        double* pv = v.part_v + (size_t)stripe * ld;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (cidx[j] < k) pv[cidx[j]] = vacc[j];
@@ -1270,9 +1369,11 @@ __global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
             if (row < k) {
                 double sacc = s_tau[t][0];
                 for (int i = 1; i < BLK / 64; ++i) sacc += s_tau[t][i];
-                v.part_tau[(size_t)blockIdx.y * ld + row] = sacc;
+                v.part_tau[(size_t)chunk * ld + row] = sacc;
             }
         }
+    }
+    if (TILED) __syncthreads();  // s_tau is reused by the next tile
     }
 }
 // Delayed-update mode: W = W0 + sum_j U[j] V[j]^T with at most J pending rank-1
@@ -1395,6 +1496,135 @@ __global__ void __launch_bounds__(BLK) k_fused_lr(DevView v, int fold_only) {
         }
     }
 }
+// Fold kernel of the large-nucleus tiling (16 rows x 1024 columns per block, at most 16 pending terms).
+// Register budget decides its speed: the fold needs the block's V entries (they do not depend on the
+// row) and a tile of W in registers at once, and it must keep enough waves per SIMD to overlap its load,
+// FMA and store phases.  Each thread therefore owns 2 columns at a time (the block walks its 1024
+// columns in two halves): 32 V values + a 4-row tile = ~110 VGPRs, 4 waves per SIMD.
+template <bool WITH_V, bool NT>
+__global__ void __launch_bounds__(BLK) k_fused_lr16(DevView v, int fold_only) {
+    constexpr int TRB = 16, ST = 4, JM = 16;
+    Ctl* c = v.ctl;
+    if (!fold_only && (c->halt || c->it.status != ITER_PIVOT)) return;
+    const int k = c->k, ld = v.ld;
+    const int nlow = c->nlow;
+    if (!(fold_only || c->fold)) return;
+    const int tid = threadIdx.x;
+    __shared__ double s_tau[TRB][BLK / 64];
+    __shared__ double s_u[JM][TRB];
+    // 1-D grid striding over the (stripe, chunk) tiles of the current k (see k_fused_w, TILED)
+    const int nchunks_k = (k + FW_TC - 1) / FW_TC;
+    const int ntiles = ((k + TRB - 1) / TRB) * nchunks_k;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int stripe = tile / nchunks_k, chunk = tile % nchunks_k;
+    const int row0 = stripe * TRB;
+    const int col0 = chunk * FW_TC;
+    __syncthreads();  // the previous tile's readers of s_u / s_tau are done
+    for (int i = tid; i < JM * TRB; i += BLK) {
+        int j = i / TRB, a = i % TRB;
+        int row = row0 + a;
+        s_u[j][a] = (j < nlow && row < k) ? v.U[(size_t)j * ld + row] : 0.0;
+    }
+    if (tid < TRB * (BLK / 64)) (&s_tau[0][0])[tid] = 0.0;
+    __syncthreads();
+    const int wv = tid >> 6, l = tid & 63;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const int c0 = col0 + half * (FW_TC / 2) + 2 * tid;
+        if (col0 + half * (FW_TC / 2) >= k) break;
+        const bool pair = c0 + 1 < k, one = c0 < k;
+        double vj[JM][2];
+#pragma unroll
+        for (int j = 0; j < JM; ++j) {
+            vj[j][0] = vj[j][1] = 0.0;
+            if (j < nlow) {
+                const double* Vj = v.V + (size_t)j * ld;
+                if (pair) {
+                    double2 t = *reinterpret_cast<const double2*>(Vj + c0);
+                    vj[j][0] = t.x;
+                    vj[j][1] = t.y;
+                } else if (one) {
+                    vj[j][0] = Vj[c0];
+                }
+            }
+        }
+        double rk0 = 0.0, rk1 = 0.0;
+        if (!fold_only) {
+            if (one) rk0 = v.rK[c0];
+            if (pair) rk1 = v.rK[c0 + 1];
+        }
+        double vacc0 = 0.0, vacc1 = 0.0;
+#pragma unroll 1
+        for (int sub = 0; sub < TRB / ST; ++sub) {
+            const int rbase = row0 + sub * ST;
+            if (rbase >= k) break;
+            double w[ST][2];
+#pragma unroll
+            for (int a = 0; a < ST; ++a) {
+                const int row = rbase + a;
+                w[a][0] = w[a][1] = 0.0;
+                if (row >= k) continue;
+                const double* wp = v.W + (size_t)row * ld;
+                if (pair) {
+                    double2 t = fw_load2<NT>(wp + c0);
+                    w[a][0] = t.x;
+                    w[a][1] = t.y;
+                } else if (one) {
+                    w[a][0] = wp[c0];
+                }
+            }
+            // explicit FMA: the build runs with -ffp-contract=off (the update formulas mirror the
+            // reference's separate multiply and add), but a fold is already a re-association of 16
+            // updates; one rounding per term is both cheaper and more accurate
+#pragma unroll
+            for (int j = 0; j < JM; ++j) {
+#pragma unroll
+                for (int a = 0; a < ST; ++a) {
+                    const double u = s_u[j][sub * ST + a];
+                    w[a][0] = __builtin_fma(u, vj[j][0], w[a][0]);
+                    w[a][1] = __builtin_fma(u, vj[j][1], w[a][1]);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < ST; ++a) {
+                const int row = rbase + a;
+                if (row >= k) continue;
+                double* wp = v.W + (size_t)row * ld;
+                if (pair) fw_store2<NT>(wp + c0, w[a][0], w[a][1]);
+                else if (one) wp[c0] = w[a][0];
+            }
+            if (fold_only) continue;
+#pragma unroll
+            for (int a = 0; a < ST; ++a) {
+                const int row = rbase + a;
+                double tacc = w[a][0] * rk0 + w[a][1] * rk1;
+                if (WITH_V && row < k) {
+                    const double t = v.tK[row];
+                    vacc0 += w[a][0] * t;
+                    vacc1 += w[a][1] * t;
+                }
+                const double sacc = wave_sum(tacc);
+                if (l == 0) s_tau[sub * ST + a][wv] += sacc;  // this wave's own cell: no race
+            }
+        }
+        if (!fold_only && WITH_V) {
+            double* pv = v.part_v + (size_t)stripe * ld;
+            if (one) pv[c0] = vacc0;
+            if (pair) pv[c0 + 1] = vacc1;
+        }
+    }
+    if (fold_only) continue;
+    __syncthreads();
+    if (tid < TRB) {
+        int row = row0 + tid;
+        if (row < k) {
+            double sacc = s_tau[tid][0];
+            for (int i = 1; i < BLK / 64; ++i) sacc += s_tau[tid][i];
+            v.part_tau[(size_t)chunk * ld + row] = sacc;
+        }
+    }
+    }
+}
 __global__ void k_reset_nlow(DevView v) {
     v.ctl->nlow = 0;
     v.ctl->fold = 0;
@@ -1423,7 +1653,7 @@ __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push) {
             v.tauK[slot] = x;
             v.tau[p] = x;
         }
-        if (x != 0.0) push_F<G>(v, p, x, v.tau, gl);
+        if (x != 0.0 && !v.pb_on) push_F<G>(v, p, x, v.tau, gl);
         return;
     }
     if (!WITH_V) return;
@@ -1753,6 +1983,7 @@ void launch_ftran_gather(const DevView& dv, const Geom& g, hipStream_t st) {
                  hipLaunchKernelGGL(k_ftran_gather<4>, dim3(blocks_for((long)g.cap * 4)), dim3(BLK), 0, st, dv),
                  hipLaunchKernelGGL(k_ftran_gather<16>, dim3(blocks_for((long)g.cap * 16)), dim3(BLK), 0, st, dv),
                  hipLaunchKernelGGL(k_ftran_gather<64>, dim3(blocks_for((long)g.cap * 64)), dim3(BLK), 0, st, dv));
+    if (dv.pb_on) launch_blocked_push(dv, 0, st);
 }
 void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st) {
     hipLaunchKernelGGL(k_ratio_primal_p1, dim3(grid_for(g.m)), dim3(BLK), 0, st, dv, use_pse);
@@ -1807,12 +2038,15 @@ void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st) {
 // row tiles per block of the large-nucleus tiling
 constexpr int FW_RL = 1;  // measured: 4 row tiles per block slow the stream down (251 vs 163 us at k = 10 000) and the v reduce is not the bottleneck
 static inline int fw_rows(const Geom& g) { return g.big ? 16 * FW_RL : 8; }
+// 1-D grid of the tiled large-nucleus passes: enough blocks to fill the chip a few times over
+constexpr int FW_TILE_BLOCKS = 4096;
 static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fold_only, hipStream_t st) {
     const int rows = fw_rows(g);
     int nstripes = (g.cap + rows - 1) / rows, nchunks = (g.cap + FW_TC - 1) / FW_TC;
-    // the streaming pass carries one extra block row: one block per pending term (its low-rank dots)
-    dim3 gr(nstripes < LR_MAX ? LR_MAX : nstripes, nchunks + 1), gf(nstripes, nchunks), b(BLK);
+    dim3 b(BLK);
     if (rows == 8) {
+        // the streaming pass carries one extra block row: one block per pending term (its low-rank dots)
+        dim3 gr(nstripes < LR_MAX ? LR_MAX : nstripes, nchunks + 1), gf(nstripes, nchunks);
         if (!fold_only) {  // normal pivot: read-only streaming pass (exits at once on a folding pivot)
             if (with_v) hipLaunchKernelGGL((k_fused_w<8, true, true, false, false, true>), gr, b, 0, st, dv);
             else hipLaunchKernelGGL((k_fused_w<8, true, false, false, false, true>), gr, b, 0, st, dv);
@@ -1820,12 +2054,21 @@ static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fo
         if (with_v) hipLaunchKernelGGL((k_fused_lr<8, true, false>), gf, b, 0, st, dv, fold_only);
         else hipLaunchKernelGGL((k_fused_lr<8, false, false>), gf, b, 0, st, dv, fold_only);
     } else {
-        if (!fold_only) {
+        const long tiles_cap = (long)nstripes * nchunks;
+        const int nb = (int)(tiles_cap < FW_TILE_BLOCKS ? tiles_cap : FW_TILE_BLOCKS);
+        if (!fold_only) {  // cap-sized 2-D grid: measured 146 us against 154 us tiled at k = 10 000
+            dim3 gr(nstripes < LR_MAX ? LR_MAX : nstripes, nchunks + 1);
             if (with_v) hipLaunchKernelGGL((k_fused_w<16, true, true, false, true, true, FW_RL>), gr, b, 0, st, dv);
             else hipLaunchKernelGGL((k_fused_w<16, true, false, false, true, true, FW_RL>), gr, b, 0, st, dv);
         }
-        if (with_v) hipLaunchKernelGGL((k_fused_lr<16, true, true, FW_RL>), gf, b, 0, st, dv, fold_only);
-        else hipLaunchKernelGGL((k_fused_lr<16, false, true, FW_RL>), gf, b, 0, st, dv, fold_only);
+        if (dv.lrJ <= 16 && FW_RL == 1) {  // register-resident V (the default period)
+            if (with_v) hipLaunchKernelGGL((k_fused_lr16<true, true>), dim3(nb), b, 0, st, dv, fold_only);
+            else hipLaunchKernelGGL((k_fused_lr16<false, true>), dim3(nb), b, 0, st, dv, fold_only);
+        } else {
+            dim3 gf(nstripes, nchunks);
+            if (with_v) hipLaunchKernelGGL((k_fused_lr<16, true, true, FW_RL>), gf, b, 0, st, dv, fold_only);
+            else hipLaunchKernelGGL((k_fused_lr<16, false, true, FW_RL>), gf, b, 0, st, dv, fold_only);
+        }
     }
 }
 void launch_fold_lowrank(const DevView& dv, const Geom& g, hipStream_t st) {
@@ -1845,8 +2088,10 @@ void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st
         if (with_v) hipLaunchKernelGGL((k_fused_w<8, true, true, true>), gr, b, 0, st, dv);
         else hipLaunchKernelGGL((k_fused_w<8, true, false, true>), gr, b, 0, st, dv);
     } else {
-        if (with_v) hipLaunchKernelGGL((k_fused_w<16, true, true, true, true, false, FW_RL>), gr, b, 0, st, dv);
-        else hipLaunchKernelGGL((k_fused_w<16, true, false, true, true, false, FW_RL>), gr, b, 0, st, dv);
+        const long tiles_cap = (long)nstripes * nchunks;
+        const int nb = (int)(tiles_cap < FW_TILE_BLOCKS ? tiles_cap : FW_TILE_BLOCKS);
+        if (with_v) hipLaunchKernelGGL((k_fused_w<16, true, true, true, true, false, FW_RL, true>), dim3(nb), b, 0, st, dv);
+        else hipLaunchKernelGGL((k_fused_w<16, true, false, true, true, false, FW_RL, true>), dim3(nb), b, 0, st, dv);
     }
 }
 void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st) {
@@ -1859,6 +2104,7 @@ void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t
     } while (0)
     LANES_SWITCH(g.lanes, POSTF(4), POSTF(16), POSTF(64));
 #undef POSTF
+    if (dv.pb_on) launch_blocked_push(dv, 1, st);
 }
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st) {
     hipLaunchKernelGGL(k_struct_update, dim3(blocks_for(g.cap)), dim3(BLK), 0, st, dv);

@@ -21,9 +21,9 @@ for s, e, k in tail:
     acc[k.split("(")[0][-60:]].append((e - s) * 1e-3)
 n_piv = max(len(v) for k, v in acc.items() if "update_pivot" in k)
 with open(sys.argv[1], "w") as out:
-    out.write("kernel,calls,avg_us,us_per_pivot,share_of_span\n")
+    out.write("kernel,calls,avg_us,us_per_pivot,share_of_span,min_us,median_us,max_us\n")
     for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
-        out.write(f"\"{k}\",{len(v)},{sum(v)/len(v):.2f},{sum(v)/n_piv:.2f},{sum(v)/span:.4f}\n")
+        vs = sorted(v); out.write(f"\"{k}\",{len(v)},{sum(v)/len(v):.2f},{sum(v)/n_piv:.2f},{sum(v)/span:.4f},{vs[0]:.1f},{vs[len(vs)//2]:.1f},{vs[-1]:.1f}\n")
     out.write(f"\"(wall span of the window, us per pivot)\",{n_piv},,{span/n_piv:.2f},1\n")
 print(open(sys.argv[1]).read())
 PY
