@@ -309,7 +309,8 @@ DevView* Engine::sync_view() {
     v.pb_rb = (m_ + PB_ROWS - 1) / PB_ROWS;
     v.pos_of_kslot = d_pos_of_kslot.p; v.row_of_kslot = d_row_of_kslot.p; v.W = d_W.p;
     v.U = d_U.p; v.V = d_V.p; v.pad1 = 0;
-    v.lrJ = lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 16 : 0);
+    // delayed-update period: 16 from capacity 8192, 32 from 32768 (the fold's k^2 cost outgrows the O(k J) overheads)
+    v.lrJ = lr_force >= 0 ? lr_force : (cap_ >= 32768 ? 32 : (cap_ >= 8192 ? 16 : 0));
     v.alpha_q = d_work.p;
     v.tau = d_work.p + (size_t)m_;
     v.rv = reinterpret_cast<double2*>(d_work.p + 2 * (size_t)m_);

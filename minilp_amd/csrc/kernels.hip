@@ -1503,7 +1503,7 @@ __global__ void __launch_bounds__(BLK) k_fused_lr(DevView v, int fold_only) {
 // columns in two halves): 32 V values + a 4-row tile = ~110 VGPRs, 4 waves per SIMD.
 template <bool WITH_V, bool NT>
 __global__ void __launch_bounds__(BLK) k_fused_lr16(DevView v, int fold_only) {
-    constexpr int TRB = 16, ST = 4, JM = 16;
+    constexpr int TRB = 16, JM = 16;
     Ctl* c = v.ctl;
     if (!fold_only && (c->halt || c->it.status != ITER_PIVOT)) return;
     const int k = c->k, ld = v.ld;
@@ -1511,7 +1511,7 @@ __global__ void __launch_bounds__(BLK) k_fused_lr16(DevView v, int fold_only) {
     if (!(fold_only || c->fold)) return;
     const int tid = threadIdx.x;
     __shared__ double s_tau[TRB][BLK / 64];
-    __shared__ double s_u[JM][TRB];
+    __shared__ double s_u[LR_MAX][TRB];
     // 1-D grid striding over the (stripe, chunk) tiles of the current k (see k_fused_w, TILED)
     const int nchunks_k = (k + FW_TC - 1) / FW_TC;
     const int ntiles = ((k + TRB - 1) / TRB) * nchunks_k;
@@ -1520,7 +1520,7 @@ __global__ void __launch_bounds__(BLK) k_fused_lr16(DevView v, int fold_only) {
     const int row0 = stripe * TRB;
     const int col0 = chunk * FW_TC;
     __syncthreads();  // the previous tile's readers of s_u / s_tau are done
-    for (int i = tid; i < JM * TRB; i += BLK) {
+    for (int i = tid; i < LR_MAX * TRB; i += BLK) {
         int j = i / TRB, a = i % TRB;
         int row = row0 + a;
         s_u[j][a] = (j < nlow && row < k) ? v.U[(size_t)j * ld + row] : 0.0;
@@ -1533,70 +1533,71 @@ __global__ void __launch_bounds__(BLK) k_fused_lr16(DevView v, int fold_only) {
         const int c0 = col0 + half * (FW_TC / 2) + 2 * tid;
         if (col0 + half * (FW_TC / 2) >= k) break;
         const bool pair = c0 + 1 < k, one = c0 < k;
-        double vj[JM][2];
-#pragma unroll
-        for (int j = 0; j < JM; ++j) {
-            vj[j][0] = vj[j][1] = 0.0;
-            if (j < nlow) {
-                const double* Vj = v.V + (size_t)j * ld;
-                if (pair) {
-                    double2 t = *reinterpret_cast<const double2*>(Vj + c0);
-                    vj[j][0] = t.x;
-                    vj[j][1] = t.y;
-                } else if (one) {
-                    vj[j][0] = Vj[c0];
-                }
-            }
-        }
         double rk0 = 0.0, rk1 = 0.0;
         if (!fold_only) {
             if (one) rk0 = v.rK[c0];
             if (pair) rk1 = v.rK[c0 + 1];
         }
         double vacc0 = 0.0, vacc1 = 0.0;
-#pragma unroll 1
-        for (int sub = 0; sub < TRB / ST; ++sub) {
-            const int rbase = row0 + sub * ST;
-            if (rbase >= k) break;
-            double w[ST][2];
+        // all 16 rows of the tile stay in registers while the pending terms are applied in groups of
+        // 16 (two groups when the period is 32), each group's V entries loaded once
+        double w[TRB][2];
 #pragma unroll
-            for (int a = 0; a < ST; ++a) {
-                const int row = rbase + a;
-                w[a][0] = w[a][1] = 0.0;
-                if (row >= k) continue;
-                const double* wp = v.W + (size_t)row * ld;
-                if (pair) {
-                    double2 t = fw_load2<NT>(wp + c0);
-                    w[a][0] = t.x;
-                    w[a][1] = t.y;
-                } else if (one) {
-                    w[a][0] = wp[c0];
+        for (int a = 0; a < TRB; ++a) {
+            const int row = row0 + a;
+            w[a][0] = w[a][1] = 0.0;
+            if (row >= k) continue;
+            const double* wp = v.W + (size_t)row * ld;
+            if (pair) {
+                double2 t = fw_load2<NT>(wp + c0);
+                w[a][0] = t.x;
+                w[a][1] = t.y;
+            } else if (one) {
+                w[a][0] = wp[c0];
+            }
+        }
+#pragma unroll 1
+        for (int jg = 0; jg < nlow; jg += JM) {
+            double vj[JM][2];
+#pragma unroll
+            for (int j = 0; j < JM; ++j) {
+                vj[j][0] = vj[j][1] = 0.0;
+                if (jg + j < nlow) {
+                    const double* Vj = v.V + (size_t)(jg + j) * ld;
+                    if (pair) {
+                        double2 t = *reinterpret_cast<const double2*>(Vj + c0);
+                        vj[j][0] = t.x;
+                        vj[j][1] = t.y;
+                    } else if (one) {
+                        vj[j][0] = Vj[c0];
+                    }
                 }
             }
             // explicit FMA: the build runs with -ffp-contract=off (the update formulas mirror the
-            // reference's separate multiply and add), but a fold is already a re-association of 16
-            // updates; one rounding per term is both cheaper and more accurate
+            // reference's separate multiply and add), but a fold is already a re-association of the
+            // pending updates; one rounding per term is both cheaper and more accurate
 #pragma unroll
             for (int j = 0; j < JM; ++j) {
 #pragma unroll
-                for (int a = 0; a < ST; ++a) {
-                    const double u = s_u[j][sub * ST + a];
+                for (int a = 0; a < TRB; ++a) {
+                    const double u = s_u[jg + j][a];
                     w[a][0] = __builtin_fma(u, vj[j][0], w[a][0]);
                     w[a][1] = __builtin_fma(u, vj[j][1], w[a][1]);
                 }
             }
+        }
 #pragma unroll
-            for (int a = 0; a < ST; ++a) {
-                const int row = rbase + a;
-                if (row >= k) continue;
-                double* wp = v.W + (size_t)row * ld;
-                if (pair) fw_store2<NT>(wp + c0, w[a][0], w[a][1]);
-                else if (one) wp[c0] = w[a][0];
-            }
-            if (fold_only) continue;
+        for (int a = 0; a < TRB; ++a) {
+            const int row = row0 + a;
+            if (row >= k) continue;
+            double* wp = v.W + (size_t)row * ld;
+            if (pair) fw_store2<NT>(wp + c0, w[a][0], w[a][1]);
+            else if (one) wp[c0] = w[a][0];
+        }
+        if (!fold_only) {
 #pragma unroll
-            for (int a = 0; a < ST; ++a) {
-                const int row = rbase + a;
+            for (int a = 0; a < TRB; ++a) {
+                const int row = row0 + a;
                 double tacc = w[a][0] * rk0 + w[a][1] * rk1;
                 if (WITH_V && row < k) {
                     const double t = v.tK[row];
@@ -1604,7 +1605,7 @@ __global__ void __launch_bounds__(BLK) k_fused_lr16(DevView v, int fold_only) {
                     vacc1 += w[a][1] * t;
                 }
                 const double sacc = wave_sum(tacc);
-                if (l == 0) s_tau[sub * ST + a][wv] += sacc;  // this wave's own cell: no race
+                if (l == 0) s_tau[a][wv] += sacc;  // this wave's own cell: no race
             }
         }
         if (!fold_only && WITH_V) {
@@ -2061,7 +2062,7 @@ static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fo
             if (with_v) hipLaunchKernelGGL((k_fused_w<16, true, true, false, true, true, FW_RL>), gr, b, 0, st, dv);
             else hipLaunchKernelGGL((k_fused_w<16, true, false, false, true, true, FW_RL>), gr, b, 0, st, dv);
         }
-        if (dv.lrJ <= 16 && FW_RL == 1) {  // register-resident V (the default period)
+        if (FW_RL == 1) {  // register-resident V
             if (with_v) hipLaunchKernelGGL((k_fused_lr16<true, true>), dim3(nb), b, 0, st, dv, fold_only);
             else hipLaunchKernelGGL((k_fused_lr16<false, true>), dim3(nb), b, 0, st, dv, fold_only);
         } else {

@@ -375,3 +375,28 @@ def test_differential_fuzz_small_lps():
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     assert fz.main(1500, 11) == 0
+
+
+def test_clone_and_drop_recycle_runtime_objects():
+    """A branch-and-bound driver clones and drops one Solution per node (tsp.rs:351-353): clones must
+    stay independent of their parent and of each other while streams / pinned blocks / device blocks
+    are recycled underneath."""
+    lp = lpgen.gen_mixed_lp(120, 160, 6, 11)
+    so = lpgen.build_problem(O.Problem, lp).solve()
+    sg = lpgen.build_problem(M.Problem, lp).solve()
+    base = sg.objective()
+    xs = np.asarray(so.values())
+    frac = [int(v) for v in np.argsort(-np.abs(xs - np.round(xs)))[:6]]
+    for rep in range(40):
+        v = frac[rep % len(frac)]
+        val = float(np.floor(xs[v])) + (rep % 2)
+        c = sg.clone()
+        try:
+            c = c.fix_var(v, val)
+            ref = so.clone().fix_var(v, val)
+            assert obj_close(c.objective(), ref.objective())
+        except M.Infeasible:
+            with pytest.raises(O.Infeasible):
+                so.clone().fix_var(v, val)
+        del c
+        assert sg.objective() == base  # the parent is untouched by whatever its clones did

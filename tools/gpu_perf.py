@@ -31,5 +31,7 @@ for c in range(nchunks):
     print(line, flush=True)
     if not s.budget_exhausted:
         break
+x = np.asarray(s.values())
+print("objective accumulated %.9f  recomputed c.x %.9f  status %s" % (s.objective(), float(np.dot(lp["obj"], x)), "optimal" if not s.budget_exhausted else "budget"), flush=True)  # obj_from_x
 if not os.environ.get("MLP_NO_REINV"):
     print("reinvert diff", s.reinvert())
