@@ -126,6 +126,40 @@ const char* mlp_mps_var_name(const mlp_mps* f, uint32_t i); /* MpsFile::variable
 int64_t mlp_mps_var_index(const mlp_mps* f, const char* name);
 mlp_problem* mlp_mps_problem(const mlp_mps* f);             /* MpsFile::problem mps.rs:15 (a clone) */
 
+/* ---- engine-level stepping (second table) --------------------------------------------
+ * The iteration of Solver::optimize / restore_feasibility (solver.rs:487-547) one stage per call, paced
+ * by the host: what a host-side Solver would bind instead of BasisSolver::{solve, solve_transp,
+ * push_eta_matrix} (solver.rs:1273-1339) and the scans of choose_pivot / pivot.  Every stage runs the
+ * same kernels as the replayed graph; vectors stay on the device (read them with mlp_solution_state:
+ * "col_coeffs" after FTRAN, "row_coeffs" after ROW, ...); only the scalars below cross the boundary.
+ *
+ *   mlp_problem_solve_ex(p, &s, 0, 0);                         // set up, no pivot yet
+ *   while (mlp_engine_open(s, &info) == MLP_ITER_PIVOT)        // pricing: entering column (primal) / leaving row (dual)
+ *       do st = mlp_engine_stage(s, info.next_stage, &info);   // FTRAN, RATIO, BTRAN, BASIS, ROW, APPLY in the phase's order
+ *       while (st == MLP_ITER_PIVOT || st == MLP_ITER_FLIP);   // after APPLY the next iteration is already priced
+ *
+ * mlp_engine_open picks the phase initial_solve would run next (dual loop while primal-infeasible,
+ * then recalc_obj_coeffs + primal loop) and returns the status of the pricing decision; a terminal
+ * status (OPTIMAL, FEASIBLE, INFEASIBLE, UNBOUNDED) closes the loop, after FEASIBLE call open again.
+ * Return values < 0 are errors (mlp_last_error), e.g. a stage called out of order. */
+enum { MLP_STAGE_FTRAN = 0, MLP_STAGE_RATIO = 1, MLP_STAGE_BTRAN = 2, MLP_STAGE_BASIS = 3, MLP_STAGE_ROW = 4, MLP_STAGE_APPLY = 5 };
+enum { MLP_ITER_PIVOT = 0, MLP_ITER_FLIP = 1, MLP_ITER_OPTIMAL = 2, MLP_ITER_UNBOUNDED = 3, MLP_ITER_FEASIBLE = 4,
+       MLP_ITER_INFEASIBLE = 5, MLP_ITER_SINGULAR = 6 };
+typedef struct mlp_iter_info {
+    int32_t status;      /* MLP_ITER_* of the open iteration (after APPLY: of the next one) */
+    int32_t phase;       /* 0 primal (optimize), 1 dual (restore_feasibility) */
+    int32_t next_stage;  /* the stage mlp_engine_stage expects next, -1 when no iteration is open */
+    int32_t reserved;
+    int64_t col, row;    /* entering non-basic position q, leaving basic position r (-1 while undecided) */
+    int64_t entering_var, leaving_var;
+    double pivot_coeff;  /* alpha_rq (solver.rs:1073) */
+    double step;         /* change of the entering variable (solver.rs:828) */
+    double objective;    /* cur_obj_val after the decision (solver.rs:1027) */
+    uint64_t nucleus_size;
+} mlp_iter_info;
+int mlp_engine_open(mlp_solution* s, mlp_iter_info* out);
+int mlp_engine_stage(mlp_solution* s, int stage, mlp_iter_info* out);
+
 /* ---- driver helper (host only; examples/tsp.rs:437-539) -------------------------------------------
  * Stoer-Wagner global minimum cut of a dense symmetric n x n weight matrix (row-major, zero diagonal):
  * returns the cut weight and marks one side of the cut in side_out[n] (0/1).  Used by the TSP

@@ -36,6 +36,15 @@ class MlpStats(C.Structure):
                    ("update_launches", C.c_uint64), ("max_pivot_err", C.c_double)])
 
 
+class MlpIterInfo(C.Structure):  # include/minilp_hip.h: mlp_iter_info
+    _fields_ = [("status", C.c_int32), ("phase", C.c_int32), ("next_stage", C.c_int32), ("reserved", C.c_int32),
+                ("col", C.c_int64), ("row", C.c_int64), ("entering_var", C.c_int64), ("leaving_var", C.c_int64),
+                ("pivot_coeff", C.c_double), ("step", C.c_double), ("objective", C.c_double), ("nucleus_size", C.c_uint64)]
+
+
+STAGE_FTRAN, STAGE_RATIO, STAGE_BTRAN, STAGE_BASIS, STAGE_ROW, STAGE_APPLY = range(6)
+ITER_PIVOT, ITER_FLIP, ITER_OPTIMAL, ITER_UNBOUNDED, ITER_FEASIBLE, ITER_INFEASIBLE, ITER_SINGULAR = range(7)
+
 _lib = None
 
 
@@ -104,6 +113,8 @@ def lib():
     sig("mlp_mps_var_index", i64, vp, C.c_char_p)
     sig("mlp_mps_problem", vp, vp)
     sig("mlp_util_min_cut", C.c_double, u32, pdbl, C.POINTER(C.c_uint8))
+    sig("mlp_engine_open", i32, vp, C.POINTER(MlpIterInfo))
+    sig("mlp_engine_stage", i32, vp, i32, C.POINTER(MlpIterInfo))
     _lib = L
     return L
 
@@ -303,6 +314,23 @@ class Solution:
     def enable_sharding(self, rank, world, shm_name):
         """Column-block sharding of the pricing path (include/minilp_hip.h); see minilp_amd.dist."""
         _raise(lib().mlp_solution_enable_sharding(self._h, int(rank), int(world), shm_name.encode()))
+
+    # ---- engine-level stepping (include/minilp_hip.h: mlp_engine_open / mlp_engine_stage)
+    def engine_open(self):
+        """Pricing decision of the phase initial_solve would run next; returns (status, info dict)."""
+        info = MlpIterInfo()
+        st = lib().mlp_engine_open(self._h, C.byref(info))
+        if st < 0:
+            _raise(st)
+        return st, {n: getattr(info, n) for n, _ in MlpIterInfo._fields_}
+
+    def engine_stage(self, stage):
+        """One stage (STAGE_*) of the open iteration; returns (status, info dict)."""
+        info = MlpIterInfo()
+        st = lib().mlp_engine_stage(self._h, int(stage), C.byref(info))
+        if st < 0:
+            _raise(st)
+        return st, {n: getattr(info, n) for n, _ in MlpIterInfo._fields_}
 
     def reinvert(self):
         d = C.c_double()

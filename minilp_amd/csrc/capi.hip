@@ -131,6 +131,33 @@ int mlp_solution_continue(mlp_solution* s, int64_t budget) {
         s->eng->initial_solve();
     });
 }
+static void copy_info(const Engine::StepInfo& si, mlp_iter_info* out) {
+    if (!out) return;
+    out->status = si.status; out->phase = si.phase; out->next_stage = si.next_stage; out->reserved = 0;
+    out->col = si.col; out->row = si.row; out->entering_var = si.entering_var; out->leaving_var = si.leaving_var;
+    out->pivot_coeff = si.pivot_coeff; out->step = si.step; out->objective = si.objective;
+    out->nucleus_size = si.nucleus_size;
+}
+int mlp_engine_open(mlp_solution* s, mlp_iter_info* out) {
+    int status = MLP_EINVAL;
+    int rc = guarded([&] {
+        if (!s) throw MlpError(MLP_EINVAL, "NULL solution");
+        Engine::StepInfo si{};
+        status = s->eng->step_open(&si);
+        copy_info(si, out);
+    });
+    return rc != 0 ? (rc > 0 ? MLP_EINVAL : rc) : status;
+}
+int mlp_engine_stage(mlp_solution* s, int stage, mlp_iter_info* out) {
+    int status = MLP_EINVAL;
+    int rc = guarded([&] {
+        if (!s) throw MlpError(MLP_EINVAL, "NULL solution");
+        Engine::StepInfo si{};
+        status = s->eng->step_stage(stage, &si);
+        copy_info(si, out);
+    });
+    return rc != 0 ? (rc > 0 ? MLP_EINVAL : rc) : status;
+}
 int mlp_solution_budget_exhausted(const mlp_solution* s) { return s->eng->budget_exhausted ? 1 : 0; }
 int mlp_solution_reinvert(mlp_solution* s, double* max_diff) {
     return guarded([&] {

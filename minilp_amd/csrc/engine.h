@@ -12,6 +12,8 @@
 
 namespace mlp {
 
+enum Stage { STAGE_FTRAN = 0, STAGE_RATIO = 1, STAGE_BTRAN = 2, STAGE_BASIS = 3, STAGE_ROW = 4, STAGE_APPLY = 5 };
+
 struct MlpError : std::runtime_error {
     int code;
     MlpError(int c, const std::string& s) : std::runtime_error(s), code(c) {}
@@ -245,6 +247,22 @@ private:
     int col_nnz(int var) const { return h_cptr[var + 1] - h_cptr[var]; }
 
     void record_iteration(int phase, bool with_events);  // enqueue the kernel sequence of ONE iteration
+    void launch_stage(int phase, int stage, bool with_events);
+  public:
+    // engine-level stepping (include/minilp_hip.h: mlp_engine_open / mlp_engine_stage)
+    struct StepInfo {
+        int32_t status, phase, next_stage;
+        int64_t col, row, entering_var, leaving_var;
+        double pivot_coeff, step, objective;
+        uint64_t nucleus_size;
+    };
+    int step_phase = 0, step_pos = -1;
+    int step_open(StepInfo* out);
+    int step_stage(int stage, StepInfo* out);
+    int step_finish(int phase, int status);
+    void fill_step_info(StepInfo* out, int phase) const;
+
+  private:
     int run_loop(int phase);                             // batches of replays until terminal / budget
     int process_records(int phase, int launched);
     void optimize();              // solver.rs:487-511

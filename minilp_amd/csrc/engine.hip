@@ -660,44 +660,163 @@ double Engine::cur_obj_val() {
 
 // ------------------------------------------------------------------ one iteration = a fixed kernel sequence
 // primal: choose_pivot + pivot (solver.rs:695-853, 1023-1104); dual: solver.rs:529-533.
-void Engine::record_iteration(int phase, bool with_events) {
+// Stage order of one iteration (the engine-level C ABI steps through the same table):
+//   primal: FTRAN -> RATIO (+ BTRAN head, plan) -> BTRAN -> BASIS (fused W pass + tails) -> ROW -> APPLY
+//   dual  : BTRAN -> ROW -> RATIO (+ FTRAN head) -> FTRAN (+ plan) -> BASIS -> APPLY
+static const int kStageOrder[2][6] = {{STAGE_FTRAN, STAGE_RATIO, STAGE_BTRAN, STAGE_BASIS, STAGE_ROW, STAGE_APPLY},
+                                      {STAGE_BTRAN, STAGE_ROW, STAGE_RATIO, STAGE_FTRAN, STAGE_BASIS, STAGE_APPLY}};
+void Engine::launch_stage(int phase, int stage, bool with_events) {
     const DevView& dv = hview;
     const Geom g = geom();
     const int pse = enable_pse ? 1 : 0, dse = enable_dse ? 1 : 0;
     // The pricing decision (q for primal, r for dual) is already in Ctl: it was taken by the
     // previous iteration's update kernel, or by the standalone pricing kernel at batch start.
-    if (phase == 0) {
-        launch_ftran_prep(dv, 1, st);          // K2 head: entering column scalars, singleton rows, list
-        launch_ftran_gather(dv, g, st);        // K2: alpha_q = B^-1 a_q
-        launch_ratio_primal(dv, g, pse, st);   // K5 p1 (+ ||alpha||^2, y_S), p2 (+ K3 head + partition plan)
-        launch_btran(dv, g, pse, st);          // K3: rho, rK, ||rho||^2  |  tK = alpha_K - F^T y_S
-    } else {
-        launch_btran_prep(dv, 1, 0, st);       // K3 head (device-driven by it.r)
-        launch_btran(dv, g, 0, st);            // K3
-        if (with_events) HIPCHECK(hipEventRecord(ev[0], st));
-        launch_sweep(dv, g, 0, 0, st);         // K4: alpha_r = rho^T N
-        if (with_events) HIPCHECK(hipEventRecord(ev[1], st));
-        launch_ratio_dual(dv, g, st);          // K7 p1, p2 (+ K2 head)
-        launch_ftran_gather(dv, g, st);        // K2
-        launch_post_ftran(dv, g, pse, st);     // alpha_sq, y_S, partition plan
-        if (pse) launch_btran_rhs(dv, g, st);  // tK
+    switch (stage) {
+    case STAGE_FTRAN:
+        if (phase == 0) launch_ftran_prep(dv, 1, st);  // K2 head: entering column scalars, singleton rows, list
+        launch_ftran_gather(dv, g, st);                // K2: alpha_q = B^-1 a_q (dual: the head ran in RATIO)
+        if (phase == 1) {
+            launch_post_ftran(dv, g, pse, st);         // alpha_sq, y_S, partition plan
+            if (pse) launch_btran_rhs(dv, g, st);      // tK
+        }
+        break;
+    case STAGE_RATIO:
+        if (phase == 0) launch_ratio_primal(dv, g, pse, st);  // K5 p1 (+ ||alpha||^2, y_S), p2 (+ K3 head + plan)
+        else launch_ratio_dual(dv, g, st);                    // K7 p1, p2 (+ K2 head)
+        break;
+    case STAGE_BTRAN:
+        if (phase == 1) launch_btran_prep(dv, 1, 0, st);      // K3 head (device-driven by it.r)
+        launch_btran(dv, g, phase == 0 ? pse : 0, st);        // K3: rho, rK, ||rho||^2  |  tK = alpha_K - F^T y_S
+        break;
+    case STAGE_BASIS:
+        if (with_events) HIPCHECK(hipEventRecord(ev[2], st));
+        launch_fused_w(dv, g, pse, st);                       // tauK / vK partials + eta update of W
+        if (with_events) HIPCHECK(hipEventRecord(ev[3], st));
+        launch_post_fused(dv, g, pse, st);                    // tau by position (F push)  |  v reduce + scatter
+        break;
+    case STAGE_ROW:
+        if (phase == 0) {
+            if (with_events) HIPCHECK(hipEventRecord(ev[0], st));
+            launch_sweep(dv, g, pse ? 1 : 0, 1, st);          // K4 (+ PSE helper in the same pass)  |  partition change
+            if (with_events) HIPCHECK(hipEventRecord(ev[1], st));
+        } else {
+            if (with_events) HIPCHECK(hipEventRecord(ev[0], st));
+            launch_sweep(dv, g, 0, 0, st);                    // K4: alpha_r = rho^T N
+            if (with_events) HIPCHECK(hipEventRecord(ev[1], st));
+        }
+        break;
+    case STAGE_APPLY:
+        if (phase == 1) {                                     // the dual path changes the partition here
+            if (pse) launch_sweep(dv, g, 2, 1, st);           // PSE helper  |  partition change
+            else launch_structure_update(dv, g, st);
+        }
+        if (with_events) HIPCHECK(hipEventRecord(ev[4], st));
+        launch_update_pivot(dv, g, phase, dse, pse, st);      // K8 + zero the work vectors + price the next iteration
+        if (with_events) HIPCHECK(hipEventRecord(ev[5], st));
+        break;
+    default:
+        throw MlpError(-1, "unknown stage");
     }
-    if (with_events) HIPCHECK(hipEventRecord(ev[2], st));
-    launch_fused_w(dv, g, pse, st);            // tauK / vK partials + eta update of W
-    if (with_events) HIPCHECK(hipEventRecord(ev[3], st));
-    launch_post_fused(dv, g, pse, st);         // tau by position (F push)  |  v reduce + scatter
-    if (phase == 0) {
-        if (with_events) HIPCHECK(hipEventRecord(ev[0], st));
-        launch_sweep(dv, g, pse ? 1 : 0, 1, st);  // K4 (+ PSE helper in the same pass)  |  partition change
-        if (with_events) HIPCHECK(hipEventRecord(ev[1], st));
-    } else if (pse) {
-        launch_sweep(dv, g, 2, 1, st);
-    } else {
-        launch_structure_update(dv, g, st);
+}
+void Engine::record_iteration(int phase, bool with_events) {
+    for (int i = 0; i < 6; ++i) launch_stage(phase, kStageOrder[phase][i], with_events);
+}
+
+// ------------------------------------------------------------------ engine-level stepping
+// The same kernels, one stage per call, paced by the host: what a host-side Solver (the reference's
+// choose_pivot / pivot split, solver.rs:487-547) would call through the C ABI.  step_open() takes the
+// pricing decision for the phase initial_solve would run next; step_stage() must then be called with
+// the stages in the order of kStageOrder; after STAGE_APPLY the basis bookkeeping has been replayed
+// and the next iteration is already priced.
+void Engine::fill_step_info(StepInfo* out, int phase) const {
+    if (!out) return;
+    const IterState& it = h_ctl->it;
+    out->status = it.status; out->phase = phase;
+    out->col = it.q; out->row = it.r;
+    out->entering_var = it.entering_var; out->leaving_var = it.leaving_var;
+    out->pivot_coeff = it.pivot_coeff; out->step = it.entering_diff; out->objective = it.obj;
+    out->nucleus_size = (uint64_t)k_;
+    out->next_stage = (step_pos >= 0 && step_pos < 6) ? kStageOrder[phase][step_pos] : -1;
+}
+int Engine::step_finish(int phase, int status) {  // terminal statuses: what optimize / restore_feasibility do
+    step_pos = -1;
+    if (phase == 0 && status == ITER_OPTIMAL) {
+        dual_feasible = true;
+        resume_in_optimize = false;
+        enable_pse = false;  // solver.rs:482
+    } else if (phase == 1 && status == ITER_FEASIBLE) {
+        primal_feasible = true;
     }
-    if (with_events) HIPCHECK(hipEventRecord(ev[4], st));
-    launch_update_pivot(dv, g, phase, dse, pse, st);  // K8 + zero the work vectors + price the next iteration
-    if (with_events) HIPCHECK(hipEventRecord(ev[5], st));
+    return status;
+}
+int Engine::step_open(StepInfo* out) {
+    if (shard_world > 1) throw MlpError(-1, "the stepping API is not available on a sharded solution");
+    int phase;
+    if (!primal_feasible) phase = 1;
+    else if (!dual_feasible) {
+        if (!resume_in_optimize) recalc_obj_coeffs();
+        resume_in_optimize = true;
+        phase = 0;
+    } else {
+        pull_ctl();
+        h_ctl->it.status = ITER_OPTIMAL;
+        step_pos = -1;
+        fill_step_info(out, 0);
+        return ITER_OPTIMAL;
+    }
+    step_phase = phase;
+    pivot_budget = -1;
+    budget_exhausted = false;
+    sync_view();
+    ensure_nucleus_cap(k_ + 2);
+    sync_view();
+    launch_reset_ring(hview, st);
+    launch_clear_work(hview, st);
+    if (phase == 0) launch_price_primal(hview, geom(), enable_pse ? 1 : 0, st);
+    else launch_price_dual(hview, geom(), enable_dse ? 1 : 0, st);
+    pull_ctl();
+    int status = h_ctl->it.status;
+    step_pos = 0;
+    if (status != ITER_PIVOT) {
+        process_records(phase, 1);
+        status = step_finish(phase, status);
+    }
+    fill_step_info(out, phase);
+    return status;
+}
+int Engine::step_stage(int stage, StepInfo* out) {
+    if (step_pos < 0 || step_pos >= 6) throw MlpError(-1, "step_stage: no open iteration (call mlp_engine_open first)");
+    const int phase = step_phase;
+    if (stage != kStageOrder[phase][step_pos])
+        throw MlpError(-1, "step_stage: stages must follow the iteration's order (next expected: " +
+                               std::to_string(kStageOrder[phase][step_pos]) + ")");
+    if (step_pos == 0) {
+        sync_view();
+        ensure_nucleus_cap(k_ + 2);
+        sync_view();
+        launch_reset_ring(hview, st);  // one record per stepped iteration
+    }
+    launch_stage(phase, stage, false);
+    pull_ctl();
+    step_pos += 1;
+    int status = h_ctl->it.status;
+    if (stage == STAGE_APPLY) {
+        // replay the bookkeeping of the iteration just closed; the ring may already hold the terminal
+        // record of the NEXT pricing decision (optimal / feasible), which process_records returns
+        int res = process_records(phase, 1);
+        if (h_ctl->max_pivot_err > stats.max_pivot_err) stats.max_pivot_err = h_ctl->max_pivot_err;
+        step_pos = 0;
+        status = res;
+        if (res != ITER_PIVOT) status = step_finish(phase, res);
+        else if (!(h_ctl->max_pivot_err <= refresh_tol) && k_ > 0) rebuild_inverse();
+        h_ctl->it.status = status;
+    } else if (status != ITER_PIVOT && status != ITER_FLIP) {
+        // UNBOUNDED / INFEASIBLE / SINGULAR decided inside the iteration
+        process_records(phase, 1);
+        status = step_finish(phase, status);
+    }
+    fill_step_info(out, phase);
+    return status;
 }
 
 hipGraphExec_t Engine::get_graph(int phase) {

@@ -400,3 +400,68 @@ def test_clone_and_drop_recycle_runtime_objects():
                 so.clone().fix_var(v, val)
         del c
         assert sg.objective() == base  # the parent is untouched by whatever its clones did
+
+
+def _drive_by_stages(sol, log=None):
+    """Host-paced solve through the engine-level ABI: open -> stages -> ... -> terminal."""
+    pivots = 0
+    while True:
+        st, info = sol.engine_open()
+        if st in (M.api.ITER_OPTIMAL, M.api.ITER_INFEASIBLE, M.api.ITER_UNBOUNDED):
+            return st, pivots
+        if st == M.api.ITER_FEASIBLE:
+            continue  # the dual loop is done: open again for the primal phase
+        assert st == M.api.ITER_PIVOT
+        while st in (M.api.ITER_PIVOT, M.api.ITER_FLIP):
+            seen = []
+            while True:
+                stage = info["next_stage"]
+                seen.append(stage)
+                st, info = sol.engine_stage(stage)
+                if stage == M.api.STAGE_APPLY or st not in (M.api.ITER_PIVOT, M.api.ITER_FLIP):
+                    break
+            if stage == M.api.STAGE_APPLY:
+                pivots += 1
+                if log is not None:
+                    log.append(tuple(seen))
+
+
+@pytest.mark.parametrize("fam,kw", [("sparse", dict(m=200, n=200, k=10, seed=4)), ("mixed", dict(m=100, n=150, k=6, seed=3)),
+                                    ("dense", dict(m=60, n=60, seed=2))], ids=str)
+def test_engine_level_stepping_reproduces_the_solve(fam, kw):
+    lp = GEN[fam](**kw)
+    so = lpgen.build_problem(O.Problem, lp).solve(trace=True)
+    ref = lpgen.build_problem(M.Problem, lp).solve(trace=True)
+    stepped = lpgen.build_problem(M.Problem, lp).solve(budget=0, trace=True)
+    orders = []
+    st, pivots = _drive_by_stages(stepped, orders)
+    assert st == M.api.ITER_OPTIMAL
+    if fam != "mixed":  # integer data: exact ties, only the optimum is comparable (DESIGN.md §8)
+        assert [t[:5] for t in stepped.trace()] == [t[:5] for t in ref.trace()] == [t[:5] for t in so.trace()]
+        assert pivots == len(ref.trace())
+        assert np.abs(np.asarray(stepped.values()) - np.asarray(so.values())).max() <= X_ATOL
+    assert pivots == len(stepped.trace())
+    assert obj_close(stepped.objective(), so.objective())
+    check_feasible(lp, stepped.values())
+    primal = (M.api.STAGE_FTRAN, M.api.STAGE_RATIO, M.api.STAGE_BTRAN, M.api.STAGE_BASIS, M.api.STAGE_ROW, M.api.STAGE_APPLY)
+    dual = (M.api.STAGE_BTRAN, M.api.STAGE_ROW, M.api.STAGE_RATIO, M.api.STAGE_FTRAN, M.api.STAGE_BASIS, M.api.STAGE_APPLY)
+    assert set(orders) <= {primal, dual}
+    # a solved model can be warm-started as usual afterwards
+    x = np.asarray(so.values())
+    expr = [(0, 1.0), (1, 1.0)]
+    rhs = 0.5 * float(x[0] + x[1]) + 0.01
+    assert obj_close(stepped.add_constraint(expr, M.LE, rhs).objective(), so.add_constraint(expr, O.LE, rhs).objective())
+
+
+def test_engine_level_stages_out_of_order_are_refused():
+    lp = GEN["sparse"](m=50, n=40, k=8, seed=3)
+    s = lpgen.build_problem(M.Problem, lp).solve(budget=0)
+    with pytest.raises(M.InternalError):
+        s.engine_stage(M.api.STAGE_FTRAN)          # nothing open yet
+    st, info = s.engine_open()
+    assert st == M.api.ITER_PIVOT and info["next_stage"] == M.api.STAGE_FTRAN and info["col"] >= 0
+    with pytest.raises(M.InternalError):
+        s.engine_stage(M.api.STAGE_ROW)            # FTRAN comes first in the primal order
+    st, info = s.engine_stage(M.api.STAGE_FTRAN)
+    alpha = s.state("col_coeffs")                  # the vector stays on the device; white-box read-back
+    assert np.count_nonzero(alpha) > 0 and info["next_stage"] == M.api.STAGE_RATIO
