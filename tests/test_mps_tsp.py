@@ -165,3 +165,28 @@ def test_tsp_bn130_reaches_reference_optimum():
     assert sorted(tour) == list(range(130))
     assert abs(s.tour_cost(tour) - BN130_OPT) < 1e-6
     assert s.stats["cuts"] > 100 and s.stats["clones"] > 100
+
+
+def test_solve_mps_example_cli_oracle_backend(tmp_path):  # examples/solve_mps.rs:19-43 counterpart
+    import subprocess
+    import sys
+    from tests.test_oracle_kat import MPS_TESTPROB
+    p = tmp_path / "testprob.mps"
+    p.write_text(MPS_TESTPROB)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "solve_mps.py"), str(p), "--backend", "oracle"],
+                         capture_output=True, text=True, check=True).stdout
+    assert "objective: 54" in out and "XONE = 4" in out and "YTWO = -1" in out and "ZTHREE = 6" in out
+
+
+@pytest.mark.gpu
+def test_solve_mps_example_cli_hip_backend(tmp_path):
+    import subprocess
+    import sys
+    from tests.test_oracle_kat import MPS_TESTPROB
+    p = tmp_path / "testprob.mps"
+    p.write_text(MPS_TESTPROB)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "solve_mps.py"), str(p)],
+                         capture_output=True, text=True, check=True).stdout
+    assert "objective: 54" in out and "XONE = 4" in out and "YTWO = -1" in out and "ZTHREE = 6" in out
