@@ -1,5 +1,7 @@
 """CPU: the oracle against the committed HiGHS golden objectives, the generators' determinism,
 and oracle-internal size-independent properties."""
+import os
+
 import numpy as np
 import pytest
 
@@ -7,6 +9,7 @@ from minilp_amd import lpgen
 from oracle import minilp_oracle as mo
 from tests.common import GEN, HIGHS_RTOL, check_feasible, highs_cases, obj_close, objective_of
 
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SMALL = [c for c in highs_cases() if c["args"]["m"] <= 1000 and not (c["family"] == "dense" and c["args"]["m"] >= 1000)]
 
 
@@ -49,3 +52,43 @@ def test_budget_protocol_resumes_identically():
         part.continue_solve(7)
     assert [t[:5] for t in part.trace()] == [t[:5] for t in full.trace()]
     assert part.objective() == full.objective()
+
+
+def _check_certificate(path):
+    """An optimality certificate (primal x, dual y) produced by tools/certify_cfg4.py on the GPU box and
+    committed as data: verified here with sparse mat-vecs only — no LP solver, no oracle, no GPU.
+    Weak duality: A x <= b, x >= 0, A^T y >= c, y >= 0 and c.x == b.y prove that x is optimal."""
+    import json
+
+    import scipy.sparse as sp
+    z = np.load(path)
+    meta = json.loads(str(z["meta"]))
+    lp = lpgen.gen_sparse_lp(meta["rows"], meta["cols"], meta["nnz_per_row"], meta["seed"])
+    m, n = lp["m"], lp["n"]
+    x = np.zeros(n)
+    x[z["x_idx"]] = z["x_val"]
+    y = np.zeros(m)
+    y[z["y_idx"]] = z["y_val"]
+    A = sp.csr_matrix((lp["data"], lp["indices"], lp["indptr"]), shape=(m, n))
+    c, b = lp["obj"], lp["rhs"]
+    scale = max(1.0, float(np.abs(b).max()))
+    assert (A @ x - b).max() <= 1e-9 * scale and x.min() >= -1e-9           # primal feasible
+    assert (c - A.T @ y).max() <= 1e-9 and y.min() >= -1e-9                  # dual feasible
+    primal, dual = float(c @ x), float(b @ y)
+    assert abs(primal - dual) <= 1e-9 * max(1.0, abs(primal))               # no duality gap => optimal
+    assert abs(primal - meta["objective_accumulated"]) <= 2e-9 * max(1.0, abs(primal))  # what objective() reported
+    return meta, primal
+
+
+def test_optimality_certificate_small_instance():
+    meta, primal = _check_certificate(os.path.join(GOLDEN, "cfg_small_certificate.npz"))
+    assert meta["rows"] == 2000 and abs(primal - 1341.8557336311) < 1e-6
+
+
+def test_optimality_certificate_config4():
+    """BASELINE config 4 (100 000 x 100 000, 10^7 non-zeros) solved to optimality on one MI355X."""
+    path = os.path.join(GOLDEN, "cfg4_certificate.npz")
+    if not os.path.exists(path):
+        pytest.skip("certificate not generated yet")
+    meta, primal = _check_certificate(path)
+    assert meta["rows"] == 100000 and meta["cols"] == 100000
