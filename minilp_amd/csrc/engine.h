@@ -112,7 +112,7 @@ struct PivotRecord {
 struct Stats {
     uint64_t iterations = 0, basis_changes = 0, bound_flips = 0, primal_iters = 0, dual_iters = 0, reinversions = 0;
     double fused_bytes = 0, fused_ms = 0, sweep_bytes = 0, sweep_ms = 0;
-    uint64_t fused_launches = 0, sweep_launches = 0;
+    uint64_t fused_launches = 0, sweep_launches = 0, final_refreshes = 0;
     double update_ms = 0;
     uint64_t update_launches = 0;
     double solve_wall_s = 0;
@@ -226,12 +226,17 @@ private:
     // --- iteration graphs: [phase][pse]
     bool use_graph = true, use_branches = false;
     int batch = 16;
-    hipGraphExec_t gexec[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    hipGraph_t ggraph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    Geom ggeom[2][2];
+    long final_refresh_pivots = 50000;  // MLP_FINAL_REFRESH: re-examine optimality on recomputed reduced costs after this many pivots (0 = never)
+    uint64_t iters_since_recalc = 0;
+    int graph_iters = 8;  // MLP_GRAPH_ITERS: iterations per graph once a geometry has run for a while (1 = off)
+    // graph slots: [0] one iteration per graph, [1] graph_iters iterations per graph (long runs)
+    hipGraphExec_t gexec[2][2][2] = {};
+    hipGraph_t ggraph[2][2][2] = {};
+    Geom ggeom[2][2][2];
+    uint64_t graph_batches_in_geom = 0;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // sweep0/1, fused0/1, update0/1
     void drop_graphs();
-    hipGraphExec_t get_graph(int phase);
+    hipGraphExec_t get_graph(int phase, int multi);
 
     Geom geom() const;
     DevView* sync_view();

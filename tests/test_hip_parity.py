@@ -465,3 +465,20 @@ def test_engine_level_stages_out_of_order_are_refused():
     st, info = s.engine_stage(M.api.STAGE_FTRAN)
     alpha = s.state("col_coeffs")                  # the vector stays on the device; white-box read-back
     assert np.count_nonzero(alpha) > 0 and info["next_stage"] == M.api.STAGE_RATIO
+
+
+def test_final_refresh_of_reduced_costs_keeps_the_optimum(monkeypatch):
+    """Long runs re-examine optimality on reduced costs recomputed from the basis (engine.hip, optimize());
+    forced here after a handful of pivots: same optimum, same point, and the refresh is counted."""
+    monkeypatch.setenv("MLP_FINAL_REFRESH", "5")
+    for fam, kw in (("sparse", dict(m=300, n=500, k=20, seed=5)), ("mixed", dict(m=300, n=400, k=8, seed=4)),
+                    ("dense", dict(m=150, n=100, seed=3))):
+        lp = GEN[fam](**kw)
+        so = lpgen.build_problem(O.Problem, lp).solve()
+        sg = lpgen.build_problem(M.Problem, lp).solve()
+        if sg.stats()["primal_iters"] >= 5:  # the refresh belongs to the primal loop (optimize)
+            assert sg.stats()["final_refreshes"] >= 1
+        assert obj_close(sg.objective(), so.objective())
+        check_feasible(lp, sg.values())
+        if fam != "mixed":
+            assert np.abs(np.asarray(sg.values()) - np.asarray(so.values())).max() <= X_ATOL
