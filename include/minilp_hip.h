@@ -87,10 +87,11 @@ int mlp_solution_reinvert(mlp_solution* s, double* max_diff);
 /* Column-block sharding of the pricing path across the GPUs of one node (one process per GPU,
  * DESIGN.md §6).  Every rank builds the SAME problem, calls mlp_problem_solve_ex(budget = 0), then
  * this function with its rank, the world size and the name of a POSIX shared-memory mailbox of
- * 256 * world zeroed bytes created by the launcher, and then the same sequence of
+ * 512 * world zeroed bytes created by the launcher, and then the same sequence of
  * mlp_solution_continue calls.  Rank r owns non-basic positions [n*r/world, n*(r+1)/world): its
  * tableau-row sweep, d/gamma update and pricing scan cover only that block; candidates are exchanged
- * through the mailbox once per pivot.  Primal simplex loop only; the Solution mutators are refused. */
+ * through the mailbox (primal: pricing all-gather + ratio decision; dual: leaving row, pass-1 minimum, pass-2
+ * candidate).  Primal and dual loops; the Solution mutators are refused. */
 int mlp_solution_enable_sharding(mlp_solution* s, int rank, int world, const char* shm_name);
 
 typedef struct mlp_stats {

@@ -469,7 +469,7 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name) {
         view_dirty = true;
         return;
     }
-    size_t bytes = sizeof(MailRec) * 4 * (size_t)world;
+    size_t bytes = sizeof(MailRec) * 2 * MAIL_KINDS * (size_t)world;
     int fd = shm_open(shm_name, O_RDWR, 0600);
     if (fd < 0) throw MlpError(-1, std::string("enable_sharding: shm_open failed for ") + shm_name);
     struct stat sb;
@@ -896,8 +896,6 @@ int Engine::process_records(int phase, int launched) {
 }
 
 int Engine::run_loop(int phase) {
-    if (shard_world > 1 && phase != 0)
-        throw MlpError(-1, "sharded pricing covers the primal simplex loop only (DESIGN.md §6)");
     for (;;) {
         if (pivot_budget == 0) {
             budget_exhausted = true;
@@ -1018,6 +1016,7 @@ void Engine::restore_feasibility() {
     if (budget_exhausted) return;
     if (res == ITER_INFEASIBLE) throw LpFail{1};
     if (res == ITER_SINGULAR) throw MlpError(-2, "singular basis (solver.rs:1301)");
+    if (res == ITER_COMM) throw MlpError(-3, "sharded pricing: a peer rank did not answer (mailbox spin bound)");
     if (res != ITER_FEASIBLE) throw MlpError(-3, "dual loop ended with unexpected status " + std::to_string(res));
     primal_feasible = true;
 }

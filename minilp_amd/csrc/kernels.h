@@ -76,13 +76,15 @@ struct Ctl {
     int nlow;   // number of pending rank-1 terms
     int fold;   // this pivot's fused pass folds the pending terms into W0 (set by the plan)
     double lr_c[LR_MAX], lr_e[LR_MAX], lr_g[LR_MAX], lr_h[LR_MAX];  // V[j].a_list, U[j].b_list, V[j].rho_K, U[j].t_K
-    unsigned long long xepoch[2];  // sharded mode: exchange counters (kind 0: pricing, kind 1: ratio decision)
+    unsigned long long xepoch[4];  // sharded mode: exchange counters (kind 0: pricing, 1: primal ratio decision,
+                                   // 2: dual ratio pass-1 minimum, 3: dual ratio pass-2 candidate)
     double max_pivot_err;  // max over the batch of |alpha_q[r] - alpha_r[q]| / max(1,|alpha_q[r]|): drift monitor of W
     PivotRec ring[RING];
 };
 
 // Sharded pricing: one 64-byte mailbox record per (kind, parity, rank) in host
 // memory mapped into every rank's GPU; a rank writes only its own slot and polls the others.
+constexpr int MAIL_KINDS = 4;
 struct alignas(64) MailRec {
     unsigned long long epoch;
     double f[7];
@@ -155,7 +157,7 @@ struct DevView {
     Ctl* ctl;
     // column-block sharding of the pricing path: this rank owns non-basic positions [nb_lo, nb_hi)
     int nb_lo, nb_hi, rank, world;
-    MailRec* mail;  // [2 kinds][2 parities][world], null when world == 1
+    MailRec* mail;  // [MAIL_KINDS][2 parities][world], null when world == 1
 };
 
 // fused pass tiling

@@ -290,32 +290,36 @@ __device__ __forceinline__ void comm_fail(Ctl* c, int phase) {
     c->halt = 1;
     push_rec(c, phase);
 }
-// all-gather of the per-shard pricing candidates, run by ONE WAVE: lane r polls rank r's slot (one
-// PCIe round trip for all peers), then the wave reduces them identically on every rank
-// (score desc, position asc) and adopts the winner's reduced cost d_q.  Result valid in lane 0.
-__device__ bool exchange_best_wave(const DevView& v, Ctl* c, int phase, Cand& best, double dq_local, int lane) {
+// all-gather of per-shard candidates, run by ONE WAVE: lane r polls rank r's slot (one PCIe round trip
+// for all peers), then the wave reduces them identically on every rank (score desc, position asc) and
+// adopts the winner's payloads.  kind 0: primal pricing (payload d_q); kind 3: dual ratio pass 2
+// (payloads alpha_rq and d_q).  Result valid in lane 0.
+__device__ bool exchange_best_wave(const DevView& v, Ctl* c, int phase, Cand& best, double pay_local, int lane,
+                                   int kind = 0, double pay2_local = 0.0) {
     if (v.world <= 1) return true;
-    unsigned long long ep = c->xepoch[0] + 1ull;
+    unsigned long long ep = c->xepoch[kind] + 1ull;
     if (lane == 0) {
-        double f[7] = {best.key, (double)best.idx, dq_local, 0.0, 0.0, 0.0, 0.0};
-        mail_post(mail_slot(v, 0, ep, v.rank), ep, f);
+        double f[7] = {best.key, (double)best.idx, pay_local, pay2_local, 0.0, 0.0, 0.0};
+        mail_post(mail_slot(v, kind, ep, v.rank), ep, f);
     }
     Cand g = cand_none();
-    double dq = 0.0;
+    double dq = 0.0, p2 = 0.0;
     int owner = -1;
     bool ok = true;
     for (int r2 = lane; r2 < v.world; r2 += 64) {
         Cand t = best;
-        double td = dq_local;
+        double td = pay_local, t2 = pay2_local;
         if (r2 != v.rank) {
             double h[7];
-            if (!mail_wait(mail_slot(v, 0, ep, r2), ep, h)) ok = false;
+            if (!mail_wait(mail_slot(v, kind, ep, r2), ep, h)) ok = false;
             t = Cand{h[0], (int)h[1]};
             td = h[2];
+            t2 = h[3];
         }
         if (owner < 0 || cand_better(t, g)) {
             g = t;
             dq = td;
+            p2 = t2;
             owner = r2;
         }
     }
@@ -326,23 +330,78 @@ __device__ bool exchange_best_wave(const DevView& v, Ctl* c, int phase, Cand& be
         t.key = __shfl_down(g.key, o, 64);
         t.idx = __shfl_down(g.idx, o, 64);
         double td = __shfl_down(dq, o, 64);
+        double t2 = __shfl_down(p2, o, 64);
         int to = __shfl_down(owner, o, 64);
         if (to >= 0 && (owner < 0 || cand_better(t, g))) {
             g = t;
             dq = td;
+            p2 = t2;
             owner = to;
         }
     }
     if (lane == 0) {
-        c->xepoch[0] = ep;
+        c->xepoch[kind] = ep;
         if (!ok) {
             comm_fail(c, phase);
         } else {
-            if (g.idx != NONE_IDX && owner != v.rank) v.d[g.idx] = dq;  // non-owners hold no valid d outside their block
+            if (g.idx != NONE_IDX && owner != v.rank) {  // non-owners hold no valid d / alpha_r outside their block
+                v.d[g.idx] = dq;
+                if (kind == 3) v.alpha_r[g.idx] = p2;
+            }
             best = g;
         }
     }
     return ok;
+}
+// all-reduce MIN of one double per rank (dual ratio pass 1, kind 2); same wave-parallel poll.
+__device__ bool exchange_min_wave(const DevView& v, Ctl* c, double& mn, int lane) {
+    if (v.world <= 1) return true;
+    unsigned long long ep = c->xepoch[2] + 1ull;
+    if (lane == 0) {
+        double f[7] = {mn, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        mail_post(mail_slot(v, 2, ep, v.rank), ep, f);
+    }
+    double g = INFINITY;
+    bool ok = true;
+    for (int r2 = lane; r2 < v.world; r2 += 64) {
+        double t = mn;
+        if (r2 != v.rank) {
+            double h[7];
+            if (!mail_wait(mail_slot(v, 2, ep, r2), ep, h)) ok = false;
+            t = h[0];
+        }
+        if (t < g) g = t;
+    }
+    ok = __all(ok);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double t = __shfl_down(g, o, 64);
+        if (t < g) g = t;
+    }
+    if (lane == 0) {
+        c->xepoch[2] = ep;
+        if (!ok) comm_fail(c, 1);
+        else mn = g;
+    }
+    return ok;
+}
+// Dual pricing runs over the (replicated) basic side, but x_B carries float atomics and is reproducible
+// only to rounding across ranks: every rank adopts rank 0's leaving row (kind 0, one lane).
+__device__ bool adopt_rank0_candidate(const DevView& v, Ctl* c, Cand& best) {
+    if (v.world <= 1) return true;
+    const unsigned long long ep = ++c->xepoch[0];
+    if (v.rank == 0) {
+        double f[7] = {best.key, (double)best.idx, 0.0, 0.0, 0.0, 0.0, 0.0};
+        mail_post(mail_slot(v, 0, ep, 0), ep, f);
+        return true;
+    }
+    double h[7];
+    if (!mail_wait(mail_slot(v, 0, ep, 0), ep, h)) {
+        comm_fail(c, 1);
+        return false;
+    }
+    best = Cand{h[0], (int)h[1]};
+    return true;
 }
 
 // Partition-change plan, run by ONE thread once q, r and the final alpha_q are
@@ -573,6 +632,7 @@ __device__ __forceinline__ void close_and_open(const DevView& v, Ctl* c, int pha
     Cand b{s_key, s_idx};
     bool ok = true;
     if (phase == 0) ok = exchange_best_wave(v, c, phase, b, s_pay, threadIdx.x);
+    else if (threadIdx.x == 0) ok = adopt_rank0_candidate(v, c, b);
     if (threadIdx.x == 0 && ok) open_iteration(c, phase, b);
 }
 __global__ void __launch_bounds__(BLK) k_price_primal(DevView v, int use_pse) {
@@ -600,7 +660,7 @@ __global__ void __launch_bounds__(BLK) k_price_dual(DevView v, int use_dse) {
         if (cand_better(t, best)) best = t;
     }
     if (!grid_best(best, v)) return;
-    if (threadIdx.x == 0) open_iteration(c, 1, best);
+    if (threadIdx.x == 0 && adopt_rank0_candidate(v, c, best)) open_iteration(c, 1, best);
 }
 
 // ------------------------------------------------------------------- K2: FTRAN of one column
@@ -1146,7 +1206,7 @@ __global__ void __launch_bounds__(BLK) k_ratio_dual_p1(DevView v) {  // solver.r
     if (c->halt || c->it.status != ITER_PIVOT) return;
     int lsign = c->it.leaving_new_val > v.xB[c->it.r];
     double mn = INFINITY, dummy = 0.0;
-    for (int j = blockIdx.x * BLK + threadIdx.x; j < v.n; j += gridDim.x * BLK) {
+    for (int j = v.nb_lo + blockIdx.x * BLK + threadIdx.x; j < v.nb_hi; j += gridDim.x * BLK) {
         double coeff = v.alpha_r[j];
         uint8_t f = v.nbflags[j];
         if (!dual_eligible(coeff, f, lsign)) continue;
@@ -1154,7 +1214,13 @@ __global__ void __launch_bounds__(BLK) k_ratio_dual_p1(DevView v) {  // solver.r
         if (cur < mn) mn = cur;
     }
     if (!grid_min_sum(mn, dummy, v)) return;
-    if (threadIdx.x == 0) c->it.max_step = mn;
+    __shared__ double s_mn;
+    if (threadIdx.x == 0) s_mn = mn;
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    double g = s_mn;
+    bool ok = exchange_min_wave(v, c, g, threadIdx.x);  // sharded: minimum over all column blocks
+    if (threadIdx.x == 0 && ok) c->it.max_step = g;
 }
 // solver.rs:979-1021; the finalising block goes straight on with the FTRAN head
 __global__ void __launch_bounds__(BLK) k_ratio_dual_p2(DevView v) {
@@ -1165,7 +1231,7 @@ __global__ void __launch_bounds__(BLK) k_ratio_dual_p2(DevView v) {
     int lsign = it->leaving_new_val > v.xB[r];
     double max_step = it->max_step;
     Cand best = cand_none();
-    for (int j = blockIdx.x * BLK + threadIdx.x; j < v.n; j += gridDim.x * BLK) {
+    for (int j = v.nb_lo + blockIdx.x * BLK + threadIdx.x; j < v.nb_hi; j += gridDim.x * BLK) {
         double coeff = v.alpha_r[j];
         uint8_t f = v.nbflags[j];
         if (!dual_eligible(coeff, f, lsign)) continue;
@@ -1177,6 +1243,30 @@ __global__ void __launch_bounds__(BLK) k_ratio_dual_p2(DevView v) {
     }
     if (!grid_best(best, v)) return;
     __shared__ int s_ok;
+    __shared__ double s_key;
+    __shared__ int s_idx;
+    if (v.world > 1) {  // sharded: all-gather of the per-block candidates with (alpha_rq, d_q) as payload
+        if (threadIdx.x == 0) {
+            s_key = best.key;
+            s_idx = best.idx;
+        }
+        __syncthreads();
+        bool ok = true;
+        if (threadIdx.x < 64) {
+            Cand b{s_key, s_idx};
+            const bool have = b.idx != NONE_IDX;
+            ok = exchange_best_wave(v, c, 1, b, have ? v.d[b.idx] : 0.0, threadIdx.x, 3, have ? v.alpha_r[b.idx] : 0.0);
+            if (threadIdx.x == 0) {
+                s_key = b.key;
+                s_idx = ok ? b.idx : NONE_IDX;
+                s_ok = ok ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        if (!s_ok) return;  // communication failure: already recorded
+        best = Cand{s_key, s_idx};
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
         s_ok = 0;
         if (best.idx == NONE_IDX) {

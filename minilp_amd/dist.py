@@ -8,7 +8,7 @@ import os
 import uuid
 
 MAILREC_BYTES = 64
-KINDS, PARITIES = 2, 2
+KINDS, PARITIES = 4, 2  # kernels.h: MAIL_KINDS (pricing, primal ratio decision, dual ratio min, dual ratio candidate)
 
 
 def mailbox_bytes(world):

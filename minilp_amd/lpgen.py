@@ -70,6 +70,17 @@ def gen_sparse_lp(m, n, k, seed=4):
                 indices=cols.reshape(-1), data=vals.reshape(-1), ops=np.full(m, LE, dtype=np.int32), rhs=b)
 
 
+def gen_cover_lp(m, n, k, seed=5):
+    """Covering LP on the pattern of the config-4 family: Min c'x, Ax >= b, x >= 0 with positive data.
+    x = 0 is dual feasible (c > 0) and primal infeasible, so the whole solve is the DUAL simplex
+    (restore_feasibility with the real objective, solver.rs:513-547); continuous random data, so the
+    pivot sequence is non-degenerate."""
+    base = gen_sparse_lp(m, n, k, seed)
+    out = dict(base)
+    out.update(name=f"cover_{m}x{n}_k{k}_s{seed}", direction=MINIMIZE, ops=np.full(m, GE, dtype=np.int32))
+    return out
+
+
 def gen_mixed_lp(m, n, k, seed=3):
     """Config 3 stand-in (no NETLIB file is available offline): sparse rows with E/L/G operators,
     finite/infinite/fixed/free bounds and mixed-sign costs, built around a known feasible point so

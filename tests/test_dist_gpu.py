@@ -28,3 +28,13 @@ def test_sharded_pricing_with_the_large_nucleus_machinery():
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "traces identical: True" in r.stdout
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_dual_loop_matches_unsharded_pivot_for_pivot(world):
+    """The dual simplex loop (covering LP: dual feasible, primal infeasible at x = 0) with the three dual
+    exchanges: leaving row adopted from rank 0, pass-1 minimum all-reduce, pass-2 candidate all-gather."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_test.py"), str(world), "3000", "3500", "12", "400", "cover"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "traces identical: True" in r.stdout

@@ -482,3 +482,17 @@ def test_final_refresh_of_reduced_costs_keeps_the_optimum(monkeypatch):
         check_feasible(lp, sg.values())
         if fam != "mixed":
             assert np.abs(np.asarray(sg.values()) - np.asarray(so.values())).max() <= X_ATOL
+
+
+@pytest.mark.parametrize("kw", [dict(m=300, n=350, k=8, seed=4), dict(m=1200, n=1000, k=10, seed=6)], ids=str)
+def test_dual_simplex_only_instance_pivot_for_pivot(kw):
+    """Covering LP (Min c'x, Ax >= b, positive continuous data): dual feasible and primal infeasible at
+    x = 0, so the whole solve is the dual loop (solver.rs:513-547) — identical pivot sequence to the oracle."""
+    lp = lpgen.gen_cover_lp(**kw)
+    so = lpgen.build_problem(O.Problem, lp).solve(trace=True)
+    sg = lpgen.build_problem(M.Problem, lp).solve(trace=True)
+    assert sg.stats()["primal_iters"] == 0 and sg.stats()["dual_iters"] == len(so.trace()) > 50
+    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+    assert obj_close(sg.objective(), so.objective())
+    assert np.abs(np.asarray(sg.values()) - np.asarray(so.values())).max() <= X_ATOL
+    check_feasible(lp, sg.values())

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def worker(rank, world, port, m, n, k, pivots, out):
+def worker(rank, world, port, m, n, k, pivots, out, family="sparse"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -20,7 +20,7 @@ def worker(rank, world, port, m, n, k, pivots, out):
     from minilp_amd import dist as md
     from minilp_amd import lpgen
     M.set_device(0)
-    lp = lpgen.gen_sparse_lp(m, n, k, 4)
+    lp = lpgen.gen_cover_lp(m, n, k, 4) if family == "cover" else lpgen.gen_sparse_lp(m, n, k, 4)
     p = lpgen.build_problem(M.Problem, lp)
     s = p.solve(budget=0, trace=True)
     box = md.setup_sharding(s, dist)
@@ -53,9 +53,10 @@ def worker(rank, world, port, m, n, k, pivots, out):
 if __name__ == "__main__":
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     m, n, k, pivots = (int(x) for x in (sys.argv[2:6] if len(sys.argv) > 5 else (3000, 3000, 12, 400)))
+    family = sys.argv[6] if len(sys.argv) > 6 else "sparse"
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, world, 29533 + world, m, n, k, pivots, out)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, 29533 + world, m, n, k, pivots, out, family)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
