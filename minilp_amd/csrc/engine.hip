@@ -84,6 +84,8 @@ Engine::Engine() {
     if (sv) sweep_variant = std::atoi(sv);
     const char* bt = std::getenv("MLP_BIGTILE");
     force_big_tiles = bt && std::atoi(bt) != 0;
+    const char* bd = std::getenv("MLP_BANDED");
+    if (bd) banded_mode = std::atoi(bd) != 0 ? 1 : 0;
     const char* fr = std::getenv("MLP_FINAL_REFRESH");
     if (fr) final_refresh_pivots = std::atol(fr);
     const char* nbp = std::getenv("MLP_NO_BLOCKED_PUSH");
@@ -273,6 +275,51 @@ Geom Engine::geom() const {
     return g;
 }
 
+// Band-major copy of A for the banded sweep: for band b, a CSC over ALL columns restricted to rows
+// [b * BAND_ROWS, (b + 1) * BAND_ROWS) with 16-bit local row indices.  Columns hold ascending rows, so the
+// entries of (column, band) are a contiguous run of the plain CSC.
+bool Engine::use_banded() const {
+    if (banded_mode == 0) return false;
+    if (banded_mode == 1) return true;
+    return m_ >= 4 * BAND_ROWS && h_rcol.size() >= ((size_t)1 << 22);
+}
+void Engine::ensure_banded() {
+    if (!banded_dirty) return;
+    const int nb = (m_ + BAND_ROWS - 1) / BAND_ROWS;
+    const size_t nnz = h_crow.size();
+    std::vector<int> bptr((size_t)nb * (size_t)(N_ + 1));
+    std::vector<unsigned short> brow(nnz);
+    std::vector<double> bval(nnz);
+    // pass 1: counts per (band, column)
+    std::vector<int> cnt((size_t)nb * (size_t)N_, 0);
+    for (int var = 0; var < N_; ++var)
+        for (int e = h_cptr[var]; e < h_cptr[var + 1]; ++e) cnt[(size_t)(h_crow[e] / BAND_ROWS) * N_ + var] += 1;
+    size_t off = 0;
+    for (int b = 0; b < nb; ++b) {
+        int* bp = &bptr[(size_t)b * (N_ + 1)];
+        for (int var = 0; var < N_; ++var) {
+            bp[var] = (int)off;
+            off += (size_t)cnt[(size_t)b * N_ + var];
+        }
+        bp[N_] = (int)off;
+    }
+    // pass 2: fill (the entries of a column inside one band are consecutive and ascending)
+    std::vector<int> fill((size_t)nb * (size_t)N_, 0);
+    for (int var = 0; var < N_; ++var)
+        for (int e = h_cptr[var]; e < h_cptr[var + 1]; ++e) {
+            const int b = h_crow[e] / BAND_ROWS;
+            const size_t dst = (size_t)bptr[(size_t)b * (N_ + 1) + var] + (size_t)fill[(size_t)b * N_ + var]++;
+            brow[dst] = (unsigned short)(h_crow[e] - b * BAND_ROWS);
+            bval[dst] = h_cval[e];
+        }
+    d_bptr.upload(bptr, st); d_brow.upload(brow, st); d_bval.upload(bval, st);
+    d_band_part.ensure((size_t)nb * (size_t)num_vars, 0, st);
+    d_band_rng.ensure((size_t)nb * (size_t)num_vars, 0, st);
+    band_rng_stale = true;
+    HIPCHECK(hipStreamSynchronize(st));  // local staging buffers
+    banded_dirty = false;
+}
+
 // Row-block offsets of every column for the blocked F push: colblk[var][b] = first CSC index of column
 // var whose row is >= b * PB_ROWS (columns hold ascending rows), colblk[var][RB] = end of the column.
 void Engine::ensure_colblk() {
@@ -314,6 +361,14 @@ DevView* Engine::sync_view() {
     v.colblk = v.pb_on ? d_colblk.p : nullptr;
     v.push_part = v.pb_on ? d_push_part.p : nullptr;
     v.pb_rb = (m_ + PB_ROWS - 1) / PB_ROWS;
+    v.banded = use_banded() ? 1 : 0;
+    if (v.banded) ensure_banded();
+    v.bptr = v.banded ? d_bptr.p : nullptr;
+    v.brow = v.banded ? d_brow.p : nullptr;
+    v.bval = v.banded ? d_bval.p : nullptr;
+    v.band_part = v.banded ? d_band_part.p : nullptr;
+    v.band_rng = v.banded ? d_band_rng.p : nullptr;
+    v.nbands = (m_ + BAND_ROWS - 1) / BAND_ROWS;
     v.pos_of_kslot = d_pos_of_kslot.p; v.row_of_kslot = d_row_of_kslot.p; v.W = d_W.p;
     v.U = d_U.p; v.V = d_V.p; v.pad1 = 0;
     // delayed-update period: 16 from capacity 8192, 32 from 32768 (the fold's k^2 cost outgrows the O(k J) overheads)
@@ -337,6 +392,10 @@ DevView* Engine::sync_view() {
         eager_iters_in_geom = 0;
     }
     view_dirty = false;
+    if (band_rng_stale && hview.banded) {  // the band-major copy was (re)built: refresh the per-position segments
+        band_rng_stale = false;
+        launch_init_nb_rng(hview, geom(), st);
+    }
     return &hview;
 }
 
@@ -359,6 +418,7 @@ void Engine::upload_matrix() {
     d_rptr.upload(h_rptr, st); d_rcol.upload(h_rcol, st); d_rval.upload(h_rval, st);
     d_lo.upload(h_lo, st); d_hi.upload(h_hi, st); d_obj.upload(h_obj, st);
     colblk_dirty = true;
+    banded_dirty = true;
     view_dirty = true;
 }
 
@@ -1367,6 +1427,7 @@ Engine* Engine::clone() {
     e->resume_in_optimize = resume_in_optimize;
     e->nnz_nonbasic = nnz_nonbasic;
     e->trace = trace; e->profile = profile;
+    e->banded_mode = banded_mode;
     e->final_refresh_pivots = final_refresh_pivots; e->iters_since_recalc = iters_since_recalc;
     e->ld_pad = ld_pad; e->lr_force = lr_force; e->force_big_tiles = force_big_tiles; e->pb_disable = pb_disable;
     hipStream_t s2 = e->st;

@@ -129,6 +129,14 @@ struct DevView {
     int* colblk;
     double* push_part;
     int pb_rb, pb_on;
+    // banded tableau-row sweep (large m): a second copy of A in band-major order (bands of BAND_ROWS rows;
+    // per band a CSC with 16-bit local row indices), so that a workgroup can hold its band of (rho, v) in LDS
+    int* bptr;              // nbands x (N + 1)
+    unsigned short* brow;   // nnz
+    double* bval;           // nnz
+    double2* band_part;     // nbands x n partial (alpha_r, helper)
+    int2* band_rng;         // nbands x n: band segment of the column at each non-basic position
+    int nbands, banded;
     int* pos_of_kslot;     // cap: row slot -> position
     int* row_of_kslot;     // cap: col slot -> row
     double* W;             // cap x ld, row-major: W[rowslot(p)][colslot(i)] = (B^-1)[p, i]  (W0 in delayed-update mode)
@@ -165,6 +173,8 @@ constexpr int FW_TR = 8;     // minimum rows per block (sizes the partial buffer
 constexpr int FW_TC = 1024;  // columns per block (256 threads x 4)
 
 // Launch geometry that is baked into a captured graph.
+constexpr int BAND_ROWS = 8192;  // rows per band of the banded sweep: 128 KB of (rho, v) pairs in LDS
+constexpr int BAND_THREADS = 1024;
 constexpr int PB_ROWS = 4096;   // rows per LDS block of the blocked F push (32 KB of doubles)
 constexpr int PB_CHUNKS = 24;   // column chunks (slot ranges) of the blocked F push
 

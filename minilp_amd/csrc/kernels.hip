@@ -1180,11 +1180,84 @@ __global__ void __launch_bounds__(BLK) k_sweep(DevView v, int n_sweep) {
         if (MODE != 0) v.helper[col] = a2;
     }
 }
+// Banded sweep: the pull above is bound by the L2 request rate of its 10^7 row-indexed
+// gathers.  Here workgroup (band b, chunk c) first copies its band of the interleaved (rho, v) vector into
+// LDS (128 KB), then every thread walks one non-basic column's entries INSIDE the band (band-major copy
+// of A, ~nnz/nbands entries per column; the per-position segment is cached in band_rng like nb_rng) and
+// gathers from LDS; the per-band partial dot products go to band_part[b][j] and k_band_combine adds them
+// up in band order (fixed summation order, no atomics).
+template <int MODE>
+__global__ void __launch_bounds__(BAND_THREADS) k_sweep_band(DevView v) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    extern __shared__ double2 s_rv[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int row0 = b * BAND_ROWS;
+    const int nrows = min(BAND_ROWS, v.m - row0);
+    for (int t = tid; t < nrows; t += BAND_THREADS) s_rv[t] = v.rv[row0 + t];
+    __syncthreads();
+    const int span = v.nb_hi - v.nb_lo;
+    const int per = (span + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int c_lo = v.nb_lo + (int)blockIdx.y * per;
+    const int c_hi = min(v.nb_hi, c_lo + per);
+    const int2* rng = v.band_rng + (size_t)b * (size_t)v.n;
+    double2* out = v.band_part + (size_t)b * (size_t)v.n;
+    for (int j = c_lo + tid; j < c_hi; j += BAND_THREADS) {
+        const int2 rg = rng[j];
+        const int beg = rg.x, end = rg.y;
+        double a1 = 0.0, a2 = 0.0;
+        for (int e0 = beg; e0 < end; e0 += 8) {
+            int r[8];
+            double a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {  // independent loads first, then the LDS gathers
+                const bool ok = e0 + u < end;
+                r[u] = ok ? (int)v.brow[e0 + u] : 0;
+                a[u] = ok ? v.bval[e0 + u] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double2 t = s_rv[r[u]];
+                if (MODE != 2) a1 += a[u] * t.x;
+                if (MODE != 0) a2 += a[u] * t.y;
+            }
+        }
+        out[j] = make_double2(a1, a2);
+    }
+}
+template <int MODE>
+__global__ void __launch_bounds__(BLK) k_band_combine(DevView v, int n_comb) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    if ((int)blockIdx.x >= n_comb) {  // horizontally fused: the partition change (as in k_sweep)
+        struct_update_body(v, c, ((int)blockIdx.x - n_comb) * BLK + threadIdx.x);
+        return;
+    }
+    const int j = v.nb_lo + blockIdx.x * BLK + threadIdx.x;
+    if (j >= v.nb_hi) return;
+    double a1 = 0.0, a2 = 0.0;
+    for (int b = 0; b < v.nbands; ++b) {
+        const double2 t = v.band_part[(size_t)b * (size_t)v.n + j];
+        a1 += t.x;
+        a2 += t.y;
+    }
+    if (MODE != 2) v.alpha_r[j] = a1;
+    if (MODE != 0) v.helper[j] = a2;
+}
+// per-band segment of the column at non-basic position j (kept next to nb_rng)
+__device__ __forceinline__ void set_band_rng(const DevView& v, int j, int var) {
+    const size_t stride = (size_t)(v.m + v.n + 1);
+    for (int b = 0; b < v.nbands; ++b) {
+        const int* bp = v.bptr + (size_t)b * stride;
+        v.band_rng[(size_t)b * (size_t)v.n + j] = make_int2(bp[var], bp[var + 1]);
+    }
+}
 __global__ void __launch_bounds__(BLK) k_init_nb_rng(DevView v) {
     int j = blockIdx.x * BLK + threadIdx.x;
     if (j < v.n) {
         int var = v.nb_vars[j];
         v.nb_rng[j] = make_int2(v.csc_ptr[var], v.csc_ptr[var + 1]);
+        if (v.banded) set_band_rng(v, j, var);
     }
 }
 
@@ -1872,6 +1945,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                 }
                 v.nb_vars[q] = lv;
                 v.nb_rng[q] = make_int2(v.csc_ptr[lv], v.csc_ptr[lv + 1]);
+                if (v.banded) set_band_rng(v, q, lv);
                 v.xN[q] = lnv;
                 f = (uint8_t)((lnv == v.var_lo[lv] ? NB_AT_MIN : 0) | (lnv == v.var_hi[lv] ? NB_AT_MAX : 0));
                 v.nbflags[q] = f;
@@ -2103,7 +2177,38 @@ void launch_btran_rhs(const DevView& dv, const Geom& g, hipStream_t st) {
                  hipLaunchKernelGGL(k_btran_rhs<16>, dim3(blocks_for((long)g.cap * 16)), dim3(BLK), 0, st, dv),
                  hipLaunchKernelGGL(k_btran_rhs<64>, dim3(blocks_for((long)g.cap * 64)), dim3(BLK), 0, st, dv));
 }
+static void launch_sweep_banded(const DevView& dv, const Geom& g, int mode, int with_struct, hipStream_t st) {
+    static bool attr_set = false;
+    const size_t lds = sizeof(double2) * (size_t)BAND_ROWS;
+    if (!attr_set) {  // more than the default 64 KB of LDS per workgroup
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_band<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_band<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_band<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    // one workgroup per CU (LDS-bound): bands x chunks must not exceed the 256 CUs, or a second, almost
+    // empty round of workgroups doubles the kernel time (260 workgroups: 43 us, 247: 36 us)
+    int chunks = 256 / dv.nbands;
+    if (chunks < 1) chunks = 1;
+    dim3 gr(dv.nbands, chunks), b(BAND_THREADS);
+    const int nc = blocks_for(dv.nb_hi - dv.nb_lo);
+    const dim3 gc(nc + (with_struct ? blocks_for(g.cap) : 0));
+    if (mode == 0) {
+        hipLaunchKernelGGL(k_sweep_band<0>, gr, b, lds, st, dv);
+        hipLaunchKernelGGL(k_band_combine<0>, gc, dim3(BLK), 0, st, dv, nc);
+    } else if (mode == 1) {
+        hipLaunchKernelGGL(k_sweep_band<1>, gr, b, lds, st, dv);
+        hipLaunchKernelGGL(k_band_combine<1>, gc, dim3(BLK), 0, st, dv, nc);
+    } else {
+        hipLaunchKernelGGL(k_sweep_band<2>, gr, b, lds, st, dv);
+        hipLaunchKernelGGL(k_band_combine<2>, gc, dim3(BLK), 0, st, dv, nc);
+    }
+}
 void launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, hipStream_t st) {
+    if (dv.banded) {
+        launch_sweep_banded(dv, g, mode, with_struct, st);
+        return;
+    }
 #define SWEEP(G, U)                                                                                               \
     do {                                                                                                          \
         int n_sweep = blocks_for((long)(dv.nb_hi - dv.nb_lo) * G);                                                \

@@ -24,8 +24,9 @@ def lowrank(request):
     if big:
         os.environ["MLP_BIGTILE"] = "1"
         os.environ["MLP_LDPAD"] = "16"
+        os.environ["MLP_BANDED"] = "1"   # banded tableau-row sweep (otherwise from 32 768 rows on)
     yield j
-    for k in ("MLP_LOWRANK", "MLP_BIGTILE", "MLP_LDPAD"):
+    for k in ("MLP_LOWRANK", "MLP_BIGTILE", "MLP_LDPAD", "MLP_BANDED"):
         os.environ.pop(k, None)
 
 
