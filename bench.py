@@ -172,7 +172,10 @@ def main():
         roofline = None
         if dom:
             kname = {"fused": "k_fused_w (tau=W*rho, v=W^T*t, eta update of the nucleus inverse)",
-                     "sweep": "k_sweep (tableau row rho^T N [+ PSE helper] as a CSC pull over A)"}[dom]
+                     "sweep": ("k_sweep_band + k_band_combine (tableau row rho^T N [+ PSE helper]: band-major copy of A, "
+                               "the band of (rho, v) held in LDS, per-band partials combined in band order)"
+                               if st.get("banded_sweep") else
+                               "k_sweep (tableau row rho^T N [+ PSE helper] as a CSC pull over A)")}[dom]
             roofline = dict(bound="hbm", kernel=kname, achieved=kern[dom]["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=kern[dom]["gbs"] / HBM_PEAK_GBS, traffic=pmc_traffic(a, dom),
                             traffic_unit="HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic.json)",

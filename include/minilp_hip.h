@@ -104,6 +104,7 @@ typedef struct mlp_stats {
     uint64_t kase[5]; /* basis changes by partition case: nucleus->nucleus, singleton->nucleus (grow), nucleus->singleton
                          (shrink), singleton->singleton (column swap), same-row singleton swap */
     double update_ms; uint64_t update_launches; /* K8 (x_B/d/gamma/beta update + next pricing scan), HIP-event time */
+    uint64_t banded_sweep;    /* 1 when the tableau-row pass runs as the banded sweep (large m), 0 for the CSC pull */
     uint64_t final_refreshes; /* times optimality was re-examined on recomputed reduced costs (long runs only) */
     double max_pivot_err; /* drift monitor: max |alpha_q[r] - alpha_r[q]| / max(1,|alpha_q[r]|) seen so far */
 } mlp_stats;

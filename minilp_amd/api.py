@@ -33,7 +33,7 @@ class MlpStats(C.Structure):
                 + [(n, C.c_double) for n in ("fused_bytes", "fused_ms", "sweep_bytes", "sweep_ms")]
                 + [(n, C.c_uint64) for n in ("fused_launches", "sweep_launches")]
                 + [("solve_wall_s", C.c_double), ("kase", C.c_uint64 * 5), ("update_ms", C.c_double),
-                   ("update_launches", C.c_uint64), ("final_refreshes", C.c_uint64), ("max_pivot_err", C.c_double)])
+                   ("update_launches", C.c_uint64), ("banded_sweep", C.c_uint64), ("final_refreshes", C.c_uint64), ("max_pivot_err", C.c_double)])
 
 
 class MlpIterInfo(C.Structure):  # include/minilp_hip.h: mlp_iter_info

@@ -252,6 +252,7 @@ void mlp_solution_stats(const mlp_solution* s, mlp_stats* o) {
     o->fused_bytes = t.fused_bytes; o->fused_ms = t.fused_ms; o->sweep_bytes = t.sweep_bytes; o->sweep_ms = t.sweep_ms;
     o->fused_launches = t.fused_launches; o->sweep_launches = t.sweep_launches;
     o->update_ms = t.update_ms; o->update_launches = t.update_launches; o->final_refreshes = t.final_refreshes;
+    o->banded_sweep = e->banded_active() ? 1 : 0;
     o->solve_wall_s = t.solve_wall_s;
     o->max_pivot_err = t.max_pivot_err;
     for (int i = 0; i < 5; ++i) o->kase[i] = t.kase[i];

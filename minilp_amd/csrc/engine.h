@@ -186,13 +186,15 @@ private:
     DevBuf<int> d_kslot_of_pos, d_srow_of_pos, d_kslot_of_row, d_pos_of_srow, d_pos_of_kslot, d_row_of_kslot;
     DevBuf<RowInfo> d_rowinfo;
     DevBuf<int> d_bptr;             // banded sweep: band-major copy of A
-    DevBuf<unsigned short> d_brow;
+    DevBuf<unsigned int> d_brow;
     DevBuf<double> d_bval;
     DevBuf<double2> d_band_part;
-    DevBuf<int2> d_band_rng;
-    bool banded_dirty = true, band_rng_stale = false;
+    bool banded_dirty = true;
     int banded_mode = -1;           // MLP_BANDED: 1 force on, 0 off, -1 auto (m >= 4 bands and >= 2^22 non-zeros)
     bool use_banded() const;
+  public:
+    bool banded_active() const { return use_banded(); }
+  private:
     void ensure_banded();
     DevBuf<int> d_colblk;        // blocked F push (large nucleus): row-block offsets per column
     DevBuf<double> d_push_part;  // ... and its PB_CHUNKS x m partial sums

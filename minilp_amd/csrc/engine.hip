@@ -288,8 +288,8 @@ void Engine::ensure_banded() {
     const int nb = (m_ + BAND_ROWS - 1) / BAND_ROWS;
     const size_t nnz = h_crow.size();
     std::vector<int> bptr((size_t)nb * (size_t)(N_ + 1));
-    std::vector<unsigned short> brow(nnz);
-    std::vector<double> bval(nnz);
+    std::vector<unsigned int> brow(nnz + 8, 0u);  // + 8: the kernel reads whole groups of 8 entries
+    std::vector<double> bval(nnz + 8, 0.0);
     // pass 1: counts per (band, column)
     std::vector<int> cnt((size_t)nb * (size_t)N_, 0);
     for (int var = 0; var < N_; ++var)
@@ -309,13 +309,11 @@ void Engine::ensure_banded() {
         for (int e = h_cptr[var]; e < h_cptr[var + 1]; ++e) {
             const int b = h_crow[e] / BAND_ROWS;
             const size_t dst = (size_t)bptr[(size_t)b * (N_ + 1) + var] + (size_t)fill[(size_t)b * N_ + var]++;
-            brow[dst] = (unsigned short)(h_crow[e] - b * BAND_ROWS);
+            brow[dst] = (unsigned int)(h_crow[e] - b * BAND_ROWS);
             bval[dst] = h_cval[e];
         }
     d_bptr.upload(bptr, st); d_brow.upload(brow, st); d_bval.upload(bval, st);
     d_band_part.ensure((size_t)nb * (size_t)num_vars, 0, st);
-    d_band_rng.ensure((size_t)nb * (size_t)num_vars, 0, st);
-    band_rng_stale = true;
     HIPCHECK(hipStreamSynchronize(st));  // local staging buffers
     banded_dirty = false;
 }
@@ -367,7 +365,6 @@ DevView* Engine::sync_view() {
     v.brow = v.banded ? d_brow.p : nullptr;
     v.bval = v.banded ? d_bval.p : nullptr;
     v.band_part = v.banded ? d_band_part.p : nullptr;
-    v.band_rng = v.banded ? d_band_rng.p : nullptr;
     v.nbands = (m_ + BAND_ROWS - 1) / BAND_ROWS;
     v.pos_of_kslot = d_pos_of_kslot.p; v.row_of_kslot = d_row_of_kslot.p; v.W = d_W.p;
     v.U = d_U.p; v.V = d_V.p; v.pad1 = 0;
@@ -392,10 +389,6 @@ DevView* Engine::sync_view() {
         eager_iters_in_geom = 0;
     }
     view_dirty = false;
-    if (band_rng_stale && hview.banded) {  // the band-major copy was (re)built: refresh the per-position segments
-        band_rng_stale = false;
-        launch_init_nb_rng(hview, geom(), st);
-    }
     return &hview;
 }
 

@@ -132,10 +132,9 @@ struct DevView {
     // banded tableau-row sweep (large m): a second copy of A in band-major order (bands of BAND_ROWS rows;
     // per band a CSC with 16-bit local row indices), so that a workgroup can hold its band of (rho, v) in LDS
     int* bptr;              // nbands x (N + 1)
-    unsigned short* brow;   // nnz
-    double* bval;           // nnz
+    unsigned int* brow;     // nnz + 8: row index inside the band (32-bit so that 8 of them load as two 16-byte words)
+    double* bval;           // nnz + 8
     double2* band_part;     // nbands x n partial (alpha_r, helper)
-    int2* band_rng;         // nbands x n: band segment of the column at each non-basic position
     int nbands, banded;
     int* pos_of_kslot;     // cap: row slot -> position
     int* row_of_kslot;     // cap: col slot -> row

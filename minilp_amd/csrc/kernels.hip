@@ -1183,9 +1183,12 @@ __global__ void __launch_bounds__(BLK) k_sweep(DevView v, int n_sweep) {
 // Banded sweep: the pull above is bound by the L2 request rate of its 10^7 row-indexed
 // gathers.  Here workgroup (band b, chunk c) first copies its band of the interleaved (rho, v) vector into
 // LDS (128 KB), then every thread walks one non-basic column's entries INSIDE the band (band-major copy
-// of A, ~nnz/nbands entries per column; the per-position segment is cached in band_rng like nb_rng) and
+// of A, ~nnz/nbands entries per column; caching the per-position segments like nb_rng was tried and only
+// moved the cost into k_update_pivot) and
 // gathers from LDS; the per-band partial dot products go to band_part[b][j] and k_band_combine adds them
 // up in band order (fixed summation order, no atomics).
+typedef unsigned int uint4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
 template <int MODE>
 __global__ void __launch_bounds__(BAND_THREADS) k_sweep_band(DevView v) {
     Ctl* c = v.ctl;
@@ -1200,21 +1203,29 @@ __global__ void __launch_bounds__(BAND_THREADS) k_sweep_band(DevView v) {
     const int per = (span + (int)gridDim.y - 1) / (int)gridDim.y;
     const int c_lo = v.nb_lo + (int)blockIdx.y * per;
     const int c_hi = min(v.nb_hi, c_lo + per);
-    const int2* rng = v.band_rng + (size_t)b * (size_t)v.n;
+    const int* bp = v.bptr + (size_t)b * (size_t)(v.m + v.n + 1);
     double2* out = v.band_part + (size_t)b * (size_t)v.n;
     for (int j = c_lo + tid; j < c_hi; j += BAND_THREADS) {
-        const int2 rg = rng[j];
-        const int beg = rg.x, end = rg.y;
+        const int var = v.nb_vars[j];
+        const int beg = bp[var], end = bp[var + 1];
         double a1 = 0.0, a2 = 0.0;
         for (int e0 = beg; e0 < end; e0 += 8) {
-            int r[8];
-            double a[8];
+            // Eight entries per step as 2 + 4 sixteen-byte loads per lane (a lane's entries are contiguous;
+            // eight scalar loads each touch 64 different lines per wave and the kernel becomes bound by the
+            // texture-address unit: 35.5 us).  Reading past `end` is harmless: the arrays carry 8 spare
+            // entries, a neighbour's rows are valid indices of this band, and the values are masked.
+            const uint4u r0 = *reinterpret_cast<const uint4u*>(v.brow + e0);
+            const uint4u r1 = *reinterpret_cast<const uint4u*>(v.brow + e0 + 4);
+            const dbl2u x0 = *reinterpret_cast<const dbl2u*>(v.bval + e0);
+            const dbl2u x1 = *reinterpret_cast<const dbl2u*>(v.bval + e0 + 2);
+            const dbl2u x2 = *reinterpret_cast<const dbl2u*>(v.bval + e0 + 4);
+            const dbl2u x3 = *reinterpret_cast<const dbl2u*>(v.bval + e0 + 6);
+            const unsigned r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            double a[8] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y, x3.x, x3.y};
+            const int nv = end - e0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {  // independent loads first, then the LDS gathers
-                const bool ok = e0 + u < end;
-                r[u] = ok ? (int)v.brow[e0 + u] : 0;
-                a[u] = ok ? v.bval[e0 + u] : 0.0;
-            }
+            for (int u = 1; u < 8; ++u)
+                if (u >= nv) a[u] = 0.0;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const double2 t = s_rv[r[u]];
@@ -1244,20 +1255,11 @@ __global__ void __launch_bounds__(BLK) k_band_combine(DevView v, int n_comb) {
     if (MODE != 2) v.alpha_r[j] = a1;
     if (MODE != 0) v.helper[j] = a2;
 }
-// per-band segment of the column at non-basic position j (kept next to nb_rng)
-__device__ __forceinline__ void set_band_rng(const DevView& v, int j, int var) {
-    const size_t stride = (size_t)(v.m + v.n + 1);
-    for (int b = 0; b < v.nbands; ++b) {
-        const int* bp = v.bptr + (size_t)b * stride;
-        v.band_rng[(size_t)b * (size_t)v.n + j] = make_int2(bp[var], bp[var + 1]);
-    }
-}
 __global__ void __launch_bounds__(BLK) k_init_nb_rng(DevView v) {
     int j = blockIdx.x * BLK + threadIdx.x;
     if (j < v.n) {
         int var = v.nb_vars[j];
         v.nb_rng[j] = make_int2(v.csc_ptr[var], v.csc_ptr[var + 1]);
-        if (v.banded) set_band_rng(v, j, var);
     }
 }
 
@@ -1945,7 +1947,6 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                 }
                 v.nb_vars[q] = lv;
                 v.nb_rng[q] = make_int2(v.csc_ptr[lv], v.csc_ptr[lv + 1]);
-                if (v.banded) set_band_rng(v, q, lv);
                 v.xN[q] = lnv;
                 f = (uint8_t)((lnv == v.var_lo[lv] ? NB_AT_MIN : 0) | (lnv == v.var_hi[lv] ? NB_AT_MAX : 0));
                 v.nbflags[q] = f;

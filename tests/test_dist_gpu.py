@@ -23,7 +23,7 @@ def test_sharded_pricing_matches_unsharded_pivot_for_pivot(world, pivots):
 def test_sharded_pricing_with_the_large_nucleus_machinery():
     """Same gate with the delayed-update mode, the 16-row non-temporal tiles, the padded pitch of W and
     the blocked F push forced on (they are otherwise used from capacity 8192 on)."""
-    env = dict(os.environ, MLP_LOWRANK="3", MLP_BIGTILE="1", MLP_LDPAD="16")
+    env = dict(os.environ, MLP_LOWRANK="3", MLP_BIGTILE="1", MLP_LDPAD="16", MLP_BANDED="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_test.py"), "2", "4000", "3500", "12", "400"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -21,8 +21,13 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if r.get("Counter_Name") == c:
                 acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
-        if "k_sweep" in k or "k_fused_w" in k:
-            res["sweep" if "k_sweep" in k else "fused"][c] = dict(avg_kb=sum(v) / len(v), launches=len(v), kernel=k)
+        # the tableau-row pass is k_sweep, or k_sweep_band + k_band_combine (summed per launch)
+        key = "sweep" if ("k_sweep" in k or "k_band_combine" in k) else ("fused" if "k_fused_w" in k else None)
+        if key is None:
+            continue
+        d = res[key].setdefault(c, dict(avg_kb=0.0, launches=len(v), kernel=""))
+        d["avg_kb"] += sum(v) / len(v)
+        d["kernel"] = (d["kernel"] + " + " if d["kernel"] else "") + k
 doc = dict(workload=dict(rows=100000, cols=100000, nnz_per_row=100, seed=4, pivots="0..1200"),
            method="rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes); traffic = 2*FETCH_SIZE + WRITE_SIZE (KB -> bytes); see tools/pmc_calib.sh for the calibration",
            kernels={})
