@@ -273,6 +273,7 @@ private:
         uint64_t nucleus_size;
     };
     int step_phase = 0, step_pos = -1;
+    bool stepping = false;
     int step_open(StepInfo* out);
     int step_stage(int stage, StepInfo* out);
     int step_finish(int phase, int status);

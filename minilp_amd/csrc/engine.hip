@@ -729,6 +729,9 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     const DevView& dv = hview;
     const Geom g = geom();
     const int pse = enable_pse ? 1 : 0, dse = enable_dse ? 1 : 0;
+    // banded sweep, primal iteration: k_update_pivot sums the per-band partials itself (no combine launch);
+    // the host-paced stepping API keeps the separate combine so that row_coeffs is readable after STAGE_ROW
+    const int inl = (dv.banded && phase == 0 && !stepping) ? 1 : 0;
     // The pricing decision (q for primal, r for dual) is already in Ctl: it was taken by the
     // previous iteration's update kernel, or by the standalone pricing kernel at batch start.
     switch (stage) {
@@ -757,7 +760,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     case STAGE_ROW:
         if (phase == 0) {
             if (with_events) HIPCHECK(hipEventRecord(ev[0], st));
-            launch_sweep(dv, g, pse ? 1 : 0, 1, st);          // K4 (+ PSE helper in the same pass)  |  partition change
+            launch_sweep(dv, g, pse ? 1 : 0, 1, st, inl);     // K4 (+ PSE helper in the same pass)  |  partition change
             if (with_events) HIPCHECK(hipEventRecord(ev[1], st));
         } else {
             if (with_events) HIPCHECK(hipEventRecord(ev[0], st));
@@ -771,7 +774,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
             else launch_structure_update(dv, g, st);
         }
         if (with_events) HIPCHECK(hipEventRecord(ev[4], st));
-        launch_update_pivot(dv, g, phase, dse, pse, st);      // K8 + zero the work vectors + price the next iteration
+        launch_update_pivot(dv, g, phase, dse, pse, st, inl); // K8 + zero the work vectors + price the next iteration
         if (with_events) HIPCHECK(hipEventRecord(ev[5], st));
         break;
     default:
@@ -856,7 +859,9 @@ int Engine::step_stage(int stage, StepInfo* out) {
         sync_view();
         launch_reset_ring(hview, st);  // one record per stepped iteration
     }
+    stepping = true;
     launch_stage(phase, stage, false);
+    stepping = false;
     pull_ctl();
     step_pos += 1;
     int status = h_ctl->it.status;

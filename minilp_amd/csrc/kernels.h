@@ -195,13 +195,13 @@ void launch_post_ftran(const DevView& dv, const Geom& g, int use_pse, hipStream_
 void launch_btran_prep(const DevView& dv, int derive_dual, int plan_after, hipStream_t st);  // BTRAN head (one wave)
 void launch_btran(const DevView& dv, const Geom& g, int with_rhs, hipStream_t st);        // rho, rK, rho_sq [| tK]
 void launch_btran_rhs(const DevView& dv, const Geom& g, hipStream_t st);                  // tK alone
-void launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, hipStream_t st);  // K4 [| partition change]
+void launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, hipStream_t st, int inline_combine = 0);  // K4 [| partition change]
 void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st);                 // K7 p1, p2 (+FTRAN head)
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st);        // tauK/vK partials + eta update of W
 void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st);     // tau push | v reduce+scatter
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st);
-void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_dse, int use_pse, hipStream_t st);  // K8 + clear + next pricing
+void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_dse, int use_pse, hipStream_t st, int inline_comb = 0);  // K8 + clear + next pricing
 // non-graph helpers
 void launch_set_iter(const DevView& dv, int status, int q, int r, double lnv, int forced, hipStream_t st);
 void launch_reset_ring(const DevView& dv, hipStream_t st);

@@ -1190,18 +1190,23 @@ __global__ void __launch_bounds__(BLK) k_sweep(DevView v, int n_sweep) {
 typedef unsigned int uint4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
 template <int MODE>
-__global__ void __launch_bounds__(BAND_THREADS) k_sweep_band(DevView v) {
+__global__ void __launch_bounds__(BAND_THREADS) k_sweep_band(DevView v, int chunks) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     extern __shared__ double2 s_rv[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n_band_blocks = v.nbands * chunks;
+    if ((int)blockIdx.x >= n_band_blocks) {  // horizontally fused: the partition change (primal iteration)
+        struct_update_body(v, c, ((int)blockIdx.x - n_band_blocks) * BAND_THREADS + threadIdx.x);
+        return;
+    }
+    const int b = (int)blockIdx.x / chunks, chunk = (int)blockIdx.x % chunks, tid = threadIdx.x;
     const int row0 = b * BAND_ROWS;
     const int nrows = min(BAND_ROWS, v.m - row0);
     for (int t = tid; t < nrows; t += BAND_THREADS) s_rv[t] = v.rv[row0 + t];
     __syncthreads();
     const int span = v.nb_hi - v.nb_lo;
-    const int per = (span + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int c_lo = v.nb_lo + (int)blockIdx.y * per;
+    const int per = (span + chunks - 1) / chunks;
+    const int c_lo = v.nb_lo + chunk * per;
     const int c_hi = min(v.nb_hi, c_lo + per);
     const int* bp = v.bptr + (size_t)b * (size_t)(v.m + v.n + 1);
     double2* out = v.band_part + (size_t)b * (size_t)v.n;
@@ -1877,7 +1882,7 @@ __global__ void __launch_bounds__(BLK) k_reduce_v(DevView v) {
 // read for the last time here), and (b) prices the NEXT iteration from the values it has just
 // written (K1 when next_phase = 0, K6 when 1), so neither a memset nor a pricing kernel is needed
 // inside the replayed graph.
-__global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int use_dse, int use_pse) {
+__global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int use_dse, int use_pse, int inline_comb) {
     Ctl* c = v.ctl;
     if (c->halt) return;
     const IterState* it = &c->it;
@@ -1935,7 +1940,15 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                 double lnv = it->leaving_new_val;
                 // the pivot element computed two ways (FTRAN side / BTRAN side) measures the drift of W
                 if (q >= v.nb_lo && q < v.nb_hi) {
-                    double fa = 1.0 / it->inv_alpha, ba = v.alpha_r[q];
+                    double ba;
+                    if (inline_comb) {
+                        ba = 0.0;
+                        for (int b = 0; b < v.nbands; ++b) ba += v.band_part[(size_t)b * (size_t)v.n + q].x;
+                        v.alpha_r[q] = ba;
+                    } else {
+                        ba = v.alpha_r[q];
+                    }
+                    double fa = 1.0 / it->inv_alpha;
                     double err = fabs(fa - ba) / fmax(1.0, fabs(fa));
                     if (err > c->max_pivot_err || err != err) c->max_pivot_err = err;
                 }
@@ -1952,12 +1965,33 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                 v.nbflags[q] = f;
             }
         } else if (!flip && t >= v.nb_lo && t < v.nb_hi) {
-            double ar = v.alpha_r[t];
+            double ar, hp = 0.0;
+            if (inline_comb) {  // banded sweep: sum the per-band partials here (band order) instead of a combine launch
+                double s1 = 0.0, s2 = 0.0;
+                for (int b0 = 0; b0 < v.nbands; b0 += 8) {  // eight independent loads in flight, summed in band order
+                    double2 pb[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        pb[u] = (b0 + u < v.nbands) ? v.band_part[(size_t)(b0 + u) * (size_t)v.n + t] : make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        s1 += pb[u].x;
+                        s2 += pb[u].y;
+                    }
+                }
+                ar = s1;
+                hp = s2;
+                v.alpha_r[t] = ar;
+                if (use_pse) v.helper[t] = hp;
+            } else {
+                ar = v.alpha_r[t];
+                if (use_pse) hp = v.helper[t];
+            }
             if (ar != 0.0) {
                 dd -= it->pivot_obj * ar;
                 v.d[t] = dd;
                 if (use_pse) {
-                    gm += -2.0 * ar * v.helper[t] / pc + it->alpha_sq * ar * ar / (pc * pc);
+                    gm += -2.0 * ar * hp / pc + it->alpha_sq * ar * ar / (pc * pc);
                     v.gamma[t] = gm;
                 }
             }
@@ -2178,7 +2212,7 @@ void launch_btran_rhs(const DevView& dv, const Geom& g, hipStream_t st) {
                  hipLaunchKernelGGL(k_btran_rhs<16>, dim3(blocks_for((long)g.cap * 16)), dim3(BLK), 0, st, dv),
                  hipLaunchKernelGGL(k_btran_rhs<64>, dim3(blocks_for((long)g.cap * 64)), dim3(BLK), 0, st, dv));
 }
-static void launch_sweep_banded(const DevView& dv, const Geom& g, int mode, int with_struct, hipStream_t st) {
+static void launch_sweep_banded(const DevView& dv, const Geom& g, int mode, int with_struct, int inline_combine, hipStream_t st) {
     static bool attr_set = false;
     const size_t lds = sizeof(double2) * (size_t)BAND_ROWS;
     if (!attr_set) {  // more than the default 64 KB of LDS per workgroup
@@ -2187,27 +2221,27 @@ static void launch_sweep_banded(const DevView& dv, const Geom& g, int mode, int 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_band<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    // one workgroup per CU (LDS-bound): bands x chunks must not exceed the 256 CUs, or a second, almost
-    // empty round of workgroups doubles the kernel time (260 workgroups: 43 us, 247: 36 us)
-    int chunks = 256 / dv.nbands;
+    // One workgroup per CU (LDS-bound): all blocks of the launch must fit the 256 CUs at once, or a second,
+    // almost empty round of workgroups doubles the kernel time (260 workgroups: 43 us, 247: 36 us).  In the
+    // primal iteration the per-band partials are summed by k_update_pivot itself (inline_combine) and the
+    // partition change rides in the tail blocks of this launch; otherwise k_band_combine does both.
+    const int struct_blocks = (inline_combine && with_struct) ? (g.cap + BAND_THREADS - 1) / BAND_THREADS : 0;
+    int chunks = (256 - struct_blocks) / dv.nbands;
     if (chunks < 1) chunks = 1;
-    dim3 gr(dv.nbands, chunks), b(BAND_THREADS);
+    const dim3 gr(dv.nbands * chunks + struct_blocks), b(BAND_THREADS);
+    if (mode == 0) hipLaunchKernelGGL(k_sweep_band<0>, gr, b, lds, st, dv, chunks);
+    else if (mode == 1) hipLaunchKernelGGL(k_sweep_band<1>, gr, b, lds, st, dv, chunks);
+    else hipLaunchKernelGGL(k_sweep_band<2>, gr, b, lds, st, dv, chunks);
+    if (inline_combine) return;
     const int nc = blocks_for(dv.nb_hi - dv.nb_lo);
     const dim3 gc(nc + (with_struct ? blocks_for(g.cap) : 0));
-    if (mode == 0) {
-        hipLaunchKernelGGL(k_sweep_band<0>, gr, b, lds, st, dv);
-        hipLaunchKernelGGL(k_band_combine<0>, gc, dim3(BLK), 0, st, dv, nc);
-    } else if (mode == 1) {
-        hipLaunchKernelGGL(k_sweep_band<1>, gr, b, lds, st, dv);
-        hipLaunchKernelGGL(k_band_combine<1>, gc, dim3(BLK), 0, st, dv, nc);
-    } else {
-        hipLaunchKernelGGL(k_sweep_band<2>, gr, b, lds, st, dv);
-        hipLaunchKernelGGL(k_band_combine<2>, gc, dim3(BLK), 0, st, dv, nc);
-    }
+    if (mode == 0) hipLaunchKernelGGL(k_band_combine<0>, gc, dim3(BLK), 0, st, dv, nc);
+    else if (mode == 1) hipLaunchKernelGGL(k_band_combine<1>, gc, dim3(BLK), 0, st, dv, nc);
+    else hipLaunchKernelGGL(k_band_combine<2>, gc, dim3(BLK), 0, st, dv, nc);
 }
-void launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, hipStream_t st) {
+void launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, hipStream_t st, int inline_combine) {
     if (dv.banded) {
-        launch_sweep_banded(dv, g, mode, with_struct, st);
+        launch_sweep_banded(dv, g, mode, with_struct, inline_combine, st);
         return;
     }
 #define SWEEP(G, U)                                                                                               \
@@ -2306,9 +2340,10 @@ void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st) {
     hipLaunchKernelGGL(k_struct_update, dim3(blocks_for(g.cap)), dim3(BLK), 0, st, dv);
 }
-void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_dse, int use_pse, hipStream_t st) {
+void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_dse, int use_pse, hipStream_t st, int inline_comb) {
     int t = g.m > g.n ? g.m : g.n;
-    hipLaunchKernelGGL(k_update_pivot, dim3(blocks_for(t)), dim3(BLK), 0, st, dv, phase, use_dse, use_pse);
+    // inline_comb (primal iteration with the banded sweep): the update kernel sums the per-band partials itself
+    hipLaunchKernelGGL(k_update_pivot, dim3(blocks_for(t)), dim3(BLK), 0, st, dv, phase, use_dse, use_pse, inline_comb);
 }
 void launch_set_iter(const DevView& dv, int status, int q, int r, double lnv, int forced, hipStream_t st) {
     hipLaunchKernelGGL(k_set_iter, dim3(1), dim3(1), 0, st, dv, status, q, r, lnv, forced);
