@@ -172,8 +172,8 @@ def main():
         roofline = None
         if dom:
             kname = {"fused": "k_fused_w (tau=W*rho, v=W^T*t, eta update of the nucleus inverse)",
-                     "sweep": ("k_sweep_band + k_band_combine (tableau row rho^T N [+ PSE helper]: band-major copy of A, "
-                               "the band of (rho, v) held in LDS, per-band partials combined in band order)"
+                     "sweep": ("k_sweep_band (tableau row rho^T N [+ PSE helper]: band-major copy of A, the band of (rho, v) "
+                               "held in LDS; the per-band partials are summed in band order by k_update_pivot)"
                                if st.get("banded_sweep") else
                                "k_sweep (tableau row rho^T N [+ PSE helper] as a CSC pull over A)")}[dom]
             roofline = dict(bound="hbm", kernel=kname, achieved=kern[dom]["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
