@@ -1,0 +1,56 @@
+"""Differential fuzz on medium instances of the generator families (every back-end feature on by env
+rotation): objective parity with the oracle and feasibility; pivot-for-pivot on the non-degenerate families."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import minilp_amd as M
+from minilp_amd import lpgen
+from oracle import minilp_oracle as O
+from tests.common import check_feasible, obj_close
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(12345)
+ENVS = [{}, {"MLP_LOWRANK": "3", "MLP_BIGTILE": "1", "MLP_LDPAD": "16", "MLP_BANDED": "1"}, {"MLP_BANDED": "1"},
+        {"MLP_LOWRANK": "16", "MLP_BIGTILE": "1"}, {"MLP_GRAPH_ITERS": "1"}, {"MLP_NO_GRAPH": "1"}]
+bad = 0
+t0 = time.time()
+for case in range(n_cases):
+    fam = ["sparse", "cover", "mixed", "dense"][case % 4]
+    m = int(rng.integers(40, 500)); n = int(rng.integers(40, 500)); k = int(rng.integers(3, min(n, 25)))
+    seed = int(rng.integers(1, 10**6))
+    if fam == "sparse":
+        if n > m: m, n = n, m
+        lp = lpgen.gen_sparse_lp(m, n, k, seed)
+    elif fam == "cover":
+        lp = lpgen.gen_cover_lp(m, n, k, seed)
+    elif fam == "mixed":
+        lp = lpgen.gen_mixed_lp(m, n, min(k, 8), seed)
+    else:
+        lp = lpgen.gen_dense_lp(min(m, 150), min(n, 150), seed)
+    env = ENVS[case % len(ENVS)]
+    for kk in ("MLP_LOWRANK", "MLP_BIGTILE", "MLP_LDPAD", "MLP_BANDED", "MLP_GRAPH_ITERS", "MLP_NO_GRAPH"):
+        os.environ.pop(kk, None)
+    os.environ.update(env)
+    try:
+        so = lpgen.build_problem(O.Problem, lp).solve(trace=True)
+        ostat = "ok"
+    except (O.Infeasible, O.Unbounded) as e:
+        ostat = type(e).__name__
+    try:
+        sg = lpgen.build_problem(M.Problem, lp).solve(trace=True)
+        gstat = "ok"
+    except (M.Infeasible, M.Unbounded) as e:
+        gstat = type(e).__name__
+    ok = ostat == gstat
+    if ok and ostat == "ok":
+        ok = obj_close(sg.objective(), so.objective())
+        try:
+            check_feasible(lp, sg.values())
+        except AssertionError:
+            ok = False
+        if ok and fam != "mixed":
+            ok = [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+    if not ok:
+        bad += 1
+        print("MISMATCH", case, fam, lp["name"], env, ostat, gstat, flush=True)
+print("cases %d mismatches %d in %.1fs" % (n_cases, bad, time.time() - t0))
