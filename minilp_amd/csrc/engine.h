@@ -186,7 +186,7 @@ private:
     DevBuf<int> d_kslot_of_pos, d_srow_of_pos, d_kslot_of_row, d_pos_of_srow, d_pos_of_kslot, d_row_of_kslot;
     DevBuf<RowInfo> d_rowinfo;
     DevBuf<int> d_bptr;             // banded sweep: band-major copy of A
-    DevBuf<unsigned int> d_brow;
+    DevBuf<unsigned short> d_brow;
     DevBuf<double> d_bval;
     DevBuf<double2> d_band_part;
     bool banded_dirty = true;

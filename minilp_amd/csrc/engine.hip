@@ -93,7 +93,7 @@ Engine::Engine() {
     const char* bs = std::getenv("MLP_BATCH");
     if (bs) batch = std::max(1, std::min(RING, std::atoi(bs)));
     const char* gi = std::getenv("MLP_GRAPH_ITERS");
-    if (gi) graph_iters = std::max(1, std::min(8, std::atoi(gi)));
+    if (gi) graph_iters = std::max(1, std::min(32, std::atoi(gi)));
 }
 // ------------------------------------------------------------------ per-Solution runtime objects
 // Two streams, six events and the pinned Ctl mirror cost 4-5 ms to create and 3 ms to destroy; the
@@ -286,11 +286,9 @@ bool Engine::use_banded() const {
 void Engine::ensure_banded() {
     if (!banded_dirty) return;
     const int nb = (m_ + BAND_ROWS - 1) / BAND_ROWS;
-    const size_t nnz = h_crow.size();
     std::vector<int> bptr((size_t)nb * (size_t)(N_ + 1));
-    std::vector<unsigned int> brow(nnz + 8, 0u);  // + 8: the kernel reads whole groups of 8 entries
-    std::vector<double> bval(nnz + 8, 0.0);
-    // pass 1: counts per (band, column)
+    // pass 1: counts per (band, column), rounded up to an even number (16-bit rows: an even segment start
+    // keeps the 16-byte row loads 4-byte aligned; the pad entry has value 0)
     std::vector<int> cnt((size_t)nb * (size_t)N_, 0);
     for (int var = 0; var < N_; ++var)
         for (int e = h_cptr[var]; e < h_cptr[var + 1]; ++e) cnt[(size_t)(h_crow[e] / BAND_ROWS) * N_ + var] += 1;
@@ -299,17 +297,19 @@ void Engine::ensure_banded() {
         int* bp = &bptr[(size_t)b * (N_ + 1)];
         for (int var = 0; var < N_; ++var) {
             bp[var] = (int)off;
-            off += (size_t)cnt[(size_t)b * N_ + var];
+            off += (size_t)((cnt[(size_t)b * N_ + var] + 1) & ~1);
         }
         bp[N_] = (int)off;
     }
+    std::vector<unsigned short> brow(off + 8, (unsigned short)0);  // + 8: the kernel reads whole groups of 8 entries
+    std::vector<double> bval(off + 8, 0.0);
     // pass 2: fill (the entries of a column inside one band are consecutive and ascending)
     std::vector<int> fill((size_t)nb * (size_t)N_, 0);
     for (int var = 0; var < N_; ++var)
         for (int e = h_cptr[var]; e < h_cptr[var + 1]; ++e) {
             const int b = h_crow[e] / BAND_ROWS;
             const size_t dst = (size_t)bptr[(size_t)b * (N_ + 1) + var] + (size_t)fill[(size_t)b * N_ + var]++;
-            brow[dst] = (unsigned int)(h_crow[e] - b * BAND_ROWS);
+            brow[dst] = (unsigned short)(h_crow[e] - b * BAND_ROWS);
             bval[dst] = h_cval[e];
         }
     d_bptr.upload(bptr, st); d_brow.upload(brow, st); d_bval.upload(bval, st);

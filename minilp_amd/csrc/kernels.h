@@ -132,8 +132,9 @@ struct DevView {
     // banded tableau-row sweep (large m): a second copy of A in band-major order (bands of BAND_ROWS rows;
     // per band a CSC with 16-bit local row indices), so that a workgroup can hold its band of (rho, v) in LDS
     int* bptr;              // nbands x (N + 1)
-    unsigned int* brow;     // nnz + 8: row index inside the band (32-bit so that 8 of them load as two 16-byte words)
-    double* bval;           // nnz + 8
+    unsigned short* brow;   // row index inside the band, 16 bits; every (band, column) segment has an even length
+                            // (zero-valued pad entry), so that 8 of them load as one 4-byte-aligned 16-byte word
+    double* bval;           // same length as brow (+ 8 spare entries)
     double2* band_part;     // nbands x n partial (alpha_r, helper)
     int nbands, banded;
     int* pos_of_kslot;     // cap: row slot -> position

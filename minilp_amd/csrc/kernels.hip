@@ -1215,17 +1215,17 @@ __global__ void __launch_bounds__(BAND_THREADS) k_sweep_band(DevView v, int chun
         const int beg = bp[var], end = bp[var + 1];
         double a1 = 0.0, a2 = 0.0;
         for (int e0 = beg; e0 < end; e0 += 8) {
-            // Eight entries per step as 2 + 4 sixteen-byte loads per lane (a lane's entries are contiguous;
+            // Eight entries per step as 1 + 4 sixteen-byte loads per lane (a lane's entries are contiguous;
             // eight scalar loads each touch 64 different lines per wave and the kernel becomes bound by the
             // texture-address unit: 35.5 us).  Reading past `end` is harmless: the arrays carry 8 spare
             // entries, a neighbour's rows are valid indices of this band, and the values are masked.
-            const uint4u r0 = *reinterpret_cast<const uint4u*>(v.brow + e0);
-            const uint4u r1 = *reinterpret_cast<const uint4u*>(v.brow + e0 + 4);
+            const uint4u rr = *reinterpret_cast<const uint4u*>(v.brow + e0);  // eight 16-bit rows; e0 is even
             const dbl2u x0 = *reinterpret_cast<const dbl2u*>(v.bval + e0);
             const dbl2u x1 = *reinterpret_cast<const dbl2u*>(v.bval + e0 + 2);
             const dbl2u x2 = *reinterpret_cast<const dbl2u*>(v.bval + e0 + 4);
             const dbl2u x3 = *reinterpret_cast<const dbl2u*>(v.bval + e0 + 6);
-            const unsigned r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            const unsigned r[8] = {rr.x & 0xffffu, rr.x >> 16, rr.y & 0xffffu, rr.y >> 16,
+                                   rr.z & 0xffffu, rr.z >> 16, rr.w & 0xffffu, rr.w >> 16};
             double a[8] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y, x3.x, x3.y};
             const int nv = end - e0;
 #pragma unroll
