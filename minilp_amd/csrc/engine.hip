@@ -473,6 +473,7 @@ void Engine::flush_lowrank() {
     HIPCHECK(hipStreamSynchronize(st));
 }
 void Engine::pull_ctl() {
+    HIPCHECK(hipGetLastError());  // a rejected kernel launch (bad configuration) must not pass silently
     HIPCHECK(hipMemcpyAsync(h_ctl, d_ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
     k_ = h_ctl->k;
@@ -1026,6 +1027,7 @@ int Engine::run_loop(int phase) {
                 stats.update_ms += ms;
                 stats.update_launches += 1;
             }
+            (void)hipGetLastError();  // an event pair that was not recorded this iteration is not an error
         }
         // drift monitor: the pivot element from FTRAN and from the tableau row must agree
         if (h_ctl->max_pivot_err > stats.max_pivot_err) stats.max_pivot_err = h_ctl->max_pivot_err;

@@ -2216,6 +2216,7 @@ static void launch_sweep_banded(const DevView& dv, const Geom& g, int mode, int 
     static bool attr_set = false;
     const size_t lds = sizeof(double2) * (size_t)BAND_ROWS;
     if (!attr_set) {  // more than the default 64 KB of LDS per workgroup
+        // (a failure here makes the launches below fail, which Engine::pull_ctl reports through hipGetLastError)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_band<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_band<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_band<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2303,11 +2304,12 @@ static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fo
     }
 }
 void launch_fold_lowrank(const DevView& dv, const Geom& g, hipStream_t st) {
-    if (!dv.lrJ) return;
+    if (!dv.lrJ || g.cap <= 0) return;
     launch_fused_lr(dv, g, 0, 1, st);
     hipLaunchKernelGGL(k_reset_nlow, dim3(1), dim3(1), 0, st, dv);
 }
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st) {
+    if (g.cap <= 0) return;  // a model without kept rows has no nucleus: nothing to stream (and no valid grid)
     if (dv.lrJ) {
         launch_fused_lr(dv, g, with_v, 0, st);
         return;
@@ -2350,6 +2352,7 @@ void launch_set_iter(const DevView& dv, int status, int q, int r, double lnv, in
 }
 void launch_reset_ring(const DevView& dv, hipStream_t st) { hipLaunchKernelGGL(k_reset_ring, dim3(1), dim3(1), 0, st, dv); }
 void launch_btran_dense(const DevView& dv, const Geom& g, hipStream_t st) {
+    if (g.cap <= 0) return;
     // c_B by position -> alpha_q, y_S -> rv.y; then tK, vK = W^T tK, scatter into rv.y
     hipLaunchKernelGGL(k_gather_basic_obj, dim3(blocks_for(g.m)), dim3(BLK), 0, st, dv);
     launch_btran_rhs(dv, g, st);
