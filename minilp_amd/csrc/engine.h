@@ -190,6 +190,7 @@ private:
     DevBuf<double> d_bval;
     DevBuf<double2> d_band_part;
     bool banded_dirty = true;
+    int det_mode = -1;              // MLP_DETERMINISTIC: 1 force the pulled F products, 0 never, -1 auto (<= 2^21 non-zeros)
     int banded_mode = -1;           // MLP_BANDED: 1 force on, 0 off, -1 auto (m >= 4 bands and >= 2^22 non-zeros)
     bool use_banded() const;
   public:

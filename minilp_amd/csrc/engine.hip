@@ -84,6 +84,8 @@ Engine::Engine() {
     if (sv) sweep_variant = std::atoi(sv);
     const char* bt = std::getenv("MLP_BIGTILE");
     force_big_tiles = bt && std::atoi(bt) != 0;
+    const char* dm = std::getenv("MLP_DETERMINISTIC");
+    if (dm) det_mode = std::atoi(dm) != 0 ? 1 : 0;
     const char* bd = std::getenv("MLP_BANDED");
     if (bd) banded_mode = std::atoi(bd) != 0 ? 1 : 0;
     const char* fr = std::getenv("MLP_FINAL_REFRESH");
@@ -359,6 +361,7 @@ DevView* Engine::sync_view() {
     v.colblk = v.pb_on ? d_colblk.p : nullptr;
     v.push_part = v.pb_on ? d_push_part.p : nullptr;
     v.pb_rb = (m_ + PB_ROWS - 1) / PB_ROWS;
+    v.det_pull = (!v.pb_on && (det_mode == 1 || (det_mode < 0 && h_rcol.size() <= ((size_t)1 << 21)))) ? 1 : 0;
     v.banded = use_banded() ? 1 : 0;
     if (v.banded) ensure_banded();
     v.bptr = v.banded ? d_bptr.p : nullptr;
@@ -1427,7 +1430,7 @@ Engine* Engine::clone() {
     e->resume_in_optimize = resume_in_optimize;
     e->nnz_nonbasic = nnz_nonbasic;
     e->trace = trace; e->profile = profile;
-    e->banded_mode = banded_mode;
+    e->banded_mode = banded_mode; e->det_mode = det_mode;
     e->final_refresh_pivots = final_refresh_pivots; e->iters_since_recalc = iters_since_recalc;
     e->ld_pad = ld_pad; e->lr_force = lr_force; e->force_big_tiles = force_big_tiles; e->pb_disable = pb_disable;
     hipStream_t s2 = e->st;

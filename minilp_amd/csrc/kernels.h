@@ -137,6 +137,8 @@ struct DevView {
     double* bval;           // same length as brow (+ 8 spare entries)
     double2* band_part;     // nbands x n partial (alpha_r, helper)
     int nbands, banded;
+    int det_pull;  // small models: the F products are pulled per singleton row (fixed summation order) instead of
+                   // pushed with float atomics, so that a solve is reproducible bit for bit from run to run
     int* pos_of_kslot;     // cap: row slot -> position
     int* row_of_kslot;     // cap: col slot -> row
     double* W;             // cap x ld, row-major: W[rowslot(p)][colslot(i)] = (B^-1)[p, i]  (W0 in delayed-update mode)

@@ -705,7 +705,7 @@ __global__ void __launch_bounds__(BLK) k_ftran_gather(DevView v) {
         v.aK[slot] = acc;
         v.alpha_q[p] = acc;
     }
-    if (acc != 0.0 && !v.pb_on) push_F<G>(v, p, acc, v.alpha_q, gl);
+    if (acc != 0.0 && !v.pb_on && !v.det_pull) push_F<G>(v, p, acc, v.alpha_q, gl);
 }
 
 // Blocked F push of the large-nucleus regime.  y_S -= D^-1 F x_K through device-scope f64 atomics costs
@@ -793,6 +793,41 @@ __global__ void __launch_bounds__(BLK) k_push_combine(DevView v, int which) {
         double* out = which ? v.tau : v.alpha_q;
         out[ri.pos] -= s / ri.diag;
     }
+}
+// Deterministic form of the same product for small models: y_S[p] -= (sum over the nucleus columns in row
+// i_p of A[i_p, col] * x_K[slot(col)]) / diag_p, pulled through the CSR row with a fixed reduction tree.
+// It touches every entry of the singleton rows per call (nnz(A) work instead of nnz of the nucleus columns),
+// which is affordable only while the matrix is small; in exchange two runs of the same solve take the
+// same pivots, which matters on degenerate models (a branch-and-bound tree over TSP relaxations varied
+// between 460 and 10 700 nodes from run to run with the atomics).
+template <int G>
+__global__ void __launch_bounds__(BLK) k_pull_F(DevView v, int which) {
+    const Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    const int p = (blockIdx.x * BLK + threadIdx.x) / G;
+    const int gl = threadIdx.x & (G - 1);
+    if (p >= v.m || v.kslot_of_pos[p] >= 0) return;
+    const int i = v.srow_of_pos[p];
+    const double* xK = which ? v.tauK : v.aK;
+    double acc = 0.0;
+    const int end = v.csr_ptr[i + 1];
+    for (int e = v.csr_ptr[i] + gl; e < end; e += G) {
+        const int loc = v.var_loc[v.csr_col[e]];
+        if (loc >= 0) {
+            const int s = v.kslot_of_pos[loc];
+            if (s >= 0) acc += v.csr_val[e] * xK[s];
+        }
+    }
+    acc = group_sum<G>(acc);
+    if (gl == 0 && acc != 0.0) {
+        double* out = which ? v.tau : v.alpha_q;
+        out[p] -= acc / v.sdiag_of_pos[p];
+    }
+}
+static void launch_pull_F(const DevView& dv, const Geom& g, int which, hipStream_t st) {
+    if (g.lanes <= 4) hipLaunchKernelGGL(k_pull_F<4>, dim3(blocks_for((long)dv.m * 4)), dim3(BLK), 0, st, dv, which);
+    else if (g.lanes <= 16) hipLaunchKernelGGL(k_pull_F<16>, dim3(blocks_for((long)dv.m * 16)), dim3(BLK), 0, st, dv, which);
+    else hipLaunchKernelGGL(k_pull_F<64>, dim3(blocks_for((long)dv.m * 64)), dim3(BLK), 0, st, dv, which);
 }
 static void launch_blocked_push(const DevView& dv, int which, hipStream_t st) {
     hipLaunchKernelGGL(k_push_stage1, dim3(dv.pb_rb, PB_CHUNKS), dim3(BLK), 0, st, dv, which);
@@ -1824,7 +1859,7 @@ __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push) {
             v.tauK[slot] = x;
             v.tau[p] = x;
         }
-        if (x != 0.0 && !v.pb_on) push_F<G>(v, p, x, v.tau, gl);
+        if (x != 0.0 && !v.pb_on && !v.det_pull) push_F<G>(v, p, x, v.tau, gl);
         return;
     }
     if (!WITH_V) return;
@@ -2184,6 +2219,7 @@ void launch_ftran_gather(const DevView& dv, const Geom& g, hipStream_t st) {
                  hipLaunchKernelGGL(k_ftran_gather<16>, dim3(blocks_for((long)g.cap * 16)), dim3(BLK), 0, st, dv),
                  hipLaunchKernelGGL(k_ftran_gather<64>, dim3(blocks_for((long)g.cap * 64)), dim3(BLK), 0, st, dv));
     if (dv.pb_on) launch_blocked_push(dv, 0, st);
+    else if (dv.det_pull) launch_pull_F(dv, g, 0, st);
 }
 void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st) {
     hipLaunchKernelGGL(k_ratio_primal_p1, dim3(grid_for(g.m)), dim3(BLK), 0, st, dv, use_pse);
@@ -2338,6 +2374,7 @@ void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t
     LANES_SWITCH(g.lanes, POSTF(4), POSTF(16), POSTF(64));
 #undef POSTF
     if (dv.pb_on) launch_blocked_push(dv, 1, st);
+    else if (dv.det_pull) launch_pull_F(dv, g, 1, st);
 }
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st) {
     hipLaunchKernelGGL(k_struct_update, dim3(blocks_for(g.cap)), dim3(BLK), 0, st, dv);
