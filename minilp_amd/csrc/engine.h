@@ -239,7 +239,8 @@ private:
     bool use_graph = true, use_branches = false;
     int batch = 16;
     long final_refresh_pivots = 50000;  // MLP_FINAL_REFRESH: re-examine optimality on recomputed reduced costs after this many pivots (0 = never)
-    uint64_t iters_since_recalc = 0;
+    uint64_t iters_since_recalc = 0, iters_since_polish = 0;
+    bool basic_values_feasible();
     int graph_iters = 8;  // MLP_GRAPH_ITERS: iterations per graph once a geometry has run for a while (1 = off)
     // graph slots: [0] one iteration per graph, [1] graph_iters iterations per graph (long runs)
     hipGraphExec_t gexec[2][2][2] = {};
@@ -275,6 +276,7 @@ private:
     };
     int step_phase = 0, step_pos = -1;
     bool stepping = false;
+    void recalc_basic_vals();  // x_B recomputed from the basis (polish of long runs)
     int step_open(StepInfo* out);
     int step_stage(int stage, StepInfo* out);
     int step_finish(int phase, int status);

@@ -931,6 +931,7 @@ int Engine::process_records(int phase, int launched) {
         if (r.status == ITER_PIVOT || r.status == ITER_FLIP) {
             stats.iterations += 1;
             iters_since_recalc += 1;
+            iters_since_polish += 1;
             if (r.phase == 0) stats.primal_iters += 1;
             else stats.dual_iters += 1;
             values_dirty = true;
@@ -1049,11 +1050,38 @@ void Engine::initial_solve() {
         resume_in_optimize = true;
         optimize();
     }
+    // Polish of a long run: the basic values, too, have been updated incrementally pivot after pivot
+    // (solver.rs:1049-1055).  Recompute x_B = B^-1 (b - N x_N) from the basis; if a bound is then violated
+    // by more than the tolerance, the dual loop repairs it (the reduced costs were just recomputed and are
+    // dual feasible) and the primal loop confirms optimality.  Bounded; short runs never get here.
+    for (int round = 0; round < 3 && !budget_exhausted && final_refresh_pivots > 0 &&
+                        iters_since_polish >= (uint64_t)final_refresh_pivots; ++round) {
+        iters_since_polish = 0;
+        if (k_ > 0) rebuild_inverse();  // fresh K^-1 from A first: the polish is only as accurate as the inverse it uses
+        recalc_basic_vals();
+        recalc_obj_coeffs();  // objective (and reduced costs) of the recomputed point
+        stats.final_refreshes += 1;
+        if (basic_values_feasible()) break;
+        // The dual loop repairs the bound violations.  The primal loop is deliberately NOT re-entered
+        // afterwards: the reference never runs it after a dual phase either (solver.rs:470-485, 633), and
+        // on a run that ended in the dual loop the Harris test may have left reduced costs a hair beyond the
+        // tolerance, which a primal pricing pass would mistake for an improving (possibly unbounded) column.
+        primal_feasible = false;
+        restore_feasibility();
+    }
     if (!budget_exhausted) {
         resume_in_optimize = false;
         enable_pse = false;  // solver.rs:482
     }
     stats.solve_wall_s += now_s() - t0;
+}
+// any basic value outside its bounds by more than EPS?  (the dual pricing scan, solver.rs:855-917)
+bool Engine::basic_values_feasible() {
+    sync_view();
+    launch_reset_ring(hview, st);
+    launch_price_dual(hview, geom(), enable_dse ? 1 : 0, st);
+    pull_ctl();
+    return h_ctl->it.status == ITER_FEASIBLE;
 }
 void Engine::optimize() {
     for (;;) {
@@ -1112,6 +1140,18 @@ void Engine::recalc_obj_coeffs() {
     const Geom g = geom();
     launch_btran_dense(dv, g, st);  // y = B^-T c_B -> rv.y
     launch_recalc_d(dv, g, st);
+}
+
+// x_B = B^-1 (b - N x_N) from scratch (solver.rs:1177-1197 is the reference's unused counterpart).
+void Engine::recalc_basic_vals() {
+    flush_lowrank();  // the dense solve reads W0 as the whole inverse
+    sync_view();
+    DevBuf<double> rhs, r;
+    rhs.upload(h_rhs, st);
+    r.ensure((size_t)m_ + 8, 0, st);
+    launch_recalc_basic_vals(hview, geom(), rhs.p, r.p, st);
+    HIPCHECK(hipStreamSynchronize(st));
+    values_dirty = true;
 }
 
 void Engine::fix_var(int var, double val) {  // solver.rs:378-415
@@ -1432,6 +1472,7 @@ Engine* Engine::clone() {
     e->trace = trace; e->profile = profile;
     e->banded_mode = banded_mode; e->det_mode = det_mode;
     e->final_refresh_pivots = final_refresh_pivots; e->iters_since_recalc = iters_since_recalc;
+    e->iters_since_polish = iters_since_polish;
     e->ld_pad = ld_pad; e->lr_force = lr_force; e->force_big_tiles = force_big_tiles; e->pb_disable = pb_disable;
     hipStream_t s2 = e->st;
     e->upload_matrix();

@@ -2397,6 +2397,57 @@ void launch_btran_dense(const DevView& dv, const Geom& g, hipStream_t st) {
     hipLaunchKernelGGL((k_fused_w<16, false, true, false>), dim3(nstripes, nchunks), dim3(BLK), 0, st, dv);
     hipLaunchKernelGGL(k_reduce_v<16>, dim3(blocks_for(g.cap)), dim3(BLK), 0, st, dv);
 }
+// ---- recomputation of the basic values from the basis: x_B = B^-1 (b - N x_N)
+// (the reference has recalc_basic_var_vals, solver.rs:1177-1197, as dead code; used here to polish long runs)
+// step 1: r_i = b_i - sum over the NON-basic entries of row i of a * x_N   (G lanes per CSR row)
+template <int G>
+__global__ void __launch_bounds__(BLK) k_residual_rhs(DevView v, const double* rhs, double* r) {
+    const int i = (blockIdx.x * BLK + threadIdx.x) / G;
+    const int gl = threadIdx.x & (G - 1);
+    if (i >= v.m) return;
+    double acc = 0.0;
+    const int end = v.csr_ptr[i + 1];
+    for (int e = v.csr_ptr[i] + gl; e < end; e += G) {
+        const int loc = v.var_loc[v.csr_col[e]];
+        if (loc < 0) acc += v.csr_val[e] * v.xN[-1 - loc];
+    }
+    acc = group_sum<G>(acc);
+    if (gl == 0) r[i] = rhs[i] - acc;
+}
+// step 2: seed the tau path of the fused pass with r: rK by nucleus slot, tau = D^-1 r_S by singleton position
+__global__ void __launch_bounds__(BLK) k_seed_dense_ftran(DevView v, const double* r) {
+    const int t = blockIdx.x * BLK + threadIdx.x;
+    Ctl* c = v.ctl;
+    if (t == 0) {
+        c->it.status = ITER_PIVOT;
+        c->halt = 0;
+        c->up.kase = -1;
+        c->fold = 0;
+    }
+    if (t < c->k) v.rK[t] = r[v.row_of_kslot[t]];
+    if (t < v.m && v.kslot_of_pos[t] < 0) v.tau[t] = r[v.srow_of_pos[t]] / v.sdiag_of_pos[t];
+}
+__global__ void __launch_bounds__(BLK) k_copy_tau_to_xb(DevView v) {
+    const int p = blockIdx.x * BLK + threadIdx.x;
+    if (p < v.m) v.xB[p] = v.tau[p];
+}
+// x_B = B^-1 r through the tau path: tau_K = W r_K (fused pass without update), then -F tau_K into the
+// singleton positions (post-fused tail), exactly as tau = B^-1 rho is computed every pivot.
+void launch_recalc_basic_vals(const DevView& dv, const Geom& g, const double* rhs, double* r_tmp, hipStream_t st) {
+    if (g.lanes <= 4) hipLaunchKernelGGL(k_residual_rhs<4>, dim3(blocks_for((long)g.m * 4)), dim3(BLK), 0, st, dv, rhs, r_tmp);
+    else if (g.lanes <= 16) hipLaunchKernelGGL(k_residual_rhs<16>, dim3(blocks_for((long)g.m * 16)), dim3(BLK), 0, st, dv, rhs, r_tmp);
+    else hipLaunchKernelGGL(k_residual_rhs<64>, dim3(blocks_for((long)g.m * 64)), dim3(BLK), 0, st, dv, rhs, r_tmp);
+    launch_clear_work(dv, st);
+    const int t = g.m > g.cap ? g.m : g.cap;
+    hipLaunchKernelGGL(k_seed_dense_ftran, dim3(blocks_for(t)), dim3(BLK), 0, st, dv, (const double*)r_tmp);
+    if (g.cap > 0) {
+        const int nstripes = (g.cap + 16 - 1) / 16, nchunks = (g.cap + FW_TC - 1) / FW_TC;
+        hipLaunchKernelGGL((k_fused_w<16, true, false, false>), dim3(nstripes, nchunks), dim3(BLK), 0, st, dv);
+    }
+    launch_post_fused(dv, g, 0, st);
+    hipLaunchKernelGGL(k_copy_tau_to_xb, dim3(blocks_for(g.m)), dim3(BLK), 0, st, dv);
+    launch_clear_work(dv, st);
+}
 void launch_recalc_d(const DevView& dv, const Geom& g, hipStream_t st) {
     LANES_SWITCH(g.lanes,
                  hipLaunchKernelGGL(k_recalc_d<4>, dim3(blocks_for((long)g.n * 4)), dim3(BLK), 0, st, dv),
