@@ -4,8 +4,14 @@
 // is GEMM-shaped: every kernel is an HBM/L2-bound stream with wave64 shuffle reductions, so there
 // is no MFMA here (DESIGN.md §4 gives the algorithmic bytes per kernel).
 //
-// All pivot kernels take a pointer to the device-resident DevView and read the nucleus size and
-// the pivot scalars from its Ctl block, so one iteration is a fixed launch sequence (hipGraph).
+// All pivot kernels take the DevView BY VALUE (pointers and sizes) and read the nucleus size and the pivot
+// scalars from the device-resident Ctl block, so one iteration is a fixed launch sequence (hipGraph).
+//
+// Map of the file: helpers and grid-wide reductions; mailbox exchanges of the sharded mode; partition plan;
+// stage heads (FTRAN / BTRAN); K1/K6 pricing; K2 FTRAN (+ blocked and pulled forms of the F product);
+// K5 primal ratio test; K3 BTRAN; partition change; K4 tableau row (CSC pull and banded sweep); K7 dual
+// ratio test; fused pass over the nucleus inverse (in place / streaming / fold) and its tails; K8 update
+// (+ next pricing); helpers for recalc / re-inversion; launch wrappers.
 #include "kernels.h"
 
 #include <limits.h>
