@@ -1149,7 +1149,10 @@ void Engine::recalc_basic_vals() {
     DevBuf<double> rhs, r;
     rhs.upload(h_rhs, st);
     r.ensure((size_t)m_ + 8, 0, st);
-    launch_recalc_basic_vals(hview, geom(), rhs.p, r.p, st);
+    launch_recalc_basic_vals(hview, geom(), rhs.p, r.p, 0, st);
+    // two steps of iterative refinement with the same inverse: x_B += B^-1 (b - A x)
+    launch_recalc_basic_vals(hview, geom(), rhs.p, r.p, 1, st);
+    launch_recalc_basic_vals(hview, geom(), rhs.p, r.p, 1, st);
     HIPCHECK(hipStreamSynchronize(st));
     values_dirty = true;
 }

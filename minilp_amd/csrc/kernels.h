@@ -210,7 +210,7 @@ void launch_set_iter(const DevView& dv, int status, int q, int r, double lnv, in
 void launch_reset_ring(const DevView& dv, hipStream_t st);
 void launch_btran_dense(const DevView& dv, const Geom& g, hipStream_t st);  // y = B^-T c_B -> rv.x (c_B gathered into alpha_q)
 void launch_recalc_d(const DevView& dv, const Geom& g, hipStream_t st);     // d_c = obj - a_c.y ; obj
-void launch_recalc_basic_vals(const DevView& dv, const Geom& g, const double* rhs, double* r_tmp, hipStream_t st);  // x_B = B^-1 (b - N x_N)
+void launch_recalc_basic_vals(const DevView& dv, const Geom& g, const double* rhs, double* r_tmp, int refine, hipStream_t st);  // x_B = B^-1 (b - N x_N); refine: x_B += B^-1 (b - A x)
 void launch_shift_nonbasic(const DevView& dv, const Geom& g, int col, double val, hipStream_t st);
 void launch_sq_norms_add_row(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_copy_rho_sq_to_beta(const DevView& dv, int row, hipStream_t st);

@@ -2406,8 +2406,9 @@ void launch_btran_dense(const DevView& dv, const Geom& g, hipStream_t st) {
 // ---- recomputation of the basic values from the basis: x_B = B^-1 (b - N x_N)
 // (the reference has recalc_basic_var_vals, solver.rs:1177-1197, as dead code; used here to polish long runs)
 // step 1: r_i = b_i - sum over the NON-basic entries of row i of a * x_N   (G lanes per CSR row)
+// (refine = 1: the full residual b - A x of the current point, for one step of iterative refinement)
 template <int G>
-__global__ void __launch_bounds__(BLK) k_residual_rhs(DevView v, const double* rhs, double* r) {
+__global__ void __launch_bounds__(BLK) k_residual_rhs(DevView v, const double* rhs, double* r, int refine) {
     const int i = (blockIdx.x * BLK + threadIdx.x) / G;
     const int gl = threadIdx.x & (G - 1);
     if (i >= v.m) return;
@@ -2416,6 +2417,7 @@ __global__ void __launch_bounds__(BLK) k_residual_rhs(DevView v, const double* r
     for (int e = v.csr_ptr[i] + gl; e < end; e += G) {
         const int loc = v.var_loc[v.csr_col[e]];
         if (loc < 0) acc += v.csr_val[e] * v.xN[-1 - loc];
+        else if (refine) acc += v.csr_val[e] * v.xB[loc];
     }
     acc = group_sum<G>(acc);
     if (gl == 0) r[i] = rhs[i] - acc;
@@ -2433,16 +2435,16 @@ __global__ void __launch_bounds__(BLK) k_seed_dense_ftran(DevView v, const doubl
     if (t < c->k) v.rK[t] = r[v.row_of_kslot[t]];
     if (t < v.m && v.kslot_of_pos[t] < 0) v.tau[t] = r[v.srow_of_pos[t]] / v.sdiag_of_pos[t];
 }
-__global__ void __launch_bounds__(BLK) k_copy_tau_to_xb(DevView v) {
+__global__ void __launch_bounds__(BLK) k_copy_tau_to_xb(DevView v, int refine) {
     const int p = blockIdx.x * BLK + threadIdx.x;
-    if (p < v.m) v.xB[p] = v.tau[p];
+    if (p < v.m) v.xB[p] = refine ? v.xB[p] + v.tau[p] : v.tau[p];
 }
 // x_B = B^-1 r through the tau path: tau_K = W r_K (fused pass without update), then -F tau_K into the
 // singleton positions (post-fused tail), exactly as tau = B^-1 rho is computed every pivot.
-void launch_recalc_basic_vals(const DevView& dv, const Geom& g, const double* rhs, double* r_tmp, hipStream_t st) {
-    if (g.lanes <= 4) hipLaunchKernelGGL(k_residual_rhs<4>, dim3(blocks_for((long)g.m * 4)), dim3(BLK), 0, st, dv, rhs, r_tmp);
-    else if (g.lanes <= 16) hipLaunchKernelGGL(k_residual_rhs<16>, dim3(blocks_for((long)g.m * 16)), dim3(BLK), 0, st, dv, rhs, r_tmp);
-    else hipLaunchKernelGGL(k_residual_rhs<64>, dim3(blocks_for((long)g.m * 64)), dim3(BLK), 0, st, dv, rhs, r_tmp);
+void launch_recalc_basic_vals(const DevView& dv, const Geom& g, const double* rhs, double* r_tmp, int refine, hipStream_t st) {
+    if (g.lanes <= 4) hipLaunchKernelGGL(k_residual_rhs<4>, dim3(blocks_for((long)g.m * 4)), dim3(BLK), 0, st, dv, rhs, r_tmp, refine);
+    else if (g.lanes <= 16) hipLaunchKernelGGL(k_residual_rhs<16>, dim3(blocks_for((long)g.m * 16)), dim3(BLK), 0, st, dv, rhs, r_tmp, refine);
+    else hipLaunchKernelGGL(k_residual_rhs<64>, dim3(blocks_for((long)g.m * 64)), dim3(BLK), 0, st, dv, rhs, r_tmp, refine);
     launch_clear_work(dv, st);
     const int t = g.m > g.cap ? g.m : g.cap;
     hipLaunchKernelGGL(k_seed_dense_ftran, dim3(blocks_for(t)), dim3(BLK), 0, st, dv, (const double*)r_tmp);
@@ -2451,7 +2453,7 @@ void launch_recalc_basic_vals(const DevView& dv, const Geom& g, const double* rh
         hipLaunchKernelGGL((k_fused_w<16, true, false, false>), dim3(nstripes, nchunks), dim3(BLK), 0, st, dv);
     }
     launch_post_fused(dv, g, 0, st);
-    hipLaunchKernelGGL(k_copy_tau_to_xb, dim3(blocks_for(g.m)), dim3(BLK), 0, st, dv);
+    hipLaunchKernelGGL(k_copy_tau_to_xb, dim3(blocks_for(g.m)), dim3(BLK), 0, st, dv, refine);
     launch_clear_work(dv, st);
 }
 void launch_recalc_d(const DevView& dv, const Geom& g, hipStream_t st) {
