@@ -92,3 +92,16 @@ def test_optimality_certificate_config4():
         pytest.skip("certificate not generated yet")
     meta, primal = _check_certificate(path)
     assert meta["rows"] == 100000 and meta["cols"] == 100000
+
+
+def test_cover_family_is_a_dual_only_solve_in_the_oracle():
+    """gen_cover_lp (Min c'x, Ax >= b, positive data) starts dual feasible and primal infeasible: the
+    reference algorithm solves it with the dual loop alone (solver.rs:470-485, 513-547)."""
+    lp = lpgen.gen_cover_lp(120, 150, 6, 9)
+    s = lpgen.build_problem(mo.Problem, lp).solve()
+    st = s.stats()
+    assert st["primal_iters"] == 0 and st["dual_iters"] > 10
+    x = s.values()
+    check_feasible(lp, x)
+    assert obj_close(objective_of(lp, x), s.objective(), 1e-9)
+    assert lpgen.gen_cover_lp(120, 150, 6, 9)["data"].tobytes() == lp["data"].tobytes()  # deterministic generator
