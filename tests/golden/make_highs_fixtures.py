@@ -27,8 +27,10 @@ CASES = [
     ("mixed", dict(m=300, n=400, k=8, seed=4)),
     ("mixed", dict(m=1000, n=1500, k=6, seed=5)),
     ("mixed", dict(m=6000, n=10000, k=4, seed=3)),   # BASELINE config 3 stand-in: ~10k vars, sparse, via MPS
+    ("cover", dict(m=300, n=350, k=8, seed=4)),      # dual-only solves (Min c'x, Ax >= b)
+    ("cover", dict(m=1200, n=1000, k=10, seed=6)),
 ]
-GEN = {"sparse": lpgen.gen_sparse_lp, "dense": lpgen.gen_dense_lp, "mixed": lpgen.gen_mixed_lp}
+GEN = {"sparse": lpgen.gen_sparse_lp, "dense": lpgen.gen_dense_lp, "mixed": lpgen.gen_mixed_lp, "cover": lpgen.gen_cover_lp}
 
 
 def solve_highs(lp):
