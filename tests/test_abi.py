@@ -126,3 +126,19 @@ def test_null_solution_handle_is_an_error_not_a_crash():
     assert lib.mlp_solution_num_vars(None) == 0
     h = C.c_void_p()
     assert lib.mlp_solution_fix_var(C.byref(h), 0, 1.0) == -1
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/minilp_hip.h must compile as C99 (and as C++) on its own."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "minilp_hip.h"\nint main(void) { mlp_iter_info i; mlp_stats s; (void)i; (void)s; return MLP_STAGE_APPLY; }\n')
+    for cc, flags in (("gcc", ["-std=c99", "-pedantic"]), ("g++", ["-std=c++17", "-x", "c++"])):
+        if shutil.which(cc) is None:
+            continue
+        r = subprocess.run([cc, *flags, "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-fsyntax-only", str(src)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
