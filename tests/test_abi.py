@@ -142,3 +142,34 @@ def test_public_header_is_plain_c(tmp_path):
         r = subprocess.run([cc, *flags, "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-fsyntax-only", str(src)],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def _build_toy(tmp_path):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "toy")
+    libdir = os.path.join(root, "minilp_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "toy.c"),
+                        "-L", libdir, "-lminilp_hip", "-Wl,-rpath," + libdir, "-lm", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_plain_c_program_links_against_the_abi_and_fails_loudly_without_a_gpu(tmp_path):
+    import subprocess
+    exe = _build_toy(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    if r.returncode != 0:  # no GPU in this container: the product must say so, not fall back
+        assert "no HIP device" in r.stderr and "no CPU fallback" in r.stderr
+    else:
+        assert "objective 7 x 1 y 3" in r.stdout
+
+
+@pytest.mark.gpu
+def test_plain_c_program_solves_the_readme_toy(tmp_path):
+    import subprocess
+    r = subprocess.run([_build_toy(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "objective 7 x 1 y 3" in r.stdout
+    assert "warm-started objective 6.5 x 0.5 y 3" in r.stdout
