@@ -63,7 +63,7 @@ extern "C" {
     pub fn mlp_problem_add_constraints_csr(p: *mut mlp_problem, m: u64, indptr: *const u64, vars: *const u32,
                                            coeffs: *const c_double, cmp_ops: *const i32, rhs: *const c_double) -> c_int;
     pub fn mlp_problem_solve(p: *const mlp_problem, out: *mut *mut mlp_solution) -> c_int;
-    pub fn mlp_problem_solve_ex(p: *const mlp_problem, out: *mut *mut mlp_solution, pivot_budget: i64, flags: c_int) -> c_int;
+    pub fn mlp_problem_solve_ex(p: *const mlp_problem, out: *mut *mut mlp_solution, pivot_budget: i64, flags: u32) -> c_int;
 
     pub fn mlp_solution_clone(s: *const mlp_solution) -> *mut mlp_solution;
     pub fn mlp_solution_free(s: *mut mlp_solution);
