@@ -58,10 +58,27 @@ def _worker(rank, world, port, q):
             sc, ps = struct.unpack("<dd", bytes(mm[o2 + 8: o2 + 24]))
             cands.append((sc, int(ps)))
         results.append(md.combine_candidates(cands))
+    # the dual loop's exchanges on the same object: kind 2 = all-reduce MIN of the pass-1 ratio, kind 3 = pass-2
+    # candidate with two payloads (alpha_rq, d_q); kinds are disjoint slots, so they may share epochs with kind 0
+    for epoch in range(1, 4):
+        mine = float((rank + 2) * epoch) / 7.0
+        off = slot(2, epoch, rank)
+        mm[off + 8: off + 16] = np.frombuffer(struct.pack("<d", mine), dtype=np.uint8)
+        mm[off: off + 8] = np.frombuffer(struct.pack("<Q", epoch), dtype=np.uint8)
+        vals = []
+        for r2 in range(world):
+            o2 = slot(2, epoch, r2)
+            t0 = time.time()
+            while struct.unpack("<Q", bytes(mm[o2: o2 + 8]))[0] != epoch:
+                assert time.time() - t0 < 20
+            vals.append(struct.unpack("<d", bytes(mm[o2 + 8: o2 + 16]))[0])
+        results.append(("min", min(vals)))
+        assert min(vals) == 2.0 * epoch / 7.0  # rank 0 holds the smallest ratio
+    assert slot(3, 1, world - 1) + rec <= md.mailbox_bytes(world) and md.KINDS == 4
     gathered = [None] * world
     dist.all_gather_object(gathered, results)
     if rank == 0:
-        q.put(all(g == gathered[0] for g in gathered) and len(results) == 5)
+        q.put(all(g == gathered[0] for g in gathered) and len(results) == 8)
         md.remove_mailbox(name)
     dist.barrier()
     dist.destroy_process_group()
