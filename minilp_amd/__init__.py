@@ -5,8 +5,8 @@ HIP for gfx950 in `csrc/`, reached through the C ABI of `include/minilp_hip.h`. 
 Python mirror of the reference's public interface (lib.rs:61-464).  There is no CPU fallback: without
 the built extension or without a GPU every solve raises.
 """
-from .api import (EQ, GE, LE, MAXIMIZE, MINIMIZE, Infeasible, InternalError, MpsFile, Problem, Solution,
+from .api import (EQ, GE, LE, MAXIMIZE, MINIMIZE, Infeasible, InternalError, LinearExpr, MpsFile, Problem, Solution,
                   Unbounded, device_count, lib, lib_path, min_cut, set_device)
 
-__all__ = ["Problem", "Solution", "MpsFile", "MINIMIZE", "MAXIMIZE", "EQ", "LE", "GE", "Infeasible", "Unbounded",
+__all__ = ["Problem", "Solution", "MpsFile", "LinearExpr", "MINIMIZE", "MAXIMIZE", "EQ", "LE", "GE", "Infeasible", "Unbounded",
            "InternalError", "device_count", "set_device", "lib", "lib_path", "min_cut"]

@@ -137,6 +137,31 @@ def _raise(st):
     raise InternalError(st, lib().mlp_last_error().decode())
 
 
+class LinearExpr:
+    """lib.rs:84-158: a linear expression, built term by term (`LinearExpr.empty().add(x, 1.0)`) or from any
+    iterable of (variable, coefficient) pairs.  Every method that takes an expression accepts either form."""
+
+    def __init__(self, terms=()):
+        self.vars, self.coeffs = [], []
+        for var, coeff in terms:
+            self.add(var, coeff)
+
+    @classmethod
+    def empty(cls):  # lib.rs:92
+        return cls()
+
+    def add(self, var, coeff):  # lib.rs:98
+        self.vars.append(int(var))
+        self.coeffs.append(float(coeff))
+        return self
+
+    def __iter__(self):
+        return iter(zip(self.vars, self.coeffs))
+
+    def __len__(self):
+        return len(self.vars)
+
+
 def _terms(expr):
     pairs = list(expr)
     idx = np.ascontiguousarray([int(p[0]) for p in pairs], dtype=np.uint32)

@@ -173,3 +173,17 @@ def test_plain_c_program_solves_the_readme_toy(tmp_path):
     assert r.returncode == 0, r.stderr
     assert "objective 7 x 1 y 3" in r.stdout
     assert "warm-started objective 6.5 x 0.5 y 3" in r.stdout
+
+
+def test_linear_expr_mirror_builds_the_same_constraint():  # lib.rs:84-158
+    p = M.Problem(M.MINIMIZE)
+    x, y, z = (p.add_var(1.0, (0.0, 4.0)) for _ in range(3))
+    e = M.LinearExpr.empty().add(z, 3.0).add(x, 1.0)
+    assert len(e) == 2 and list(e) == [(z, 3.0), (x, 1.0)]
+    p.add_constraint(e, M.LE, 5.0)
+    p.add_constraint([(z, 3.0), (x, 1.0)], M.LE, 5.0)
+    p.add_constraint(M.LinearExpr([(y, 2.0)]), M.GE, 1.0)
+    c = p.constraints()
+    assert (c[0][0] == c[1][0]).all() and (c[0][1] == c[1][1]).all() and c[0][2:] == c[1][2:]
+    assert list(c[0][0]) == [x, z] and list(c[0][1]) == [1.0, 3.0]   # stored sorted by variable, like CsVec::new
+    assert list(c[2][0]) == [y]
