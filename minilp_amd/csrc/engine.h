@@ -52,8 +52,8 @@ struct ProblemData {  // lib.rs:193-200
 struct DevPool {
     static constexpr size_t kMaxBlock = (size_t)64 << 20;   // larger blocks are not cached
     static constexpr size_t kMaxCached = (size_t)4 << 30;   // total bytes kept in the cache
-    static void* get(size_t bytes, size_t* got_bytes);
-    static void put(void* p, size_t bytes);
+    static void* get(size_t bytes, size_t* got_bytes, int* device);   // on the current device
+    static void put(void* p, size_t bytes, int device);                // back to the free list of ITS device
     static void trim();  // hipFree everything cached
 };
 
@@ -62,12 +62,13 @@ struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;        // elements
     size_t bytes = 0;      // size of the block as obtained from the pool
+    int dev = 0;           // device the block lives on
     DevBuf() {}
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) DevPool::put(p, bytes);
+        if (p) DevPool::put(p, bytes, dev);
         p = nullptr;
         cap = 0;
         bytes = 0;
@@ -76,20 +77,22 @@ struct DevBuf {
     void ensure(size_t n, size_t keep, hipStream_t st) {
         if (n <= cap) return;
         size_t want = n + n / 2 + 64, got = 0;
-        T* np = static_cast<T*>(DevPool::get(want * sizeof(T), &got));
+        int ndev = 0;
+        T* np = static_cast<T*>(DevPool::get(want * sizeof(T), &got, &ndev));
         if (p && keep) HIPCHECK(hipMemcpyAsync(np, p, keep * sizeof(T), hipMemcpyDeviceToDevice, st));
         if (p) {
             HIPCHECK(hipStreamSynchronize(st));
-            DevPool::put(p, bytes);
+            DevPool::put(p, bytes, dev);
         }
         p = np;
+        dev = ndev;
         bytes = got;
         cap = got / sizeof(T);
     }
     void alloc_exact(size_t n) {  // fresh allocation of (at least) n elements (contents undefined)
         release();
         size_t got = 0;
-        p = static_cast<T*>(DevPool::get(n * sizeof(T), &got));
+        p = static_cast<T*>(DevPool::get(n * sizeof(T), &got, &dev));
         bytes = got;
         cap = n;
     }

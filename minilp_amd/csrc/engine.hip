@@ -175,7 +175,7 @@ void Engine::release_runtime() {  // both streams are idle (synchronised by the 
 namespace {
 struct PoolState {
     std::mutex mu;
-    std::map<size_t, std::vector<void*>> free_blocks;  // by block size
+    std::map<std::pair<int, size_t>, std::vector<void*>> free_blocks;  // by (device, block size)
     size_t cached = 0;
 };
 PoolState& pool() {
@@ -188,14 +188,17 @@ size_t round_block(size_t bytes) {
     return b;
 }
 }  // namespace
-void* DevPool::get(size_t bytes, size_t* got_bytes) {
+void* DevPool::get(size_t bytes, size_t* got_bytes, int* device) {
     if (bytes == 0) bytes = 1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    *device = dev;
     if (bytes <= kMaxBlock) {
         const size_t b = round_block(bytes);
         {
             PoolState& s = pool();
             std::lock_guard<std::mutex> lk(s.mu);
-            auto it = s.free_blocks.find(b);
+            auto it = s.free_blocks.find(std::make_pair(dev, b));
             if (it != s.free_blocks.end() && !it->second.empty()) {
                 void* p = it->second.back();
                 it->second.pop_back();
@@ -217,13 +220,13 @@ void* DevPool::get(size_t bytes, size_t* got_bytes) {
     *got_bytes = bytes;
     return p;
 }
-void DevPool::put(void* p, size_t bytes) {
+void DevPool::put(void* p, size_t bytes, int device) {
     if (!p) return;
     if (bytes <= kMaxBlock && bytes == round_block(bytes)) {
         PoolState& s = pool();
         std::lock_guard<std::mutex> lk(s.mu);
         if (s.cached + bytes <= kMaxCached) {
-            s.free_blocks[bytes].push_back(p);
+            s.free_blocks[std::make_pair(device, bytes)].push_back(p);
             s.cached += bytes;
             return;
         }
@@ -448,7 +451,7 @@ void Engine::ensure_nucleus_cap(int need) {
                                   (size_t)k_ * sizeof(double), (size_t)k_, hipMemcpyDeviceToDevice, st));
     HIPCHECK(hipStreamSynchronize(st));
     d_W.release();
-    d_W.p = nW.p; d_W.cap = nW.cap; d_W.bytes = nW.bytes; nW.p = nullptr; nW.cap = 0; nW.bytes = 0;
+    d_W.p = nW.p; d_W.cap = nW.cap; d_W.bytes = nW.bytes; d_W.dev = nW.dev; nW.p = nullptr; nW.cap = 0; nW.bytes = 0;
     size_t keep = (size_t)k_;
     d_pos_of_kslot.ensure(ncap, keep, st); d_row_of_kslot.ensure(ncap, keep, st);
     d_aK.ensure(ncap, keep, st); d_rK.ensure(ncap, keep, st); d_tK.ensure(ncap, keep, st);
