@@ -260,6 +260,7 @@ void mlp_solution_stats(const mlp_solution* s, mlp_stats* o) {
 void mlp_solution_reset_stats(mlp_solution* s) {
     guarded([&] { s->eng->resolve_events(); });
     s->eng->stats = Stats();
+    s->eng->restart_sampling();  // profile mode: the next batch is a sampled one, so a short timed region still has samples
 }
 uint64_t mlp_solution_trace_len(const mlp_solution* s) { return s->eng->trace_log.size(); }
 void mlp_solution_trace_get(const mlp_solution* s, uint64_t i, int32_t* phase, int64_t* col, int64_t* row,

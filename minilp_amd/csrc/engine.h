@@ -198,6 +198,7 @@ private:
     bool use_banded() const;
   public:
     bool banded_active() const { return use_banded(); }
+    void restart_sampling() { batches_run = 0; }
   private:
     void ensure_banded();
     DevBuf<int> d_colblk;        // blocked F push (large nucleus): row-block offsets per column
