@@ -187,3 +187,22 @@ def test_linear_expr_mirror_builds_the_same_constraint():  # lib.rs:84-158
     assert (c[0][0] == c[1][0]).all() and (c[0][1] == c[1][1]).all() and c[0][2:] == c[1][2:]
     assert list(c[0][0]) == [x, z] and list(c[0][1]) == [1.0, 3.0]   # stored sorted by variable, like CsVec::new
     assert list(c[2][0]) == [y]
+
+
+def test_bench_contract_pieces_that_need_no_gpu():
+    """bench.py: CLI defaults (N = 1, K/W that finish in minutes) and the committed PMC traffic figure
+    that feeds roofline.traffic for the default workload."""
+    import subprocess
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, check=True).stdout
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in out
+    sys.path.insert(0, root)
+    import bench
+    a = types.SimpleNamespace(rows=100000, cols=100000, nnz_per_row=100, seed=4)
+    t = bench.pmc_traffic(a, "sweep")
+    assert t is not None and 1.0e8 < t < 3.0e8          # HBM bytes per launch of the dominant kernel
+    assert bench.pmc_traffic(types.SimpleNamespace(rows=10, cols=10, nnz_per_row=2, seed=1), "sweep") is None
+    assert bench.HBM_PEAK_GBS == 8000.0
