@@ -76,6 +76,8 @@ struct Ctl {
     int nlow;   // number of pending rank-1 terms
     int fold;   // this pivot's fused pass folds the pending terms into W0 (set by the plan)
     double lr_c[LR_MAX], lr_e[LR_MAX], lr_g[LR_MAX], lr_h[LR_MAX];  // V[j].a_list, U[j].b_list, V[j].rho_K, U[j].t_K
+    int ratio_epoch;          // fused primal ratio test: launch counter published by pass 1's last block
+    double ratio_max_step;    // ... and the step bound it publishes
     unsigned long long xepoch[4];  // sharded mode: exchange counters (kind 0: pricing, 1: primal ratio decision,
                                    // 2: dual ratio pass-1 minimum, 3: dual ratio pass-2 candidate)
     double max_pivot_err;  // max over the batch of |alpha_q[r] - alpha_r[q]| / max(1,|alpha_q[r]|): drift monitor of W

@@ -17,6 +17,8 @@
 #include <limits.h>
 #include <math.h>
 
+#include <cstdlib>
+
 namespace mlp {
 
 #define NONE_IDX INT_MAX
@@ -880,26 +882,11 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_p1(DevView v, int use_pse)
         c->it.alpha_sq = sq + 1.0;
     }
 }
-// pass 2 (solver.rs:800-853); the finalising block goes straight on with the BTRAN head + plan
-__global__ void __launch_bounds__(BLK) k_ratio_primal_p2(DevView v) {
-    Ctl* c = v.ctl;
-    if (c->halt || c->it.status != ITER_PIVOT) return;
+// Finalising block of the primal ratio test: the decision (solver.rs:820-853), in sharded mode the adoption
+// of rank 0's decision, then the BTRAN head and the partition plan.
+__device__ void ratio_primal_finish(const DevView& v, Ctl* c, Cand best) {
     IterState* it = &c->it;
-    int sign = it->sign;
-    double max_step = it->max_step;
-    Cand best = cand_none();
-    for (int p = blockIdx.x * BLK + threadIdx.x; p < v.m; p += gridDim.x * BLK) {
-        double coeff = v.alpha_q[p];
-        double ca = fabs(coeff);
-        if (ca < EPS) continue;
-        bool tm;
-        double cur = leaving_step(v, p, coeff, sign, tm) / ca;
-        if (cur <= max_step) {
-            Cand t{ca, p};
-            if (cand_better(t, best)) best = t;
-        }
-    }
-    if (!grid_best(best, v)) return;
+    const int sign = it->sign;
     __shared__ int s_r;
     if (threadIdx.x == 0) {
         const int q = it->q;
@@ -964,6 +951,115 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_p2(DevView v) {
     }
     __syncthreads();
     if (s_r >= 0 && threadIdx.x < 64) btran_prep_wave(v, c, threadIdx.x, s_r, 0, 1, 0);
+}
+
+// pass 2 (solver.rs:800-853); the finalising block goes straight on with the BTRAN head + plan
+__global__ void __launch_bounds__(BLK) k_ratio_primal_p2(DevView v) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    IterState* it = &c->it;
+    int sign = it->sign;
+    double max_step = it->max_step;
+    Cand best = cand_none();
+    for (int p = blockIdx.x * BLK + threadIdx.x; p < v.m; p += gridDim.x * BLK) {
+        double coeff = v.alpha_q[p];
+        double ca = fabs(coeff);
+        if (ca < EPS) continue;
+        bool tm;
+        double cur = leaving_step(v, p, coeff, sign, tm) / ca;
+        if (cur <= max_step) {
+            Cand t{ca, p};
+            if (cand_better(t, best)) best = t;
+        }
+    }
+    if (!grid_best(best, v)) return;
+    ratio_primal_finish(v, c, best);
+}
+
+// Both Harris passes in ONE launch (primal): pass 1's grid-wide minimum is published by its last-arriving
+// block, every block waits for it (a 98-block grid is always co-resident) and runs pass 2 on the elements it
+// still holds in registers; the second ticketed reduction ends in ratio_primal_finish as before.  Saves a
+// kernel boundary and the second read of alpha_q / x_B / bounds.
+__global__ void __launch_bounds__(BLK) k_ratio_primal_fused(DevView v, int use_pse) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    const int sign = c->it.sign;
+    const int epoch0 = c->ratio_epoch;  // written by the previous launch of this kernel: stable here
+    constexpr int PT = 4;               // elements per thread (grid_for's default)
+    double ca[PT], stp[PT];
+    int pos[PT];
+    double mn = INFINITY, sq = 0.0;
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+        const int p = (int)blockIdx.x * BLK + threadIdx.x + u * (int)gridDim.x * BLK;
+        pos[u] = -1;
+        ca[u] = 0.0;
+        stp[u] = 0.0;
+        if (p >= v.m) continue;
+        const double coeff = v.alpha_q[p];
+        if (use_pse) {
+            sq += coeff * coeff;
+            if (v.kslot_of_pos[p] < 0) v.rv[v.srow_of_pos[p]].y = coeff / v.sdiag_of_pos[p];
+        }
+        const double a = fabs(coeff);
+        if (a < EPS) continue;
+        bool tm;
+        const double st = leaving_step(v, p, coeff, sign, tm);
+        pos[u] = p;
+        ca[u] = a;
+        stp[u] = st;
+        const double cur = (st + EPS) / a;
+        if (cur < mn) mn = cur;
+    }
+    __shared__ double s_max_step;
+    if (grid_min_sum(mn, sq, v)) {  // last arriver of pass 1: publish the step bound
+        if (threadIdx.x == 0) {
+            double max_step = fabs(c->it.entering_other - c->it.entering_cur);
+            if (mn < max_step) max_step = mn;
+            c->it.max_step = max_step;
+            c->it.alpha_sq = sq + 1.0;
+            st_agent(&c->ratio_max_step, max_step);
+            // the ticket is reused by pass 2 INSIDE this launch: its reset must be visible to the other blocks'
+            // atomics (grid_min_sum resets it with a plain store, which only a kernel boundary publishes)
+            __hip_atomic_store(v.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st_agent(&c->ratio_epoch, epoch0 + 1);
+        }
+    }
+    __shared__ int s_gave_up;
+    if (threadIdx.x == 0) {
+        s_gave_up = 0;
+        long spins = 0;
+        while (ld_agent(&c->ratio_epoch) != epoch0 + 1) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > 20000000L) {  // seconds: cannot happen while the grid is co-resident; never hang the GPU
+                s_gave_up = 1;
+                break;
+            }
+        }
+        s_max_step = ld_agent(&c->ratio_max_step);
+    }
+    __syncthreads();
+    if (s_gave_up) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            c->it.status = ITER_SINGULAR;
+            c->halt = 1;
+            push_rec(c, 0);
+        }
+        return;
+    }
+    const double max_step = s_max_step;
+    Cand best = cand_none();
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {  // ascending positions per thread, so ties keep the lowest position
+        if (pos[u] < 0) continue;
+        if (stp[u] / ca[u] <= max_step) {
+            Cand t{ca[u], pos[u]};
+            if (cand_better(t, best)) best = t;
+        }
+    }
+    if (!grid_best(best, v)) return;
+    ratio_primal_finish(v, c, best);
 }
 
 // dual path, after FTRAN: the FTRAN-side pivot, ||alpha_q||^2 and y_S (PSE), then the plan
@@ -2228,8 +2324,14 @@ void launch_ftran_gather(const DevView& dv, const Geom& g, hipStream_t st) {
     else if (dv.det_pull) launch_pull_F(dv, g, 0, st);
 }
 void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st) {
-    hipLaunchKernelGGL(k_ratio_primal_p1, dim3(grid_for(g.m)), dim3(BLK), 0, st, dv, use_pse);
-    hipLaunchKernelGGL(k_ratio_primal_p2, dim3(grid_for(g.m)), dim3(BLK), 0, st, dv);  // + BTRAN head + plan
+    const int nb = grid_for(g.m);
+    static const bool two_kernels = std::getenv("MLP_RATIO_TWO_KERNELS") != nullptr;
+    if (!two_kernels && (long)nb * BLK * 4 >= (long)g.m) {  // every element fits the fused kernel's registers
+        hipLaunchKernelGGL(k_ratio_primal_fused, dim3(nb), dim3(BLK), 0, st, dv, use_pse);  // both passes + BTRAN head + plan
+        return;
+    }
+    hipLaunchKernelGGL(k_ratio_primal_p1, dim3(nb), dim3(BLK), 0, st, dv, use_pse);
+    hipLaunchKernelGGL(k_ratio_primal_p2, dim3(nb), dim3(BLK), 0, st, dv);  // + BTRAN head + plan
 }
 void launch_post_ftran(const DevView& dv, const Geom& g, int use_pse, hipStream_t st) {
     hipLaunchKernelGGL(k_post_ftran, dim3(use_pse ? grid_for(g.m) : 1), dim3(BLK), 0, st, dv, use_pse);
