@@ -80,3 +80,16 @@ def test_lowrank_mode_config4_budget():
         assert sg.reinvert() < 1e-6
     finally:
         os.environ.pop("MLP_LOWRANK", None)
+
+
+def test_engine_level_stepping_with_the_large_model_machinery(lowrank):
+    """The host-paced stage API over the banded sweep (separate combine launch), the blocked F push and the
+    delayed-update mode: same optimum and, on the sparse family, the same pivots as the oracle."""
+    from tests.test_hip_parity import _drive_by_stages
+    lp = lpgen.gen_sparse_lp(200, 200, 10, 4)
+    so = lpgen.build_problem(O.Problem, lp).solve(trace=True)
+    sg = lpgen.build_problem(M.Problem, lp).solve(budget=0, trace=True)
+    st, pivots = _drive_by_stages(sg)
+    assert st == M.api.ITER_OPTIMAL and pivots == len(so.trace())
+    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+    assert obj_close(sg.objective(), so.objective())
