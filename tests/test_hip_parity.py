@@ -531,3 +531,19 @@ def test_config4_first_2000_pivots_match_the_oracle_trace_fixture():
     first_diff = next((i for i, (a, b) in enumerate(zip(got, ref)) if a != b), None)
     assert first_diff is None, (first_diff, got[first_diff], ref[first_diff])
     assert obj_close(s.objective(), float(z["objective"]))
+
+
+def test_large_dual_only_instance_matches_the_oracle_trace_fixture():
+    """Dual simplex at scale: cover family 40 000 x 40 000, 60 non-zeros per row (tableau-row sweep in its
+    alpha_r-only mode, dual Harris test, atomic F pushes, nucleus growing to thousands of columns), first 5 000
+    pivots against the committed oracle trace (tests/golden/make_cover_trace.py)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cover40k_oracle_trace.npz"))
+    ref = [tuple(int(x) for x in row) for row in z["trace"]]
+    lp = lpgen.gen_cover_lp(40000, 40000, 60, 8)
+    s = lpgen.build_problem(M.Problem, lp).solve(budget=len(ref), trace=True)
+    got = [tuple(int(x) for x in t[:5]) for t in s.trace()]
+    assert len(got) == len(ref) and s.stats()["primal_iters"] == 0
+    first_diff = next((i for i, (a, b) in enumerate(zip(got, ref)) if a != b), None)
+    assert first_diff is None, (first_diff, got[first_diff], ref[first_diff])
+    assert obj_close(s.objective(), float(z["objective"]))
