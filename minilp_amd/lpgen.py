@@ -81,6 +81,24 @@ def gen_cover_lp(m, n, k, seed=5):
     return out
 
 
+def gen_twophase_lp(m, n, k, seed=6, ge_every=7):
+    """Two-phase instance on the pattern of the config-4 family: Max c'x with every `ge_every`-th row turned
+    into a >= row, both kinds of right-hand side built around the interior point x0 = 0.3 so that the LP is
+    feasible and bounded.  x = 0 is neither primal feasible (the >= rows) nor dual feasible (Max, c > 0):
+    the solve is the dual loop on the artificial objective (solver.rs:261, 513-547), recalc_obj_coeffs, then
+    the primal loop with steepest edge (solver.rs:470-511); continuous random data, non-degenerate."""
+    base = gen_sparse_lp(m, n, k, seed)
+    x0 = np.full(n, 0.3)
+    lhs = np.add.reduceat(base["data"] * x0[base["indices"]], base["indptr"][:-1])
+    u = uniform01(_stream(seed, 31), m)
+    ge = (np.arange(m) % ge_every) == 0
+    ops = np.where(ge, GE, LE).astype(np.int32)
+    rhs = np.where(ge, lhs * (0.5 + 0.4 * u), lhs * (1.2 + 0.8 * u))
+    out = dict(base)
+    out.update(name=f"twophase_{m}x{n}_k{k}_s{seed}", ops=ops, rhs=rhs)
+    return out
+
+
 def gen_mixed_lp(m, n, k, seed=3):
     """Config 3 stand-in (no NETLIB file is available offline): sparse rows with E/L/G operators,
     finite/infinite/fixed/free bounds and mixed-sign costs, built around a known feasible point so

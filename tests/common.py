@@ -8,7 +8,7 @@ import numpy as np
 from minilp_amd import lpgen
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GEN = {"sparse": lpgen.gen_sparse_lp, "dense": lpgen.gen_dense_lp, "mixed": lpgen.gen_mixed_lp, "cover": lpgen.gen_cover_lp}
+GEN = {"sparse": lpgen.gen_sparse_lp, "dense": lpgen.gen_dense_lp, "mixed": lpgen.gen_mixed_lp, "cover": lpgen.gen_cover_lp, "twophase": lpgen.gen_twophase_lp}
 
 # Parity contract (SURVEY.md §7 hard part 5): f64 everywhere,
 #   |dobj| <= OBJ_RTOL * max(1, |obj|);  |dx|inf <= X_ATOL on instances with a unique optimum.

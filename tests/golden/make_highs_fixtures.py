@@ -29,8 +29,10 @@ CASES = [
     ("mixed", dict(m=6000, n=10000, k=4, seed=3)),   # BASELINE config 3 stand-in: ~10k vars, sparse, via MPS
     ("cover", dict(m=300, n=350, k=8, seed=4)),      # dual-only solves (Min c'x, Ax >= b)
     ("cover", dict(m=1200, n=1000, k=10, seed=6)),
+    ("twophase", dict(m=300, n=350, k=8, seed=6)),   # dual loop on the artificial objective, then primal
+    ("twophase", dict(m=1200, n=1000, k=10, seed=6)),
 ]
-GEN = {"sparse": lpgen.gen_sparse_lp, "dense": lpgen.gen_dense_lp, "mixed": lpgen.gen_mixed_lp, "cover": lpgen.gen_cover_lp}
+GEN = {"sparse": lpgen.gen_sparse_lp, "dense": lpgen.gen_dense_lp, "mixed": lpgen.gen_mixed_lp, "cover": lpgen.gen_cover_lp, "twophase": lpgen.gen_twophase_lp}
 
 
 def solve_highs(lp):

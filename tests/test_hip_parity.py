@@ -547,3 +547,18 @@ def test_large_dual_only_instance_matches_the_oracle_trace_fixture():
     first_diff = next((i for i, (a, b) in enumerate(zip(got, ref)) if a != b), None)
     assert first_diff is None, (first_diff, got[first_diff], ref[first_diff])
     assert obj_close(s.objective(), float(z["objective"]))
+
+
+@pytest.mark.parametrize("kw", [dict(m=300, n=350, k=8, seed=6), dict(m=1200, n=1000, k=10, seed=6)], ids=str)
+def test_two_phase_instance_pivot_for_pivot(kw):
+    """gen_twophase_lp: dual loop on the artificial objective, recalc_obj_coeffs, primal loop with steepest edge
+    (solver.rs:261, 470-547) — the full initial_solve flow on non-degenerate data, identical pivots to the oracle."""
+    lp = lpgen.gen_twophase_lp(**kw)
+    so = lpgen.build_problem(O.Problem, lp).solve(trace=True)
+    sg = lpgen.build_problem(M.Problem, lp).solve(trace=True)
+    st = sg.stats()
+    assert st["dual_iters"] > 10 and st["primal_iters"] > 100
+    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+    assert obj_close(sg.objective(), so.objective())
+    assert np.abs(np.asarray(sg.values()) - np.asarray(so.values())).max() <= X_ATOL
+    check_feasible(lp, sg.values())
