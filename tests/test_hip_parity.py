@@ -517,7 +517,7 @@ def test_small_models_are_reproducible_bit_for_bit():
     assert np.asarray(a.values()).tobytes() == np.asarray(b.values()).tobytes() and a.objective() == b.objective()
 
 
-def test_config4_first_2000_pivots_match_the_oracle_trace_fixture():
+def test_config4_first_pivots_match_the_oracle_trace_fixture():
     """BASELINE config 4: the first 2 000 pivots (entering position, leaving row, entering / leaving variable)
     against the oracle's trace, committed as a fixture (tests/golden/make_cfg4_trace.py: 173 s of CPU in the
     build container, too slow to regenerate inside this test)."""
@@ -527,7 +527,7 @@ def test_config4_first_2000_pivots_match_the_oracle_trace_fixture():
     lp = lpgen.gen_sparse_lp(100000, 100000, 100, 4)
     s = lpgen.build_problem(M.Problem, lp).solve(budget=len(ref), trace=True)
     got = [tuple(int(x) for x in t[:5]) for t in s.trace()]
-    assert len(got) == len(ref) == 2000
+    assert len(got) == len(ref) >= 2000
     first_diff = next((i for i, (a, b) in enumerate(zip(got, ref)) if a != b), None)
     assert first_diff is None, (first_diff, got[first_diff], ref[first_diff])
     assert obj_close(s.objective(), float(z["objective"]))
