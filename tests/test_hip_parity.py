@@ -562,3 +562,21 @@ def test_two_phase_instance_pivot_for_pivot(kw):
     assert obj_close(sg.objective(), so.objective())
     assert np.abs(np.asarray(sg.values()) - np.asarray(so.values())).max() <= X_ATOL
     check_feasible(lp, sg.values())
+
+
+def test_two_phase_instance_at_scale_matches_the_oracle_trace_fixture():
+    """gen_twophase_lp 10 000 x 10 000 (every 40th row a >= row): 647 dual pivots on the artificial objective,
+    recalc_obj_coeffs, then the primal loop with steepest edge — the first ~6 000 pivots against the committed
+    oracle trace (tests/golden/make_twophase_trace.py)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "twophase10k_oracle_trace.npz"))
+    ref = [tuple(int(x) for x in row) for row in z["trace"]]
+    lp = lpgen.gen_twophase_lp(10000, 10000, 30, 9, ge_every=40)
+    # the budget counts loop iterations: the one that ends phase 1 ("no infeasible row") is not a pivot, in the
+    # oracle (budget 6 000 -> 5 999 pivots) and in the engine alike
+    s = lpgen.build_problem(M.Problem, lp).solve(budget=len(ref) + 1, trace=True)
+    got = [tuple(int(x) for x in t[:5]) for t in s.trace()]
+    assert len(got) == len(ref) and s.stats()["dual_iters"] == int(z["dual_iters"]) > 100
+    first_diff = next((i for i, (a, b) in enumerate(zip(got, ref)) if a != b), None)
+    assert first_diff is None, (first_diff, got[first_diff], ref[first_diff])
+    assert obj_close(s.objective(), float(z["objective"]))
