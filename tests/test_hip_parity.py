@@ -580,3 +580,33 @@ def test_two_phase_instance_at_scale_matches_the_oracle_trace_fixture():
     first_diff = next((i for i, (a, b) in enumerate(zip(got, ref)) if a != b), None)
     assert first_diff is None, (first_diff, got[first_diff], ref[first_diff])
     assert obj_close(s.objective(), float(z["objective"]))
+
+
+def test_warm_start_sequence_at_medium_scale():
+    """Solution::add_constraint (lib.rs:368 -> solver.rs:549-634) twelve times on a 3 000 x 2 500 instance
+    (nucleus of ~1 000 columns, graph replay in the re-solves): objective and feasibility after every cut, and
+    fix_var / unfix_var / clone on top (lib.rs:390-403)."""
+    lp = lpgen.gen_sparse_lp(3000, 2500, 12, 33)
+    so, sg = lpgen.build_problem(O.Problem, lp).solve(), lpgen.build_problem(M.Problem, lp).solve()
+    assert obj_close(sg.objective(), so.objective())
+    x = np.asarray(so.values())
+    rows = []
+    for step in range(12):
+        order = np.argsort(-x)
+        vars_ = [int(v) for v in order[3 * step: 3 * step + 5]]
+        lhs = float(sum(x[v] for v in vars_))
+        expr = [(v, 1.0) for v in vars_]
+        rhs = 0.8 * lhs
+        so, sg = so.add_constraint(expr, O.LE, rhs), sg.add_constraint(expr, M.LE, rhs)
+        rows.append((vars_, rhs))
+        assert obj_close(sg.objective(), so.objective()), step
+        x = np.asarray(so.values())
+        xg = np.asarray(sg.values())
+        assert np.abs(xg - x).max() <= 1e-6
+        for vs, r in rows:
+            assert sum(xg[v] for v in vs) <= r + 1e-7
+    v = int(np.argmax(x))
+    so2, sg2 = so.clone().fix_var(v, 0.0), sg.clone().fix_var(v, 0.0)
+    assert obj_close(sg2.objective(), so2.objective())
+    (so3, wo), (sg3, wg) = so2.unfix_var(v), sg2.unfix_var(v)
+    assert wo == wg and obj_close(sg3.objective(), so3.objective()) and obj_close(sg3.objective(), so.objective())
