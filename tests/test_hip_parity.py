@@ -518,8 +518,8 @@ def test_small_models_are_reproducible_bit_for_bit():
 
 
 def test_config4_first_pivots_match_the_oracle_trace_fixture():
-    """BASELINE config 4: the first 3 200 pivots (the whole benchmark window) (entering position, leaving row, entering / leaving variable)
-    against the oracle's trace, committed as a fixture (tests/golden/make_cfg4_trace.py: 382 s of CPU in the
+    """BASELINE config 4: the first 5 000 pivots (the whole benchmark window and beyond) (entering position, leaving row, entering / leaving variable)
+    against the oracle's trace, committed as a fixture (tests/golden/make_cfg4_trace.py: 759 s of CPU in the
     build container, too slow to regenerate inside this test)."""
     import os
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg4_oracle_trace.npz"))
