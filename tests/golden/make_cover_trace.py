@@ -17,5 +17,6 @@ s = lpgen.build_problem(O.Problem, lp).solve(budget=N, trace=True)
 tr = s.trace()
 print("oracle", len(tr), "pivots in %.1f s; obj %r; stats %s" % (time.time() - t, s.objective(), {k: s.stats()[k] for k in ("primal_iters", "dual_iters")}), flush=True)
 arr = np.array([[t_[0], t_[1], t_[2], t_[3], t_[4]] for t_ in tr], dtype=np.int32)
-np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "cover40k_oracle_trace.npz"), trace=arr,
+OUT = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "cover40k_oracle_trace.npz")
+np.savez_compressed(OUT, trace=arr,
                     objective=np.array(s.objective()), pivots=np.array(len(tr)))
