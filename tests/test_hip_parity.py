@@ -518,8 +518,8 @@ def test_small_models_are_reproducible_bit_for_bit():
 
 
 def test_config4_first_pivots_match_the_oracle_trace_fixture():
-    """BASELINE config 4: the first 5 000 pivots (the whole benchmark window and beyond) (entering position, leaving row, entering / leaving variable)
-    against the oracle's trace, committed as a fixture (tests/golden/make_cfg4_trace.py: 759 s of CPU in the
+    """BASELINE config 4: the first 8 000 pivots (the whole benchmark window and beyond; the engine follows the oracle up to pivot 9 652) (entering position, leaving row, entering / leaving variable)
+    against the oracle's trace, committed as a fixture (tests/golden/make_cfg4_trace.py: 2 509 s of CPU for 10 500 pivots in the
     build container, too slow to regenerate inside this test)."""
     import os
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg4_oracle_trace.npz"))
@@ -530,7 +530,8 @@ def test_config4_first_pivots_match_the_oracle_trace_fixture():
     assert len(got) == len(ref) >= 2000
     first_diff = next((i for i, (a, b) in enumerate(zip(got, ref)) if a != b), None)
     assert first_diff is None, (first_diff, got[first_diff], ref[first_diff])
-    assert obj_close(s.objective(), float(z["objective"]))
+    if np.isfinite(float(z["objective"])):  # a fixture cut out of a longer oracle run carries no objective
+        assert obj_close(s.objective(), float(z["objective"]))
 
 
 def test_large_dual_only_instance_matches_the_oracle_trace_fixture():
