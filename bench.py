@@ -3,13 +3,24 @@
 100 000 vars x 100 000 constraints, 100 nnz/row), fixed-pivot-budget protocol.
 
 A "step" is ONE simplex iteration (pricing -> FTRAN -> ratio test -> BTRAN -> tableau row ->
-basis-inverse update -> x_B/d/gamma/beta updates) of the device-resident solver.  W warm-up
-pivots from the slack basis, then exactly K timed pivots bracketed by barrier + synchronize.
-N > 1: one process per GPU (torch.distributed, RCCL); see DESIGN.md §6 for what is sharded.
+basis-inverse update -> x_B/d/gamma/beta updates) of the device-resident solver.
+
+`value` (the driver-timed figure): W warm-up pivots from the slack basis, then exactly K timed pivots
+bracketed by barrier + synchronize.  That window is the cheapest stretch of a 1.09 M-pivot solve, so the
+same JSON line also carries (N = 1, rank 0, outside the timed region):
+  * `windows.mid` / `windows.late`: a fixed number of pivots from the two committed MID-SOLVE bases of the same
+    instance (tests/golden/cfg4_basis_p*.bin.gz, nucleus ~10 000 and ~20 000: where the solve spends its time),
+    each with pivots/s, us per pivot and per-kernel bytes / GB/s / fraction of the HBM roofline;
+  * `roofline.ftran`: the FTRAN entries north_star asks for;
+  * `full_solve`: total solve wall time of the last full run of config 4 (profiles/, with its commit);
+  * `cpu_baseline`: the oracle timed on the host cores.
+N > 1: one process per GPU (torch.distributed, RCCL); ONE LP, pricing path sharded; a failure of
+the sharded set-up is an error, never a silent fall-back to replicas.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gzip
 import json
 import os
 import sys
@@ -19,6 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+MID_BASIS = os.path.join(ROOT, "tests", "golden", "cfg4_basis_p45000.bin.gz")
+LATE_BASIS = os.path.join(ROOT, "tests", "golden", "cfg4_basis_p240000.bin.gz")
 
 
 def parse():
@@ -32,6 +45,9 @@ def parse():
     ap.add_argument("--seed", type=int, default=4)
     ap.add_argument("--cpu-pivots", type=int, default=500, help="bounded CPU-baseline sample (pivots after warm-up; ~20 s of CPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-windows", action="store_true", help="skip the mid / late windows from the saved bases")
+    ap.add_argument("--window-steps", type=int, nargs=2, default=[512, 256], metavar=("MID", "LATE"))
+    ap.add_argument("--samples", type=int, default=32, help="pivots of the event-bracketed sampling pass after a timed region")
     ap.add_argument("--independent", action="store_true",
                     help="N > 1: one independent LP per rank (weak scaling) instead of column-block sharded pricing of ONE LP")
     return ap.parse_args()
@@ -43,16 +59,17 @@ def pmc_traffic(a, which):
     MI355X_MICROARCH.md prescribes and as tools/pmc_calib.sh confirms).  PMC counters cannot be
     collected from inside the timed run, so the figure is the committed per-launch average; null when
     the workload differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        doc = json.load(open(path))
-    except OSError:
-        return None
-    w = doc.get("workload", {})
-    if (w.get("rows"), w.get("cols"), w.get("nnz_per_row"), w.get("seed")) != (a.rows, a.cols, a.nnz_per_row, a.seed):
-        return None
-    k = doc.get("kernels", {}).get(which)
-    return k["hbm_bytes_per_launch"] if k else None
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            doc = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except OSError:
+            continue
+        w = doc.get("workload", {})
+        if (w.get("rows"), w.get("cols"), w.get("nnz_per_row"), w.get("seed")) != (a.rows, a.cols, a.nnz_per_row, a.seed):
+            return None, None
+        k = doc.get("kernels", {}).get(which)
+        return (k["hbm_bytes_per_launch"], name) if k else (None, None)
+    return None, None
 
 
 def cpu_baseline(lp, warmup, sample):
@@ -70,9 +87,82 @@ def cpu_baseline(lp, warmup, sample):
     n = (it1["primal_iters"] + it1["dual_iters"]) - (it0["primal_iters"] + it0["dual_iters"])
     return dict(value=n / dt, unit="pivots/s", cores=1, kind="port",
                 sample=f"oracle (C++ restatement of minilp 0.2.2, 1 thread) on the same instance: pivots "
-                       f"{warmup}..{warmup + n} from the slack basis in {dt:.2f}s (its fastest stretch; "
-                       f"the GPU figure covers pivots {warmup}..{warmup}+steps)",
+                       f"{warmup}..{warmup + n} from the slack basis in {dt:.2f}s (its fastest stretch; it slows to "
+                       f"~7 pivots/s by pivot 2 500 and cannot reach the mid / late windows in hours)",
                 host_cpus=os.cpu_count())
+
+
+def kernel_report(st):
+    """Per-kernel averages of the event-bracketed (sampled) iterations: algorithmic bytes, GB/s, roofline fraction."""
+    out = {}
+    for name in ("fused", "sweep", "ftran"):
+        n_l = st[name + "_launches"]
+        if n_l and st[name + "_ms"] > 0:
+            gbs = st[name + "_bytes"] / (st[name + "_ms"] * 1e-3) / 1e9
+            out[name] = dict(launches=int(n_l), avg_us=st[name + "_ms"] * 1e3 / n_l,
+                             algorithmic_bytes_per_launch=st[name + "_bytes"] / n_l, gbs=gbs, frac=gbs / HBM_PEAK_GBS,
+                             total_ms=st[name + "_ms"])
+    if st["update_launches"]:
+        out["update"] = dict(launches=int(st["update_launches"]), avg_us=st["update_ms"] * 1e3 / st["update_launches"])
+    if st["iter_samples"]:
+        out["iteration"] = dict(samples=int(st["iter_samples"]), avg_us=st["iter_ms"] * 1e3 / st["iter_samples"])
+    return out
+
+
+KERNEL_NAMES = {
+    "fused": "k_fused_w (tau = W rho [the second FTRAN, solver.rs:1157], v = W^T t, eta update / streaming pass of the nucleus inverse)",
+    "sweep_band": ("k_sweep_band (tableau row rho^T N [+ PSE helper]: band-major copy of A, the band of (rho, v) held in "
+                   "LDS; per-band partials summed in band order by k_update_pivot)"),
+    "sweep": "k_sweep (tableau row rho^T N [+ PSE helper] as a CSC pull over A)",
+    "ftran": "k_ftran_prep + k_ftran_gather (+ F push): alpha_q = B^-1 a_q, the listed columns of the nucleus inverse",
+}
+
+
+def window_from_basis(M, prob, path, warm, steps, samples):
+    """`steps` timed pivots from a committed mid-solve basis (after `warm` untimed ones), then an event-bracketed
+    sampling pass of `samples` pivots for the per-kernel figures."""
+    import torch
+    with gzip.open(path, "rb") as f:
+        blob = f.read()
+    t0 = time.perf_counter()
+    s = prob.solve_from_basis(blob, budget=0, profile=True)   # device re-inversion + x_B, d recomputed from the basis
+    load_s = time.perf_counter() - t0
+    k0 = int(s.stats()["nucleus_size"])
+    s.continue_solve(warm)
+    s.reset_stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.continue_solve(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = s.stats()
+    done = int(st["iterations"])
+    s.set_sampling(True)
+    s.continue_solve(samples)
+    st2 = s.stats()
+    kern = kernel_report(st2)
+    k1 = int(st2["nucleus_size"])
+    out = dict(basis=os.path.basename(path), nucleus_size_at_start=k0, nucleus_size_at_end=k1, warmup=warm, steps=done,
+               pivots_per_s=done / dt, us_per_pivot=dt * 1e6 / max(done, 1), load_basis_s=load_s,
+               objective_at_end=s.objective(), max_pivot_err=st2["max_pivot_err"], kernels=kern,
+               sampling=f"{samples}-pivot event-bracketed pass right after the timed pivots (eager launches, "
+                        f"{int(st2['iter_samples'])} iterations sampled); the timed pivots run as graph replays")
+    del s
+    return out
+
+
+def full_solve_record():
+    """Total solve wall time of the last full run of config 4 (1 GPU, slack basis to certified optimum)."""
+    for name in ("r02_config4_full_solve.json", "r01_config4_certificate.json"):
+        try:
+            doc = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except OSError:
+            continue
+        return dict(total_solve_wall_s=doc["solve_wall_s"], pivots=doc["pivots"], avg_pivots_per_s=doc["pivots"] / doc["solve_wall_s"],
+                    objective=doc.get("primal_objective", doc.get("objective_accumulated")), relative_gap=doc.get("relative_gap"),
+                    source="profiles/" + name, commit=doc.get("commit"),
+                    note="measured by tools/certify_cfg4.py on one MI355X (too long for the default bench run)")
+    return None
 
 
 def main():
@@ -104,48 +194,24 @@ def main():
     # K1) sharded over disjoint blocks of non-basic positions, candidates exchanged once per pivot
     #  => strong scaling.  --independent: one LP per rank, no data-path exchange => weak.
     from minilp_amd import dist as mdist
-
-    def all_ok(ok):  # every rank must take the same branch
-        if world == 1:
-            return bool(ok)
-        t_ok = torch.tensor([1 if ok else 0], dtype=torch.int32, device=red_dev)
-        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
-        return int(t_ok.item()) == 1
-
-    def run(sharded):
-        lp = lpgen.gen_sparse_lp(a.rows, a.cols, a.nnz_per_row, a.seed + (0 if sharded or world == 1 else rank))
-        s = lpgen.build_problem(M.Problem, lp).solve(budget=0, profile=True)
-        mailbox = None
-        try:
-            if sharded:
-                mailbox = mdist.setup_sharding(s, dist)
-            s.continue_solve(a.warmup)       # W untimed warm-up pivots
-            s.reset_stats()
-            barrier()
-            t0 = time.perf_counter()
-            s.continue_solve(a.steps)        # exactly K timed pivots
-            barrier()
-            return lp, s, mailbox, time.perf_counter() - t0, None
-        except Exception as e:               # sharded mode: a failed exchange fails on every rank (bounded waits)
-            if not sharded:
-                raise
-            return lp, s, mailbox, 0.0, e
-
     sharded = world > 1 and not a.independent
-    note = None
-    lp, s, mailbox, dt, err = run(sharded)
-    if sharded and not all_ok(err is None):
-        # the per-pivot exchange could not be set up / timed out on this node: report the same
-        # workload as independent replicas (one LP of the family per rank) instead of nothing
-        print(f"[rank {rank}] sharded pricing failed ({err}); falling back to independent LPs", file=sys.stderr, flush=True)
-        note = f"sharded pricing failed on this node ({err if err else 'on a peer'}); independent LPs reported"
-        if mailbox and rank == 0:
-            mdist.remove_mailbox(mailbox)
-        del s
-        sharded = False
-        lp, s, mailbox, dt, err = run(False)
-    st = s.stats()
-    done = st["iterations"]
+    lp = lpgen.gen_sparse_lp(a.rows, a.cols, a.nnz_per_row, a.seed + (0 if sharded or world == 1 else rank))
+    prob = lpgen.build_problem(M.Problem, lp)
+    s = prob.solve(budget=0, profile=True)
+    mailbox = None
+    if sharded:
+        # raises on EVERY rank when any rank cannot join (setup_sharding all-gathers the errors): a sharded run
+        # that cannot be set up is a failed run, not a run of something else
+        mailbox = mdist.setup_sharding(s, dist)
+    s.continue_solve(a.warmup)       # W untimed warm-up pivots
+    s.reset_stats()
+    barrier()
+    t0 = time.perf_counter()
+    s.continue_solve(a.steps)        # exactly K timed pivots
+    barrier()
+    dt = time.perf_counter() - t0
+    st_timed = s.stats()
+    done = st_timed["iterations"]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -155,36 +221,35 @@ def main():
         total = float(c.item()) / world if sharded else float(c.item())   # sharded: every rank counts the same pivots
     else:
         total = float(done)
+    # event-bracketed sampling pass (outside the timed region, same solve, the pivots that follow): >= 8 samples
+    # of every kernel whatever K is; all ranks run it (the sharded exchange needs every rank)
+    samples_in_region = int(st_timed["sweep_launches"])
+    s.set_sampling(True)
+    s.continue_solve(a.samples)
+    st = s.stats()
     if rank == 0:
-        kern = {}
-        for name in ("fused", "sweep"):
-            n_l = st[name + "_launches"]
-            if n_l:
-                us = st[name + "_ms"] * 1e3 / n_l
-                gbs = st[name + "_bytes"] / (st[name + "_ms"] * 1e-3) / 1e9
-                kern[name] = dict(launches=n_l, avg_us=us, algorithmic_bytes_per_launch=st[name + "_bytes"] / n_l, gbs=gbs,
-                                  total_ms=st[name + "_ms"])
-        dom = max(kern, key=lambda k: kern[k]["total_ms"]) if kern else None
+        kern = kernel_report(st)
+        dom = max((k for k in ("fused", "sweep") if k in kern), key=lambda k: kern[k]["total_ms"], default=None)
         # the pricing path that shards over column blocks = tableau-row sweep + d/gamma update + pricing scan
         pricing_us = None
-        if st["update_launches"] and "sweep" in kern:
-            pricing_us = kern["sweep"]["avg_us"] + st["update_ms"] * 1e3 / st["update_launches"]
+        if "update" in kern and "sweep" in kern:
+            pricing_us = kern["sweep"]["avg_us"] + kern["update"]["avg_us"]
         roofline = None
         if dom:
-            kname = {"fused": "k_fused_w (tau=W*rho, v=W^T*t, eta update of the nucleus inverse)",
-                     "sweep": ("k_sweep_band (tableau row rho^T N [+ PSE helper]: band-major copy of A, the band of (rho, v) "
-                               "held in LDS; the per-band partials are summed in band order by k_update_pivot)"
-                               if st.get("banded_sweep") else
-                               "k_sweep (tableau row rho^T N [+ PSE helper] as a CSC pull over A)")}[dom]
-            roofline = dict(bound="hbm", kernel=kname, achieved=kern[dom]["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=kern[dom]["gbs"] / HBM_PEAK_GBS, traffic=pmc_traffic(a, dom),
-                            traffic_unit="HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
+            which = ("sweep_band" if st.get("banded_sweep") else "sweep") if dom == "sweep" else dom
+            traffic, traffic_src = pmc_traffic(a, dom)
+            roofline = dict(bound="hbm", kernel=KERNEL_NAMES[which], achieved=kern[dom]["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=kern[dom]["frac"], traffic=traffic,
+                            traffic_unit=f"HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/{traffic_src})" if traffic else None,
                             avg_launch_us=kern[dom]["avg_us"], launches=kern[dom]["launches"],
                             algorithmic_bytes_per_launch=kern[dom]["algorithmic_bytes_per_launch"],
-                            other_kernels={k: v for k, v in kern.items() if k != dom})
+                            samples=f"{samples_in_region} sampled iterations inside the timed region + a {a.samples}-pivot "
+                                    f"event-bracketed pass right after it (HIP events on the launch stream)",
+                            other_kernels={k: v for k, v in kern.items() if k not in (dom, "ftran")},
+                            ftran=dict(kernel=KERNEL_NAMES["ftran"], window="slack-basis window", **kern["ftran"]) if "ftran" in kern else None)
         out = dict(metric="simplex pivots/sec", value=total / dt, unit="pivots/s", n_gpus=world, steps=a.steps,
                    warmup=a.warmup, ms_per_step=dt * 1e3 / max(done, 1), higher_is_better=True,
-                   scaling=("strong" if sharded else "weak"),
+                   scaling=("weak" if (world > 1 and not sharded) else "strong"),
                    vs_baseline=None, dtype="f64", data="synthetic",
                    config=dict(workload=f"config 4: random LP {a.rows} vars x {a.cols} constraints, {a.nnz_per_row} nnz/row "
                                         f"(0.1% fill), Max c'x, Ax<=b, x>=0; primal simplex with PSE+DSE from the slack basis; "
@@ -192,14 +257,37 @@ def main():
                                rows=a.rows, cols=a.cols, nnz=int(st["nnz"]), seed=a.seed,
                                parallelism=("1 GPU" if world == 1 else
                                             (f"{world} GPUs: one LP, pricing path sharded over {world} column blocks, "
-                                             f"per-pivot candidate exchange through a host-mapped mailbox; FTRAN/BTRAN/W replicated"
+                                             f"per-pivot candidate exchange through {mdist.transport_name(s)}; FTRAN/BTRAN/W replicated"
                                              if sharded else f"{world} GPUs, one independent LP of the family per rank")) + (" [oversubscribed test rig: all ranks on one GPU]" if oversub else ""),
-                               nucleus_size_at_end=int(st["nucleus_size"]), objective_at_end=s.objective(),
-                               completed_steps=int(done), bound_flips=int(st["bound_flips"]),
-                               pricing_path_us_per_pivot=pricing_us, note=note),
+                               nucleus_size_at_end=int(st_timed["nucleus_size"]), objective_at_end=s.objective(),
+                               completed_steps=int(done), bound_flips=int(st_timed["bound_flips"]),
+                               pricing_path_us_per_pivot=pricing_us,
+                               vs_baseline_note="BASELINE.md §1: the reference publishes no number for this metric"),
                    roofline=roofline)
-        if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(lp, a.warmup, a.cpu_pivots)
+        if world == 1:
+            del s
+            s = None
+            if not a.no_windows:
+                windows = {}
+                for name, path, warm, steps in (("mid", MID_BASIS, 64, a.window_steps[0]), ("late", LATE_BASIS, 32, a.window_steps[1])):
+                    if (a.rows, a.cols, a.nnz_per_row, a.seed) != (100000, 100000, 100, 4) or not os.path.exists(path):
+                        windows[name] = None
+                        continue
+                    windows[name] = window_from_basis(M, prob, path, warm, steps, min(a.samples, 16))
+                out["windows"] = windows
+                if roofline and windows.get("late") and "fused" in windows["late"]["kernels"]:
+                    roofline["ftran"] = dict(
+                        column=roofline.get("ftran"),
+                        tau_late_window=dict(kernel=KERNEL_NAMES["fused"], window="late window (saved basis)",
+                                             **windows["late"]["kernels"]["fused"]),
+                        column_late_window=dict(kernel=KERNEL_NAMES["ftran"], window="late window (saved basis)",
+                                                **windows["late"]["kernels"].get("ftran", {})),
+                        note="north_star's FTRAN target: the solve against the basis factor.  Here B^-1 is the explicit nucleus "
+                             "inverse: the column FTRAN reads |list| columns of it (latency-bound, a few MB), the second FTRAN "
+                             "of every pivot (tau = B^-1 rho, solver.rs:1157) is the k^2 stream of k_fused_w")
+            out["full_solve"] = full_solve_record()
+            if not a.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(lp, a.warmup, a.cpu_pivots)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -8,7 +8,8 @@
  *   - opaque handles, plain pointers and sizes, no C++/torch types;
  *   - status codes: 0 OK, 1 Infeasible, 2 Unbounded (lib.rs:172-178 `Error`), <0 internal
  *     (-1 invalid argument / reference panic condition, -2 singular basis, -3 HIP error,
- *      -4 no GPU / extension unavailable).  mlp_last_error() returns the message;
+ *      -4 no GPU / extension unavailable, -5 the dense nucleus inverse (8 k^2 bytes) does not fit in HBM).
+ *     mlp_last_error() returns the message;
  *   - not thread-safe per handle; distinct handles are independent;
  *   - Solution mutators follow the reference's consume-on-error rule (lib.rs:359, 385): on a
  *     non-zero status the solution is freed and *s is set to NULL;
@@ -30,7 +31,7 @@ typedef struct mlp_solution mlp_solution; /* lib.rs:313-318 `Solution` (owns the
 enum { MLP_MINIMIZE = 0, MLP_MAXIMIZE = 1 };      /* lib.rs:61-68  OptimizationDirection */
 enum { MLP_EQ = 0, MLP_LE = 1, MLP_GE = 2 };      /* lib.rs:160-169 ComparisonOp */
 enum { MLP_OK = 0, MLP_INFEASIBLE = 1, MLP_UNBOUNDED = 2,
-       MLP_EINVAL = -1, MLP_ESINGULAR = -2, MLP_EHIP = -3, MLP_ENOGPU = -4 };
+       MLP_EINVAL = -1, MLP_ESINGULAR = -2, MLP_EHIP = -3, MLP_ENOGPU = -4, MLP_ENOMEM = -5 };
 
 const char* mlp_last_error(void);
 /* Number of visible HIP devices (0 => every solve returns MLP_ENOGPU; there is no CPU fallback). */
@@ -76,9 +77,24 @@ int mlp_solution_add_gomory_cut(mlp_solution** s, uint32_t var);               /
 /* ---- Engine-level controls (no counterpart in the reference: its pivot loop exposes no
  *      counter; these implement the fixed-pivot-budget measurement of §8d) ---- */
 /* Like mlp_problem_solve but stops after `budget` simplex iterations (budget < 0: run to optimality).
- * flags: bit0 = record a pivot trace, bit1 = time the dominant kernels with HIP events. */
+ * flags: bit0 = record a pivot trace, bit1 = time the dominant kernels with HIP events (sampled iterations),
+ * bit2 = with bit1: every iteration is a sampled one. */
 int mlp_problem_solve_ex(const mlp_problem* p, mlp_solution** out, int64_t budget, uint32_t flags);
 int mlp_solution_continue(mlp_solution* s, int64_t budget);
+/* Basis checkpoint ("pivots from a saved mid-solve basis"; the reference has no basis I/O — its
+ * Solver state is solver.rs:14-58).  mlp_solution_save_basis returns the size of the blob and copies it when
+ * buf != NULL and cap is large enough (0 on error).  mode 0: basic / non-basic sets (solver.rs:37, 44), non-basic
+ * flags and values (solver.rs:45-49); mode 1: + the steepest-edge weights as f32 (they only steer pricing);
+ * mode 2: + x_B, d, gamma, beta and the objective as f64 — a solve loaded from a mode-2 blob continues pivot for
+ * pivot like the uninterrupted one.  mlp_problem_solve_from_basis builds the same problem (Solver::try_new),
+ * installs the basis, re-inverts the nucleus on the device (BasisSolver::reset, solver.rs:1286-1303), recomputes
+ * x_B and the reduced costs from the basis (modes 0/1; solver.rs:1177-1231) and continues like mlp_problem_solve_ex.
+ * A blob of another model (row / variable counts differ, sets do not partition the variables) => MLP_EINVAL. */
+uint64_t mlp_solution_save_basis(const mlp_solution* s, int mode, void* buf, uint64_t cap);
+int mlp_problem_solve_from_basis(const mlp_problem* p, const void* blob, uint64_t len, mlp_solution** out, int64_t budget,
+                                 uint32_t flags);
+/* flags bit1 (HIP-event timing): sample EVERY iteration as an eager, event-bracketed one (measurement passes) */
+int mlp_solution_set_sampling(mlp_solution* s, int every_iteration);
 int mlp_solution_budget_exhausted(const mlp_solution* s);
 /* Recompute the dense nucleus inverse from A (the counterpart of BasisSolver::reset,
  * solver.rs:1286-1303); returns max |W_incremental - W_fresh| through *max_diff when non-NULL. */
@@ -107,6 +123,10 @@ typedef struct mlp_stats {
     uint64_t banded_sweep;    /* 1 when the tableau-row pass runs as the banded sweep (large m), 0 for the CSC pull */
     uint64_t final_refreshes; /* times optimality was re-examined on recomputed reduced costs (long runs only) */
     double max_pivot_err; /* drift monitor: max |alpha_q[r] - alpha_r[q]| / max(1,|alpha_q[r]|) seen so far */
+    /* FTRAN of the entering column (head + gather of the listed columns of the nucleus inverse + F push):
+     * algorithmic bytes 8 k |list| + 12 nnz(nucleus columns) + 12 nnz(a_q), HIP-event time of sampled iterations */
+    double ftran_bytes, ftran_ms; uint64_t ftran_launches;
+    double iter_ms; uint64_t iter_samples; /* whole sampled iterations, first kernel to last (HIP events) */
 } mlp_stats;
 void mlp_solution_stats(const mlp_solution* s, mlp_stats* out);
 void mlp_solution_reset_stats(mlp_solution* s);

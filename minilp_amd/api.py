@@ -33,7 +33,9 @@ class MlpStats(C.Structure):
                 + [(n, C.c_double) for n in ("fused_bytes", "fused_ms", "sweep_bytes", "sweep_ms")]
                 + [(n, C.c_uint64) for n in ("fused_launches", "sweep_launches")]
                 + [("solve_wall_s", C.c_double), ("kase", C.c_uint64 * 5), ("update_ms", C.c_double),
-                   ("update_launches", C.c_uint64), ("banded_sweep", C.c_uint64), ("final_refreshes", C.c_uint64), ("max_pivot_err", C.c_double)])
+                   ("update_launches", C.c_uint64), ("banded_sweep", C.c_uint64), ("final_refreshes", C.c_uint64), ("max_pivot_err", C.c_double),
+                   ("ftran_bytes", C.c_double), ("ftran_ms", C.c_double), ("ftran_launches", C.c_uint64),
+                   ("iter_ms", C.c_double), ("iter_samples", C.c_uint64)])
 
 
 class MlpIterInfo(C.Structure):  # include/minilp_hip.h: mlp_iter_info
@@ -86,6 +88,9 @@ def lib():
     sig("mlp_problem_constraint", u64, vp, u64, pu32, pdbl, u64, C.POINTER(i32), pdbl)
     sig("mlp_problem_solve_ex", i32, vp, C.POINTER(vp), i64, u32)
     sig("mlp_solution_continue", i32, vp, i64)
+    sig("mlp_solution_save_basis", u64, vp, i32, vp, u64)
+    sig("mlp_problem_solve_from_basis", i32, vp, vp, u64, C.POINTER(vp), i64, u32)
+    sig("mlp_solution_set_sampling", i32, vp, i32)
     sig("mlp_solution_budget_exhausted", i32, vp)
     sig("mlp_solution_reinvert", i32, vp, pdbl)
     sig("mlp_solution_enable_sharding", i32, vp, i32, i32, C.c_char_p)
@@ -260,6 +265,15 @@ class Problem:
         _raise(lib().mlp_problem_solve_ex(self._h, C.byref(out), budget, (1 if trace else 0) | (2 if profile else 0)))
         return Solution(out)
 
+    def solve_from_basis(self, blob, budget=-1, trace=False, profile=False):
+        """Build the solver for this problem, install a basis saved by `Solution.save_basis` and continue."""
+        blob = bytes(blob)
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        out = C.c_void_p()
+        _raise(lib().mlp_problem_solve_from_basis(self._h, C.cast(buf, C.c_void_p), len(blob), C.byref(out), budget,
+                                                  (1 if trace else 0) | (2 if profile else 0)))
+        return Solution(out)
+
 
 class Solution:
     """lib.rs:313-424.  Mutators consume self like the Rust receivers and return the new Solution;
@@ -327,6 +341,19 @@ class Solution:
         h = self._take()
         _raise(lib().mlp_solution_add_gomory_cut(C.byref(h), int(var)))
         return Solution(h)
+
+    def save_basis(self, mode=2):
+        """Basis checkpoint as bytes (include/minilp_hip.h): 0 sets + flags + x_N, 1 + f32 weights, 2 full f64 state."""
+        n = lib().mlp_solution_save_basis(self._h, int(mode), None, 0)
+        if n == 0:
+            raise InternalError(-1, lib().mlp_last_error().decode())
+        buf = (C.c_char * n)()
+        if lib().mlp_solution_save_basis(self._h, int(mode), C.cast(buf, C.c_void_p), n) != n:
+            raise InternalError(-1, lib().mlp_last_error().decode())
+        return bytes(buf)
+
+    def set_sampling(self, every_iteration):
+        _raise(lib().mlp_solution_set_sampling(self._h, 1 if every_iteration else 0))
 
     # --- engine-level controls (fixed pivot budget, stats, trace)
     def continue_solve(self, budget):

@@ -116,6 +116,7 @@ int mlp_problem_solve_ex(const mlp_problem* p, mlp_solution** out, int64_t budge
         s->eng->pivot_budget = budget;
         s->eng->trace = flags & 1u;
         s->eng->profile = flags & 2u;
+        s->eng->sample_every = (flags & 4u) ? 1 : 0;
         s->eng->try_new(p->pd);      // lib.rs:292-297
         s->eng->initial_solve();     // lib.rs:298
     });
@@ -124,6 +125,40 @@ int mlp_problem_solve_ex(const mlp_problem* p, mlp_solution** out, int64_t budge
     return st;
 }
 int mlp_problem_solve(const mlp_problem* p, mlp_solution** out) { return mlp_problem_solve_ex(p, out, -1, 0); }
+int mlp_problem_solve_from_basis(const mlp_problem* p, const void* blob, uint64_t len, mlp_solution** out, int64_t budget,
+                                 uint32_t flags) {
+    *out = nullptr;
+    mlp_solution* s = new mlp_solution();
+    int st = guarded([&] {
+        s->eng = new Engine();
+        s->eng->pivot_budget = budget;
+        s->eng->trace = flags & 1u;
+        s->eng->profile = flags & 2u;
+        s->eng->sample_every = (flags & 4u) ? 1 : 0;
+        s->eng->try_new(p->pd);
+        s->eng->load_basis(static_cast<const uint8_t*>(blob), (size_t)len);
+        s->eng->initial_solve();
+    });
+    if (st != 0) delete s;
+    else *out = s;
+    return st;
+}
+uint64_t mlp_solution_save_basis(const mlp_solution* s, int mode, void* buf, uint64_t cap) {
+    uint64_t need = 0;
+    int st = guarded([&] {
+        if (!s) throw MlpError(MLP_EINVAL, "NULL solution");
+        std::vector<uint8_t> b = s->eng->save_basis(mode);
+        need = b.size();
+        if (buf && cap >= need) std::memcpy(buf, b.data(), b.size());
+    });
+    return st == 0 ? need : 0;
+}
+int mlp_solution_set_sampling(mlp_solution* s, int every_iteration) {
+    return guarded([&] {
+        if (!s) throw MlpError(MLP_EINVAL, "NULL solution");
+        s->eng->sample_every = every_iteration ? 1 : 0;
+    });
+}
 int mlp_solution_continue(mlp_solution* s, int64_t budget) {
     return guarded([&] {
         s->eng->pivot_budget = budget;
@@ -183,7 +218,7 @@ void mlp_solution_free(mlp_solution* s) { delete s; }
 double mlp_solution_objective(const mlp_solution* s) {  // lib.rs:334-339
     if (!s) return std::nan("");
     double v = 0.0;
-    guarded([&] { v = s->eng->cur_obj_val(); });
+    if (guarded([&] { v = s->eng->cur_obj_val(); }) != MLP_OK) return std::nan("");  // HIP failure: never a plausible 0
     return s->eng->direction == 1 ? -v : v;
 }
 uint32_t mlp_solution_num_vars(const mlp_solution* s) { return s ? (uint32_t)s->eng->num_vars : 0; }
@@ -242,7 +277,6 @@ int mlp_solution_add_gomory_cut(mlp_solution** s, uint32_t var) {
 
 void mlp_solution_stats(const mlp_solution* s, mlp_stats* o) {
     Engine* e = s->eng;
-    guarded([&] { e->resolve_events(); });
     const Stats& t = e->stats;
     std::memset(o, 0, sizeof(*o));
     o->iterations = t.iterations; o->basis_changes = t.basis_changes; o->bound_flips = t.bound_flips;
@@ -255,6 +289,8 @@ void mlp_solution_stats(const mlp_solution* s, mlp_stats* o) {
     o->banded_sweep = e->banded_active() ? 1 : 0;
     o->solve_wall_s = t.solve_wall_s;
     o->max_pivot_err = t.max_pivot_err;
+    o->ftran_bytes = t.ftran_bytes; o->ftran_ms = t.ftran_ms; o->ftran_launches = t.ftran_launches;
+    o->iter_ms = t.iter_ms; o->iter_samples = t.iter_samples;
     for (int i = 0; i < 5; ++i) o->kase[i] = t.kase[i];
 }
 void mlp_solution_reset_stats(mlp_solution* s) {

@@ -116,6 +116,11 @@ struct Stats {
     uint64_t iterations = 0, basis_changes = 0, bound_flips = 0, primal_iters = 0, dual_iters = 0, reinversions = 0;
     double fused_bytes = 0, fused_ms = 0, sweep_bytes = 0, sweep_ms = 0;
     uint64_t fused_launches = 0, sweep_launches = 0, final_refreshes = 0;
+    // FTRAN of the entering column (head + gather + F push): HIP-event time and algorithmic bytes
+    double ftran_bytes = 0, ftran_ms = 0;
+    uint64_t ftran_launches = 0;
+    double iter_ms = 0;  // whole sampled iterations (first kernel to last), HIP events
+    uint64_t iter_samples = 0;
     double update_ms = 0;
     uint64_t update_launches = 0;
     double solve_wall_s = 0;
@@ -141,6 +146,11 @@ public:
     double cur_obj_val();                                                   // solver.rs:51
     Engine* clone();                                                        // #[derive(Clone)] solver.rs:14
     double reinvert(bool replace);  // from-scratch nucleus inversion; returns max |W - W_fresh|
+    // Basis checkpoint (include/minilp_hip.h: mlp_solution_save_basis / mlp_problem_solve_from_basis).
+    // mode 0: basic / non-basic sets, flags and x_N; 1: + steepest-edge weights as f32; 2: + x_B, d, gamma,
+    // beta, objective as f64 (a loaded solve continues pivot for pivot).
+    std::vector<uint8_t> save_basis(int mode);
+    void load_basis(const uint8_t* blob, size_t len);  // call after try_new on the same problem
     void enable_sharding(int rank, int world, const char* shm_name);  // column-block pricing across ranks
     bool sharded() const { return shard_world > 1; }
 
@@ -150,6 +160,7 @@ public:
     bool budget_exhausted = false;
     bool resume_in_optimize = false;
     bool trace = false, profile = false;
+    int sample_every = 0;  // profile mode: 0 = default cadence (every 8th / 4th batch), 1 = every iteration is a sampled eager one
     std::vector<PivotRecord> trace_log;
     Stats stats;
     void resolve_events() {}
@@ -251,7 +262,8 @@ private:
     hipGraph_t ggraph[2][2][2] = {};
     Geom ggeom[2][2][2];
     uint64_t graph_batches_in_geom = 0;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // sweep0/1, fused0/1, update0/1
+    hipEvent_t ev[10] = {};  // sweep0/1, fused0/1, update0/1, ftran0/1, iteration0/1
+    size_t nnz_nucleus_cols();  // non-zeros of the nucleus basic columns (algorithmic bytes of the F products)
     void drop_graphs();
     hipGraphExec_t get_graph(int phase, int multi);
 

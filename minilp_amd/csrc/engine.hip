@@ -13,9 +13,11 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <climits>
 #include <cstring>
 #include <limits>
 #include <map>
+#include <memory>
 #include <mutex>
 
 #include <fcntl.h>
@@ -133,13 +135,18 @@ void Engine::acquire_runtime() {
                 return;
             }
     }
-    HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    HIPCHECK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
-    for (int i = 0; i < 3; ++i) {
-        HIPCHECK(hipEventCreateWithFlags(&evFork[i], hipEventDisableTiming));
-        HIPCHECK(hipEventCreateWithFlags(&evJoin[i], hipEventDisableTiming));
+    try {
+        HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIPCHECK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+        for (int i = 0; i < 3; ++i) {
+            HIPCHECK(hipEventCreateWithFlags(&evFork[i], hipEventDisableTiming));
+            HIPCHECK(hipEventCreateWithFlags(&evJoin[i], hipEventDisableTiming));
+        }
+        HIPCHECK(hipHostMalloc((void**)&h_ctl, sizeof(Ctl), hipHostMallocDefault));
+    } catch (...) {
+        release_runtime();  // destroys what was created so far (the destructor does not run for a throwing constructor)
+        throw;
     }
-    HIPCHECK(hipHostMalloc((void**)&h_ctl, sizeof(Ctl), hipHostMallocDefault));
 }
 void Engine::release_runtime() {  // both streams are idle (synchronised by the destructor)
     RtBundle b;
@@ -440,12 +447,25 @@ void Engine::ensure_nucleus_cap(int need) {
     if (need <= cap_) return;
     flush_lowrank();  // pending rank-1 terms are folded before the buffers move
     HIPCHECK(hipStreamSynchronize(st));
-    int ncap = std::max(256, cap_ * 2);
-    while (ncap < need) ncap *= 2;
+    long ncap_l = std::max(256L, (long)cap_ * 2);
+    while (ncap_l < need) ncap_l *= 2;
+    // geometric growth, but never beyond the number of rows (rounded up to the column tile of the fused pass):
+    // a 100 000-row model whose nucleus passes 65 536 slots gets a 100 352-slot W, not a 131 072-slot one
+    const long m_cap = (((long)m_ + FW_TC - 1) / FW_TC) * FW_TC;
+    if (ncap_l > m_cap && m_cap >= need) ncap_l = m_cap;
+    const int ncap = (int)ncap_l;
     DevBuf<double> nW;
     const int old_ld = ld();
     const int nld = ncap + pad_for(ncap);
-    nW.alloc_exact((size_t)ncap * nld);
+    try {
+        nW.alloc_exact((size_t)ncap * nld);
+    } catch (MlpError& e) {
+        // the dense nucleus inverse is the memory wall of this design (8 k^2 bytes): report it as
+        // such instead of a bare HIP error; the solution stays valid at its current capacity
+        throw MlpError(-5, "nucleus inverse does not fit: " + std::to_string(ncap) + " x " + std::to_string(nld) +
+                               " doubles (" + std::to_string(((size_t)ncap * nld * 8) >> 20) + " MiB) for a nucleus of " +
+                               std::to_string(need) + " columns; " + e.what());
+    }
     if (k_ > 0)
         HIPCHECK(hipMemcpy2DAsync(nW.p, (size_t)nld * sizeof(double), d_W.p, (size_t)old_ld * sizeof(double),
                                   (size_t)k_ * sizeof(double), (size_t)k_, hipMemcpyDeviceToDevice, st));
@@ -743,8 +763,10 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     // previous iteration's update kernel, or by the standalone pricing kernel at batch start.
     switch (stage) {
     case STAGE_FTRAN:
+        if (with_events) HIPCHECK(hipEventRecord(ev[6], st));
         if (phase == 0) launch_ftran_prep(dv, 1, st);  // K2 head: entering column scalars, singleton rows, list
         launch_ftran_gather(dv, g, st);                // K2: alpha_q = B^-1 a_q (dual: the head ran in RATIO)
+        if (with_events) HIPCHECK(hipEventRecord(ev[7], st));
         if (phase == 1) {
             launch_post_ftran(dv, g, pse, st);         // alpha_sq, y_S, partition plan
             if (pse) launch_btran_rhs(dv, g, st);      // tK
@@ -789,7 +811,17 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     }
 }
 void Engine::record_iteration(int phase, bool with_events) {
+    if (with_events) HIPCHECK(hipEventRecord(ev[8], st));
     for (int i = 0; i < 6; ++i) launch_stage(phase, kStageOrder[phase][i], with_events);
+    if (with_events) HIPCHECK(hipEventRecord(ev[9], st));
+}
+size_t Engine::nnz_nucleus_cols() {
+    size_t s = 0;
+    for (int p = 0; p < m_; ++p) {
+        const int c = col_nnz(h_basic_vars[p]);
+        if (c != 1) s += (size_t)c;
+    }
+    return s;
 }
 
 // ------------------------------------------------------------------ engine-level stepping
@@ -970,7 +1002,7 @@ int Engine::run_loop(int phase) {
         // profile mode: every 8th batch is ONE eager iteration bracketed by HIP events on the
         // launch stream (sweep and fused pass), the others are graph replays as usual
         const bool long_run = use_graph && graph_iters > 1 && graph_batches_in_geom >= 8;
-        const bool sample = profile && (batches_run % (long_run ? 4 : 8) == 0);
+        const bool sample = profile && (sample_every == 1 || batches_run % (long_run ? 4 : 8) == 0);
         batches_run += 1;
         // Capturing a graph costs milliseconds and is invalidated by every add_constraint (m changes),
         // so short warm-start re-solves run eagerly; the graph is captured once the same geometry has
@@ -1013,6 +1045,7 @@ int Engine::run_loop(int phase) {
         }
         const size_t nnz_before = nnz_nonbasic;
         const int k_before = k_;
+        const size_t nnz_nuc_before = sample ? nnz_nucleus_cols() : 0;
         pull_ctl();
         int res = process_records(phase, B);
         if (sample && h_ctl->ring_n >= 1 && h_ctl->ring[0].status == ITER_PIVOT) {
@@ -1033,6 +1066,18 @@ int Engine::run_loop(int phase) {
             if (hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) {
                 stats.update_ms += ms;
                 stats.update_launches += 1;
+            }
+            if (hipEventElapsedTime(&ms, ev[6], ev[7]) == hipSuccess) {
+                // FTRAN of the entering column (as built): the listed columns of W (8 k |list|),
+                // the column itself and the F push through the nucleus columns (12 B per entry)
+                stats.ftran_ms += ms;
+                stats.ftran_bytes += 8.0 * (double)k_before * (double)h_ctl->ring[0].klist_n + 12.0 * (double)nnz_nuc_before +
+                                     12.0 * (double)col_nnz(h_ctl->ring[0].entering_var);
+                stats.ftran_launches += 1;
+            }
+            if (hipEventElapsedTime(&ms, ev[8], ev[9]) == hipSuccess) {
+                stats.iter_ms += ms;
+                stats.iter_samples += 1;
             }
             (void)hipGetLastError();  // an event pair that was not recorded this iteration is not an error
         }
@@ -1093,6 +1138,9 @@ void Engine::optimize() {
         if (res == ITER_UNBOUNDED) throw LpFail{2};
         if (res == ITER_SINGULAR) throw MlpError(-2, "singular basis (solver.rs:1301)");
         if (res == ITER_COMM) throw MlpError(-3, "sharded pricing: a peer rank did not answer (mailbox spin bound)");
+        if (res == ITER_STALL)
+            throw MlpError(-3, "primal ratio test: the in-kernel wait timed out (grid not co-resident on this device / partition); "
+                               "set MLP_RATIO_TWO_KERNELS=1");
         if (res != ITER_OPTIMAL) throw MlpError(-3, "primal loop ended with unexpected status " + std::to_string(res));
         // Like the reference (solver.rs:1073-1080) the reduced costs are updated incrementally, pivot after
         // pivot.  After a very long run (config 4: 10^6 pivots) they have drifted by ~1e-6, far above the
@@ -1457,11 +1505,181 @@ double Engine::reinvert(bool replace) {
     return diff;
 }
 
+
+// ------------------------------------------------------------------ basis checkpoint
+// The reference has no basis I/O; SURVEY §8(d) asks for "pivots from a saved mid-solve basis", which needs
+// one.  A checkpoint is a flat, self-describing blob:
+//   header | int32 basic_vars[m] | int32 nb_vars[n] | uint8 nb_flags[n] (padded to 8) | f64 x_N[n]
+//   mode 1: f32 gamma[n] | f32 beta[m] (padded to 8)        (steepest-edge weights, pricing heuristics)
+//   mode 2: f64 x_B[m] | f64 d[n] | f64 gamma[n] | f64 beta[m]
+// Loading re-inverts the nucleus from A on the device (the counterpart of BasisSolver::reset,
+// solver.rs:1286-1303).  Mode 2 restores every per-pivot vector bit for bit, so the loaded solve continues
+// pivot for pivot; modes 0/1 recompute x_B = B^-1 (b - N x_N) (solver.rs:1177-1197) and the reduced costs
+// (solver.rs:1199-1231) from the basis and take the weights from the blob (mode 1) or reset them to 1.
+namespace {
+struct BasisHeader {
+    char magic[8];
+    uint32_t version, mode;
+    uint64_t m, n;
+    uint32_t flags;  // bit0 primal_feasible, bit1 dual_feasible, bit2 enable_pse, bit3 enable_dse, bit4 resume_in_optimize
+    uint32_t pad;
+    double obj;
+    uint64_t pivots;
+};
+constexpr char kBasisMagic[8] = {'M', 'L', 'P', 'B', 'A', 'S', 'I', 'S'};
+inline size_t pad8(size_t x) { return (x + 7) & ~(size_t)7; }
+size_t basis_blob_size(int mode, size_t m, size_t n) {
+    size_t s = sizeof(BasisHeader) + pad8(4 * m) + pad8(4 * n) + pad8(n) + 8 * n;
+    if (mode == 1) s += pad8(4 * n) + pad8(4 * m);
+    if (mode == 2) s += 8 * (m + n + n + m);
+    return s;
+}
+}  // namespace
+std::vector<uint8_t> Engine::save_basis(int mode) {
+    if (mode < 0 || mode > 2) throw MlpError(-1, "save_basis: mode must be 0, 1 or 2");
+    if (shard_world > 1) throw MlpError(-1, "save_basis: not available on a sharded solution");
+    HIPCHECK(hipStreamSynchronize(st));
+    pull_ctl();
+    const size_t mm = (size_t)m_, nn = (size_t)num_vars;
+    std::vector<uint8_t> out(basis_blob_size(mode, mm, nn), 0);
+    BasisHeader h;
+    std::memset(&h, 0, sizeof(h));
+    std::memcpy(h.magic, kBasisMagic, 8);
+    h.version = 1; h.mode = (uint32_t)mode; h.m = mm; h.n = nn;
+    h.flags = (primal_feasible ? 1u : 0u) | (dual_feasible ? 2u : 0u) | (enable_pse ? 4u : 0u) | (enable_dse ? 8u : 0u) |
+              (resume_in_optimize ? 16u : 0u);
+    h.obj = h_ctl->it.obj;
+    h.pivots = stats.iterations;
+    uint8_t* p = out.data();
+    std::memcpy(p, &h, sizeof(h)); p += sizeof(h);
+    std::memcpy(p, h_basic_vars.data(), 4 * mm); p += pad8(4 * mm);
+    std::memcpy(p, h_nb_vars.data(), 4 * nn); p += pad8(4 * nn);
+    if (nn) HIPCHECK(hipMemcpy(p, d_nbflags.p, nn, hipMemcpyDeviceToHost));
+    p += pad8(nn);
+    if (nn) HIPCHECK(hipMemcpy(p, d_xN.p, 8 * nn, hipMemcpyDeviceToHost));
+    p += 8 * nn;
+    if (mode == 1) {
+        std::vector<double> g(nn), b(mm);
+        if (nn) HIPCHECK(hipMemcpy(g.data(), d_gamma.p, 8 * nn, hipMemcpyDeviceToHost));
+        if (mm) HIPCHECK(hipMemcpy(b.data(), d_beta.p, 8 * mm, hipMemcpyDeviceToHost));
+        float* f = reinterpret_cast<float*>(p);
+        for (size_t i = 0; i < nn; ++i) f[i] = (float)g[i];
+        p += pad8(4 * nn);
+        f = reinterpret_cast<float*>(p);
+        for (size_t i = 0; i < mm; ++i) f[i] = (float)b[i];
+        p += pad8(4 * mm);
+    } else if (mode == 2) {
+        if (mm) HIPCHECK(hipMemcpy(p, d_xB.p, 8 * mm, hipMemcpyDeviceToHost));
+        p += 8 * mm;
+        if (nn) HIPCHECK(hipMemcpy(p, d_d.p, 8 * nn, hipMemcpyDeviceToHost));
+        p += 8 * nn;
+        if (nn) HIPCHECK(hipMemcpy(p, d_gamma.p, 8 * nn, hipMemcpyDeviceToHost));
+        p += 8 * nn;
+        if (mm) HIPCHECK(hipMemcpy(p, d_beta.p, 8 * mm, hipMemcpyDeviceToHost));
+        p += 8 * mm;
+    }
+    return out;
+}
+void Engine::load_basis(const uint8_t* blob, size_t len) {
+    if (shard_world > 1) throw MlpError(-1, "load_basis: not available on a sharded solution");
+    if (!blob || len < sizeof(BasisHeader)) throw MlpError(-1, "load_basis: blob too short");
+    BasisHeader h;
+    std::memcpy(&h, blob, sizeof(h));
+    if (std::memcmp(h.magic, kBasisMagic, 8) != 0 || h.version != 1 || h.mode > 2)
+        throw MlpError(-1, "load_basis: not a basis blob of this library (magic / version / mode)");
+    const size_t mm = (size_t)m_, nn = (size_t)num_vars;
+    if (h.m != mm || h.n != nn)
+        throw MlpError(-1, "load_basis: the basis belongs to a model with " + std::to_string(h.m) + " kept rows and " +
+                               std::to_string(h.n) + " variables, this one has " + std::to_string(mm) + " and " + std::to_string(nn));
+    const int mode = (int)h.mode;
+    if (len < basis_blob_size(mode, mm, nn)) throw MlpError(-1, "load_basis: blob truncated");
+    const uint8_t* p = blob + sizeof(h);
+    std::vector<int> bv(mm), nv(nn);
+    std::memcpy(bv.data(), p, 4 * mm); p += pad8(4 * mm);
+    std::memcpy(nv.data(), p, 4 * nn); p += pad8(4 * nn);
+    std::vector<uint8_t> flags(p, p + nn); p += pad8(nn);
+    std::vector<double> xN(nn);
+    std::memcpy(xN.data(), p, 8 * nn); p += 8 * nn;
+    // the two sets must partition the variables
+    std::vector<int> loc(N_, INT32_MIN);
+    for (size_t r = 0; r < mm; ++r) {
+        const int v = bv[r];
+        if (v < 0 || v >= N_ || loc[v] != INT32_MIN) throw MlpError(-1, "load_basis: basic_vars is not a set of variables of this model");
+        loc[v] = (int)r;
+    }
+    for (size_t c = 0; c < nn; ++c) {
+        const int v = nv[c];
+        if (v < 0 || v >= N_ || loc[v] != INT32_MIN) throw MlpError(-1, "load_basis: nb_vars overlaps basic_vars or repeats a variable");
+        loc[v] = -1 - (int)c;
+    }
+    HIPCHECK(hipStreamSynchronize(st));
+    h_basic_vars = bv;
+    h_nb_vars = nv;
+    h_var_loc = loc;
+    h_nb_fixed.assign(nn, 0);
+    std::vector<double> loB(mm), hiB(mm);
+    for (size_t r = 0; r < mm; ++r) { loB[r] = h_lo[bv[r]]; hiB[r] = h_hi[bv[r]]; }
+    nnz_nonbasic = 0;
+    for (size_t c = 0; c < nn; ++c) {
+        h_nb_fixed[c] = (flags[c] & NB_FIXED) ? 1 : 0;
+        nnz_nonbasic += (size_t)col_nnz(nv[c]);
+    }
+    d_basic_vars.upload(h_basic_vars, st); d_nb_vars.upload(h_nb_vars, st); d_var_loc.upload(h_var_loc, st);
+    d_loB.upload(loB, st); d_hiB.upload(hiB, st);
+    d_nbflags.upload(flags, st); d_xN.upload(xN, st);
+    HIPCHECK(hipStreamSynchronize(st));  // local staging buffers
+    sync_view();
+    launch_init_nb_rng(hview, geom(), st);
+    rebuild_inverse();  // classify singleton / nucleus columns, invert the nucleus from A on the device
+    enable_dse = (h.flags & 8u) != 0;
+    if (mode == 2) {
+        std::vector<double> xB(mm), d(nn), gm(nn), bt(mm);
+        std::memcpy(xB.data(), p, 8 * mm); p += 8 * mm;
+        std::memcpy(d.data(), p, 8 * nn); p += 8 * nn;
+        std::memcpy(gm.data(), p, 8 * nn); p += 8 * nn;
+        std::memcpy(bt.data(), p, 8 * mm); p += 8 * mm;
+        d_xB.upload(xB, st); d_d.upload(d, st); d_gamma.upload(gm, st); d_beta.upload(bt, st);
+        HIPCHECK(hipMemcpyAsync(&d_ctl.p->it.obj, &h.obj, sizeof(double), hipMemcpyHostToDevice, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        primal_feasible = (h.flags & 1u) != 0;
+        dual_feasible = (h.flags & 2u) != 0;
+        enable_pse = (h.flags & 4u) != 0;
+        resume_in_optimize = (h.flags & 16u) != 0;
+    } else {
+        std::vector<double> gm(nn, 1.0), bt(mm, 1.0);
+        if (mode == 1) {
+            const float* f = reinterpret_cast<const float*>(p);
+            for (size_t i = 0; i < nn; ++i) gm[i] = (double)f[i];
+            p += pad8(4 * nn);
+            f = reinterpret_cast<const float*>(p);
+            for (size_t i = 0; i < mm; ++i) bt[i] = (double)f[i];
+            p += pad8(4 * mm);
+        }
+        d_gamma.upload(gm, st); d_beta.upload(bt, st);
+        HIPCHECK(hipStreamSynchronize(st));
+        recalc_basic_vals();                       // x_B = B^-1 (b - N x_N), two refinement steps
+        primal_feasible = basic_values_feasible();
+        dual_feasible = (h.flags & 2u) != 0;
+        enable_pse = (h.flags & 4u) != 0;
+        if (!primal_feasible && !dual_feasible)
+            throw MlpError(-1, "load_basis: the basis is neither primal feasible nor saved as dual feasible (the artificial-"
+                               "objective phase needs a mode-2 checkpoint)");
+        recalc_obj_coeffs();                       // d and the objective of the real cost vector
+        resume_in_optimize = primal_feasible && !dual_feasible;
+    }
+    iters_since_recalc = 0;
+    iters_since_polish = 0;
+    values_dirty = true;
+    budget_exhausted = false;
+    HIPCHECK(hipStreamSynchronize(st));
+}
+
 // ------------------------------------------------------------------ clone (lib.rs:313 / solver.rs:14)
 Engine* Engine::clone() {
     flush_lowrank();
     pull_maps();
-    Engine* e = new Engine();
+    std::unique_ptr<Engine> owner(new Engine());  // a throw below (hipMalloc failure, ...) must not leak the half-built clone
+    Engine* e = owner.get();
     e->num_vars = num_vars; e->direction = direction;
     e->m_ = m_; e->N_ = N_;
     e->h_obj = h_obj; e->h_lo = h_lo; e->h_hi = h_hi; e->h_rhs = h_rhs;
@@ -1510,7 +1728,7 @@ Engine* Engine::clone() {
     HIPCHECK(hipStreamSynchronize(s2));
     std::memcpy(e->h_ctl, h_ctl, sizeof(Ctl));
     e->values_dirty = true;
-    return e;
+    return owner.release();
 }
 
 // ------------------------------------------------------------------ white-box state (tests)

@@ -24,6 +24,7 @@ enum IterStatus : int {
     ITER_SINGULAR = 6,    // partition plan found two singleton columns on one row
     ITER_NONE = 7,        // nothing recorded (halted replay)
     ITER_COMM = 8,        // sharded mode: a peer did not answer within the spin bound
+    ITER_STALL = 9,       // an in-kernel wait between two passes of one launch timed out (grid not co-resident)
 };
 
 // Per-iteration scalars, written by kernels.
@@ -59,6 +60,7 @@ struct StructUpdate {  // how the (P_K, R_K) partition changes 
 
 struct PivotRec {  // one per executed iteration, host reads them back in batches
     int status, phase, q, r, entering_var, leaving_var, kase, k_after;
+    int klist_n, blist_n;  // lengths of the FTRAN / BTRAN input lists of this iteration (algorithmic bytes)
     double pivot_coeff, obj;
 };
 constexpr int RING = 64;

@@ -264,6 +264,8 @@ __device__ __forceinline__ void push_rec(Ctl* c, int phase) {  // single thread
         r.leaving_var = c->it.leaving_var;
         r.kase = c->up.kase;
         r.k_after = c->k;
+        r.klist_n = c->it.klist_n;
+        r.blist_n = c->it.blist_n;
         r.pivot_coeff = c->it.pivot_coeff;
         r.obj = c->it.obj;
     }
@@ -1042,7 +1044,7 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_fused(DevView v, int use_p
     __syncthreads();
     if (s_gave_up) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {
-            c->it.status = ITER_SINGULAR;
+            c->it.status = ITER_STALL;  // not a property of the model: the grid was not co-resident (see launch_ratio_primal)
             c->halt = 1;
             push_rec(c, 0);
         }
@@ -2326,7 +2328,20 @@ void launch_ftran_gather(const DevView& dv, const Geom& g, hipStream_t st) {
 void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st) {
     const int nb = grid_for(g.m);
     static const bool two_kernels = std::getenv("MLP_RATIO_TWO_KERNELS") != nullptr;
-    if (!two_kernels && (long)nb * BLK * 4 >= (long)g.m) {  // every element fits the fused kernel's registers
+    // The fused kernel's blocks wait inside the launch for its last-arriving block, which is only safe while the
+    // WHOLE grid is co-resident: bound the grid by what this device (or partition: CPX mode, CU mask) can hold at
+    // once, per the occupancy calculator, with a 2x margin for kernels of other queues sharing the CUs.
+    static int max_coresident = -1;
+    if (max_coresident < 0) {
+        int dev = 0, per_cu = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_ratio_primal_fused), BLK, 0) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+            max_coresident = per_cu * cus / 2;
+        else
+            max_coresident = 0;  // unknown: always take the two-kernel path
+    }
+    if (!two_kernels && nb <= max_coresident && (long)nb * BLK * 4 >= (long)g.m) {  // every element fits the fused kernel's registers
         hipLaunchKernelGGL(k_ratio_primal_fused, dim3(nb), dim3(BLK), 0, st, dv, use_pse);  // both passes + BTRAN head + plan
         return;
     }

@@ -3,6 +3,7 @@
 // [BOUNDS] / ENDATA, '*' comments, first RHS/RANGES/BOUNDS vector only, bound types UP LO FX FR,
 // negative UP without LO => (-inf, ub] (mps.rs:299), a RANGES entry => a >= row and a <= row
 // (mps.rs:306-321).  Errors carry the line number like the reference's io::Error text.
+#include <charconv>
 #include <cmath>
 #include <cstdlib>
 #include <limits>
@@ -28,9 +29,28 @@ struct Col {
     throw MlpError(-1, "line " + std::to_string(line) + ": " + msg);
 }
 double to_f64(const std::string& s, size_t line) {
-    char* end = nullptr;
-    double v = std::strtod(s.c_str(), &end);
-    if (end == s.c_str() || *end != '\0') fail(line, "couldn't parse float from string: `" + s + "`");
+    // Locale-independent like the reference's f64::from_str (mps.rs:330-336): std::from_chars ignores LC_NUMERIC
+    // (strtod would read "1,5" under a comma locale and stop at the '.' of "1.5") and rejects hex floats.
+    const char* b = s.c_str();
+    const char* e = b + s.size();
+    if (b != e && *b == '+') {  // from_str accepts one leading '+', from_chars does not
+        ++b;
+        if (b != e && (*b == '+' || *b == '-')) fail(line, "couldn't parse float from string: `" + s + "`");
+    }
+    double v = 0.0;
+    const std::from_chars_result r = std::from_chars(b, e, v, std::chars_format::general);
+    if (r.ptr != e || b == e) fail(line, "couldn't parse float from string: `" + s + "`");
+    if (r.ec == std::errc::result_out_of_range) {  // from_str saturates: 1e999 -> inf, 1e-999 -> 0
+        const bool neg = *b == '-';
+        const size_t epos = s.find_first_of("eE");
+        bool overflow;
+        if (epos != std::string::npos) overflow = s.find('-', epos) == std::string::npos;
+        else overflow = s.find('.') == std::string::npos || s.find('.') > 300;
+        v = overflow ? std::numeric_limits<double>::infinity() : 0.0;
+        if (neg) v = -v;
+    } else if (r.ec != std::errc()) {
+        fail(line, "couldn't parse float from string: `" + s + "`");
+    }
     return v;
 }
 }  // namespace

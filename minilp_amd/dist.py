@@ -70,3 +70,8 @@ def combine_candidates(cands):
         if best[1] < 0 or score > best[0] or (score == best[0] and pos < best[1]):
             best = (score, pos)
     return best
+
+
+def transport_name(solution=None):
+    """Human-readable name of the per-pivot exchange transport (bench.py's config.parallelism)."""
+    return "a host-mapped shared-memory mailbox (PCIe)"

@@ -202,7 +202,64 @@ def test_bench_contract_pieces_that_need_no_gpu():
     sys.path.insert(0, root)
     import bench
     a = types.SimpleNamespace(rows=100000, cols=100000, nnz_per_row=100, seed=4)
-    t = bench.pmc_traffic(a, "sweep")
-    assert t is not None and 1.0e8 < t < 3.0e8          # HBM bytes per launch of the dominant kernel
-    assert bench.pmc_traffic(types.SimpleNamespace(rows=10, cols=10, nnz_per_row=2, seed=1), "sweep") is None
+    t, src = bench.pmc_traffic(a, "sweep")
+    assert t is not None and 1.0e8 < t < 3.0e8 and src.endswith(".json")   # HBM bytes per launch of the dominant kernel
+    assert bench.pmc_traffic(types.SimpleNamespace(rows=10, cols=10, nnz_per_row=2, seed=1), "sweep")[0] is None
     assert bench.HBM_PEAK_GBS == 8000.0
+    rec = bench.full_solve_record()
+    assert rec and rec["total_solve_wall_s"] > 0 and rec["pivots"] > 10 ** 6 and rec["source"].startswith("profiles/")
+
+
+def test_mid_solve_basis_fixtures_are_wellformed():
+    """tests/golden/cfg4_basis_p*.bin.gz (made on the GPU by tools/make_cfg4_basis.py): mode-1 checkpoints of
+    config 4 whose basic / non-basic sets partition the 200 000 variables; bench.py's mid / late windows load them."""
+    import gzip
+    import json
+    import struct
+    import numpy as np
+    import bench
+    idx = [json.loads(l) for l in open(os.path.join(ROOT, "tests", "golden", "cfg4_basis_index.jsonl"))]
+    for path, rec in zip((bench.MID_BASIS, bench.LATE_BASIS), idx):
+        blob = gzip.open(path, "rb").read()
+        assert os.path.basename(path) == rec["file"] and len(blob) == rec["raw_bytes"]
+        magic, version, mode, m, n, flags, _pad, obj, pivots = struct.unpack_from("<8sIIQQIIdQ", blob, 0)
+        assert (magic, version, mode, m, n) == (b"MLPBASIS", 1, 1, 100000, 100000)
+        assert pivots == rec["pivots"] and abs(obj + rec["objective"]) <= 1e-9 * abs(obj)   # stored for the minimised form
+        assert flags & 1 and not flags & 2 and flags & 4                                    # primal phase, steepest edge on
+        bv = np.frombuffer(blob, dtype=np.int32, count=m, offset=56)
+        nv = np.frombuffer(blob, dtype=np.int32, count=n, offset=56 + 4 * m)
+        both = np.sort(np.concatenate([bv, nv]))
+        assert (both == np.arange(m + n)).all()
+        structural_basics = int((bv < n).sum())
+        assert rec["nucleus_size"] <= structural_basics <= rec["nucleus_size"] + 64   # nucleus = non-singleton basic columns
+
+
+def _mps_with_number(tok):
+    return f"NAME t\nROWS\n N c\n L r\nCOLUMNS\n x c 1 r {tok}\nRHS\n rhs r 4\nENDATA\n"
+
+
+def test_mps_numbers_parse_like_f64_from_str_whatever_the_locale():
+    """mps.rs:330-336 parses numbers with f64::from_str: locale-independent, no hex floats, a leading '+' is fine,
+    out-of-range magnitudes saturate.  (strtod is LC_NUMERIC-dependent and accepts 0x1p3.)"""
+    import locale
+    old = locale.setlocale(locale.LC_NUMERIC)
+    switched = None
+    for name in ("de_DE.UTF-8", "de_DE.utf8", "fr_FR.UTF-8", "fr_FR.utf8", "ru_RU.UTF-8"):
+        try:
+            locale.setlocale(locale.LC_NUMERIC, name)  # a comma-decimal locale, if the image has one
+            switched = name
+            break
+        except locale.Error:
+            continue
+    try:
+        for tok, want in [("1.5", 1.5), ("+1.5", 1.5), ("-2.5e-1", -0.25), (".5", 0.5), ("1.", 1.0), ("1e999", INF), ("-1e999", -INF),
+                          ("1e-999", 0.0), ("inf", INF), ("1E2", 100.0)]:
+            f = M.MpsFile.parse(_mps_with_number(tok), M.MINIMIZE)
+            (idx, val, op, rhs), = f.problem.constraints()
+            assert val[0] == want, (tok, val[0], switched)
+        for bad in ("0x1p3", "1,5", "1.5x", "+-1", "--1", "e5", "+"):
+            with pytest.raises(ValueError) as e:
+                M.MpsFile.parse(_mps_with_number(bad), M.MINIMIZE)
+            assert "parse float" in str(e.value), bad
+    finally:
+        locale.setlocale(locale.LC_NUMERIC, old)
