@@ -7,7 +7,7 @@ rows = 2, Stoer–Wagner min cut to find violated subtour rows (cut weight < 2 -
 branching with `fix_var` on cloned solutions.  Written against the Problem/Solution API only, so it
 runs on any backend module that mirrors it (`minilp_amd` on the GPU, or the CPU oracle in tests).
 
-usage: python examples/tsp.py tests/golden/bn130.tsp [--nodes N] [--backend hip|oracle]
+usage: python examples/tsp.py tests/golden/bn130.tsp [--nodes N] [--max-bb-nodes K]
 """
 import argparse
 import math
@@ -200,15 +200,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("file")
     ap.add_argument("--nodes", type=int, default=None, help="use only the first N cities")
-    ap.add_argument("--backend", default="hip", choices=["hip", "oracle"])
     ap.add_argument("--max-bb-nodes", type=int, default=None)
     a = ap.parse_args()
     import os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    if a.backend == "hip":
-        import minilp_amd as backend
-    else:
-        from oracle import minilp_oracle as backend
+    import minilp_amd as backend  # the MI355X engine; there is no CPU back end (tests pass their checker to TspSolver)
     name, pts = read_tsplib(a.file, a.nodes)
     t0 = time.time()
     s = TspSolver(backend, pts, log=lambda m: print("[%.1fs] %s" % (time.time() - t0, m), flush=True))

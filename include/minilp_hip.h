@@ -102,13 +102,18 @@ int mlp_solution_reinvert(mlp_solution* s, double* max_diff);
 
 /* Column-block sharding of the pricing path across the GPUs of one node (one process per GPU,
  * DESIGN.md §6).  Every rank builds the SAME problem, calls mlp_problem_solve_ex(budget = 0), then
- * this function with its rank, the world size and the name of a POSIX shared-memory mailbox of
- * 512 * world zeroed bytes created by the launcher, and then the same sequence of
+ * this function with its rank, the world size (<= 16) and the name of a POSIX shared-memory object of
+ * 640 * world zeroed bytes created by the launcher (the rendezvous), and then the same sequence of
  * mlp_solution_continue calls.  Rank r owns non-basic positions [n*r/world, n*(r+1)/world): its
- * tableau-row sweep, d/gamma update and pricing scan cover only that block; candidates are exchanged
- * through the mailbox (primal: pricing all-gather + ratio decision; dual: leaving row, pass-1 minimum, pass-2
- * candidate).  Primal and dual loops; the Solution mutators are refused. */
+ * tableau-row sweep, d/gamma update and pricing scan cover only that block; candidates are exchanged once or
+ * twice per pivot (primal: pricing all-gather + ratio decision; dual: leaving row, pass-1 minimum, pass-2
+ * candidate) from inside the pivot kernels.  Transport: every rank keeps a mailbox in its own HBM, the peers map
+ * it through HIP IPC (the handles travel through the rendezvous object) and write their 64-byte records into it
+ * over xGMI; polling is local.  MLP_MAILBOX=host selects the older host-memory mailbox (PCIe) instead.  The call
+ * returns when every rank has mapped every mailbox (bounded waits: a missing rank is an error, MLP_EHIP).
+ * Primal and dual loops; the Solution mutators are refused.  mlp_solution_transport names the transport in use. */
 int mlp_solution_enable_sharding(mlp_solution* s, int rank, int world, const char* shm_name);
+const char* mlp_solution_transport(const mlp_solution* s);
 
 typedef struct mlp_stats {
     uint64_t iterations, basis_changes, bound_flips, primal_iters, dual_iters, reinversions;

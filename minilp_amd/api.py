@@ -94,6 +94,7 @@ def lib():
     sig("mlp_solution_budget_exhausted", i32, vp)
     sig("mlp_solution_reinvert", i32, vp, pdbl)
     sig("mlp_solution_enable_sharding", i32, vp, i32, i32, C.c_char_p)
+    sig("mlp_solution_transport", C.c_char_p, vp)
     sig("mlp_solution_clone", vp, vp)
     sig("mlp_solution_free", None, vp)
     sig("mlp_solution_objective", dbl, vp)
@@ -366,6 +367,9 @@ class Solution:
     def enable_sharding(self, rank, world, shm_name):
         """Column-block sharding of the pricing path (include/minilp_hip.h); see minilp_amd.dist."""
         _raise(lib().mlp_solution_enable_sharding(self._h, int(rank), int(world), shm_name.encode()))
+
+    def transport(self):
+        return lib().mlp_solution_transport(self._h).decode()
 
     # ---- engine-level stepping (include/minilp_hip.h: mlp_engine_open / mlp_engine_stage)
     def engine_open(self):

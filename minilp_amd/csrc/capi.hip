@@ -205,6 +205,8 @@ int mlp_solution_enable_sharding(mlp_solution* s, int rank, int world, const cha
     return guarded([&] { s->eng->enable_sharding(rank, world, shm_name); });
 }
 
+const char* mlp_solution_transport(const mlp_solution* s) { return s ? s->eng->transport.c_str() : "none"; }
+
 mlp_solution* mlp_solution_clone(const mlp_solution* s) {
     mlp_solution* c = new mlp_solution();
     int st = guarded([&] { c->eng = s->eng->clone(); });

@@ -233,6 +233,14 @@ private:
     int shard_rank = 0, shard_world = 1;
     MailRec* d_mail = nullptr;
     void* mail_host = nullptr;
+    bool mail_registered = false;
+    void* own_box = nullptr;               // peer transport: this rank's mailbox in its own HBM
+    void* peer_box[MAX_WORLD] = {};        // ... and the peers' boxes as mapped through HIP IPC
+    int mail_fanout = 1;
+    void release_mailboxes();
+  public:
+    std::string transport = "none";        // human-readable name of the exchange transport
+  private:
     void* blas = nullptr;  // rocblas_handle for the blocked re-inversion
     size_t mail_bytes = 0;
     double refresh_tol = 1e-7;  // re-invert W when the two-way pivot check disagrees by more than this

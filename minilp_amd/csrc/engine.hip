@@ -256,10 +256,7 @@ Engine::~Engine() {
     for (auto& e : ev)
         if (e) (void)hipEventDestroy(e);
     if (blas) (void)rocblas_destroy_handle(reinterpret_cast<rocblas_handle>(blas));
-    if (mail_host) {
-        (void)hipHostUnregister(mail_host);
-        (void)munmap(mail_host, mail_bytes);
-    }
+    release_mailboxes();
     release_runtime();
 }
 void Engine::drop_graphs() {
@@ -394,6 +391,8 @@ DevView* Engine::sync_view() {
     v.ctl = d_ctl.p;
     v.nb_rng = d_nb_rng.p;
     v.rank = shard_rank; v.world = shard_world; v.mail = d_mail;
+    for (int r = 0; r < MAX_WORLD; ++r) v.mail_peer[r] = reinterpret_cast<MailRec*>(peer_box[r]);
+    v.mail_fanout = shard_world > 1 ? mail_fanout : 0; v.pad2 = 0;
     v.nb_lo = shard_world > 1 ? (int)((long)num_vars * shard_rank / shard_world) : 0;
     v.nb_hi = shard_world > 1 ? (int)((long)num_vars * (shard_rank + 1) / shard_world) : num_vars;
     if (std::memcmp(&old, &hview, sizeof(DevView)) != 0) {
@@ -476,7 +475,7 @@ void Engine::ensure_nucleus_cap(int need) {
     d_pos_of_kslot.ensure(ncap, keep, st); d_row_of_kslot.ensure(ncap, keep, st);
     d_aK.ensure(ncap, keep, st); d_rK.ensure(ncap, keep, st); d_tK.ensure(ncap, keep, st);
     d_tauK.ensure(ncap, keep, st); d_vK.ensure(ncap, keep, st);
-    int nstripes = (ncap + FW_TR - 1) / FW_TR + 1, nchunks = (ncap + FW_TC - 1) / FW_TC + 1;
+    int nstripes = (ncap + FW_TR - 1) / FW_TR + 1, nchunks = (ncap + 512 - 1) / 512 + 1;  // 512: column chunks of k_stream_w
     d_part_v.ensure((size_t)nstripes * nld, 0, st);
     d_part_tau.ensure((size_t)nchunks * nld, 0, st);
     d_U.ensure((size_t)LR_MAX * nld, 0, st);
@@ -539,32 +538,134 @@ void Engine::push_maps() {
 }
 
 // ------------------------------------------------------------------ column-block sharding
-// The mailbox is a POSIX shared-memory object created (zeroed) by the launcher; every rank maps it
-// and registers it with HIP so that kernels on every GPU read and write the same host pages.
+// Rendezvous: a POSIX shared-memory object created (zeroed) by the launcher, mapped by every rank:
+//   [0, 512 * world)                 host-transport mailbox (MLP_MAILBOX=host), registered with HIP
+//   [512 * world, 640 * world)       one 128-byte rendezvous record per rank: HIP IPC handle of its device box
+// Peer transport (default): every rank allocates its box in its OWN HBM (uncached, falling back to fine-grained),
+// publishes the IPC handle, opens the peers' handles (peer access is enabled lazily by hipIpcOpenMemHandle), and
+// the pivot kernels then write their 64-byte records straight into the peers' boxes over xGMI and poll locally.
+namespace {
+struct Rendezvous {  // 128 bytes
+    uint64_t ready;  // 1: handle valid, 2: every peer handle opened by this rank
+    int32_t device, pid;
+    hipIpcMemHandle_t handle;  // 64 bytes
+    uint8_t pad[128 - 8 - 8 - sizeof(hipIpcMemHandle_t)];
+};
+static_assert(sizeof(Rendezvous) == 128, "rendezvous record layout");
+constexpr size_t kHostBoxBytesPerRank = sizeof(MailRec) * 2 * MAIL_KINDS;  // 512
+bool wait_flag(volatile uint64_t* f, uint64_t want, double seconds) {
+    const double t0 = now_s();
+    while (__atomic_load_n(f, __ATOMIC_ACQUIRE) < want) {
+        if (now_s() - t0 > seconds) return false;
+        usleep(200);
+    }
+    return true;
+}
+}  // namespace
+void Engine::release_mailboxes() {
+    for (int r = 0; r < MAX_WORLD; ++r) {
+        if (peer_box[r] && r != shard_rank) (void)hipIpcCloseMemHandle(peer_box[r]);
+        peer_box[r] = nullptr;
+    }
+    if (own_box) (void)hipFree(own_box);
+    own_box = nullptr;
+    if (mail_host) {
+        if (mail_registered) (void)hipHostUnregister(mail_host);
+        (void)munmap(mail_host, mail_bytes);
+    }
+    mail_host = nullptr;
+    mail_registered = false;
+    d_mail = nullptr;
+}
 void Engine::enable_sharding(int rank, int world, const char* shm_name) {
-    if (world < 1 || rank < 0 || rank >= world) throw MlpError(-1, "enable_sharding: bad rank/world");
+    if (world < 1 || world > MAX_WORLD || rank < 0 || rank >= world)
+        throw MlpError(-1, "enable_sharding: bad rank/world (at most " + std::to_string(MAX_WORLD) + " ranks)");
     HIPCHECK(hipStreamSynchronize(st));
+    release_mailboxes();
     if (world == 1) {
-        shard_rank = 0; shard_world = 1; d_mail = nullptr;
+        shard_rank = 0; shard_world = 1;
         view_dirty = true;
         return;
     }
-    size_t bytes = sizeof(MailRec) * 2 * MAIL_KINDS * (size_t)world;
+    const char* mb = std::getenv("MLP_MAILBOX");
+    const bool host_transport = mb && std::string(mb) == "host";
+    const size_t host_bytes = kHostBoxBytesPerRank * (size_t)world;
+    const size_t bytes = host_bytes + sizeof(Rendezvous) * (size_t)world;
     int fd = shm_open(shm_name, O_RDWR, 0600);
     if (fd < 0) throw MlpError(-1, std::string("enable_sharding: shm_open failed for ") + shm_name);
     struct stat sb;
     if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < bytes) {
         close(fd);
-        throw MlpError(-1, "enable_sharding: mailbox object too small");
+        throw MlpError(-1, "enable_sharding: mailbox object too small (need 640 * world bytes)");
     }
     void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (p == MAP_FAILED) throw MlpError(-1, "enable_sharding: mmap failed");
-    HIPCHECK(hipHostRegister(p, bytes, hipHostRegisterMapped));
-    void* dp = nullptr;
-    HIPCHECK(hipHostGetDevicePointer(&dp, p, 0));
     mail_host = p; mail_bytes = bytes;
-    d_mail = reinterpret_cast<MailRec*>(dp);
+    shard_rank = rank;  // release_mailboxes() skips this rank's own entry of peer_box
+    try {
+        if (host_transport) {
+            HIPCHECK(hipHostRegister(p, bytes, hipHostRegisterMapped));
+            mail_registered = true;
+            void* dp = nullptr;
+            HIPCHECK(hipHostGetDevicePointer(&dp, p, 0));
+            d_mail = reinterpret_cast<MailRec*>(dp);
+            for (int r = 0; r < world; ++r) peer_box[r] = nullptr;
+            mail_fanout = 1;
+            transport = "host-mapped shared-memory mailbox (PCIe)";
+        } else {
+            const size_t box_bytes = host_bytes;  // same layout: [kind][parity][rank]
+            hipError_t e = hipExtMallocWithFlags(&own_box, box_bytes, hipDeviceMallocUncached);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                own_box = nullptr;
+                e = hipExtMallocWithFlags(&own_box, box_bytes, hipDeviceMallocFinegrained);
+            }
+            if (e != hipSuccess) throw MlpError(-3, std::string("enable_sharding: cannot allocate the device mailbox: ") + hipGetErrorString(e));
+            HIPCHECK(hipMemset(own_box, 0, box_bytes));
+            HIPCHECK(hipDeviceSynchronize());
+            Rendezvous* rv = reinterpret_cast<Rendezvous*>(static_cast<uint8_t*>(p) + host_bytes);
+            Rendezvous* mine = rv + rank;
+            HIPCHECK(hipIpcGetMemHandle(&mine->handle, own_box));
+            int dev = 0;
+            HIPCHECK(hipGetDevice(&dev));
+            mine->device = dev;
+            mine->pid = (int32_t)getpid();
+            __atomic_store_n(&mine->ready, (uint64_t)1, __ATOMIC_RELEASE);
+            for (int r = 0; r < world; ++r) {
+                if (r == rank) {
+                    peer_box[r] = own_box;
+                    continue;
+                }
+                if (!wait_flag(&rv[r].ready, 1, 120.0))
+                    throw MlpError(-3, "enable_sharding: rank " + std::to_string(r) + " did not publish its mailbox handle within 120 s");
+                if (rv[r].pid == mine->pid) throw MlpError(-1, "enable_sharding: two ranks in one process are not supported");
+                void* q = nullptr;
+                hipError_t eo = hipIpcOpenMemHandle(&q, rv[r].handle, hipIpcMemLazyEnablePeerAccess);
+                if (eo != hipSuccess)
+                    throw MlpError(-3, "enable_sharding: hipIpcOpenMemHandle of rank " + std::to_string(r) + "'s mailbox (device " +
+                                           std::to_string(rv[r].device) + " from device " + std::to_string(dev) + ") failed: " +
+                                           hipGetErrorString(eo));
+                peer_box[r] = q;
+            }
+            __atomic_store_n(&mine->ready, (uint64_t)2, __ATOMIC_RELEASE);
+            // nobody may start posting before every rank has mapped every box it will be written from / polled in
+            for (int r = 0; r < world; ++r)
+                if (r != rank && !wait_flag(&rv[r].ready, 2, 120.0))
+                    throw MlpError(-3, "enable_sharding: rank " + std::to_string(r) + " did not finish mapping the mailboxes within 120 s");
+            d_mail = reinterpret_cast<MailRec*>(own_box);
+            mail_fanout = world;
+            bool same_dev = true;
+            for (int r = 0; r < world; ++r) same_dev = same_dev && rv[r].device == dev;
+            transport = same_dev ? "device-resident mailboxes mapped through HIP IPC (all ranks on one GPU)"
+                                 : "device-resident mailboxes in each GPU's HBM, written by the peers over xGMI (HIP IPC peer mappings)";
+        }
+    } catch (...) {
+        release_mailboxes();
+        shard_rank = 0; shard_world = 1;
+        view_dirty = true;
+        throw;
+    }
     shard_rank = rank; shard_world = world;
     view_dirty = true;
 }
@@ -1060,7 +1161,9 @@ int Engine::run_loop(int phase) {
                 stats.fused_ms += ms;
                 // read + write of W; a non-folding pivot of the delayed-update mode only reads it
                 const bool read_only = hview.lrJ > 0 && !h_ctl->fold;
-                stats.fused_bytes += (read_only ? 8.0 : 16.0) * (double)k_before * (double)k_before;
+                // a folding pivot of the large-nucleus mode reads and writes W0 (fold) and then streams it once more
+                const double fold_factor = (hview.lrJ > 0 && geom().big) ? 24.0 : 16.0;
+                stats.fused_bytes += (read_only ? 8.0 : fold_factor) * (double)k_before * (double)k_before;
                 stats.fused_launches += 1;
             }
             if (hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) {
@@ -1759,6 +1862,13 @@ uint64_t Engine::state(const char* what, double* out, uint64_t cap) {
     else if (w == "col_coeffs") from_dev_d(d_work.p, mm);
     else if (w == "row_coeffs") from_dev_d(d_alpha_r.p, nn);
     else if (w == "tau") from_dev_d(d_work.p + mm, mm);
+    else if (w == "inv_basis_row_coeffs" || w == "v") {  // (rho, v) interleaved by row (solver.rs:56, 1114)
+        std::vector<double> both(2 * mm);
+        if (mm) HIPCHECK(hipMemcpy(both.data(), d_work.p + 2 * mm, 2 * mm * sizeof(double), hipMemcpyDeviceToHost));
+        tmp.resize(mm);
+        const size_t off = (w == "v") ? 1 : 0;
+        for (size_t i = 0; i < mm; ++i) tmp[i] = both[2 * i + off];
+    } else if (w == "sq_norms_update_helper") from_dev_d(d_helper.p, nn);
     else if (w == "nb_flags") {
         std::vector<uint8_t> t(nn);
         if (nn) HIPCHECK(hipMemcpy(t.data(), d_nbflags.p, nn, hipMemcpyDeviceToHost));

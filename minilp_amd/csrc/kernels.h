@@ -89,6 +89,7 @@ struct Ctl {
 // Sharded pricing: one 64-byte mailbox record per (kind, parity, rank) in host
 // memory mapped into every rank's GPU; a rank writes only its own slot and polls the others.
 constexpr int MAIL_KINDS = 4;
+constexpr int MAX_WORLD = 16;  // ranks of one sharded solve (one node: 8 GPUs; test rigs oversubscribe one GPU)
 struct alignas(64) MailRec {
     unsigned long long epoch;
     double f[7];
@@ -171,7 +172,14 @@ struct DevView {
     Ctl* ctl;
     // column-block sharding of the pricing path: this rank owns non-basic positions [nb_lo, nb_hi)
     int nb_lo, nb_hi, rank, world;
-    MailRec* mail;  // [MAIL_KINDS][2 parities][world], null when world == 1
+    // Mailboxes of the per-pivot exchanges, one box of [MAIL_KINDS][2 parities][world] records per rank.  `mail` is
+    // the box this rank POLLS.  Peer transport (default): the box lives in this GPU's own HBM (uncached /
+    // fine-grained), every peer maps it through a HIP IPC handle and writes its slot into it over xGMI, so a post
+    // is `mail_fanout` = world remote stores and a wait polls local memory.  Host transport (MLP_MAILBOX=host):
+    // one box in host memory shared by all ranks (mail_fanout = 1, every poll crosses PCIe).
+    MailRec* mail;                   // null when world == 1
+    MailRec* mail_peer[MAX_WORLD];   // mail_peer[r]: rank r's box as mapped into this process (mail_peer[rank] == mail)
+    int mail_fanout, pad2;
 };
 
 // fused pass tiling
@@ -206,7 +214,7 @@ void launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, h
 void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st);                 // K7 p1, p2 (+FTRAN head)
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st);        // tauK/vK partials + eta update of W
-void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st);     // tau push | v reduce+scatter
+void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic = 0);  // tau push | v reduce+scatter (classic: partials of k_fused_w's tiling)
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_dse, int use_pse, hipStream_t st, int inline_comb = 0);  // K8 + clear + next pricing
 // non-graph helpers

@@ -280,10 +280,38 @@ __device__ __forceinline__ void push_rec(Ctl* c, int phase) {  // single thread
 __device__ __forceinline__ MailRec* mail_slot(const DevView& v, int kind, unsigned long long epoch, int rank) {
     return v.mail + ((size_t)(kind * 2 + (int)(epoch & 1ull)) * v.world + rank);
 }
-__device__ __forceinline__ void mail_post(MailRec* slot, unsigned long long epoch, const double* f) {
+// this rank's slot inside the box of `peer` (the box that peer polls)
+__device__ __forceinline__ MailRec* mail_slot_at(const DevView& v, int peer, int kind, unsigned long long epoch) {
+    return v.mail_peer[peer] + ((size_t)(kind * 2 + (int)(epoch & 1ull)) * v.world + v.rank);
+}
+__device__ __forceinline__ void mail_store(MailRec* slot, unsigned long long epoch, const double* f) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) __hip_atomic_store(&slot->f[i], f[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&slot->epoch, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Post this rank's record of (kind, epoch) to every box that must see it.  Wave-parallel form: lane l < fanout
+// writes into peer l's box (one round of xGMI stores for all peers); call with the whole wave.
+__device__ __forceinline__ void mail_post_wave(const DevView& v, int kind, unsigned long long epoch, const double* f, int lane) {
+    if (v.mail_fanout <= 1) {
+        if (lane == 0) mail_store(mail_slot(v, kind, epoch, v.rank), epoch, f);
+    } else if (lane < v.mail_fanout) {
+        mail_store(mail_slot_at(v, lane, kind, epoch), epoch, f);
+    }
+}
+// Single-thread form: all payloads first, one release fence, then the epochs.
+__device__ __forceinline__ void mail_post(const DevView& v, int kind, unsigned long long epoch, const double* f) {
+    if (v.mail_fanout <= 1) {
+        mail_store(mail_slot(v, kind, epoch, v.rank), epoch, f);
+        return;
+    }
+    for (int r = 0; r < v.mail_fanout; ++r) {
+        MailRec* slot = mail_slot_at(v, r, kind, epoch);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) __hip_atomic_store(&slot->f[i], f[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __atomic_thread_fence(__ATOMIC_RELEASE);  // system scope: the payloads are visible before any epoch
+    for (int r = 0; r < v.mail_fanout; ++r)
+        __hip_atomic_store(&mail_slot_at(v, r, kind, epoch)->epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ bool mail_wait(MailRec* slot, unsigned long long epoch, double* f) {
     for (long spins = 0;; ++spins) {
@@ -308,9 +336,10 @@ __device__ bool exchange_best_wave(const DevView& v, Ctl* c, int phase, Cand& be
                                    int kind = 0, double pay2_local = 0.0) {
     if (v.world <= 1) return true;
     unsigned long long ep = c->xepoch[kind] + 1ull;
-    if (lane == 0) {
-        double f[7] = {best.key, (double)best.idx, pay_local, pay2_local, 0.0, 0.0, 0.0};
-        mail_post(mail_slot(v, kind, ep, v.rank), ep, f);
+    {   // `best` and the payloads are valid in lane 0 only: broadcast them, then lane l posts into peer l's box
+        double f[7] = {__shfl(best.key, 0, 64), (double)__shfl(best.idx, 0, 64), __shfl(pay_local, 0, 64),
+                       __shfl(pay2_local, 0, 64), 0.0, 0.0, 0.0};
+        mail_post_wave(v, kind, ep, f, lane);
     }
     Cand g = cand_none();
     double dq = 0.0, p2 = 0.0;
@@ -367,9 +396,9 @@ __device__ bool exchange_best_wave(const DevView& v, Ctl* c, int phase, Cand& be
 __device__ bool exchange_min_wave(const DevView& v, Ctl* c, double& mn, int lane) {
     if (v.world <= 1) return true;
     unsigned long long ep = c->xepoch[2] + 1ull;
-    if (lane == 0) {
-        double f[7] = {mn, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        mail_post(mail_slot(v, 2, ep, v.rank), ep, f);
+    {
+        double f[7] = {__shfl(mn, 0, 64), 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        mail_post_wave(v, 2, ep, f, lane);
     }
     double g = INFINITY;
     bool ok = true;
@@ -402,7 +431,7 @@ __device__ bool adopt_rank0_candidate(const DevView& v, Ctl* c, Cand& best) {
     const unsigned long long ep = ++c->xepoch[0];
     if (v.rank == 0) {
         double f[7] = {best.key, (double)best.idx, 0.0, 0.0, 0.0, 0.0, 0.0};
-        mail_post(mail_slot(v, 0, ep, 0), ep, f);
+        mail_post(v, 0, ep, f);
         return true;
     }
     double h[7];
@@ -919,7 +948,7 @@ __device__ void ratio_primal_finish(const DevView& v, Ctl* c, Cand best) {
             const unsigned long long ep = ++c->xepoch[1];
             if (v.rank == 0) {
                 double f[7] = {(double)status, (double)r, coeff, lnv, diff, enew, pobj};
-                mail_post(mail_slot(v, 1, ep, 0), ep, f);
+                mail_post(v, 1, ep, f);
             } else {
                 double h[7];
                 ok = mail_wait(mail_slot(v, 1, ep, 0), ep, h);
@@ -1814,10 +1843,14 @@ template <bool WITH_V, bool NT>
 __global__ void __launch_bounds__(BLK) k_fused_lr16(DevView v, int fold_only) {
     constexpr int TRB = 16, JM = 16;
     Ctl* c = v.ctl;
-    if (!fold_only && (c->halt || c->it.status != ITER_PIVOT)) return;
+    // mode (parameter `fold_only`): 0 = a folding pivot folds AND produces the tau / v partials (16 x 1024 tiling);
+    // 1 = host-requested fold outside the pivot loop; 2 = a folding pivot only folds, k_stream_w then reads the folded W0
+    const int mode = fold_only;
+    if (mode != 1 && (c->halt || c->it.status != ITER_PIVOT)) return;
     const int k = c->k, ld = v.ld;
     const int nlow = c->nlow;
-    if (!(fold_only || c->fold)) return;
+    if (!(mode == 1 || c->fold)) return;
+    fold_only = mode != 0;
     const int tid = threadIdx.x;
     __shared__ double s_tau[TRB][BLK / 64];
     __shared__ double s_u[LR_MAX][TRB];
@@ -1935,6 +1968,103 @@ __global__ void __launch_bounds__(BLK) k_fused_lr16(DevView v, int fold_only) {
     }
     }
 }
+
+// Streaming pass of the large-nucleus delayed-update mode (every pivot): tau_K = W0 rho_K and v_K = W0^T t_K partials
+// in ONE read of W0, nothing written back.  Shape found with tools/stream_bench.hip (MI355X, k = 20 480: 546 us =
+// 6.1 TB/s against 645 us for the 16 x 1024 tiles of k_fused_w; k = 10 240: 127 us = 6.6 TB/s against 161 us; a bare
+// sum of W with the same loads runs at 7.0 / 6.4 TB/s):
+//   * a block owns a strip of SW_CH = 512 columns x SW_RB = 512 rows and walks it in steps of SW_RS = 8 rows; a thread
+//     owns one pair of columns, so a step is 8 independent 16-byte non-temporal loads per lane, and the loads of step
+//     i + 1 are issued before step i is consumed (register double buffer);
+//   * v accumulates in registers over the whole strip: part_v has k / 512 rows instead of k / 16 (the old tiling wrote
+//     and re-read 8 k^2 / 16 bytes of partials per pivot: 100 us of k_post_fused at k = 20 000);
+//   * the 8 row sums of a step go through an LDS transpose (two alternating buffers, one barrier per step).
+// The last LR_MAX blocks compute the low-rank dots g_j = V[j].rho_K, h_j = U[j].t_K for k_post_fused.  On a folding
+// pivot k_fused_lr16 (mode 2) has already applied the pending terms to W0, so the dots are skipped and the pass
+// reads the folded matrix.
+constexpr int SW_CH = 512, SW_RB = 512, SW_RS = 8;
+constexpr int SW_MAX_BLOCKS = 8192;
+template <bool WITH_V>
+__global__ void __launch_bounds__(BLK) k_stream_w(DevView v) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    const int k = c->k, ld = v.ld;
+    const int tid = threadIdx.x;
+    const int n_tile_blocks = (int)gridDim.x - LR_MAX;
+    if ((int)blockIdx.x >= n_tile_blocks) {
+        const int j = (int)blockIdx.x - n_tile_blocks;
+        if (c->fold || j >= c->nlow) return;
+        const double* Vj = v.V + (size_t)j * ld;
+        const double* Uj = v.U + (size_t)j * ld;
+        double g = 0.0, h = 0.0;
+        for (int s = tid; s < k; s += BLK) {
+            g += Vj[s] * v.rK[s];
+            if (WITH_V) h += Uj[s] * v.tK[s];
+        }
+        g = block_sum(g);
+        h = block_sum(h);
+        if (tid == 0) {
+            c->lr_g[j] = g;
+            c->lr_h[j] = h;
+        }
+        return;
+    }
+    __shared__ double s_t[2][SW_RS][BLK + 1];
+    constexpr int G = BLK / SW_RS;  // lanes that share a row in the reduction of a step (32)
+    const int rrow = tid / G, gl = tid % G;
+    const int nch = (k + SW_CH - 1) / SW_CH, nstr = (k + SW_RB - 1) / SW_RB;
+    const double* __restrict__ Wp = v.W;
+    const double* __restrict__ tKp = v.tK;
+    for (int tile = blockIdx.x; tile < nstr * nch; tile += n_tile_blocks) {
+        const int strip = tile / nch, chunk = tile % nch;
+        const int rbeg = strip * SW_RB, rend = min(k, rbeg + SW_RB);
+        const int c0 = chunk * SW_CH + 2 * tid;
+        const bool pair = c0 + 1 < k, one = c0 < k;
+        const double rk0 = one ? v.rK[c0] : 0.0, rk1 = pair ? v.rK[c0 + 1] : 0.0;
+        double vacc0 = 0.0, vacc1 = 0.0;
+        dbl2_t w[SW_RS], wn[SW_RS];
+        auto load_step = [&](dbl2_t (&dst)[SW_RS], int r0) {
+#pragma unroll
+            for (int a = 0; a < SW_RS; ++a) {
+                const int row = r0 + a;
+                dst[a] = dbl2_t{0.0, 0.0};
+                if (row < rend) {
+                    const double* wp = Wp + (size_t)row * ld + c0;
+                    if (pair) dst[a] = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t*>(wp));
+                    else if (one) dst[a].x = *wp;
+                }
+            }
+        };
+        load_step(w, rbeg);
+        int buf = 0;
+        for (int r0 = rbeg; r0 < rend; r0 += SW_RS, buf ^= 1) {
+            if (r0 + SW_RS < rend) load_step(wn, r0 + SW_RS);
+#pragma unroll
+            for (int a = 0; a < SW_RS; ++a) {
+                s_t[buf][a][tid] = w[a].x * rk0 + w[a].y * rk1;
+                if (WITH_V) {
+                    const double t = (r0 + a < rend) ? tKp[r0 + a] : 0.0;
+                    vacc0 += w[a].x * t;
+                    vacc1 += w[a].y * t;
+                }
+            }
+            __syncthreads();  // one barrier per step: the two LDS buffers alternate
+            double sum = 0.0;
+#pragma unroll
+            for (int j = 0; j < BLK / G; ++j) sum += s_t[buf][rrow][gl + j * G];
+            sum = group_sum<G>(sum);
+            if (gl == 0 && r0 + rrow < rend) v.part_tau[(size_t)chunk * ld + r0 + rrow] = sum;
+#pragma unroll
+            for (int a = 0; a < SW_RS; ++a) w[a] = wn[a];
+        }
+        __syncthreads();  // the next tile's first step may reuse the buffer the slowest wave is still reducing
+        if (WITH_V) {
+            double* pv = v.part_v + (size_t)strip * ld;
+            if (one) pv[c0] = vacc0;
+            if (pair) pv[c0 + 1] = vacc1;
+        }
+    }
+}
 __global__ void k_reset_nlow(DevView v) {
     v.ctl->nlow = 0;
     v.ctl->fold = 0;
@@ -1942,7 +2072,7 @@ __global__ void k_reset_nlow(DevView v) {
 // After the fused pass (horizontally fused): blocks [0, n_push) finish tau = B^-1 rho by position
 // (tau_K from the per-chunk partials in a fixed order, then the push of -F tau_K, solver.rs:1157);
 // the remaining blocks reduce the v partials in a fixed order and scatter v_K by row (solver.rs:1114).
-template <int G, bool WITH_V, int TR>
+template <int G, bool WITH_V, int TR, int TC = FW_TC>
 __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
@@ -1951,7 +2081,7 @@ __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push) {
         int slot = (blockIdx.x * BLK + threadIdx.x) / G;
         int gl = threadIdx.x & (G - 1);
         if (slot >= k) return;
-        const int nchunks = (k + FW_TC - 1) / FW_TC;
+        const int nchunks = (k + TC - 1) / TC;
         double x = 0.0;
         for (int j = 0; j < nchunks; ++j) x += v.part_tau[(size_t)j * v.ld + slot];
         if (v.lrJ && !c->fold) {  // low-rank part of W_eff * rho_K
@@ -2431,6 +2561,11 @@ constexpr int FW_RL = 1;  // measured: 4 row tiles per block slow the stream dow
 static inline int fw_rows(const Geom& g) { return g.big ? 16 * FW_RL : 8; }
 // 1-D grid of the tiled large-nucleus passes: enough blocks to fill the chip a few times over
 constexpr int FW_TILE_BLOCKS = 4096;
+// MLP_STREAM_STRIPS=0 keeps the older 16 x 1024 tiling of the large-nucleus streaming pass (A/B measurements)
+static bool stream_strips() {
+    static const bool on = !(std::getenv("MLP_STREAM_STRIPS") && std::atoi(std::getenv("MLP_STREAM_STRIPS")) == 0);
+    return on;
+}
 static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fold_only, hipStream_t st) {
     const int rows = fw_rows(g);
     int nstripes = (g.cap + rows - 1) / rows, nchunks = (g.cap + FW_TC - 1) / FW_TC;
@@ -2447,6 +2582,17 @@ static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fo
     } else {
         const long tiles_cap = (long)nstripes * nchunks;
         const int nb = (int)(tiles_cap < FW_TILE_BLOCKS ? tiles_cap : FW_TILE_BLOCKS);
+        if (FW_RL == 1 && stream_strips()) {
+            // a folding pivot folds first (mode 2: no partials), then EVERY pivot streams W0 once (k_stream_w)
+            hipLaunchKernelGGL((k_fused_lr16<false, true>), dim3(nb), b, 0, st, dv, fold_only ? 1 : 2);
+            if (!fold_only) {
+                const long tiles = (long)((g.cap + SW_RB - 1) / SW_RB) * ((g.cap + SW_CH - 1) / SW_CH);
+                const int nt = (int)(tiles < SW_MAX_BLOCKS ? tiles : SW_MAX_BLOCKS);
+                if (with_v) hipLaunchKernelGGL(k_stream_w<true>, dim3(nt + LR_MAX), b, 0, st, dv);
+                else hipLaunchKernelGGL(k_stream_w<false>, dim3(nt + LR_MAX), b, 0, st, dv);
+            }
+            return;
+        }
         if (!fold_only) {  // cap-sized 2-D grid: measured 146 us against 154 us tiled at k = 10 000
             dim3 gr(nstripes < LR_MAX ? LR_MAX : nstripes, nchunks + 1);
             if (with_v) hipLaunchKernelGGL((k_fused_w<16, true, true, false, true, true, FW_RL>), gr, b, 0, st, dv);
@@ -2486,7 +2632,20 @@ void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st
         else hipLaunchKernelGGL((k_fused_w<16, true, false, true, true, false, FW_RL, true>), dim3(nb), b, 0, st, dv);
     }
 }
-void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st) {
+void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic) {
+    if (!classic && dv.lrJ && fw_rows(g) != 8 && FW_RL == 1 && stream_strips()) {  // partials of k_stream_w: 512-row strips, 512-column chunks
+#define POSTS(G)                                                                                                  \
+    do {                                                                                                          \
+        int n_push = blocks_for((long)g.cap * G);                                                                 \
+        if (with_v) hipLaunchKernelGGL((k_post_fused<G, true, SW_RB, SW_CH>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push); \
+        else hipLaunchKernelGGL((k_post_fused<G, false, SW_RB, SW_CH>), dim3(n_push), dim3(BLK), 0, st, dv, n_push); \
+    } while (0)
+        LANES_SWITCH(g.lanes, POSTS(4), POSTS(16), POSTS(64));
+#undef POSTS
+        if (dv.pb_on) launch_blocked_push(dv, 1, st);
+        else if (dv.det_pull) launch_pull_F(dv, g, 1, st);
+        return;
+    }
 #define POSTF(G)                                                                                                  \
     do {                                                                                                          \
         int n_push = blocks_for((long)g.cap * G);                                                                 \
@@ -2569,7 +2728,7 @@ void launch_recalc_basic_vals(const DevView& dv, const Geom& g, const double* rh
         const int nstripes = (g.cap + 16 - 1) / 16, nchunks = (g.cap + FW_TC - 1) / FW_TC;
         hipLaunchKernelGGL((k_fused_w<16, true, false, false>), dim3(nstripes, nchunks), dim3(BLK), 0, st, dv);
     }
-    launch_post_fused(dv, g, 0, st);
+    launch_post_fused(dv, g, 0, st, 1);  // partials in the classic 16 x 1024 tiling (k_fused_w above)
     hipLaunchKernelGGL(k_copy_tau_to_xb, dim3(blocks_for(g.m)), dim3(BLK), 0, st, dv, refine);
     launch_clear_work(dv, st);
 }

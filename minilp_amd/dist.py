@@ -1,8 +1,10 @@
 """One-process-per-GPU helpers for the sharded pricing path.
 
-Control plane only (no arithmetic): the mailbox that the pivot kernels use is a POSIX shared-memory
-object, created and zeroed by rank 0; `torch.distributed` (RCCL on GPUs, gloo in the CPU tests)
-carries its name, the barriers and the timing reductions.
+Control plane only (no arithmetic).  The pivot kernels exchange their per-pivot candidates through mailboxes
+that live in each GPU's own HBM and are written by the peers over xGMI (HIP IPC peer mappings); the IPC handles
+travel through a small POSIX shared-memory rendezvous object created and zeroed by rank 0, whose first part
+doubles as the host-memory mailbox of the fallback transport (MLP_MAILBOX=host).  `torch.distributed` (RCCL on
+GPUs, gloo in the CPU tests) carries the object's name, the barriers and the timing reductions.
 """
 import os
 import uuid
@@ -11,8 +13,16 @@ MAILREC_BYTES = 64
 KINDS, PARITIES = 4, 2  # kernels.h: MAIL_KINDS (pricing, primal ratio decision, dual ratio min, dual ratio candidate)
 
 
-def mailbox_bytes(world):
+RENDEZVOUS_BYTES = 128  # engine.hip: one record per rank (ready flag, device, pid, 64-byte HIP IPC handle)
+
+
+def host_box_bytes(world):
     return MAILREC_BYTES * KINDS * PARITIES * world
+
+
+def mailbox_bytes(world):
+    """Size of the shared-memory object: host-transport mailbox + the rendezvous records (640 bytes per rank)."""
+    return host_box_bytes(world) + RENDEZVOUS_BYTES * world
 
 
 def shard_range(n, rank, world):
@@ -74,4 +84,4 @@ def combine_candidates(cands):
 
 def transport_name(solution=None):
     """Human-readable name of the per-pivot exchange transport (bench.py's config.parallelism)."""
-    return "a host-mapped shared-memory mailbox (PCIe)"
+    return solution.transport() if solution is not None else "none"

@@ -732,6 +732,10 @@ struct Solver {  // solver.rs:14-58
     Counters cnt;
     int64_t pivot_budget = -1;  // <0: unlimited; else stop loops after this many more pivots
     bool budget_exhausted = false;
+    // test instrumentation (not in the reference): with capture on, the two extra solves of a pivot are kept so that
+    // the per-stage differential tests can compare them (v = B^-T alpha_q, solver.rs:1114; tau = B^-1 rho, solver.rs:1157)
+    bool capture = false;
+    std::vector<double> dbg_v, dbg_tau, dbg_rho;
     bool resume_in_optimize = false;
     bool trace = false;
     std::vector<PivotRecord> trace_log;
@@ -1308,6 +1312,10 @@ struct Solver {  // solver.rs:14-58
 
     void update_primal_sq_norms(usize entering_col, double pivot_coeff) {  // solver.rs:1106-1151 (Forrest–Goldfarb)
         ScatteredVec& tmp = basis_solver.solve_transp(col_coeffs.indices.data(), col_coeffs.values.data(), col_coeffs.len());
+        if (capture) {
+            dbg_v.assign(num_constraints(), 0.0);
+            for (usize r : tmp.nonzero) dbg_v[r] = tmp.values[r];
+        }
         for (usize r : tmp.nonzero) {  // solver.rs:1117-1123
             for (usize q = orig_constraints.indptr[r]; q < orig_constraints.indptr[r + 1]; ++q) {
                 const VarState& s = var_states[orig_constraints.indices[q]];
@@ -1340,6 +1348,12 @@ struct Solver {  // solver.rs:14-58
     void update_dual_sq_norms(usize leaving_row, double pivot_coeff) {  // solver.rs:1153-1174
         ScatteredVec& tau = basis_solver.solve(inv_basis_row_coeffs.indices.data(), inv_basis_row_coeffs.values.data(),
                                                inv_basis_row_coeffs.len());
+        if (capture) {
+            dbg_tau.assign(num_constraints(), 0.0);
+            for (usize r : tau.nonzero) dbg_tau[r] = tau.values[r];
+            dbg_rho.assign(num_constraints(), 0.0);
+            for (usize p = 0; p < inv_basis_row_coeffs.len(); ++p) dbg_rho[inv_basis_row_coeffs.indices[p]] = inv_basis_row_coeffs.values[p];
+        }
         double pivot_sq_norm = inv_basis_row_coeffs.sq_norm();
         double pivot_coeff_sq = pivot_coeff * pivot_coeff;
         for (usize p = 0; p < col_coeffs.len(); ++p) {
@@ -1708,6 +1722,7 @@ int orc_solution_continue(Solution* s, int64_t budget) {
     });
 }
 int orc_solution_budget_exhausted(const Solution* s) { return s->solver.budget_exhausted ? 1 : 0; }
+void orc_solution_set_capture(Solution* s, int on) { s->solver.capture = on != 0; }
 
 Solution* orc_solution_clone(const Solution* s) { return new Solution(*s); }
 void orc_solution_free(Solution* s) { delete s; }
@@ -1815,6 +1830,14 @@ uint64_t orc_solution_state(const Solution* s, const char* what, double* out, ui
     else if (w == "csc_indptr") from_usize(v.orig_constraints_csc.indptr);
     else if (w == "csc_indices") from_usize(v.orig_constraints_csc.indices);
     else if (w == "csc_data") tmp = v.orig_constraints_csc.data;
+    else if (w == "col_coeffs") {  // alpha_q of the last pivot, dense by basic position (solver.rs:54)
+        tmp.assign(v.basic_vars.size(), 0.0);
+        for (usize p = 0; p < v.col_coeffs.len(); ++p) tmp[v.col_coeffs.indices[p]] = v.col_coeffs.values[p];
+    } else if (w == "row_coeffs") tmp = v.row_coeffs.values;          // alpha_r, dense by non-basic position (solver.rs:57)
+    else if (w == "sq_norms_update_helper") tmp = v.sq_norms_update_helper;
+    else if (w == "inv_basis_row_coeffs") tmp = v.dbg_rho;             // rho_r by row (capture mode)
+    else if (w == "dbg_v") tmp = v.dbg_v;                               // B^-T alpha_q by row (capture mode)
+    else if (w == "dbg_tau") tmp = v.dbg_tau;                           // B^-1 rho_r by position (capture mode)
     else if (w == "nb_at_min") { for (auto& st : v.nb_var_states) tmp.push_back(st.at_min); }
     else if (w == "nb_at_max") { for (auto& st : v.nb_var_states) tmp.push_back(st.at_max); }
     else return (uint64_t)-1;

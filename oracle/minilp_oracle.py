@@ -87,6 +87,7 @@ def lib():
     sig("orc_solution_trace_get", None, vp, u64, C.POINTER(C.c_int32), C.POINTER(i64), C.POINTER(i64),
         C.POINTER(i64), C.POINTER(i64), pdbl, pdbl)
     sig("orc_solution_state", u64, vp, C.c_char_p, pdbl, u64)
+    sig("orc_solution_set_capture", None, vp, C.c_int)
     sig("orc_lu_factorize", i32, u64, pu64, pu64, pdbl, dbl, C.POINTER(vp))
     sig("orc_lu_free", None, vp)
     sig("orc_lu_nnz", u64, vp)
@@ -259,6 +260,10 @@ class Solution:
         return Solution(h)
 
     # --- instrumentation
+    def set_capture(self, on=True):
+        """Keep the two extra solves of every pivot (v, tau) and rho for the per-stage differential tests."""
+        lib().orc_solution_set_capture(self._h, 1 if on else 0)
+
     def continue_solve(self, budget):
         _raise(lib().orc_solution_continue(self._h, budget))
 

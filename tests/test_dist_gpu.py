@@ -1,6 +1,7 @@
-"""GPU: the sharded pricing path with 2 and 3 ranks (processes) sharing the one visible GPU — the
-mailbox lives in host memory, so the full device-side exchange protocol runs.  Gate:
-the sharded run picks the identical pivot sequence to the unsharded run."""
+"""GPU: the sharded pricing path with 2 and 3 ranks (one process each).  Ranks use distinct devices when the box
+has that many GPUs (tools/shard_test.py), otherwise they share the one visible GPU — the device mailboxes are
+mapped across processes through HIP IPC either way, so the full device-side exchange protocol runs.
+Gate: the sharded run picks the identical pivot sequence to the unsharded run."""
 import os
 import subprocess
 import sys
@@ -38,3 +39,19 @@ def test_sharded_dual_loop_matches_unsharded_pivot_for_pivot(world):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "traces identical: True" in r.stdout
+
+
+def test_host_mailbox_transport_still_works():
+    """MLP_MAILBOX=host: the older transport (one mailbox in host memory, polled across PCIe) behind the same protocol."""
+    env = dict(os.environ, MLP_MAILBOX="host")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_test.py"), "2", "3000", "3000", "12", "300"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "traces identical: True" in r.stdout and "host-mapped" in r.stdout
+
+
+def test_default_transport_is_device_resident():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_test.py"), "2", "3000", "3000", "12", "300"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "traces identical: True" in r.stdout and "device-resident mailboxes" in r.stdout

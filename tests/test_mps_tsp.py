@@ -167,16 +167,20 @@ def test_tsp_bn130_reaches_reference_optimum():
     assert s.stats["cuts"] > 100 and s.stats["clones"] > 100
 
 
-def test_solve_mps_example_cli_oracle_backend(tmp_path):  # examples/solve_mps.rs:19-43 counterpart
-    import subprocess
+def test_solve_mps_example_driver_with_the_checker(tmp_path, capsys):  # examples/solve_mps.rs:19-43 counterpart
+    """The example's driver code run on the oracle module (the CLI itself only knows the GPU engine)."""
     import sys
     from tests.test_oracle_kat import MPS_TESTPROB
     p = tmp_path / "testprob.mps"
     p.write_text(MPS_TESTPROB)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "examples", "solve_mps.py"), str(p), "--backend", "oracle"],
-                         capture_output=True, text=True, check=True).stdout
+    sys.path.insert(0, os.path.join(root, "examples"))
+    import solve_mps
+    assert solve_mps.run(O, str(p)) == 0
+    out = capsys.readouterr().out
     assert "objective: 54" in out and "XONE = 4" in out and "YTWO = -1" in out and "ZTHREE = 6" in out
+    assert "--backend" not in open(os.path.join(root, "examples", "solve_mps.py")).read()
+    assert "--backend" not in open(os.path.join(root, "examples", "tsp.py")).read()
 
 
 @pytest.mark.gpu

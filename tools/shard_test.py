@@ -1,5 +1,6 @@
-"""Sharded-pricing protocol test: WORLD processes, all on GPU 0 (the mailbox is host memory, so the
-exchange protocol is exercised even on a single-GPU box), gloo for the control plane."""
+"""Sharded-pricing protocol test: WORLD processes, one per GPU when the box has that many, otherwise all on
+GPU 0 (the device mailboxes are mapped across processes through HIP IPC either way, so the exchange protocol
+is exercised even on a single-GPU box); gloo for the control plane."""
 import os
 import sys
 import time
@@ -19,7 +20,8 @@ def worker(rank, world, port, m, n, k, pivots, out, family="sparse"):
     import minilp_amd as M
     from minilp_amd import dist as md
     from minilp_amd import lpgen
-    M.set_device(0)
+    ndev = M.device_count()
+    M.set_device(rank if ndev >= world else 0)   # distinct devices whenever the box has them
     lp = lpgen.gen_cover_lp(m, n, k, 4) if family == "cover" else lpgen.gen_sparse_lp(m, n, k, 4)
     p = lpgen.build_problem(M.Problem, lp)
     s = p.solve(budget=0, trace=True)
@@ -36,6 +38,7 @@ def worker(rank, world, port, m, n, k, pivots, out, family="sparse"):
         ref = p.solve(budget=pivots, trace=True)
         rtr = [t[:5] for t in ref.trace()]
         ok = all(g["trace"] == rtr for g in gathered)
+        print("transport:", s.transport(), "| devices visible:", ndev, flush=True)
         print("sharded world=%d: pivots=%s obj=%s dt=%s | unsharded pivots=%d obj=%.12g | traces identical: %s" % (
             world, [g["n"] for g in gathered], ["%.12g" % g["obj"] for g in gathered], ["%.3f" % g["dt"] for g in gathered],
             len(rtr), ref.objective(), ok), flush=True)
