@@ -497,6 +497,29 @@ __device__ void plan_update(const DevView& v, Ctl* c, int phase) {
     }
 }
 
+// acc += sum over the lanes b of `mask` (ascending) of coef_b * row[slot_b]: the listed entries of one 64-entry chunk
+// travel by shuffle in list order; four gathers are issued before the four adds (same summation order as a sequential
+// walk, a quarter of the load waits)
+__device__ __forceinline__ void lr_dot_listed(unsigned long long mask, int slot, double coef, const double* row, bool mine, double& acc) {
+    while (mask) {
+        int sb[4];
+        double ab[4], x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool have = mask != 0ull;
+            const int b = have ? __ffsll((long long)mask) - 1 : 0;
+            sb[u] = __shfl(slot, b, 64);
+            ab[u] = have ? __shfl(coef, b, 64) : 0.0;
+            if (!have) sb[u] = 0;
+            mask &= mask - 1ull;  // (0 stays 0)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = mine ? row[sb[u] < 0 ? 0 : sb[u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (ab[u] != 0.0) acc += ab[u] * x[u];
+    }
+}
 // ------------------------------------------------------------------- wave-level stage heads
 // FTRAN head (one wave): derive the entering column's scalars, land its singleton-row entries in
 // alpha_q and list its entries on nucleus rows.  alpha_q = B^-1 a_q  (solver.rs:671-677).
@@ -517,6 +540,12 @@ __device__ void ftran_prep_wave(const DevView& v, Ctl* c, int lane, int derive_p
     }
     int base = v.csc_ptr[var], end = v.csc_ptr[var + 1];
     int cnt = 0;
+    // delayed-update mode: c_j = V[j] . (listed entries of a_q), lane j serves pending term j (LR_MAX <= 64).  The
+    // listed entries travel by shuffle in list order (the same summation order as a walk over the stored list), so
+    // the gathers of one chunk are independent loads instead of a chain of re-reads of the list
+    const int nlow = v.lrJ ? c->nlow : 0;
+    const double* Vrow = v.V + (size_t)(lane < nlow ? lane : 0) * v.ld;
+    double lr_acc = 0.0;
     for (int e0 = base; e0 < end; e0 += 64) {
         int e = e0 + lane;
         bool valid = e < end;
@@ -539,17 +568,10 @@ __device__ void ftran_prep_wave(const DevView& v, Ctl* c, int lane, int derive_p
             v.klist_a[off] = a;
         }
         cnt += __popcll(mask);
+        if (nlow > 0) lr_dot_listed(mask, s, a, Vrow, lane < nlow, lr_acc);
     }
     if (lane == 0) it->klist_n = cnt;
-    if (v.lrJ) {  // delayed-update mode: c_j = V[j] . (listed entries of a_q), one lane per pending term
-        const int nlow = c->nlow;
-        for (int j = lane; j < nlow; j += 64) {
-            const double* Vj = v.V + (size_t)j * v.ld;
-            double sacc = 0.0;
-            for (int l = 0; l < cnt; ++l) sacc += ld_agent(&v.klist_a[l]) * Vj[ld_agent(&v.klist_s[l])];
-            c->lr_c[j] = sacc;
-        }
-    }
+    if (lane < nlow) c->lr_c[lane] = lr_acc;
 }
 // BTRAN head (one wave): rho = B^-T e_r (solver.rs:680-683) as a short list of rows of W.
 __device__ void btran_prep_wave(const DevView& v, Ctl* c, int lane, int r, int derive_dual, int plan_after, int phase) {
@@ -562,6 +584,9 @@ __device__ void btran_prep_wave(const DevView& v, Ctl* c, int lane, int r, int d
         it->entering_var = -1;
     }
     int sr = v.kslot_of_pos[r];
+    const int nlow = v.lrJ ? c->nlow : 0;
+    const double* Urow = v.U + (size_t)(lane < nlow ? lane : 0) * v.ld;
+    double lr_acc = 0.0;
     if (sr >= 0) {
         if (lane == 0) {
             v.blist_s[0] = sr;
@@ -589,25 +614,21 @@ __device__ void btran_prep_wave(const DevView& v, Ctl* c, int lane, int r, int d
             }
             bool isk = valid && s >= 0;
             unsigned long long mask = __ballot(isk);
+            const double coef = -a * inv;
             if (isk) {
                 int off = cnt + __popcll(mask & ((1ull << lane) - 1ull));
                 v.blist_s[off] = s;
-                v.blist_a[off] = -a * inv;
+                v.blist_a[off] = coef;
             }
             cnt += __popcll(mask);
+            // e_j = U[j] . (listed rows): lane j serves pending term j, entries travel by shuffle in list order
+            if (nlow > 0) lr_dot_listed(mask, s, coef, Urow, lane < nlow, lr_acc);
         }
         if (lane == 0) it->blist_n = cnt;
     }
-    if (v.lrJ) {  // delayed-update mode: e_j = U[j] . (listed rows), one lane per pending term
-        const int nlow = c->nlow;
-        const int nb = (sr >= 0) ? 1 : __shfl(it->blist_n, 0, 64);
-        for (int j = lane; j < nlow; j += 64) {
-            const double* Uj = v.U + (size_t)j * v.ld;
-            double sacc = 0.0;
-            if (sr >= 0) sacc = Uj[sr];
-            else for (int b = 0; b < nb; ++b) sacc += ld_agent(&v.blist_a[b]) * Uj[ld_agent(&v.blist_s[b])];
-            c->lr_e[j] = sacc;
-        }
+    if (nlow > 0) {  // delayed-update mode
+        if (sr >= 0 && lane < nlow) lr_acc = Urow[sr];
+        if (lane < nlow) c->lr_e[lane] = lr_acc;
     }
     if (plan_after && lane == 0) plan_update(v, c, phase);
 }
@@ -981,7 +1002,12 @@ __device__ void ratio_primal_finish(const DevView& v, Ctl* c, Cand best) {
         }
     }
     __syncthreads();
-    if (s_r >= 0 && threadIdx.x < 64) btran_prep_wave(v, c, threadIdx.x, s_r, 0, 1, 0);
+    if (s_r >= 0) {
+        // the BTRAN head (wave 0) and the partition plan (first lane of wave 1) are independent chains of dependent
+        // loads over disjoint outputs: side by side they cost the longer of the two instead of their sum
+        if (threadIdx.x < 64) btran_prep_wave(v, c, threadIdx.x, s_r, 0, 0, 0);
+        else if (threadIdx.x == 64) plan_update(v, c, 0);
+    }
 }
 
 // pass 2 (solver.rs:800-853); the finalising block goes straight on with the BTRAN head + plan
@@ -1378,9 +1404,24 @@ __global__ void __launch_bounds__(BAND_THREADS) k_sweep_band(DevView v, int chun
     const int c_hi = min(v.nb_hi, c_lo + per);
     const int* bp = v.bptr + (size_t)b * (size_t)(v.m + v.n + 1);
     double2* out = v.band_part + (size_t)b * (size_t)v.n;
-    for (int j = c_lo + tid; j < c_hi; j += BAND_THREADS) {
-        const int var = v.nb_vars[j];
-        const int beg = bp[var], end = bp[var + 1];
+    constexpr int CPT = 4;  // columns per thread resolved together: their three-deep index chains overlap
+    for (int j0 = c_lo + tid; j0 < c_hi; j0 += CPT * BAND_THREADS) {
+    int vars[CPT], begs[CPT], ends[CPT];
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        const int j = j0 + u * BAND_THREADS;
+        vars[u] = j < c_hi ? v.nb_vars[j] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        begs[u] = vars[u] >= 0 ? bp[vars[u]] : 0;
+        ends[u] = vars[u] >= 0 ? bp[vars[u] + 1] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        const int j = j0 + u * BAND_THREADS;
+        if (j >= c_hi) break;
+        const int beg = begs[u], end = ends[u];
         double a1 = 0.0, a2 = 0.0;
         for (int e0 = beg; e0 < end; e0 += 8) {
             // Eight entries per step as 1 + 4 sixteen-byte loads per lane (a lane's entries are contiguous;
@@ -1407,6 +1448,7 @@ __global__ void __launch_bounds__(BAND_THREADS) k_sweep_band(DevView v, int chun
             }
         }
         out[j] = make_double2(a1, a2);
+    }
     }
 }
 template <int MODE>
@@ -1982,10 +2024,11 @@ __global__ void __launch_bounds__(BLK) k_fused_lr16(DevView v, int fold_only) {
 // The last LR_MAX blocks compute the low-rank dots g_j = V[j].rho_K, h_j = U[j].t_K for k_post_fused.  On a folding
 // pivot k_fused_lr16 (mode 2) has already applied the pending terms to W0, so the dots are skipped and the pass
 // reads the folded matrix.
-constexpr int SW_CH = 512, SW_RB = 512, SW_RS = 8;
 constexpr int SW_MAX_BLOCKS = 8192;
-template <bool WITH_V>
-__global__ void __launch_bounds__(BLK) k_stream_w(DevView v) {
+template <bool WITH_V, int SW_CH, int SW_RB, int SW_RS>
+__global__ void __launch_bounds__(BLK, 4) k_stream_w(DevView v) {  // 4 waves per SIMD: keep the double buffer within 128 VGPRs
+    static_assert(SW_CH == 2 * BLK || SW_CH == 4 * BLK, "one or two column pairs per thread");
+    constexpr int NP = SW_CH / (2 * BLK);
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     const int k = c->k, ld = v.ld;
@@ -2018,35 +2061,55 @@ __global__ void __launch_bounds__(BLK) k_stream_w(DevView v) {
     for (int tile = blockIdx.x; tile < nstr * nch; tile += n_tile_blocks) {
         const int strip = tile / nch, chunk = tile % nch;
         const int rbeg = strip * SW_RB, rend = min(k, rbeg + SW_RB);
-        const int c0 = chunk * SW_CH + 2 * tid;
-        const bool pair = c0 + 1 < k, one = c0 < k;
-        const double rk0 = one ? v.rK[c0] : 0.0, rk1 = pair ? v.rK[c0 + 1] : 0.0;
-        double vacc0 = 0.0, vacc1 = 0.0;
-        dbl2_t w[SW_RS], wn[SW_RS];
-        auto load_step = [&](dbl2_t (&dst)[SW_RS], int r0) {
+        int c0[NP];
+        bool pair[NP], one[NP];
+        double rk0[NP], rk1[NP], vacc0[NP], vacc1[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            c0[p] = chunk * SW_CH + p * 2 * BLK + 2 * tid;
+            pair[p] = c0[p] + 1 < k;
+            one[p] = c0[p] < k;
+            rk0[p] = one[p] ? v.rK[c0[p]] : 0.0;
+            rk1[p] = pair[p] ? v.rK[c0[p] + 1] : 0.0;
+            vacc0[p] = vacc1[p] = 0.0;
+        }
+        // Branch-free loads: rows beyond the strip are clamped to its last row (their products are masked through
+        // t = 0 and never stored), columns beyond k to column 0 (masked by select); a lone last column (odd k) is
+        // read as a pair whose second half lies in the row's padding (ld > k there) and is masked.  Conditional
+        // loads would split the loop into many basic blocks (see k_fold_w).
+        const double* wcol[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) wcol[p] = Wp + (one[p] ? c0[p] : 0);
+        dbl2_t w[SW_RS][NP], wn[SW_RS][NP];
+        auto load_step = [&](dbl2_t (&dst)[SW_RS][NP], int r0) {
 #pragma unroll
             for (int a = 0; a < SW_RS; ++a) {
-                const int row = r0 + a;
-                dst[a] = dbl2_t{0.0, 0.0};
-                if (row < rend) {
-                    const double* wp = Wp + (size_t)row * ld + c0;
-                    if (pair) dst[a] = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t*>(wp));
-                    else if (one) dst[a].x = *wp;
+                const size_t roff = (size_t)min(r0 + a, rend - 1) * ld;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const dbl2_t t = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t*>(wcol[p] + roff));
+                    dst[a][p].x = one[p] ? t.x : 0.0;
+                    dst[a][p].y = pair[p] ? t.y : 0.0;
                 }
             }
         };
         load_step(w, rbeg);
         int buf = 0;
         for (int r0 = rbeg; r0 < rend; r0 += SW_RS, buf ^= 1) {
-            if (r0 + SW_RS < rend) load_step(wn, r0 + SW_RS);
+            if (r0 + SW_RS < rend) load_step(wn, r0 + SW_RS);  // (uniform branch: the last step has no successor)
 #pragma unroll
             for (int a = 0; a < SW_RS; ++a) {
-                s_t[buf][a][tid] = w[a].x * rk0 + w[a].y * rk1;
-                if (WITH_V) {
-                    const double t = (r0 + a < rend) ? tKp[r0 + a] : 0.0;
-                    vacc0 += w[a].x * t;
-                    vacc1 += w[a].y * t;
+                double sacc = 0.0;
+                const double t = (WITH_V && r0 + a < rend) ? tKp[r0 + a] : 0.0;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    sacc += w[a][p].x * rk0[p] + w[a][p].y * rk1[p];
+                    if (WITH_V) {
+                        vacc0[p] += w[a][p].x * t;
+                        vacc1[p] += w[a][p].y * t;
+                    }
                 }
+                s_t[buf][a][tid] = sacc;
             }
             __syncthreads();  // one barrier per step: the two LDS buffers alternate
             double sum = 0.0;
@@ -2055,13 +2118,108 @@ __global__ void __launch_bounds__(BLK) k_stream_w(DevView v) {
             sum = group_sum<G>(sum);
             if (gl == 0 && r0 + rrow < rend) v.part_tau[(size_t)chunk * ld + r0 + rrow] = sum;
 #pragma unroll
-            for (int a = 0; a < SW_RS; ++a) w[a] = wn[a];
+            for (int a = 0; a < SW_RS; ++a)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) w[a][p] = wn[a][p];
         }
         __syncthreads();  // the next tile's first step may reuse the buffer the slowest wave is still reducing
         if (WITH_V) {
             double* pv = v.part_v + (size_t)strip * ld;
-            if (one) pv[c0] = vacc0;
-            if (pair) pv[c0 + 1] = vacc1;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                if (one[p]) pv[c0[p]] = vacc0[p];
+                if (pair[p]) pv[c0[p] + 1] = vacc1[p];
+            }
+        }
+    }
+}
+
+// Fold of the pending rank-1 terms into W0 for the large-nucleus mode:  W0[r][c] += sum_j U[j][r] V[j][c], j < nlow
+// (one explicit FMA per term, in term order, like k_fused_lr16).  One read and one write of W0, 2 JM flops per
+// element: memory-bound as long as the FMAs hide behind the stream, so the kernel is shaped like k_stream_w:
+//   * a block owns FD_CH = 256 columns x FD_RB rows; a thread owns ONE column and keeps the JM values V[j][col] in
+//     registers for the whole strip (a pair of columns would need 2 JM registers and halve the occupancy);
+//   * rows are walked in steps of FD_RS = 8: the 8 x JM values U[j][row] of a step are staged in LDS (double buffer,
+//     one barrier per step) and read back as broadcast 16-byte words; the loads of step i + 1 are issued before step i
+//     is consumed.
+// mode 1: host-requested (flush outside the pivot loop); mode 2: a folding pivot (Ctl.fold), k_stream_w follows.
+constexpr int FD_CH = 256, FD_RB = 256, FD_RS = 8;
+// The hot loop is branch-free: rows and columns beyond the edge are CLAMPED (the loads are unconditional, their
+// results masked or never stored).  With `cond ? load : 0` forms the loop breaks into ~20 basic blocks and the
+// register allocator spills the V values (measured: 1.8 KB of scratch per lane).
+template <int JM>
+__global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : 3)) k_fold_w(DevView v, int mode) {
+    Ctl* c = v.ctl;
+    if (mode != 1 && (c->halt || c->it.status != ITER_PIVOT)) return;
+    if (!(mode == 1 || c->fold)) return;
+    const int k = c->k, ld = v.ld;
+    const int nlow = min(c->nlow, JM);
+    if (nlow <= 0 || k <= 0) return;
+    const int tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) double s_u[2][FD_RS][JM];
+    const int nch = (k + FD_CH - 1) / FD_CH, nstr = (k + FD_RB - 1) / FD_RB;
+    const int sa = tid / JM, sj = tid % JM;  // staging: thread -> (row of the step, term)
+    const bool stager = sa < FD_RS;
+    const int sjc = min(sj, nlow - 1);
+    double* __restrict__ Wp = v.W;
+    const double* __restrict__ Up = v.U;
+    const double* __restrict__ Vp = v.V;
+    for (int tile = blockIdx.x; tile < nstr * nch; tile += gridDim.x) {
+        const int strip = tile / nch, chunk = tile % nch;
+        const int rbeg = strip * FD_RB, rend = min(k, rbeg + FD_RB);
+        const int col = chunk * FD_CH + tid;
+        const bool active = col < k;
+        const int colc = active ? col : k - 1;
+        double vj[JM];
+#pragma unroll
+        for (int j = 0; j < JM; ++j) {
+            const double x = Vp[(size_t)min(j, nlow - 1) * ld + colc];
+            vj[j] = (active && j < nlow) ? x : 0.0;
+        }
+        double* wcol = Wp + colc;
+        double w[FD_RS], wn[FD_RS];
+        __syncthreads();  // the previous tile's readers of s_u are done
+        {
+            const int row = min(rbeg + (stager ? sa : 0), rend - 1);
+            const double x = Up[(size_t)sjc * ld + row];
+            if (stager) s_u[0][sa][sj] = (sj < nlow && rbeg + sa < rend) ? x : 0.0;
+        }
+#pragma unroll
+        for (int a = 0; a < FD_RS; ++a) w[a] = __builtin_nontemporal_load(wcol + (size_t)min(rbeg + a, rend - 1) * ld);
+        int buf = 0;
+        for (int r0 = rbeg; r0 < rend; r0 += FD_RS, buf ^= 1) {
+            __syncthreads();  // s_u[buf] is staged; s_u[buf ^ 1] is free (its readers passed this barrier)
+            if (r0 + FD_RS < rend) {  // uniform branch: the last step has no successor
+                const int rn = r0 + FD_RS;
+                const int row = min(rn + (stager ? sa : 0), rend - 1);
+                const double x = Up[(size_t)sjc * ld + row];
+                if (stager) s_u[buf ^ 1][sa][sj] = (sj < nlow && rn + sa < rend) ? x : 0.0;
+#pragma unroll
+                for (int a = 0; a < FD_RS; ++a) wn[a] = __builtin_nontemporal_load(wcol + (size_t)min(rn + a, rend - 1) * ld);
+            }
+#pragma unroll
+            for (int a = 0; a < FD_RS; ++a) {
+                double acc = w[a];
+#pragma unroll
+                for (int j = 0; j < JM; j += 2) {
+                    const double2 u = *reinterpret_cast<const double2*>(&s_u[buf][a][j]);
+                    acc = __builtin_fma(u.x, vj[j], acc);
+                    acc = __builtin_fma(u.y, vj[j + 1], acc);
+                }
+                w[a] = acc;
+            }
+            if (active) {
+                if (r0 + FD_RS <= rend) {
+#pragma unroll
+                    for (int a = 0; a < FD_RS; ++a) __builtin_nontemporal_store(w[a], wcol + (size_t)(r0 + a) * ld);
+                } else {
+#pragma unroll
+                    for (int a = 0; a < FD_RS; ++a)
+                        if (r0 + a < rend) __builtin_nontemporal_store(w[a], wcol + (size_t)(r0 + a) * ld);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < FD_RS; ++a) w[a] = wn[a];
         }
     }
 }
@@ -2078,8 +2236,11 @@ __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push) {
     if (c->halt || c->it.status != ITER_PIVOT) return;
     const int k = c->k;
     if ((int)blockIdx.x < n_push) {
-        int slot = (blockIdx.x * BLK + threadIdx.x) / G;
-        int gl = threadIdx.x & (G - 1);
+        // G lanes per slot serve the push of -F tau_K; when that product is computed elsewhere (blocked push, pulled
+        // form) one lane per slot does the reduction and the blocks beyond k / 256 exit at once
+        const bool solo = v.pb_on || v.det_pull;
+        int slot = solo ? (int)(blockIdx.x * BLK + threadIdx.x) : (int)(blockIdx.x * BLK + threadIdx.x) / G;
+        int gl = solo ? 0 : (int)(threadIdx.x & (G - 1));
         if (slot >= k) return;
         const int nchunks = (k + TC - 1) / TC;
         double x = 0.0;
@@ -2562,6 +2723,15 @@ static inline int fw_rows(const Geom& g) { return g.big ? 16 * FW_RL : 8; }
 // 1-D grid of the tiled large-nucleus passes: enough blocks to fill the chip a few times over
 constexpr int FW_TILE_BLOCKS = 4096;
 // MLP_STREAM_STRIPS=0 keeps the older 16 x 1024 tiling of the large-nucleus streaming pass (A/B measurements)
+// strip geometry of k_stream_w (columns x rows per block, rows per step); MLP_SW_VARIANT selects one for A/B runs
+struct SwGeom { int ch, rb, rs; };
+static constexpr SwGeom kSwGeoms[] = {{512, 512, 8}, {1024, 256, 4}, {1024, 128, 4}, {512, 256, 8}, {1024, 64, 4}, {512, 128, 4}};
+static int stream_variant() {
+    static const int vv = std::getenv("MLP_SW_VARIANT") ? std::atoi(std::getenv("MLP_SW_VARIANT")) : 2;
+    return (vv >= 0 && vv < (int)(sizeof(kSwGeoms) / sizeof(kSwGeoms[0]))) ? vv : 2;
+}
+static int sw_ch() { return kSwGeoms[stream_variant()].ch; }
+static int sw_rb() { return kSwGeoms[stream_variant()].rb; }
 static bool stream_strips() {
     static const bool on = !(std::getenv("MLP_STREAM_STRIPS") && std::atoi(std::getenv("MLP_STREAM_STRIPS")) == 0);
     return on;
@@ -2584,12 +2754,32 @@ static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fo
         const int nb = (int)(tiles_cap < FW_TILE_BLOCKS ? tiles_cap : FW_TILE_BLOCKS);
         if (FW_RL == 1 && stream_strips()) {
             // a folding pivot folds first (mode 2: no partials), then EVERY pivot streams W0 once (k_stream_w)
-            hipLaunchKernelGGL((k_fused_lr16<false, true>), dim3(nb), b, 0, st, dv, fold_only ? 1 : 2);
+            static const bool old_fold = std::getenv("MLP_OLD_FOLD") != nullptr;  // A/B: the 16 x 1024 fold kernel
+            if (old_fold) {
+                hipLaunchKernelGGL((k_fused_lr16<false, true>), dim3(nb), b, 0, st, dv, fold_only ? 1 : 2);
+            } else {
+                const long ftiles = (long)((g.cap + FD_RB - 1) / FD_RB) * ((g.cap + FD_CH - 1) / FD_CH);
+                const int nf = (int)(ftiles < SW_MAX_BLOCKS ? ftiles : SW_MAX_BLOCKS);
+                if (dv.lrJ <= 16) hipLaunchKernelGGL(k_fold_w<16>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2);
+                else hipLaunchKernelGGL(k_fold_w<LR_MAX>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2);
+            }
             if (!fold_only) {
-                const long tiles = (long)((g.cap + SW_RB - 1) / SW_RB) * ((g.cap + SW_CH - 1) / SW_CH);
+                const long tiles = (long)((g.cap + sw_rb() - 1) / sw_rb()) * ((g.cap + sw_ch() - 1) / sw_ch());
                 const int nt = (int)(tiles < SW_MAX_BLOCKS ? tiles : SW_MAX_BLOCKS);
-                if (with_v) hipLaunchKernelGGL(k_stream_w<true>, dim3(nt + LR_MAX), b, 0, st, dv);
-                else hipLaunchKernelGGL(k_stream_w<false>, dim3(nt + LR_MAX), b, 0, st, dv);
+#define SW_LAUNCH(CH, RB, RS)                                                                                     \
+    do {                                                                                                          \
+        if (with_v) hipLaunchKernelGGL((k_stream_w<true, CH, RB, RS>), dim3(nt + LR_MAX), b, 0, st, dv);          \
+        else hipLaunchKernelGGL((k_stream_w<false, CH, RB, RS>), dim3(nt + LR_MAX), b, 0, st, dv);                \
+    } while (0)
+                switch (stream_variant()) {
+                case 0: SW_LAUNCH(512, 512, 8); break;
+                case 1: SW_LAUNCH(1024, 256, 4); break;
+                case 3: SW_LAUNCH(512, 256, 8); break;
+                case 4: SW_LAUNCH(1024, 64, 4); break;
+                case 5: SW_LAUNCH(512, 128, 4); break;
+                default: SW_LAUNCH(1024, 128, 4); break;
+                }
+#undef SW_LAUNCH
             }
             return;
         }
@@ -2633,15 +2823,20 @@ void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st
     }
 }
 void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic) {
-    if (!classic && dv.lrJ && fw_rows(g) != 8 && FW_RL == 1 && stream_strips()) {  // partials of k_stream_w: 512-row strips, 512-column chunks
+    if (!classic && dv.lrJ && fw_rows(g) != 8 && FW_RL == 1 && stream_strips()) {  // partials of k_stream_w's strips
+#define POSTS2(G, RB, CH)                                                                                         \
+    if (sw_rb() == RB && sw_ch() == CH) {                                                                         \
+        if (with_v) hipLaunchKernelGGL((k_post_fused<G, true, RB, CH>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push); \
+        else hipLaunchKernelGGL((k_post_fused<G, false, RB, CH>), dim3(n_push), dim3(BLK), 0, st, dv, n_push);    \
+    }
 #define POSTS(G)                                                                                                  \
     do {                                                                                                          \
         int n_push = blocks_for((long)g.cap * G);                                                                 \
-        if (with_v) hipLaunchKernelGGL((k_post_fused<G, true, SW_RB, SW_CH>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push); \
-        else hipLaunchKernelGGL((k_post_fused<G, false, SW_RB, SW_CH>), dim3(n_push), dim3(BLK), 0, st, dv, n_push); \
+        POSTS2(G, 512, 512); POSTS2(G, 256, 1024); POSTS2(G, 128, 1024); POSTS2(G, 256, 512); POSTS2(G, 128, 512); POSTS2(G, 64, 1024);  \
     } while (0)
         LANES_SWITCH(g.lanes, POSTS(4), POSTS(16), POSTS(64));
 #undef POSTS
+#undef POSTS2
         if (dv.pb_on) launch_blocked_push(dv, 1, st);
         else if (dv.det_pull) launch_pull_F(dv, g, 1, st);
         return;
