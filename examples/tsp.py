@@ -196,11 +196,42 @@ class TspSolver:
         return float(sum(self.dist[tour[i], tour[(i + 1) % len(tour)]] for i in range(len(tour))))
 
 
+def tour_to_svg(pts, tour, width=600, margin=50):
+    """SVG drawing of a tour, the counterpart of `Tour::to_svg` (tsp.rs:169-208): the points are scaled to a
+    `width`-pixel-wide canvas with a `margin`, rounded to whole pixels, and the closed tour is one black 4-pixel path
+    that starts (M) at city 0 and visits the others with L commands."""
+    pts = np.asarray(pts, dtype=np.float64)
+    min_x, max_x = pts[:, 0].min(), pts[:, 0].max()
+    min_y, max_y = pts[:, 1].min(), pts[:, 1].max()
+    scale = (width - 2 * margin) / (max_x - min_x)
+
+    def rnd(x):  # f64::round: half away from zero (Python's round is half to even)
+        return int(np.floor(abs(x) + 0.5) * (1 if x >= 0 else -1))
+    height = rnd((max_y - min_y) * scale) + 2 * margin
+    tour = [int(t) for t in tour]
+    if 0 in tour:  # the reference's tours start at city 0 (tsp.rs:398-434)
+        at = tour.index(0)
+        tour = tour[at:] + tour[:at]
+    out = ['<?xml version="1.0" encoding="UTF-8" standalone="no"?>\n',
+           '<!DOCTYPE svg PUBLIC "-//W3C//DTD SVG 1.1//EN"\n',
+           '  "http://www.w3.org/Graphics/SVG/1.1/DTD/svg11.dtd">\n',
+           '<svg width="%dpx" height="%dpx" version="1.1"' % (width, height),
+           '     xmlns="http://www.w3.org/2000/svg">\n',
+           '    <path fill="none" stroke="black" stroke-width="4px" d="\n']
+    for i in tour:
+        px = rnd((pts[i, 0] - min_x) * scale) + margin
+        py = rnd((pts[i, 1] - min_y) * scale) + margin
+        out.append("        %s %d %d\n" % ("M" if i == 0 else "L", px, py))
+    out += ["        Z\n", '    "/>\n', "</svg>\n"]
+    return "".join(out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("file")
     ap.add_argument("--nodes", type=int, default=None, help="use only the first N cities")
     ap.add_argument("--max-bb-nodes", type=int, default=None)
+    ap.add_argument("--svg", default=None, help="write the tour as an SVG drawing (tsp.rs:169-208)")
     a = ap.parse_args()
     import os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -210,6 +241,10 @@ def main():
     s = TspSolver(backend, pts, log=lambda m: print("[%.1fs] %s" % (time.time() - t0, m), flush=True))
     cost, tour = s.solve(a.max_bb_nodes)
     print("problem %s (%d cities): tour cost %.10f, %s, %.1fs" % (name, len(pts), cost, s.stats, time.time() - t0))
+    print("tour:", " ".join(str(int(t) + 1) for t in tour))  # Tour::to_string (tsp.rs:161-167): 1-based city numbers
+    if a.svg:
+        with open(a.svg, "w") as f:
+            f.write(tour_to_svg(pts, tour))
 
 
 if __name__ == "__main__":

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <utility>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -100,6 +101,9 @@ struct DevBuf {
         ensure(h.size(), 0, st);
         if (!h.empty()) HIPCHECK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
     }
+    void swap(DevBuf<T>& o) {
+        std::swap(p, o.p); std::swap(cap, o.cap); std::swap(bytes, o.bytes); std::swap(dev, o.dev);
+    }
     void copy_from(const DevBuf<T>& o, size_t n, hipStream_t st) {
         ensure(n, 0, st);
         if (n) HIPCHECK(hipMemcpyAsync(p, o.p, n * sizeof(T), hipMemcpyDeviceToDevice, st));
@@ -177,8 +181,15 @@ private:
     std::vector<double> h_obj, h_lo, h_hi, h_rhs;
     std::vector<int> h_rptr, h_rcol;
     std::vector<double> h_rval;
-    std::vector<int> h_cptr, h_crow;
+    // Host view of the columns: only what the host logic needs — the length of every column and, for singleton
+    // columns, their single entry (classification of the basis in rebuild_inverse).  The CSC itself lives on the
+    // device only (built there from the uploaded CSR-side arrays at try_new, re-laid out there by add_constraint).
+    std::vector<int> h_cptr, h_crow;       // initial build only (try_new); dropped after the first device-side append
     std::vector<double> h_cval;
+    int max_col_nnz_ = 0, max_row_nnz_ = 0;   // longest column / row of A (in-kernel stage heads need them to fit an LDS list)
+    bool no_head_fusion = false;             // MLP_NO_HEAD_FUSION: keep the stage heads as launches of their own
+    std::vector<int> h_colnnz, h_single_row;
+    std::vector<double> h_single_val;
     std::vector<int> h_basic_vars, h_nb_vars, h_var_loc;
     // slot maps live on the device; pulled on demand (reinvert, add_constraint, clone)
     std::vector<int> h_kslot_of_pos, h_srow_of_pos, h_kslot_of_row, h_pos_of_srow, h_pos_of_kslot, h_row_of_kslot;
@@ -237,6 +248,8 @@ private:
     void* own_box = nullptr;               // peer transport: this rank's mailbox in its own HBM
     void* peer_box[MAX_WORLD] = {};        // ... and the peers' boxes as mapped through HIP IPC
     int mail_fanout = 1;
+    size_t xb_cap_ = 0;                    // doubles per vector slot of the exchange buffer (>= the largest possible nucleus)
+    bool no_wshard = false;                // MLP_NO_WSHARD: keep the streaming pass replicated on every rank
     void release_mailboxes();
   public:
     std::string transport = "none";        // human-readable name of the exchange transport
@@ -286,7 +299,10 @@ private:
     void pull_ctl();
     void pull_maps();
     void push_maps();
-    int col_nnz(int var) const { return h_cptr[var + 1] - h_cptr[var]; }
+    int col_nnz(int var) const { return h_colnnz[var]; }
+    DevBuf<int> d_cptr_alt, d_crow_alt, d_row_idx, d_scan_tmp;  // second CSC buffer set of the device-side append, staging
+    DevBuf<double> d_cval_alt, d_row_val;
+    void append_row_on_device(const Constraint& c, int slack, int row);
 
     void record_iteration(int phase, bool with_events);  // enqueue the kernel sequence of ONE iteration
     void launch_stage(int phase, int stage, bool with_events);

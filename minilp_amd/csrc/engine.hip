@@ -94,6 +94,10 @@ Engine::Engine() {
     if (fr) final_refresh_pivots = std::atol(fr);
     const char* nbp = std::getenv("MLP_NO_BLOCKED_PUSH");
     pb_disable = nbp && std::atoi(nbp) != 0;
+    const char* nhf = std::getenv("MLP_NO_HEAD_FUSION");
+    no_head_fusion = nhf && std::atoi(nhf) != 0;
+    const char* nws = std::getenv("MLP_NO_WSHARD");
+    no_wshard = nws && std::atoi(nws) != 0;
     const char* bs = std::getenv("MLP_BATCH");
     if (bs) batch = std::max(1, std::min(RING, std::atoi(bs)));
     const char* gi = std::getenv("MLP_GRAPH_ITERS");
@@ -272,6 +276,7 @@ void Engine::drop_graphs() {
         }
 }
 
+static constexpr size_t kMailBoxBytesPerRank = sizeof(MailRec) * 2 * MAIL_KINDS;
 Geom Engine::geom() const {
     Geom g;
     g.m = m_;
@@ -281,6 +286,8 @@ Geom Engine::geom() const {
     g.lanes = avg >= 40.0 ? 64 : (avg >= 6.0 ? 16 : 4);
     g.sweep_variant = sweep_variant;
     g.big = (cap_ > 4096 || force_big_tiles) ? 1 : 0;
+    const int lr = lr_force >= 0 ? lr_force : (cap_ >= 32768 ? 32 : (cap_ >= 8192 ? 16 : 0));  // as in sync_view
+    g.head_fused = (!no_head_fusion && lr == 0 && max_col_nnz_ <= HEAD_LIST_CAP && max_row_nnz_ <= HEAD_LIST_CAP) ? 1 : 0;
     return g;
 }
 
@@ -294,36 +301,22 @@ bool Engine::use_banded() const {
 }
 void Engine::ensure_banded() {
     if (!banded_dirty) return;
+    // built on the device from the CSC (kernels.hip: k_band_count -> exclusive scan -> k_band_fill)
     const int nb = (m_ + BAND_ROWS - 1) / BAND_ROWS;
-    std::vector<int> bptr((size_t)nb * (size_t)(N_ + 1));
-    // pass 1: counts per (band, column), rounded up to an even number (16-bit rows: an even segment start
-    // keeps the 16-byte row loads 4-byte aligned; the pad entry has value 0)
-    std::vector<int> cnt((size_t)nb * (size_t)N_, 0);
-    for (int var = 0; var < N_; ++var)
-        for (int e = h_cptr[var]; e < h_cptr[var + 1]; ++e) cnt[(size_t)(h_crow[e] / BAND_ROWS) * N_ + var] += 1;
-    size_t off = 0;
-    for (int b = 0; b < nb; ++b) {
-        int* bp = &bptr[(size_t)b * (N_ + 1)];
-        for (int var = 0; var < N_; ++var) {
-            bp[var] = (int)off;
-            off += (size_t)((cnt[(size_t)b * N_ + var] + 1) & ~1);
-        }
-        bp[N_] = (int)off;
-    }
-    std::vector<unsigned short> brow(off + 8, (unsigned short)0);  // + 8: the kernel reads whole groups of 8 entries
-    std::vector<double> bval(off + 8, 0.0);
-    // pass 2: fill (the entries of a column inside one band are consecutive and ascending)
-    std::vector<int> fill((size_t)nb * (size_t)N_, 0);
-    for (int var = 0; var < N_; ++var)
-        for (int e = h_cptr[var]; e < h_cptr[var + 1]; ++e) {
-            const int b = h_crow[e] / BAND_ROWS;
-            const size_t dst = (size_t)bptr[(size_t)b * (N_ + 1) + var] + (size_t)fill[(size_t)b * N_ + var]++;
-            brow[dst] = (unsigned short)(h_crow[e] - b * BAND_ROWS);
-            bval[dst] = h_cval[e];
-        }
-    d_bptr.upload(bptr, st); d_brow.upload(brow, st); d_bval.upload(bval, st);
+    const size_t np = (size_t)nb * (size_t)(N_ + 1);
+    d_bptr.ensure(np, 0, st);
+    d_scan_tmp.ensure(np / 4096 + 8, 0, st);
+    launch_band_count(d_cptr.p, d_crow.p, N_, nb, d_bptr.p, st);
+    launch_exclusive_scan(d_bptr.p, d_bptr.p, (long)np, d_scan_tmp.p, st);
+    int total = 0;
+    HIPCHECK(hipMemcpyAsync(&total, d_scan_tmp.p + (np + 4095) / 4096, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    d_brow.ensure((size_t)total + 8, 0, st);  // + 8: the kernel reads whole groups of 8 entries
+    d_bval.ensure((size_t)total + 8, 0, st);
+    HIPCHECK(hipMemsetAsync(d_brow.p + total, 0, 8 * sizeof(unsigned short), st));
+    HIPCHECK(hipMemsetAsync(d_bval.p + total, 0, 8 * sizeof(double), st));
+    launch_band_fill(d_cptr.p, d_crow.p, d_cval.p, N_, nb, d_bptr.p, d_brow.p, d_bval.p, st);
     d_band_part.ensure((size_t)nb * (size_t)num_vars, 0, st);
-    HIPCHECK(hipStreamSynchronize(st));  // local staging buffers
     banded_dirty = false;
 }
 
@@ -332,21 +325,9 @@ void Engine::ensure_banded() {
 void Engine::ensure_colblk() {
     if (!colblk_dirty) return;
     const int rb = (m_ + PB_ROWS - 1) / PB_ROWS;
-    std::vector<int> t((size_t)N_ * (rb + 1));
-    for (int var = 0; var < N_; ++var) {
-        int e = h_cptr[var];
-        const int end = h_cptr[var + 1];
-        int* dst = &t[(size_t)var * (rb + 1)];
-        for (int b = 0; b <= rb; ++b) {
-            const long lim = (long)b * PB_ROWS;
-            while (e < end && h_crow[e] < lim) ++e;
-            dst[b] = e;
-        }
-        dst[rb] = end;
-    }
-    d_colblk.upload(t, st);
+    d_colblk.ensure((size_t)N_ * (rb + 1), 0, st);
+    launch_build_colblk(d_cptr.p, d_crow.p, N_, rb, d_colblk.p, st);  // on the device, from the CSC
     d_push_part.ensure((size_t)PB_CHUNKS * (size_t)m_, 0, st);
-    HIPCHECK(hipStreamSynchronize(st));  // `t` is a local staging buffer
     colblk_dirty = false;
 }
 
@@ -392,7 +373,16 @@ DevView* Engine::sync_view() {
     v.nb_rng = d_nb_rng.p;
     v.rank = shard_rank; v.world = shard_world; v.mail = d_mail;
     for (int r = 0; r < MAX_WORLD; ++r) v.mail_peer[r] = reinterpret_cast<MailRec*>(peer_box[r]);
-    v.mail_fanout = shard_world > 1 ? mail_fanout : 0; v.pad2 = 0;
+    v.mail_fanout = shard_world > 1 ? mail_fanout : 0;
+    {   // exchange buffers of the row-sharded streaming pass (peer transport, large-nucleus delayed-update mode only)
+        const size_t mb = kMailBoxBytesPerRank * (size_t)std::max(shard_world, 1);
+        v.wshard = (shard_world > 1 && mail_fanout > 1 && own_box && v.lrJ > 0 && geom().big && stream_strips_enabled() &&
+                    !no_wshard && (size_t)cap_ <= xb_cap_) ? 1 : 0;
+        v.xbuf = own_box ? reinterpret_cast<double*>(static_cast<uint8_t*>(own_box) + mb) : nullptr;
+        for (int r = 0; r < MAX_WORLD; ++r)
+            v.xbuf_peer[r] = peer_box[r] ? reinterpret_cast<double*>(static_cast<uint8_t*>(peer_box[r]) + mb) : nullptr;
+        v.xb_cap = (int)xb_cap_; v.pad3 = 0;
+    }
     v.nb_lo = shard_world > 1 ? (int)((long)num_vars * shard_rank / shard_world) : 0;
     v.nb_hi = shard_world > 1 ? (int)((long)num_vars * (shard_rank + 1) / shard_world) : num_vars;
     if (std::memcmp(&old, &hview, sizeof(DevView)) != 0) {
@@ -417,6 +407,20 @@ void Engine::build_csc() {  // counting transpose of the CSR: ascending row inde
             h_crow[dst] = r;
             h_cval[dst] = h_rval[p];
         }
+    max_col_nnz_ = 0;
+    max_row_nnz_ = 0;
+    for (int r = 0; r < m_; ++r) max_row_nnz_ = std::max(max_row_nnz_, h_rptr[r + 1] - h_rptr[r]);
+    h_colnnz.resize(N_);
+    h_single_row.assign(N_, -1);
+    h_single_val.assign(N_, 0.0);
+    for (int c = 0; c < N_; ++c) {
+        h_colnnz[c] = h_cptr[c + 1] - h_cptr[c];
+        max_col_nnz_ = std::max(max_col_nnz_, h_colnnz[c]);
+        if (h_colnnz[c] == 1) {
+            h_single_row[c] = h_crow[h_cptr[c]];
+            h_single_val[c] = h_cval[h_cptr[c]];
+        }
+    }
 }
 void Engine::upload_matrix() {
     d_cptr.upload(h_cptr, st); d_crow.upload(h_crow, st); d_cval.upload(h_cval, st);
@@ -539,8 +543,8 @@ void Engine::push_maps() {
 
 // ------------------------------------------------------------------ column-block sharding
 // Rendezvous: a POSIX shared-memory object created (zeroed) by the launcher, mapped by every rank:
-//   [0, 512 * world)                 host-transport mailbox (MLP_MAILBOX=host), registered with HIP
-//   [512 * world, 640 * world)       one 128-byte rendezvous record per rank: HIP IPC handle of its device box
+//   [0, 640 * world)                 host-transport mailbox (MLP_MAILBOX=host), registered with HIP
+//   [640 * world, 768 * world)       one 128-byte rendezvous record per rank: HIP IPC handle of its device box
 // Peer transport (default): every rank allocates its box in its OWN HBM (uncached, falling back to fine-grained),
 // publishes the IPC handle, opens the peers' handles (peer access is enabled lazily by hipIpcOpenMemHandle), and
 // the pivot kernels then write their 64-byte records straight into the peers' boxes over xGMI and poll locally.
@@ -552,7 +556,7 @@ struct Rendezvous {  // 128 bytes
     uint8_t pad[128 - 8 - 8 - sizeof(hipIpcMemHandle_t)];
 };
 static_assert(sizeof(Rendezvous) == 128, "rendezvous record layout");
-constexpr size_t kHostBoxBytesPerRank = sizeof(MailRec) * 2 * MAIL_KINDS;  // 512
+constexpr size_t kHostBoxBytesPerRank = sizeof(MailRec) * 2 * MAIL_KINDS;  // 640
 bool wait_flag(volatile uint64_t* f, uint64_t want, double seconds) {
     const double t0 = now_s();
     while (__atomic_load_n(f, __ATOMIC_ACQUIRE) < want) {
@@ -596,7 +600,7 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name) {
     struct stat sb;
     if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < bytes) {
         close(fd);
-        throw MlpError(-1, "enable_sharding: mailbox object too small (need 640 * world bytes)");
+        throw MlpError(-1, "enable_sharding: mailbox object too small (need 768 * world bytes)");
     }
     void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
@@ -614,7 +618,11 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name) {
             mail_fanout = 1;
             transport = "host-mapped shared-memory mailbox (PCIe)";
         } else {
-            const size_t box_bytes = host_bytes;  // same layout: [kind][parity][rank]
+            // one allocation: the mailbox ([kind][parity][rank] records) followed by the exchange buffer of the
+            // row-sharded streaming pass ([parity][rank][tau_K | v_K partial][xb_cap] doubles), so that the one IPC
+            // mapping a peer opens covers both
+            xb_cap_ = (((size_t)std::max(m_, 1) + 1023) / 1024) * 1024 + 64;
+            const size_t box_bytes = host_bytes + sizeof(double) * 2 * (size_t)world * 2 * xb_cap_;
             hipError_t e = hipExtMallocWithFlags(&own_box, box_bytes, hipDeviceMallocUncached);
             if (e != hipSuccess) {
                 (void)hipGetLastError();
@@ -865,8 +873,12 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     switch (stage) {
     case STAGE_FTRAN:
         if (with_events) HIPCHECK(hipEventRecord(ev[6], st));
-        if (phase == 0) launch_ftran_prep(dv, 1, st);  // K2 head: entering column scalars, singleton rows, list
-        launch_ftran_gather(dv, g, st);                // K2: alpha_q = B^-1 a_q (dual: the head ran in RATIO)
+        if (phase == 0 && g.head_fused) {
+            launch_ftran_fused(dv, g, 1, st);              // K2 head inside the gather kernel (one launch)
+        } else {
+            if (phase == 0) launch_ftran_prep(dv, 1, st);  // K2 head: entering column scalars, singleton rows, list
+            launch_ftran_gather(dv, g, st);                // K2: alpha_q = B^-1 a_q (dual: the head ran in RATIO)
+        }
         if (with_events) HIPCHECK(hipEventRecord(ev[7], st));
         if (phase == 1) {
             launch_post_ftran(dv, g, pse, st);         // alpha_sq, y_S, partition plan
@@ -878,8 +890,12 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         else launch_ratio_dual(dv, g, st);                    // K7 p1, p2 (+ K2 head)
         break;
     case STAGE_BTRAN:
-        if (phase == 1) launch_btran_prep(dv, 1, 0, st);      // K3 head (device-driven by it.r)
-        launch_btran(dv, g, phase == 0 ? pse : 0, st);        // K3: rho, rK, ||rho||^2  |  tK = alpha_K - F^T y_S
+        if (phase == 1 && g.head_fused) {
+            launch_btran_fused(dv, g, 0, 1, st);                  // K3 head inside the BTRAN kernel (one launch)
+        } else {
+            if (phase == 1) launch_btran_prep(dv, 1, 0, st);      // K3 head (device-driven by it.r)
+            launch_btran(dv, g, phase == 0 ? pse : 0, st);        // K3: rho, rK, ||rho||^2  |  tK = alpha_K - F^T y_S
+        }
         break;
     case STAGE_BASIS:
         if (with_events) HIPCHECK(hipEventRecord(ev[2], st));
@@ -899,12 +915,10 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         }
         break;
     case STAGE_APPLY:
-        if (phase == 1) {                                     // the dual path changes the partition here
-            if (pse) launch_sweep(dv, g, 2, 1, st);           // PSE helper  |  partition change
-            else launch_structure_update(dv, g, st);
-        }
+        if (phase == 1 && pse) launch_sweep(dv, g, 2, 1, st);  // dual path: PSE helper  |  partition change
         if (with_events) HIPCHECK(hipEventRecord(ev[4], st));
-        launch_update_pivot(dv, g, phase, dse, pse, st, inl); // K8 + zero the work vectors + price the next iteration
+        // K8 + zero the work vectors + price the next iteration (dual path without PSE: | partition change)
+        launch_update_pivot(dv, g, phase, dse, pse, st, inl, (phase == 1 && !pse) ? 1 : 0);
         if (with_events) HIPCHECK(hipEventRecord(ev[5], st));
         break;
     default:
@@ -1163,7 +1177,8 @@ int Engine::run_loop(int phase) {
                 const bool read_only = hview.lrJ > 0 && !h_ctl->fold;
                 // a folding pivot of the large-nucleus mode reads and writes W0 (fold) and then streams it once more
                 const double fold_factor = (hview.lrJ > 0 && geom().big) ? 24.0 : 16.0;
-                stats.fused_bytes += (read_only ? 8.0 : fold_factor) * (double)k_before * (double)k_before;
+                const double stream_share = hview.wshard ? 1.0 / shard_world : 1.0;  // row-sharded pass: a rank streams its strips only
+                stats.fused_bytes += (read_only ? 8.0 * stream_share : fold_factor - 8.0 + 8.0 * stream_share) * (double)k_before * (double)k_before;
                 stats.fused_launches += 1;
             }
             if (hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) {
@@ -1396,6 +1411,54 @@ void Engine::add_gomory_cut(int var) {  // solver.rs:440-460
     add_constraint(std::move(c));
 }
 
+// Device-side row append (solver.rs:597-613 rebuilds both orientations on the host).  The host has
+// already appended the row to its CSR mirror and the variable arrays; here the same row goes to the device copies
+// without a pass over the matrix on the host and without re-uploading it: O(row) host work, one O(nnz) device copy.
+void Engine::append_row_on_device(const Constraint& c, int slack, int row) {
+    const size_t kn = c.idx.size();
+    const size_t old_nnz = h_rcol.size() - kn - 1;  // the host mirror already holds the new row (+ slack)
+    // --- CSR: append in place (capacity-doubling buffers keep their contents)
+    d_rcol.ensure(old_nnz + kn + 1, old_nnz, st);
+    d_rval.ensure(old_nnz + kn + 1, old_nnz, st);
+    d_rptr.ensure((size_t)m_ + 2, (size_t)m_ + 1, st);
+    HIPCHECK(hipMemcpyAsync(d_rcol.p + old_nnz, h_rcol.data() + old_nnz, (kn + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_rval.p + old_nnz, h_rval.data() + old_nnz, (kn + 1) * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_rptr.p + m_ + 1, &h_rptr[m_ + 1], sizeof(int), hipMemcpyHostToDevice, st));
+    // --- per-variable arrays: one new element (the slack)
+    d_lo.ensure((size_t)N_ + 1, (size_t)N_, st); d_hi.ensure((size_t)N_ + 1, (size_t)N_, st); d_obj.ensure((size_t)N_ + 1, (size_t)N_, st);
+    HIPCHECK(hipMemcpyAsync(d_lo.p + N_, &h_lo[N_], sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_hi.p + N_, &h_hi[N_], sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_obj.p + N_, &h_obj[N_], sizeof(double), hipMemcpyHostToDevice, st));
+    // --- CSC: one copy kernel into the second buffer set, then swap
+    d_row_idx.ensure(kn + 1, 0, st); d_row_val.ensure(kn + 1, 0, st);
+    if (kn) {
+        HIPCHECK(hipMemcpyAsync(d_row_idx.p, c.idx.data(), kn * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(d_row_val.p, c.val.data(), kn * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    d_cptr_alt.ensure((size_t)N_ + 2, 0, st);
+    d_crow_alt.ensure(old_nnz + kn + 1, 0, st);
+    d_cval_alt.ensure(old_nnz + kn + 1, 0, st);
+    launch_csc_append_row(d_cptr.p, d_crow.p, d_cval.p, N_, row, d_row_idx.p, d_row_val.p, (int)kn, d_cptr_alt.p, d_crow_alt.p,
+                          d_cval_alt.p, st);
+    HIPCHECK(hipStreamSynchronize(st));  // c.idx / c.val were staged from pageable memory; the old buffers become the spare set
+    d_cptr.swap(d_cptr_alt); d_crow.swap(d_crow_alt); d_cval.swap(d_cval_alt);
+    // --- host column summaries
+    for (size_t p = 0; p < kn; ++p) {
+        h_colnnz[c.idx[p]] += 1;
+        max_col_nnz_ = std::max(max_col_nnz_, h_colnnz[c.idx[p]]);
+    }
+    max_row_nnz_ = std::max(max_row_nnz_, (int)kn + 1);
+    h_colnnz.push_back(1);
+    h_single_row.push_back(row);
+    h_single_val.push_back(1.0);
+    if (!h_cptr.empty()) {  // the host CSC of the initial build is stale from here on
+        std::vector<int>().swap(h_cptr); std::vector<int>().swap(h_crow); std::vector<double>().swap(h_cval);
+    }
+    colblk_dirty = true;
+    banded_dirty = true;
+    view_dirty = true;
+}
+
 // solver.rs:549-634.  The new slack is a singleton basic column on the new row, so the nucleus
 // inverse is unchanged unless the new row touches a basic singleton column (then: rebuild).
 void Engine::add_constraint(Constraint c) {
@@ -1433,11 +1496,10 @@ void Engine::add_constraint(Constraint c) {
     h_hi.push_back(smax);
     HIPCHECK(hipStreamSynchronize(st));
     alloc_row_buffers(m_ + 1);
+    append_row_on_device(c, slack, row);  // CSR row appended, CSC re-laid out, derived copies marked for a device rebuild
     m_ += 1;
     N_ += 1;
     ensure_red();
-    build_csc();
-    upload_matrix();
     for (size_t p = 0; p < c.idx.size(); ++p)
         if (h_var_loc[c.idx[p]] < 0) nnz_nonbasic += 1;
     // new basic position `row` holding the slack (singleton on the new row)
@@ -1492,11 +1554,11 @@ void Engine::rebuild_inverse() {
     for (int p = 0; p < m_; ++p) {
         int var = h_basic_vars[p];
         if (col_nnz(var) == 1) {
-            int i = h_crow[h_cptr[var]];
+            int i = h_single_row[var];
             if (claimed[i] >= 0) throw MlpError(-2, "singular basis: two singleton columns on one row");
             claimed[i] = p;
             h_srow_of_pos[p] = i;
-            h_sdiag_of_pos[p] = h_cval[h_cptr[var]];
+            h_sdiag_of_pos[p] = h_single_val[var];
         } else {
             nuc_pos.push_back(p);
         }
@@ -1787,7 +1849,8 @@ Engine* Engine::clone() {
     e->m_ = m_; e->N_ = N_;
     e->h_obj = h_obj; e->h_lo = h_lo; e->h_hi = h_hi; e->h_rhs = h_rhs;
     e->h_rptr = h_rptr; e->h_rcol = h_rcol; e->h_rval = h_rval;
-    e->h_cptr = h_cptr; e->h_crow = h_crow; e->h_cval = h_cval;
+    e->h_colnnz = h_colnnz; e->h_single_row = h_single_row; e->h_single_val = h_single_val;
+    e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->no_head_fusion = no_head_fusion;
     e->h_basic_vars = h_basic_vars; e->h_nb_vars = h_nb_vars; e->h_var_loc = h_var_loc;
     e->h_kslot_of_pos = h_kslot_of_pos; e->h_srow_of_pos = h_srow_of_pos; e->h_kslot_of_row = h_kslot_of_row;
     e->h_pos_of_srow = h_pos_of_srow; e->h_sdiag_of_pos = h_sdiag_of_pos; e->h_nb_fixed = h_nb_fixed;
@@ -1802,7 +1865,15 @@ Engine* Engine::clone() {
     e->iters_since_polish = iters_since_polish;
     e->ld_pad = ld_pad; e->lr_force = lr_force; e->force_big_tiles = force_big_tiles; e->pb_disable = pb_disable;
     hipStream_t s2 = e->st;
-    e->upload_matrix();
+    {   // the matrix is copied device to device (the host keeps no CSC)
+        const size_t nz = h_rcol.size();
+        e->d_cptr.copy_from(d_cptr, (size_t)N_ + 1, s2); e->d_crow.copy_from(d_crow, nz, s2); e->d_cval.copy_from(d_cval, nz, s2);
+        e->d_rptr.copy_from(d_rptr, (size_t)m_ + 1, s2); e->d_rcol.copy_from(d_rcol, nz, s2); e->d_rval.copy_from(d_rval, nz, s2);
+        e->d_lo.copy_from(d_lo, (size_t)N_, s2); e->d_hi.copy_from(d_hi, (size_t)N_, s2); e->d_obj.copy_from(d_obj, (size_t)N_, s2);
+        e->colblk_dirty = true;
+        e->banded_dirty = true;
+        e->view_dirty = true;
+    }
     int mk = m_;
     e->m_ = 0;
     e->alloc_row_buffers(mk);

@@ -80,15 +80,16 @@ struct Ctl {
     double lr_c[LR_MAX], lr_e[LR_MAX], lr_g[LR_MAX], lr_h[LR_MAX];  // V[j].a_list, U[j].b_list, V[j].rho_K, U[j].t_K
     int ratio_epoch;          // fused primal ratio test: launch counter published by pass 1's last block
     double ratio_max_step;    // ... and the step bound it publishes
-    unsigned long long xepoch[4];  // sharded mode: exchange counters (kind 0: pricing, 1: primal ratio decision,
-                                   // 2: dual ratio pass-1 minimum, 3: dual ratio pass-2 candidate)
+    unsigned long long xepoch[5];  // sharded mode: exchange counters (kind 0: pricing, 1: primal ratio decision,
+                                   // 2: dual ratio pass-1 minimum, 3: dual ratio pass-2 candidate,
+                                   // 4: tau_K / v_K vectors of the row-sharded streaming pass)
     double max_pivot_err;  // max over the batch of |alpha_q[r] - alpha_r[q]| / max(1,|alpha_q[r]|): drift monitor of W
     PivotRec ring[RING];
 };
 
 // Sharded pricing: one 64-byte mailbox record per (kind, parity, rank) in host
 // memory mapped into every rank's GPU; a rank writes only its own slot and polls the others.
-constexpr int MAIL_KINDS = 4;
+constexpr int MAIL_KINDS = 5;
 constexpr int MAX_WORLD = 16;  // ranks of one sharded solve (one node: 8 GPUs; test rigs oversubscribe one GPU)
 struct alignas(64) MailRec {
     unsigned long long epoch;
@@ -179,7 +180,16 @@ struct DevView {
     // one box in host memory shared by all ranks (mail_fanout = 1, every poll crosses PCIe).
     MailRec* mail;                   // null when world == 1
     MailRec* mail_peer[MAX_WORLD];   // mail_peer[r]: rank r's box as mapped into this process (mail_peer[rank] == mail)
-    int mail_fanout, pad2;
+    int mail_fanout;
+    // Row-sharded streaming pass of the large-nucleus mode (wshard = 1, peer transport only): rank g streams the strips
+    // s with s % world == g of W0, writes its tau_K rows and its partial v_K into EVERY rank's exchange buffer (xGMI
+    // stores), and every rank assembles tau_K (rows from their owners) and v_K (partials summed in rank order) from its
+    // own buffer.  xbuf[parity][source rank][0: tau_K, 1: v_K partial][xb_cap] doubles, behind the mailbox of the same
+    // device allocation (so the peers' IPC mappings cover it).
+    int wshard;
+    double* xbuf;                    // this rank's exchange buffer (polled / read locally)
+    double* xbuf_peer[MAX_WORLD];    // rank r's exchange buffer as mapped into this process
+    int xb_cap, pad3;
 };
 
 // fused pass tiling
@@ -197,6 +207,7 @@ struct Geom {
     int lanes;  // lanes per CSC column in the pull kernels (4, 16 or 64; from the average column length)
     int sweep_variant;  // tuning knob (MLP_SWEEP): 0 default
     int big;            // fused W pass: 64-row x 1024-column blocks, non-temporal (cap > 4096, or forced by MLP_BIGTILE)
+    int head_fused;     // stage heads run inside the consuming kernel (delayed-update mode off, every column / row fits the LDS list)
 };
 
 // ---- launch wrappers (all asynchronous on `st`; the DevView is passed to the kernels by value) ----
@@ -205,6 +216,9 @@ void launch_price_primal(const DevView& dv, const Geom& g, int use_pse, hipStrea
 void launch_price_dual(const DevView& dv, const Geom& g, int use_dse, hipStream_t st);    // standalone K6
 void launch_ftran_prep(const DevView& dv, int derive_primal, hipStream_t st);             // FTRAN head (one wave)
 void launch_ftran_gather(const DevView& dv, const Geom& g, hipStream_t st);               // alpha_q = B^-1 a_q
+void launch_ftran_fused(const DevView& dv, const Geom& g, int derive_primal, hipStream_t st);   // FTRAN head + gather in one launch (Geom.head_fused)
+void launch_btran_fused(const DevView& dv, const Geom& g, int with_rhs, int derive_dual, hipStream_t st);  // BTRAN head + gather (dual iteration)
+constexpr int HEAD_LIST_CAP = 1024;  // entries an in-kernel stage head can hold (longest column / row of A)
 void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st);  // K5 p1 (+alpha_sq, y_S), p2 (+BTRAN head, plan)
 void launch_post_ftran(const DevView& dv, const Geom& g, int use_pse, hipStream_t st);    // dual path: alpha_sq, y_S, plan
 void launch_btran_prep(const DevView& dv, int derive_dual, int plan_after, hipStream_t st);  // BTRAN head (one wave)
@@ -215,8 +229,10 @@ void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st);                 // K7 p1, p2 (+FTRAN head)
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st);        // tauK/vK partials + eta update of W
 void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic = 0);  // tau push | v reduce+scatter (classic: partials of k_fused_w's tiling)
+bool stream_strips_enabled();  // large-nucleus streaming pass in strip form (MLP_STREAM_STRIPS=0 disables)
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st);
-void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_dse, int use_pse, hipStream_t st, int inline_comb = 0);  // K8 + clear + next pricing
+void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_dse, int use_pse, hipStream_t st, int inline_comb = 0,
+                         int with_struct = 0);  // K8 + clear + next pricing
 // non-graph helpers
 void launch_set_iter(const DevView& dv, int status, int q, int r, double lnv, int forced, hipStream_t st);
 void launch_reset_ring(const DevView& dv, hipStream_t st);
@@ -229,5 +245,14 @@ void launch_copy_rho_sq_to_beta(const DevView& dv, int row, hipStream_t st);
 void launch_build_nucleus(const DevView& dv, const Geom& g, double* Kd, int k, hipStream_t st);
 void launch_fold_lowrank(const DevView& dv, const Geom& g, hipStream_t st);  // W0 += U^T V, nlow := 0 (host-requested flush)
 void launch_gauss_jordan(double* Kd, double* Winv, int k, int ld, int* d_flag, double* d_scratch, hipStream_t st);
+
+// device-side matrix maintenance (add_constraint without a host pass over the non-zeros; also the initial builds)
+void launch_csc_append_row(const int* optr, const int* orow, const double* oval, int n_old, int new_row, const int* ncols,
+                           const double* nvals, int kn, int* nptr, int* nrow, double* nval, hipStream_t st);
+void launch_exclusive_scan(const int* in, int* out, long n, int* sums, hipStream_t st);  // sums: ceil(n / 4096) + 1 ints; sums[last] = total
+void launch_band_count(const int* cptr, const int* crow, int N, int nbands, int* cnt, hipStream_t st);
+void launch_band_fill(const int* cptr, const int* crow, const double* cval, int N, int nbands, const int* bptr, unsigned short* brow,
+                      double* bval, hipStream_t st);
+void launch_build_colblk(const int* cptr, const int* crow, int N, int rb, int* colblk, hipStream_t st);
 
 }  // namespace mlp

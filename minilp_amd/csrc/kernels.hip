@@ -182,17 +182,18 @@ __device__ __forceinline__ void block_best_p(Cand& c, double& pay) {  // result 
         }
     }
 }
-__device__ __forceinline__ bool grid_best_p(Cand& c, double& pay, const DevView& v) {
+__device__ __forceinline__ bool grid_best_p(Cand& c, double& pay, const DevView& v, int nblocks = -1) {
+    if (nblocks < 0) nblocks = (int)gridDim.x;  // (a launch may carry extra, horizontally fused blocks behind the reducing ones)
     block_best_p(c, pay);
     if (threadIdx.x == 0) {
         st_agent(&v.red_key[blockIdx.x], c.key);
         st_agent(&v.red_idx[blockIdx.x], c.idx);
         st_agent(&v.red_key2[blockIdx.x], pay);
     }
-    if (!last_block_arrives(v.ticket, gridDim.x)) return false;
+    if (!last_block_arrives(v.ticket, (unsigned)nblocks)) return false;
     Cand x = cand_none();
     double xp = 0.0;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) {
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
         Cand t{ld_agent(&v.red_key[i]), ld_agent(&v.red_idx[i])};
         if (cand_better(t, x)) {
             x = t;
@@ -1194,6 +1195,205 @@ __global__ void __launch_bounds__(BLK) k_btran(DevView v, int n_gather) {
     }
 }
 
+
+// ------------------------------------------------------------------- stage heads inside the consuming kernel
+// A stage head (one wave: a five-deep chain of dependent loads that turns the pivot column / row into a short list)
+// used to be its own launch in front of the kernel that consumes the list: k_ftran_prep -> k_ftran_gather in the primal
+// iteration, k_btran_prep -> k_btran in the dual one.  A launch boundary costs ~4.7 us in a replayed graph, the chain
+// itself about as much; here EVERY block of the consuming kernel runs the head for itself into LDS (the inputs are a
+// column or a row of A and the slot maps: a few hundred bytes, L2-resident), and block 0 alone performs the global side
+// effects (pivot scalars, entries on singleton rows, the list for the records).  Used while the delayed-update mode is
+// off and every column / row fits the LDS list (Geom.head_fused).
+constexpr int HEAD_CAP = 1024;
+__device__ void ftran_head_lds(const DevView& v, Ctl* c, int lane, int derive_primal, bool primary, int* ls, double* la, int* ln) {
+    IterState* it = &c->it;
+    const int q = it->q;
+    const int var = v.nb_vars[q];
+    if (primary && lane == 0) {
+        it->entering_var = var;
+        if (derive_primal) {  // solver.rs:741-748
+            double dq = v.d[q];
+            it->sign = dq < 0.0;
+            it->entering_cur = v.xN[q];
+            it->entering_other = (dq < 0.0) ? v.var_hi[var] : v.var_lo[var];
+            it->r = -1;
+            it->leaving_var = -1;
+        }
+    }
+    // other blocks of this launch push -F alpha_K into the singleton positions with atomics while block 0 lands the
+    // column's own singleton-row entries: both must then be atomic adds onto the zeroed vector
+    const bool atomic_land = !v.pb_on && !v.det_pull;
+    const int base = v.csc_ptr[var], end = v.csc_ptr[var + 1];
+    int cnt = 0;
+    for (int e0 = base; e0 < end; e0 += 64) {
+        const int e = e0 + lane;
+        const bool valid = e < end;
+        int s = -1;
+        double a = 0.0;
+        if (valid) {
+            const int i = v.csc_row[e];
+            a = v.csc_val[e];
+            s = v.kslot_of_row[i];
+            if (s < 0 && primary) {
+                const int p = v.pos_of_srow[i];
+                const double x = a / v.sdiag_of_pos[p];
+                if (atomic_land) unsafeAtomicAdd(&v.alpha_q[p], x);
+                else v.alpha_q[p] = x;
+            }
+        }
+        const bool isk = valid && s >= 0;
+        const unsigned long long mask = __ballot(isk);
+        if (isk) {
+            const int off = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+            if (off < HEAD_CAP) {
+                ls[off] = s;
+                la[off] = a;
+            }
+            if (primary) {
+                v.klist_s[off] = s;
+                v.klist_a[off] = a;
+            }
+        }
+        cnt += __popcll(mask);
+    }
+    if (lane == 0) {
+        *ln = cnt < HEAD_CAP ? cnt : HEAD_CAP;
+        if (primary) it->klist_n = cnt;
+    }
+}
+template <int G>
+__global__ void __launch_bounds__(BLK) k_ftran_fused(DevView v, int derive_primal) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    __shared__ int s_ls[HEAD_CAP];
+    __shared__ double s_la[HEAD_CAP];
+    __shared__ int s_n;
+    if (threadIdx.x < 64) ftran_head_lds(v, c, threadIdx.x, derive_primal, blockIdx.x == 0, s_ls, s_la, &s_n);
+    __syncthreads();
+    const int slot = (blockIdx.x * BLK + threadIdx.x) / G;
+    const int gl = threadIdx.x & (G - 1);
+    if (slot >= c->k) return;
+    const int n = s_n;
+    double acc = 0.0;
+    const double* wrow = v.W + (size_t)slot * v.ld;
+    for (int j = gl; j < n; j += G) acc += s_la[j] * wrow[s_ls[j]];
+    acc = group_sum<G>(acc);
+    const int p = v.pos_of_kslot[slot];
+    if (gl == 0) {
+        v.aK[slot] = acc;
+        v.alpha_q[p] = acc;
+    }
+    if (acc != 0.0 && !v.pb_on && !v.det_pull) push_F<G>(v, p, acc, v.alpha_q, gl);
+}
+__device__ void btran_head_lds(const DevView& v, Ctl* c, int lane, int derive_dual, bool primary, int* ls, double* la, int* ln) {
+    IterState* it = &c->it;
+    const int r = it->r;
+    if (derive_dual && !c->forced && primary && lane == 0) {  // solver.rs:892-916 (a host-forced row keeps the host's value)
+        const double val = v.xB[r], mn = v.loB[r];
+        it->leaving_new_val = (val < mn) ? mn : v.hiB[r];
+        it->leaving_var = v.basic_vars[r];
+        it->q = -1;
+        it->entering_var = -1;
+    }
+    const int sr = v.kslot_of_pos[r];
+    if (sr >= 0) {
+        if (lane == 0) {
+            ls[0] = sr;
+            la[0] = 1.0;
+            *ln = 1;
+            if (primary) {
+                v.blist_s[0] = sr;
+                v.blist_a[0] = 1.0;
+                it->blist_n = 1;
+            }
+        }
+        return;
+    }
+    const int i_r = v.srow_of_pos[r];
+    const double inv = 1.0 / v.sdiag_of_pos[r];
+    if (primary && lane == 0) {
+        v.rv[i_r].x = inv;
+        v.tau[r] = inv * inv;  // tau_S = (rho_S - F tauK)/diag: only row i_r of rho_S is non-zero
+    }
+    const int base = v.csr_ptr[i_r], end = v.csr_ptr[i_r + 1];
+    int cnt = 0;
+    for (int e0 = base; e0 < end; e0 += 64) {
+        const int e = e0 + lane;
+        const bool valid = e < end;
+        int s = -1;
+        double a = 0.0;
+        if (valid) {
+            const int loc = v.var_loc[v.csr_col[e]];
+            a = v.csr_val[e];
+            if (loc >= 0) s = v.kslot_of_pos[loc];
+        }
+        const bool isk = valid && s >= 0;
+        const unsigned long long mask = __ballot(isk);
+        if (isk) {
+            const int off = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+            if (off < HEAD_CAP) {
+                ls[off] = s;
+                la[off] = -a * inv;
+            }
+            if (primary) {
+                v.blist_s[off] = s;
+                v.blist_a[off] = -a * inv;
+            }
+        }
+        cnt += __popcll(mask);
+    }
+    if (lane == 0) {
+        *ln = cnt < HEAD_CAP ? cnt : HEAD_CAP;
+        if (primary) it->blist_n = cnt;
+    }
+}
+// k_btran with the BTRAN head inside (dual iteration): gather blocks build the list for themselves
+template <int G>
+__global__ void __launch_bounds__(BLK) k_btran_fused(DevView v, int n_gather, int derive_dual) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    const int k = c->k;
+    if ((int)blockIdx.x < n_gather) {
+        __shared__ int s_ls[HEAD_CAP];
+        __shared__ double s_la[HEAD_CAP];
+        __shared__ int s_n;
+        if (threadIdx.x < 64) btran_head_lds(v, c, threadIdx.x, derive_dual, blockIdx.x == 0, s_ls, s_la, &s_n);
+        __syncthreads();
+        const int n = s_n;
+        double sq = 0.0;
+        for (int s = blockIdx.x * BLK + threadIdx.x; s < k; s += n_gather * BLK) {
+            double acc = 0.0;
+            for (int j = 0; j < n; ++j) acc += s_la[j] * v.W[(size_t)s_ls[j] * v.ld + s];
+            v.rK[s] = acc;
+            v.rv[v.row_of_kslot[s]].x = acc;
+            sq += acc * acc;
+        }
+        if (!grid_sum(sq, v, n_gather)) return;
+        if (threadIdx.x == 0) {
+            const int r = c->it.r;
+            if (v.kslot_of_pos[r] < 0) {
+                const double inv = 1.0 / v.sdiag_of_pos[r];
+                sq += inv * inv;
+            }
+            c->it.rho_sq = sq;
+        }
+    } else {  // (PSE) tK = alpha_K - F^T y_S, as in k_btran
+        const int slot = (((int)blockIdx.x - n_gather) * BLK + threadIdx.x) / G;
+        const int gl = threadIdx.x & (G - 1);
+        if (slot >= k) return;
+        const int p = v.pos_of_kslot[slot];
+        const int var = v.basic_vars[p];
+        const int end = v.csc_ptr[var + 1];
+        double acc = 0.0;
+        for (int e = v.csc_ptr[var] + gl; e < end; e += G) {
+            const int i = v.csc_row[e];
+            if (v.kslot_of_row[i] < 0) acc += v.csc_val[e] * v.rv[i].y;
+        }
+        acc = group_sum<G>(acc);
+        if (gl == 0) v.tK[slot] = v.alpha_q[p] - acc;
+    }
+}
+
 // ------------------------------------------------------------------- partition change
 // B'^-1[p,i] = B^-1[p,i] - (alpha_p - [p==r]) rho_i / alpha_r, restricted to the new nucleus.
 // The case comes from the device-side plan.  Shrinking keeps the slots compact:
@@ -1512,6 +1712,7 @@ __global__ void __launch_bounds__(BLK) k_ratio_dual_p1(DevView v) {  // solver.r
     bool ok = exchange_min_wave(v, c, g, threadIdx.x);  // sharded: minimum over all column blocks
     if (threadIdx.x == 0 && ok) c->it.max_step = g;
 }
+__device__ void ratio_dual_finish(const DevView& v, Ctl* c, Cand best);
 // solver.rs:979-1021; the finalising block goes straight on with the FTRAN head
 __global__ void __launch_bounds__(BLK) k_ratio_dual_p2(DevView v) {
     Ctl* c = v.ctl;
@@ -1532,6 +1733,13 @@ __global__ void __launch_bounds__(BLK) k_ratio_dual_p2(DevView v) {
         }
     }
     if (!grid_best(best, v)) return;
+    ratio_dual_finish(v, c, best);
+}
+// Finalising block of the dual ratio test: (sharded: candidate all-gather,) the decision (solver.rs:1000-1021) and the
+// FTRAN head of the entering column.
+__device__ void ratio_dual_finish(const DevView& v, Ctl* c, Cand best) {
+    IterState* it = &c->it;
+    const int r = it->r;
     __shared__ int s_ok;
     __shared__ double s_key;
     __shared__ int s_idx;
@@ -1581,6 +1789,88 @@ __global__ void __launch_bounds__(BLK) k_ratio_dual_p2(DevView v) {
     }
     __syncthreads();
     if (s_ok && threadIdx.x < 64) ftran_prep_wave(v, c, threadIdx.x, 0);
+}
+// Both dual Harris passes in ONE launch, like k_ratio_primal_fused: pass 1's last-arriving block (after the all-reduce
+// over the ranks of a sharded solve) publishes the step bound, every block waits for it and runs pass 2 on the
+// elements it still holds in registers.  Launched only when the grid is co-resident (launch_ratio_dual).
+__global__ void __launch_bounds__(BLK) k_ratio_dual_fused(DevView v) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    IterState* it = &c->it;
+    const int lsign = it->leaving_new_val > v.xB[it->r];
+    const int epoch0 = c->ratio_epoch;
+    constexpr int PT = 4;
+    double ca[PT], dj[PT];
+    int pos[PT];
+    double mn = INFINITY, dummy = 0.0;
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+        const int j = v.nb_lo + (int)blockIdx.x * BLK + threadIdx.x + u * (int)gridDim.x * BLK;
+        pos[u] = -1;
+        ca[u] = 0.0;
+        dj[u] = 0.0;
+        if (j >= v.nb_hi) continue;
+        const double coeff = v.alpha_r[j];
+        const uint8_t f = v.nbflags[j];
+        if (!dual_eligible(coeff, f, lsign)) continue;
+        pos[u] = j;
+        ca[u] = fabs(coeff);
+        dj[u] = fabs(clamp_obj(v.d[j], f));
+        const double cur = (dj[u] + EPS) / ca[u];
+        if (cur < mn) mn = cur;
+    }
+    __shared__ double s_step;
+    __shared__ int s_state;
+    if (grid_min_sum(mn, dummy, v)) {  // last arriver of pass 1
+        if (threadIdx.x == 0) s_step = mn;
+        __syncthreads();
+        bool ok = true;
+        double g = s_step;
+        if (threadIdx.x < 64) ok = exchange_min_wave(v, c, g, threadIdx.x);  // sharded: minimum over all column blocks
+        if (threadIdx.x == 0) {
+            if (ok) it->max_step = g;
+            st_agent(&c->ratio_max_step, ok ? g : -1.0);  // a negative bound tells the waiters to give up (failure recorded)
+            __hip_atomic_store(v.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st_agent(&c->ratio_epoch, epoch0 + 1);
+        }
+    }
+    if (threadIdx.x == 0) {
+        int state = 0;
+        long spins = 0;
+        while (ld_agent(&c->ratio_epoch) != epoch0 + 1) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > 20000000L) {
+                state = 1;
+                break;
+            }
+        }
+        const double stp = ld_agent(&c->ratio_max_step);
+        if (state == 0 && stp < 0.0) state = 2;
+        s_step = stp;
+        s_state = state;
+    }
+    __syncthreads();
+    if (s_state) {
+        if (s_state == 1 && blockIdx.x == 0 && threadIdx.x == 0) {
+            it->status = ITER_STALL;
+            c->halt = 1;
+            push_rec(c, 1);
+        }
+        return;
+    }
+    const double max_step = s_step;
+    Cand best = cand_none();
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {  // ascending positions per thread: ties keep the lowest position
+        if (pos[u] < 0) continue;
+        if (dj[u] / ca[u] <= max_step) {
+            Cand t{ca[u], pos[u]};
+            if (cand_better(t, best)) best = t;
+        }
+    }
+    if (!grid_best(best, v)) return;
+    ratio_dual_finish(v, c, best);
 }
 // tK = alpha_K - F^T y_S on its own (dual path with PSE, where it cannot ride on k_btran)
 template <int G>
@@ -2055,11 +2345,14 @@ __global__ void __launch_bounds__(BLK, 4) k_stream_w(DevView v) {  // 4 waves pe
     __shared__ double s_t[2][SW_RS][BLK + 1];
     constexpr int G = BLK / SW_RS;  // lanes that share a row in the reduction of a step (32)
     const int rrow = tid / G, gl = tid % G;
-    const int nch = (k + SW_CH - 1) / SW_CH, nstr = (k + SW_RB - 1) / SW_RB;
+    const int nch = (k + SW_CH - 1) / SW_CH, nstr_all = (k + SW_RB - 1) / SW_RB;
+    // row-sharded pass: this rank streams only the strips s with s % world == rank (k_post_exchange completes the products)
+    const int sw = v.wshard ? v.world : 1, sr = v.wshard ? v.rank : 0;
+    const int nstr = nstr_all > sr ? (nstr_all - sr + sw - 1) / sw : 0;
     const double* __restrict__ Wp = v.W;
     const double* __restrict__ tKp = v.tK;
     for (int tile = blockIdx.x; tile < nstr * nch; tile += n_tile_blocks) {
-        const int strip = tile / nch, chunk = tile % nch;
+        const int strip = (tile / nch) * sw + sr, chunk = tile % nch;
         const int rbeg = strip * SW_RB, rend = min(k, rbeg + SW_RB);
         int c0[NP];
         bool pair[NP], one[NP];
@@ -2227,6 +2520,60 @@ __global__ void k_reset_nlow(DevView v) {
     v.ctl->nlow = 0;
     v.ctl->fold = 0;
 }
+
+// Row-sharded streaming pass, step 2 of 3 (k_stream_w -> k_post_exchange -> k_post_fused): reduce this rank's partials
+// (tau_K on the rows of its own strips, complete; v_K over its own strips, partial) and write them into every rank's
+// exchange buffer; the last block to finish makes the stores visible system-wide and raises this rank's flag (mailbox
+// kind 4) in every box.  k_post_fused then waits for all flags and reads only local memory.
+template <int TR, int TC>
+__global__ void __launch_bounds__(BLK) k_post_exchange(DevView v, int with_v) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    const int k = c->k, ld = v.ld;
+    const unsigned long long ep = c->xepoch[4] + 1ull;
+    const size_t par = (size_t)(ep & 1ull);
+    const int i = blockIdx.x * BLK + threadIdx.x;
+    if (i < k) {
+        const int strip = i / TR;
+        const bool mine = strip % v.world == v.rank;
+        double x = 0.0;
+        if (mine) {
+            const int nchunks = (k + TC - 1) / TC;
+            for (int j = 0; j < nchunks; ++j) x += v.part_tau[(size_t)j * ld + i];
+        }
+        double sv = 0.0;
+        if (with_v) {
+            const int nstripes = (k + TR - 1) / TR;
+            for (int t = v.rank; t < nstripes; t += v.world) sv += v.part_v[(size_t)t * ld + i];
+        }
+        const size_t off = ((par * v.world + v.rank) * 2) * (size_t)v.xb_cap + i;
+        for (int r = 0; r < v.world; ++r) {
+            double* dst = v.xbuf_peer[r] + off;
+            if (mine) __hip_atomic_store(dst, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (with_v) __hip_atomic_store(dst + v.xb_cap, sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    __threadfence_system();  // this thread's stores have reached the peers ...
+    __syncthreads();         // ... and so have the whole block's, before its first thread takes the ticket
+    if (!last_block_arrives(v.ticket, gridDim.x)) return;
+    if (threadIdx.x == 0) {
+        *v.ticket = 0;
+        c->xepoch[4] = ep;
+    }
+    if (threadIdx.x < 64) {
+        double f[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        mail_post_wave(v, 4, ep, f, threadIdx.x);
+    }
+}
+// wait (one wave) until every rank's flag of exchange `ep` is in this rank's box; false after the spin bound
+__device__ __forceinline__ bool wait_exchange_flags(const DevView& v, unsigned long long ep, int lane) {
+    bool ok = true;
+    for (int r = lane; r < v.world; r += 64) {
+        double h[7];
+        if (!mail_wait(mail_slot(v, 4, ep, r), ep, h)) ok = false;
+    }
+    return __all(ok);
+}
 // After the fused pass (horizontally fused): blocks [0, n_push) finish tau = B^-1 rho by position
 // (tau_K from the per-chunk partials in a fixed order, then the push of -F tau_K, solver.rs:1157);
 // the remaining blocks reduce the v partials in a fixed order and scatter v_K by row (solver.rs:1114).
@@ -2235,6 +2582,24 @@ __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     const int k = c->k;
+    // row-sharded streaming pass: the partials were exchanged by k_post_exchange; wait for every rank's flag, then read
+    // tau_K (each row from its owner's slot) and the v_K partials (summed in rank order) from the local buffer
+    const bool xsh = v.wshard != 0;
+    const double* xb = nullptr;
+    if (xsh) {
+        __shared__ int s_xok;
+        const unsigned long long ep = c->xepoch[4];  // raised by k_post_exchange (previous launch)
+        if (threadIdx.x < 64) {
+            const bool ok = wait_exchange_flags(v, ep, threadIdx.x);
+            if (threadIdx.x == 0) s_xok = ok ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_xok) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) comm_fail(c, 0);
+            return;
+        }
+        xb = v.xbuf + (size_t)(ep & 1ull) * v.world * 2 * (size_t)v.xb_cap;
+    }
     if ((int)blockIdx.x < n_push) {
         // G lanes per slot serve the push of -F tau_K; when that product is computed elsewhere (blocked push, pulled
         // form) one lane per slot does the reduction and the blocks beyond k / 256 exit at once
@@ -2244,7 +2609,12 @@ __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push) {
         if (slot >= k) return;
         const int nchunks = (k + TC - 1) / TC;
         double x = 0.0;
-        for (int j = 0; j < nchunks; ++j) x += v.part_tau[(size_t)j * v.ld + slot];
+        if (xsh) {
+            const int owner = (slot / TR) % v.world;
+            x = __hip_atomic_load(xb + ((size_t)owner * 2) * v.xb_cap + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            for (int j = 0; j < nchunks; ++j) x += v.part_tau[(size_t)j * v.ld + slot];
+        }
         if (v.lrJ && !c->fold) {  // low-rank part of W_eff * rho_K
             const int nlow = c->nlow;
             for (int j = 0; j < nlow; ++j) x += v.U[(size_t)j * v.ld + slot] * c->lr_g[j];
@@ -2266,7 +2636,11 @@ __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push) {
     __shared__ double s_part[8][33];
     const int nstripes = (k + TR - 1) / TR;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    if (i < k) {
+    if (xsh) {
+        if (grp == 0 && i < k)  // rank order: every rank forms the identical sum
+            for (int r = 0; r < v.world; ++r)
+                s0 += __hip_atomic_load(xb + ((size_t)r * 2 + 1) * v.xb_cap + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else if (i < k) {
         int t = grp;
         for (; t + 24 < nstripes; t += 32) {  // four independent loads in flight per lane
             s0 += v.part_v[(size_t)t * v.ld + i];
@@ -2312,12 +2686,17 @@ __global__ void __launch_bounds__(BLK) k_reduce_v(DevView v) {
 // read for the last time here), and (b) prices the NEXT iteration from the values it has just
 // written (K1 when next_phase = 0, K6 when 1), so neither a memset nor a pricing kernel is needed
 // inside the replayed graph.
-__global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int use_dse, int use_pse, int inline_comb) {
+__global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int use_dse, int use_pse, int inline_comb, int n_upd) {
     Ctl* c = v.ctl;
     if (c->halt) return;
     const IterState* it = &c->it;
     const int status = it->status;
     if (status != ITER_PIVOT && status != ITER_FLIP) return;
+    if ((int)blockIdx.x >= n_upd) {  // horizontally fused (dual iteration without PSE): the partition change, which touches
+        if (status == ITER_PIVOT)    // W and the slot maps only — nothing the update blocks read or write
+            struct_update_body(v, c, ((int)blockIdx.x - n_upd) * BLK + threadIdx.x);
+        return;
+    }
     const int t = blockIdx.x * BLK + threadIdx.x;
     const bool flip = status == ITER_FLIP;
     const int r = flip ? -1 : it->r, q = it->q;
@@ -2433,7 +2812,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
     }
     // every block arrives here only after its own updates; the last arriver closes this iteration
     // (record) and opens the next one with the pricing decision
-    if (!grid_best_p(cand, cand_d, v)) return;
+    if (!grid_best_p(cand, cand_d, v, n_upd)) return;
     close_and_open(v, c, phase, cand, cand_d, true);
 }
 
@@ -2587,6 +2966,211 @@ __global__ void __launch_bounds__(BLK) k_gj_eliminate(double* Kd, double* Wv, in
     Wv[(size_t)a * ld + cc] -= f * Wv[(size_t)j * ld + cc];
 }
 
+
+// ------------------------------------------------------------------- device-side matrix maintenance
+// Solution::add_constraint appends ONE row (solver.rs:597-613 rebuilds CSR and CSC on the host, O(nnz)).  Here the
+// matrix stays on the device: the CSR row is appended in place (capacity-doubling buffers), the CSC is re-laid out by
+// one copy kernel (a column's entries move by the number of touched columns before it, found by binary search in the
+// sorted new row; the new row index is the largest, so appending keeps every column's rows ascending), and the
+// derived copies (band-major copy of the banded sweep, row-block offsets of the blocked F push) are rebuilt by the
+// kernels below, which also serve the initial build.  No host pass over the non-zeros, no re-upload.
+template <int G>
+__global__ void __launch_bounds__(BLK) k_csc_append_row(const int* __restrict__ optr, const int* __restrict__ orow,
+                                                        const double* __restrict__ oval, int n_old, int new_row,
+                                                        const int* __restrict__ ncols, const double* __restrict__ nvals, int kn,
+                                                        int* __restrict__ nptr, int* __restrict__ nrow, double* __restrict__ nval) {
+    const int j = (blockIdx.x * BLK + threadIdx.x) / G;  // old column (variable)
+    const int gl = threadIdx.x & (G - 1);
+    if (j > n_old) return;
+    if (j == n_old) {  // the new slack column: one entry (new_row, +1), solver.rs:250
+        if (gl == 0) {
+            const int b = optr[n_old] + kn;
+            nptr[n_old] = b;
+            nptr[n_old + 1] = b + 1;
+            nrow[b] = new_row;
+            nval[b] = 1.0;
+        }
+        return;
+    }
+    int lo = 0, hi = kn;  // shift = number of touched columns < j
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (ncols[mid] < j) lo = mid + 1;
+        else hi = mid;
+    }
+    const int ob = optr[j], oe = optr[j + 1];
+    const int nb = ob + lo;
+    for (int e = ob + gl; e < oe; e += G) {
+        nrow[nb + (e - ob)] = orow[e];
+        nval[nb + (e - ob)] = oval[e];
+    }
+    if (gl == 0) {
+        nptr[j] = nb;
+        if (lo < kn && ncols[lo] == j) {
+            nrow[nb + (oe - ob)] = new_row;
+            nval[nb + (oe - ob)] = nvals[lo];
+        }
+    }
+}
+void launch_csc_append_row(const int* optr, const int* orow, const double* oval, int n_old, int new_row, const int* ncols,
+                           const double* nvals, int kn, int* nptr, int* nrow, double* nval, hipStream_t st) {
+    hipLaunchKernelGGL(k_csc_append_row<16>, dim3(blocks_for((long)(n_old + 1) * 16)), dim3(BLK), 0, st, optr, orow, oval, n_old,
+                       new_row, ncols, nvals, kn, nptr, nrow, nval);
+}
+
+// exclusive scan of n ints (in place allowed), three phases: 4096-element block scans, scan of the block sums by
+// one block, add-back.  `sums` holds ceil(n / 4096) + 1 ints.
+constexpr int SCAN_TILE = 4096;
+__global__ void __launch_bounds__(1024) k_scan_blocks(const int* in, int* out, long n, int* sums) {
+    __shared__ int s_w[16];
+    const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * 4;
+    int x[4], t = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        x[u] = base + u < n ? in[base + u] : 0;
+        t += x[u];
+    }
+    int incl = t;  // inclusive scan of the per-thread totals across the block
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += y;
+    }
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int i = 0; i < 16; ++i) {
+            const int y = s_w[i];
+            s_w[i] = acc;
+            acc += y;
+        }
+        if (sums) sums[blockIdx.x] = acc;
+    }
+    __syncthreads();
+    int excl = incl - t + s_w[wv];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (base + u < n) out[base + u] = excl;
+        excl += x[u];
+    }
+}
+__global__ void __launch_bounds__(1024) k_scan_sums(int* sums, int nb) {  // one block: exclusive scan of up to 2^20 block sums
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int x = i < nb ? sums[i] : 0;
+        int incl = x;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w2 = 0; w2 < wv; ++w2) woff += s_w[w2];
+        const int carry = s_carry;
+        if (i < nb) sums[i] = carry + woff + incl - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[nb] = s_carry;  // grand total
+}
+__global__ void __launch_bounds__(1024) k_scan_add(int* out, long n, const int* sums) {
+    const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * 4;
+    const int off = sums[blockIdx.x];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (base + u < n) out[base + u] += off;
+}
+void launch_exclusive_scan(const int* in, int* out, long n, int* sums, hipStream_t st) {
+    const int nb = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, st, in, out, n, sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, sums, nb);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, st, out, n, (const int*)sums);
+}
+
+// Band-major copy of A for the banded sweep, built on the device from the CSC (columns hold ascending rows, so the
+// entries of (column, band) are a contiguous run): count (even-rounded) per (band, column) -> exclusive scan in
+// band-major order -> fill.  bptr has nbands * (N + 1) entries; the slot [b][N] of every band carries a zero count so
+// that bptr[b][N] = end of band b's last column.
+__global__ void __launch_bounds__(BLK) k_band_count(const int* __restrict__ cptr, const int* __restrict__ crow, int N, int nbands,
+                                                     int* __restrict__ cnt) {
+    const int var = blockIdx.x * BLK + threadIdx.x;
+    if (var > N) return;
+    if (var == N) {
+        for (int b = 0; b < nbands; ++b) cnt[(size_t)b * (N + 1) + N] = 0;
+        return;
+    }
+    int e = cptr[var];
+    const int end = cptr[var + 1];
+    for (int b = 0; b < nbands; ++b) {
+        const int lim = (b + 1) * BAND_ROWS;
+        int c = 0;
+        while (e < end && crow[e] < lim) {
+            ++e;
+            ++c;
+        }
+        cnt[(size_t)b * (N + 1) + var] = (c + 1) & ~1;
+    }
+}
+__global__ void __launch_bounds__(BLK) k_band_fill(const int* __restrict__ cptr, const int* __restrict__ crow,
+                                                    const double* __restrict__ cval, int N, int nbands, const int* __restrict__ bptr,
+                                                    unsigned short* __restrict__ brow, double* __restrict__ bval) {
+    const int var = blockIdx.x * BLK + threadIdx.x;
+    if (var >= N) return;
+    int e = cptr[var];
+    const int end = cptr[var + 1];
+    for (int b = 0; b < nbands; ++b) {
+        const int lim = (b + 1) * BAND_ROWS, row0 = b * BAND_ROWS;
+        int dst = bptr[(size_t)b * (N + 1) + var];
+        const int dend = bptr[(size_t)b * (N + 1) + var + 1];
+        while (e < end && crow[e] < lim) {
+            brow[dst] = (unsigned short)(crow[e] - row0);
+            bval[dst] = cval[e];
+            ++e;
+            ++dst;
+        }
+        if (dst < dend) {  // pad entry of an odd-length segment: row 0 of the band, value 0
+            brow[dst] = 0;
+            bval[dst] = 0.0;
+        }
+    }
+}
+void launch_band_count(const int* cptr, const int* crow, int N, int nbands, int* cnt, hipStream_t st) {
+    hipLaunchKernelGGL(k_band_count, dim3(blocks_for(N + 1)), dim3(BLK), 0, st, cptr, crow, N, nbands, cnt);
+}
+void launch_band_fill(const int* cptr, const int* crow, const double* cval, int N, int nbands, const int* bptr, unsigned short* brow,
+                      double* bval, hipStream_t st) {
+    hipLaunchKernelGGL(k_band_fill, dim3(blocks_for(N)), dim3(BLK), 0, st, cptr, crow, cval, N, nbands, bptr, brow, bval);
+}
+// Row-block offsets of every column for the blocked F push: colblk[var][b] = first CSC index of column var whose row is
+// >= b * PB_ROWS, colblk[var][rb] = end of the column.
+__global__ void __launch_bounds__(BLK) k_build_colblk(const int* __restrict__ cptr, const int* __restrict__ crow, int N, int rb,
+                                                       int* __restrict__ colblk) {
+    const int var = blockIdx.x * BLK + threadIdx.x;
+    if (var >= N) return;
+    int e = cptr[var];
+    const int end = cptr[var + 1];
+    int* dst = colblk + (size_t)var * (rb + 1);
+    for (int b = 0; b <= rb; ++b) {
+        const long lim = (long)b * PB_ROWS;
+        while (e < end && crow[e] < lim) ++e;
+        dst[b] = e;
+    }
+    dst[rb] = end;
+}
+void launch_build_colblk(const int* cptr, const int* crow, int N, int rb, int* colblk, hipStream_t st) {
+    hipLaunchKernelGGL(k_build_colblk, dim3(blocks_for(N)), dim3(BLK), 0, st, cptr, crow, N, rb, colblk);
+}
+
 // ===================================================================================== launchers
 #define LANES_SWITCH(L, STMT4, STMT16, STMT32) \
     do {                                        \
@@ -2607,6 +3191,25 @@ void launch_price_dual(const DevView& dv, const Geom& g, int use_dse, hipStream_
 }
 void launch_ftran_prep(const DevView& dv, int derive_primal, hipStream_t st) {
     hipLaunchKernelGGL(k_ftran_prep, dim3(1), dim3(64), 0, st, dv, derive_primal);
+}
+void launch_ftran_fused(const DevView& dv, const Geom& g, int derive_primal, hipStream_t st) {  // head + gather in one launch
+    LANES_SWITCH(g.lanes,
+                 hipLaunchKernelGGL(k_ftran_fused<4>, dim3(blocks_for((long)g.cap * 4)), dim3(BLK), 0, st, dv, derive_primal),
+                 hipLaunchKernelGGL(k_ftran_fused<16>, dim3(blocks_for((long)g.cap * 16)), dim3(BLK), 0, st, dv, derive_primal),
+                 hipLaunchKernelGGL(k_ftran_fused<64>, dim3(blocks_for((long)g.cap * 64)), dim3(BLK), 0, st, dv, derive_primal));
+    if (dv.pb_on) launch_blocked_push(dv, 0, st);
+    else if (dv.det_pull) launch_pull_F(dv, g, 0, st);
+}
+void launch_btran_fused(const DevView& dv, const Geom& g, int with_rhs, int derive_dual, hipStream_t st) {  // head + BTRAN in one launch
+    int n_gather = blocks_for(g.cap);
+    if (n_gather > 512) n_gather = 512;
+#define BTRANF(G)                                                                                                  \
+    do {                                                                                                           \
+        int n_rhs = with_rhs ? blocks_for((long)g.cap * G) : 0;                                                    \
+        hipLaunchKernelGGL(k_btran_fused<G>, dim3(n_gather + n_rhs), dim3(BLK), 0, st, dv, n_gather, derive_dual); \
+    } while (0)
+    LANES_SWITCH(g.lanes, BTRANF(4), BTRANF(16), BTRANF(64));
+#undef BTRANF
 }
 void launch_ftran_gather(const DevView& dv, const Geom& g, hipStream_t st) {
     LANES_SWITCH(g.lanes,
@@ -2712,6 +3315,22 @@ void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st) {
     hipLaunchKernelGGL(k_init_nb_rng, dim3(blocks_for(g.n)), dim3(BLK), 0, st, dv);
 }
 void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st) {
+    const int nb = grid_for(dv.nb_hi - dv.nb_lo);
+    static const bool two_kernels = std::getenv("MLP_RATIO_TWO_KERNELS") != nullptr;
+    static int max_coresident = -1;  // see launch_ratio_primal
+    if (max_coresident < 0) {
+        int dev = 0, per_cu = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_ratio_dual_fused), BLK, 0) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+            max_coresident = per_cu * cus / 2;
+        else
+            max_coresident = 0;
+    }
+    if (!two_kernels && nb <= max_coresident && (long)nb * BLK * 4 >= (long)(dv.nb_hi - dv.nb_lo)) {
+        hipLaunchKernelGGL(k_ratio_dual_fused, dim3(nb), dim3(BLK), 0, st, dv);  // both passes + FTRAN head
+        return;
+    }
     hipLaunchKernelGGL(k_ratio_dual_p1, dim3(grid_for(g.n)), dim3(BLK), 0, st, dv);
     hipLaunchKernelGGL(k_ratio_dual_p2, dim3(grid_for(g.n)), dim3(BLK), 0, st, dv);  // + FTRAN head
 }
@@ -2732,7 +3351,9 @@ static int stream_variant() {
 }
 static int sw_ch() { return kSwGeoms[stream_variant()].ch; }
 static int sw_rb() { return kSwGeoms[stream_variant()].rb; }
-static bool stream_strips() {
+bool stream_strips_enabled();
+static bool stream_strips() { return stream_strips_enabled(); }
+bool stream_strips_enabled() {
     static const bool on = !(std::getenv("MLP_STREAM_STRIPS") && std::atoi(std::getenv("MLP_STREAM_STRIPS")) == 0);
     return on;
 }
@@ -2824,6 +3445,12 @@ void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st
 }
 void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic) {
     if (!classic && dv.lrJ && fw_rows(g) != 8 && FW_RL == 1 && stream_strips()) {  // partials of k_stream_w's strips
+#define POSTX(RB, CH)                                                                                             \
+    if (sw_rb() == RB && sw_ch() == CH) hipLaunchKernelGGL((k_post_exchange<RB, CH>), dim3(blocks_for(g.cap)), dim3(BLK), 0, st, dv, with_v);
+        if (dv.wshard) {  // row-sharded pass: exchange the partials first (k_post_fused then reads the exchange buffer)
+            POSTX(512, 512) POSTX(256, 1024) POSTX(128, 1024) POSTX(256, 512) POSTX(128, 512) POSTX(64, 1024)
+        }
+#undef POSTX
 #define POSTS2(G, RB, CH)                                                                                         \
     if (sw_rb() == RB && sw_ch() == CH) {                                                                         \
         if (with_v) hipLaunchKernelGGL((k_post_fused<G, true, RB, CH>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push); \
@@ -2856,10 +3483,14 @@ void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st) {
     hipLaunchKernelGGL(k_struct_update, dim3(blocks_for(g.cap)), dim3(BLK), 0, st, dv);
 }
-void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_dse, int use_pse, hipStream_t st, int inline_comb) {
+void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_dse, int use_pse, hipStream_t st, int inline_comb,
+                         int with_struct) {
     int t = g.m > g.n ? g.m : g.n;
     // inline_comb (primal iteration with the banded sweep): the update kernel sums the per-band partials itself
-    hipLaunchKernelGGL(k_update_pivot, dim3(blocks_for(t)), dim3(BLK), 0, st, dv, phase, use_dse, use_pse, inline_comb);
+    // with_struct (dual iteration without PSE): the partition change rides in the tail blocks of this launch
+    const int n_upd = blocks_for(t);
+    hipLaunchKernelGGL(k_update_pivot, dim3(n_upd + (with_struct ? blocks_for(g.cap) : 0)), dim3(BLK), 0, st, dv, phase, use_dse, use_pse,
+                       inline_comb, n_upd);
 }
 void launch_set_iter(const DevView& dv, int status, int q, int r, double lnv, int forced, hipStream_t st) {
     hipLaunchKernelGGL(k_set_iter, dim3(1), dim3(1), 0, st, dv, status, q, r, lnv, forced);

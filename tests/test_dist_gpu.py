@@ -21,11 +21,16 @@ def test_sharded_pricing_matches_unsharded_pivot_for_pivot(world, pivots):
     assert "traces identical: True" in r.stdout
 
 
-def test_sharded_pricing_with_the_large_nucleus_machinery():
-    """Same gate with the delayed-update mode, the 16-row non-temporal tiles, the padded pitch of W and
-    the blocked F push forced on (they are otherwise used from capacity 8192 on)."""
-    env = dict(os.environ, MLP_LOWRANK="3", MLP_BIGTILE="1", MLP_LDPAD="16", MLP_BANDED="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_test.py"), "2", "4000", "3500", "12", "400"],
+@pytest.mark.parametrize("world,extra", [(2, {}), (3, {}), (2, {"MLP_NO_WSHARD": "1"}), (2, {"MLP_MAILBOX": "host"})],
+                         ids=["2 ranks, row-sharded W stream", "3 ranks, row-sharded W stream", "2 ranks, replicated stream", "2 ranks, host mailbox"])
+def test_sharded_pricing_with_the_large_nucleus_machinery(world, extra):
+    """Same gate with the delayed-update mode, the strip-shaped streaming pass, the padded pitch of W and the blocked
+    F push forced on (they are otherwise used from capacity 8192 on).  With the peer transport the streaming pass over
+    the nucleus inverse is ROW-SHARDED: every rank streams the strips s with s % world == rank and the tau_K rows /
+    v_K partials are exchanged through the peers' device buffers (k_post_exchange); MLP_NO_WSHARD and the host
+    mailbox keep the pass replicated."""
+    env = dict(os.environ, MLP_LOWRANK="3", MLP_BIGTILE="1", MLP_LDPAD="16", MLP_BANDED="1", **extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_test.py"), str(world), "4000", "3500", "12", "400"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "traces identical: True" in r.stdout

@@ -611,3 +611,34 @@ def test_warm_start_sequence_at_medium_scale():
     assert obj_close(sg2.objective(), so2.objective())
     (so3, wo), (sg3, wg) = so2.unfix_var(v), sg2.unfix_var(v)
     assert wo == wg and obj_close(sg3.objective(), so3.objective()) and obj_close(sg3.objective(), so.objective())
+
+
+@pytest.mark.parametrize("env", [dict(MLP_BANDED="1"), dict(MLP_BANDED="1", MLP_BIGTILE="1", MLP_LOWRANK="3", MLP_LDPAD="16")], ids=["banded", "banded+large-nucleus"])
+def test_rows_appended_on_the_device_match_the_oracle_step_by_step(monkeypatch, env):
+    """Solution::add_constraint (solver.rs:549-634) keeps the matrix on the device: CSR row appended in place, CSC
+    re-laid out by one copy kernel, band-major copy and row-block offsets rebuilt by device kernels (forced on here;
+    they are otherwise used by large models only).  Ten cuts, each compared with the oracle; then the basis is
+    re-inverted from the device matrix and a clone continues independently."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    lp = GEN["sparse"](m=220, n=180, k=9, seed=61)
+    sg = lpgen.build_problem(M.Problem, lp).solve()
+    so = lpgen.build_problem(O.Problem, lp).solve()
+    rng = np.random.default_rng(5)
+    for i in range(10):
+        x = np.asarray(so.values())
+        idx = np.sort(rng.choice(lp["n"], size=6, replace=False))
+        rhs = float(x[idx].sum()) * 0.9 - 0.01
+        expr = [(int(j), 1.0) for j in idx]
+        sg = sg.add_constraint(expr, M.LE, rhs)
+        so = so.add_constraint(expr, O.LE, rhs)
+        assert obj_close(sg.objective(), so.objective()), i
+        assert np.abs(np.asarray(sg.values()) - np.asarray(so.values())).max() <= X_ATOL, i
+    assert sg.reinvert() <= 1e-8          # the basis columns come from the re-laid-out device CSC
+    c = sg.clone()                        # device-to-device copy of the matrix
+    expr = [(0, 1.0), (1, 1.0), (2, 1.0)]
+    rhs = float(np.asarray(so.values())[:3].sum()) * 0.5
+    c = c.add_constraint(expr, M.LE, rhs)
+    so2 = so.clone().add_constraint(expr, O.LE, rhs)
+    assert obj_close(c.objective(), so2.objective())
+    assert obj_close(sg.objective(), so.objective())   # the original is untouched by its clone's cut

@@ -194,3 +194,17 @@ def test_solve_mps_example_cli_hip_backend(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(root, "examples", "solve_mps.py"), str(p)],
                          capture_output=True, text=True, check=True).stdout
     assert "objective: 54" in out and "XONE = 4" in out and "YTWO = -1" in out and "ZTHREE = 6" in out
+
+
+def test_tour_svg_writer_matches_the_reference_format():
+    """`Tour::to_svg` (tsp.rs:169-208): 600-pixel canvas, 50-pixel margin, whole-pixel coordinates, one closed path
+    starting at city 0.  Hand-computed for a 4-city rectangle (scale = 500 / 10 = 50, height = round(4 * 50) + 100)."""
+    pts = [(0.0, 0.0), (10.0, 0.0), (10.0, 4.0), (0.0, 4.0)]
+    svg = tsp.tour_to_svg(pts, [2, 3, 0, 1])
+    assert svg == ('<?xml version="1.0" encoding="UTF-8" standalone="no"?>\n'
+                   '<!DOCTYPE svg PUBLIC "-//W3C//DTD SVG 1.1//EN"\n'
+                   '  "http://www.w3.org/Graphics/SVG/1.1/DTD/svg11.dtd">\n'
+                   '<svg width="600px" height="300px" version="1.1"     xmlns="http://www.w3.org/2000/svg">\n'
+                   '    <path fill="none" stroke="black" stroke-width="4px" d="\n'
+                   '        M 50 50\n        L 550 50\n        L 550 250\n        L 50 250\n        Z\n'
+                   '    "/>\n</svg>\n')
