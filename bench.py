@@ -20,6 +20,7 @@ the sharded set-up is an error, never a silent fall-back to replicas.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import datetime
 import gzip
 import json
 import os
@@ -118,9 +119,11 @@ KERNEL_NAMES = {
 }
 
 
-def window_from_basis(M, prob, path, warm, steps, samples):
+def window_from_basis(M, prob, path, warm, steps, samples, shard=None):
     """`steps` timed pivots from a committed mid-solve basis (after `warm` untimed ones), then an event-bracketed
-    sampling pass of `samples` pivots for the per-kernel figures."""
+    sampling pass of `samples` pivots for the per-kernel figures.  shard = (dist, mdist, barrier, max_over_ranks): every
+    rank loads the same basis and the solve continues SHARDED (pricing path over column blocks, streaming pass of the
+    nucleus inverse over row strips); the time is the maximum over the ranks."""
     import torch
     with gzip.open(path, "rb") as f:
         blob = f.read()
@@ -128,13 +131,37 @@ def window_from_basis(M, prob, path, warm, steps, samples):
     s = prob.solve_from_basis(blob, budget=0, profile=True)   # device re-inversion + x_B, d recomputed from the basis
     load_s = time.perf_counter() - t0
     k0 = int(s.stats()["nucleus_size"])
-    s.continue_solve(warm)
+    mailbox = None
+    err = None
+    if shard:
+        mailbox = shard[1].setup_sharding(s, shard[0])   # raises on every rank if any rank cannot join
+
+    def guarded(budget):  # a failed exchange is a bounded wait on every rank; the barriers below must still be reached
+        nonlocal err
+        try:
+            if err is None:
+                s.continue_solve(budget)
+        except Exception as e:
+            err = str(e)
+    guarded(warm)
     s.reset_stats()
+    if shard:
+        shard[2]()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    s.continue_solve(steps)
+    guarded(steps)
+    if shard:
+        shard[2]()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if shard:
+        dt = shard[3](dt)
+        if shard[3](1.0 if err else 0.0) > 0.0:   # any rank failed: report it, every rank leaves the same way
+            shard[2]()
+            if mailbox and shard[0].get_rank() == 0:
+                shard[1].remove_mailbox(mailbox)
+            del s
+            return dict(error=err or "a peer rank failed", basis=os.path.basename(path))
     st = s.stats()
     done = int(st["iterations"])
     s.set_sampling(True)
@@ -147,6 +174,11 @@ def window_from_basis(M, prob, path, warm, steps, samples):
                objective_at_end=s.objective(), max_pivot_err=st2["max_pivot_err"], kernels=kern,
                sampling=f"{samples}-pivot event-bracketed pass right after the timed pivots (eager launches, "
                         f"{int(st2['iter_samples'])} iterations sampled); the timed pivots run as graph replays")
+    if shard:
+        out["transport"] = s.transport()
+        shard[2]()
+        if mailbox and shard[0].get_rank() == 0:
+            shard[1].remove_mailbox(mailbox)
     del s
     return out
 
@@ -177,9 +209,9 @@ def main():
     if world > 1:
         torch.cuda.set_device(dev_index)
         if oversub:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=datetime.timedelta(seconds=600))
     red_dev = "cpu" if oversub else "cuda"
     import minilp_amd as M
     from minilp_amd import lpgen
@@ -256,8 +288,9 @@ def main():
                                         f"timed pivots {a.warmup}..{a.warmup + a.steps}",
                                rows=a.rows, cols=a.cols, nnz=int(st["nnz"]), seed=a.seed,
                                parallelism=("1 GPU" if world == 1 else
-                                            (f"{world} GPUs: one LP, pricing path sharded over {world} column blocks, "
-                                             f"per-pivot candidate exchange through {mdist.transport_name(s)}; FTRAN/BTRAN/W replicated"
+                                            (f"{world} GPUs: one LP, pricing path sharded over {world} column blocks (and, from a "
+                                             f"nucleus of 8 192 on, the streaming pass of the nucleus inverse over row strips), "
+                                             f"per-pivot exchanges through {mdist.transport_name(s)}; FTRAN/BTRAN heads and the fold replicated"
                                              if sharded else f"{world} GPUs, one independent LP of the family per rank")) + (" [oversubscribed test rig: all ranks on one GPU]" if oversub else ""),
                                nucleus_size_at_end=int(st_timed["nucleus_size"]), objective_at_end=s.objective(),
                                completed_steps=int(done), bound_flips=int(st_timed["bound_flips"]),
@@ -288,11 +321,31 @@ def main():
             out["full_solve"] = full_solve_record()
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(lp, a.warmup, a.cpu_pivots)
-        print(json.dumps(out), flush=True)
+    # N > 1, sharded: the late window as well (all ranks take part): this is where the row-sharded streaming pass of
+    # the nucleus inverse pays; a failure here is reported inside the line, it does not void the timed figure above
+    late_sharded = None
     if world > 1:
         dist.barrier()
         if mailbox and rank == 0:
             mdist.remove_mailbox(mailbox)
+    if world > 1 and sharded and not a.no_windows and os.path.exists(LATE_BASIS) and \
+            (a.rows, a.cols, a.nnz_per_row, a.seed) == (100000, 100000, 100, 4):
+        def max_over_ranks(x):
+            t = torch.tensor([x], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        s = None  # free the early-window solver (its device buffers) before the 8.6 GB nucleus inverse of the late basis
+        try:
+            late_sharded = window_from_basis(M, prob, LATE_BASIS, 32, a.window_steps[1], min(a.samples, 16),
+                                             shard=(dist, mdist, barrier, max_over_ranks))
+        except Exception as e:  # every rank leaves setup_sharding through the same door; later failures are bounded waits
+            late_sharded = dict(error=str(e))
+    if rank == 0:
+        if late_sharded is not None:
+            out.setdefault("windows", {})["late_sharded"] = late_sharded
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

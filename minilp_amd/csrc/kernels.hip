@@ -2563,16 +2563,17 @@ __global__ void __launch_bounds__(BLK) k_post_exchange(DevView v, int with_v) {
     if (threadIdx.x < 64) {
         double f[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         mail_post_wave(v, 4, ep, f, threadIdx.x);
+        // ... and this ONE wave waits for every rank's flag, so that the next kernel (k_post_fused) finds all the data
+        // in local memory without waiting: a wait inside k_post_fused would park thousands of spinning blocks on the
+        // CUs (and starve the peers' kernels when several ranks share a GPU)
+        bool ok = true;
+        for (int r = threadIdx.x; r < v.world; r += 64) {
+            double h[7];
+            if (!mail_wait(mail_slot(v, 4, ep, r), ep, h)) ok = false;
+        }
+        ok = __all(ok);
+        if (!ok && threadIdx.x == 0) comm_fail(c, 0);
     }
-}
-// wait (one wave) until every rank's flag of exchange `ep` is in this rank's box; false after the spin bound
-__device__ __forceinline__ bool wait_exchange_flags(const DevView& v, unsigned long long ep, int lane) {
-    bool ok = true;
-    for (int r = lane; r < v.world; r += 64) {
-        double h[7];
-        if (!mail_wait(mail_slot(v, 4, ep, r), ep, h)) ok = false;
-    }
-    return __all(ok);
 }
 // After the fused pass (horizontally fused): blocks [0, n_push) finish tau = B^-1 rho by position
 // (tau_K from the per-chunk partials in a fixed order, then the push of -F tau_K, solver.rs:1157);
@@ -2582,22 +2583,12 @@ __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     const int k = c->k;
-    // row-sharded streaming pass: the partials were exchanged by k_post_exchange; wait for every rank's flag, then read
-    // tau_K (each row from its owner's slot) and the v_K partials (summed in rank order) from the local buffer
+    // row-sharded streaming pass: the partials were exchanged by k_post_exchange; read tau_K (each row from its owner's
+    // slot) and the v_K partials (summed in rank order) from the local exchange buffer
     const bool xsh = v.wshard != 0;
     const double* xb = nullptr;
-    if (xsh) {
-        __shared__ int s_xok;
-        const unsigned long long ep = c->xepoch[4];  // raised by k_post_exchange (previous launch)
-        if (threadIdx.x < 64) {
-            const bool ok = wait_exchange_flags(v, ep, threadIdx.x);
-            if (threadIdx.x == 0) s_xok = ok ? 1 : 0;
-        }
-        __syncthreads();
-        if (!s_xok) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) comm_fail(c, 0);
-            return;
-        }
+    if (xsh) {  // k_post_exchange (previous launch) returned only after every rank's flag had arrived (or set halt)
+        const unsigned long long ep = c->xepoch[4];
         xb = v.xbuf + (size_t)(ep & 1ull) * v.world * 2 * (size_t)v.xb_cap;
     }
     if ((int)blockIdx.x < n_push) {
@@ -2697,117 +2688,126 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
             struct_update_body(v, c, ((int)blockIdx.x - n_upd) * BLK + threadIdx.x);
         return;
     }
-    const int t = blockIdx.x * BLK + threadIdx.x;
     const bool flip = status == ITER_FLIP;
     const int r = flip ? -1 : it->r, q = it->q;
     const double pc = it->pivot_coeff;
     Cand cand = cand_none();
     double cand_d = 0.0;
-    if (t < v.m) {
-        double a = v.alpha_q[t];
-        double xb = v.xB[t], lo = v.loB[t], hi = v.hiB[t], bt = use_dse ? v.beta[t] : 1.0;
-        if (t == r) {
-            int ev = it->entering_var;
-            xb = it->entering_new_val;
-            lo = v.var_lo[ev];
-            hi = v.var_hi[ev];
-            v.xB[r] = xb;
-            v.loB[r] = lo;
-            v.hiB[r] = hi;
-            if (use_dse) {
-                bt = it->rho_sq / (pc * pc);
-                v.beta[r] = bt;
-            }
-            v.basic_vars[r] = ev;
-            v.var_loc[ev] = r;
-            v.var_loc[it->leaving_var] = -1 - q;
-        } else if (a != 0.0) {
-            xb -= it->entering_diff * a;
-            v.xB[t] = xb;
-            if (use_dse && !flip) {
-                bt += -2.0 * a * v.tau[t] / pc + it->rho_sq * a * a / (pc * pc);
-                v.beta[t] = bt;
-            }
-        }
-        v.alpha_q[t] = 0.0;
-        v.tau[t] = 0.0;
-        v.rv[t] = make_double2(0.0, 0.0);
-        if (phase == 1 && !c->forced) cand = price_dual_one(xb, lo, hi, bt, t, use_dse);
-    }
-    if (t < v.n) {
-        double dd = v.d[t], gm = use_pse ? v.gamma[t] : 1.0;
-        uint8_t f = v.nbflags[t];
-        if (t == q) {
-            if (flip) {
+    // one position per thread on the usual grid; the loop only strides for very large models (launch_update_pivot)
+    const int tmax = v.m > v.n ? v.m : v.n;
+    for (int t = blockIdx.x * BLK + threadIdx.x; t < tmax; t += n_upd * BLK) {
+        Cand tc = cand_none();
+        double tc_d = 0.0;
+        if (t < v.m) {
+            double a = v.alpha_q[t];
+            double xb = v.xB[t], lo = v.loB[t], hi = v.hiB[t], bt = use_dse ? v.beta[t] : 1.0;
+            if (t == r) {
                 int ev = it->entering_var;
-                double nv = it->entering_new_val;
-                v.xN[q] = nv;
-                f = (uint8_t)((f & NB_FIXED) | (nv == v.var_lo[ev] ? NB_AT_MIN : 0) | (nv == v.var_hi[ev] ? NB_AT_MAX : 0));
-                v.nbflags[q] = f;
-            } else {
-                int lv = it->leaving_var;
-                double lnv = it->leaving_new_val;
-                // the pivot element computed two ways (FTRAN side / BTRAN side) measures the drift of W
-                if (q >= v.nb_lo && q < v.nb_hi) {
-                    double ba;
-                    if (inline_comb) {
-                        ba = 0.0;
-                        for (int b = 0; b < v.nbands; ++b) ba += v.band_part[(size_t)b * (size_t)v.n + q].x;
-                        v.alpha_r[q] = ba;
-                    } else {
-                        ba = v.alpha_r[q];
-                    }
-                    double fa = 1.0 / it->inv_alpha;
-                    double err = fabs(fa - ba) / fmax(1.0, fabs(fa));
-                    if (err > c->max_pivot_err || err != err) c->max_pivot_err = err;
+                xb = it->entering_new_val;
+                lo = v.var_lo[ev];
+                hi = v.var_hi[ev];
+                v.xB[r] = xb;
+                v.loB[r] = lo;
+                v.hiB[r] = hi;
+                if (use_dse) {
+                    bt = it->rho_sq / (pc * pc);
+                    v.beta[r] = bt;
                 }
-                dd = -it->pivot_obj;
-                v.d[q] = dd;
-                if (use_pse) {
-                    gm = it->alpha_sq / (pc * pc);
-                    v.gamma[q] = gm;
+                v.basic_vars[r] = ev;
+                v.var_loc[ev] = r;
+                v.var_loc[it->leaving_var] = -1 - q;
+            } else if (a != 0.0) {
+                xb -= it->entering_diff * a;
+                v.xB[t] = xb;
+                if (use_dse && !flip) {
+                    bt += -2.0 * a * v.tau[t] / pc + it->rho_sq * a * a / (pc * pc);
+                    v.beta[t] = bt;
                 }
-                v.nb_vars[q] = lv;
-                v.nb_rng[q] = make_int2(v.csc_ptr[lv], v.csc_ptr[lv + 1]);
-                v.xN[q] = lnv;
-                f = (uint8_t)((lnv == v.var_lo[lv] ? NB_AT_MIN : 0) | (lnv == v.var_hi[lv] ? NB_AT_MAX : 0));
-                v.nbflags[q] = f;
             }
-        } else if (!flip && t >= v.nb_lo && t < v.nb_hi) {
-            double ar, hp = 0.0;
-            if (inline_comb) {  // banded sweep: sum the per-band partials here (band order) instead of a combine launch
-                double s1 = 0.0, s2 = 0.0;
-                for (int b0 = 0; b0 < v.nbands; b0 += 8) {  // eight independent loads in flight, summed in band order
-                    double2 pb[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        pb[u] = (b0 + u < v.nbands) ? v.band_part[(size_t)(b0 + u) * (size_t)v.n + t] : make_double2(0.0, 0.0);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        s1 += pb[u].x;
-                        s2 += pb[u].y;
+            v.alpha_q[t] = 0.0;
+            v.tau[t] = 0.0;
+            v.rv[t] = make_double2(0.0, 0.0);
+            if (phase == 1 && !c->forced) tc = price_dual_one(xb, lo, hi, bt, t, use_dse);
+        }
+        if (t < v.n) {
+            double dd = v.d[t], gm = use_pse ? v.gamma[t] : 1.0;
+            uint8_t f = v.nbflags[t];
+            if (t == q) {
+                if (flip) {
+                    int ev = it->entering_var;
+                    double nv = it->entering_new_val;
+                    v.xN[q] = nv;
+                    f = (uint8_t)((f & NB_FIXED) | (nv == v.var_lo[ev] ? NB_AT_MIN : 0) | (nv == v.var_hi[ev] ? NB_AT_MAX : 0));
+                    v.nbflags[q] = f;
+                } else {
+                    int lv = it->leaving_var;
+                    double lnv = it->leaving_new_val;
+                    // the pivot element computed two ways (FTRAN side / BTRAN side) measures the drift of W
+                    if (q >= v.nb_lo && q < v.nb_hi) {
+                        double ba;
+                        if (inline_comb) {
+                            ba = 0.0;
+                            for (int b = 0; b < v.nbands; ++b) ba += v.band_part[(size_t)b * (size_t)v.n + q].x;
+                            v.alpha_r[q] = ba;
+                        } else {
+                            ba = v.alpha_r[q];
+                        }
+                        double fa = 1.0 / it->inv_alpha;
+                        double err = fabs(fa - ba) / fmax(1.0, fabs(fa));
+                        if (err > c->max_pivot_err || err != err) c->max_pivot_err = err;
+                    }
+                    dd = -it->pivot_obj;
+                    v.d[q] = dd;
+                    if (use_pse) {
+                        gm = it->alpha_sq / (pc * pc);
+                        v.gamma[q] = gm;
+                    }
+                    v.nb_vars[q] = lv;
+                    v.nb_rng[q] = make_int2(v.csc_ptr[lv], v.csc_ptr[lv + 1]);
+                    v.xN[q] = lnv;
+                    f = (uint8_t)((lnv == v.var_lo[lv] ? NB_AT_MIN : 0) | (lnv == v.var_hi[lv] ? NB_AT_MAX : 0));
+                    v.nbflags[q] = f;
+                }
+            } else if (!flip && t >= v.nb_lo && t < v.nb_hi) {
+                double ar, hp = 0.0;
+                if (inline_comb) {  // banded sweep: sum the per-band partials here (band order) instead of a combine launch
+                    double s1 = 0.0, s2 = 0.0;
+                    for (int b0 = 0; b0 < v.nbands; b0 += 8) {  // eight independent loads in flight, summed in band order
+                        double2 pb[8];
+    #pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            pb[u] = (b0 + u < v.nbands) ? v.band_part[(size_t)(b0 + u) * (size_t)v.n + t] : make_double2(0.0, 0.0);
+    #pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            s1 += pb[u].x;
+                            s2 += pb[u].y;
+                        }
+                    }
+                    ar = s1;
+                    hp = s2;
+                    v.alpha_r[t] = ar;
+                    if (use_pse) v.helper[t] = hp;
+                } else {
+                    ar = v.alpha_r[t];
+                    if (use_pse) hp = v.helper[t];
+                }
+                if (ar != 0.0) {
+                    dd -= it->pivot_obj * ar;
+                    v.d[t] = dd;
+                    if (use_pse) {
+                        gm += -2.0 * ar * hp / pc + it->alpha_sq * ar * ar / (pc * pc);
+                        v.gamma[t] = gm;
                     }
                 }
-                ar = s1;
-                hp = s2;
-                v.alpha_r[t] = ar;
-                if (use_pse) v.helper[t] = hp;
-            } else {
-                ar = v.alpha_r[t];
-                if (use_pse) hp = v.helper[t];
             }
-            if (ar != 0.0) {
-                dd -= it->pivot_obj * ar;
-                v.d[t] = dd;
-                if (use_pse) {
-                    gm += -2.0 * ar * hp / pc + it->alpha_sq * ar * ar / (pc * pc);
-                    v.gamma[t] = gm;
-                }
+            if (phase == 0 && t >= v.nb_lo && t < v.nb_hi) {
+                tc = price_primal_one(dd, gm, f, t, use_pse);
+                tc_d = dd;
             }
         }
-        if (phase == 0 && t >= v.nb_lo && t < v.nb_hi) {
-            cand = price_primal_one(dd, gm, f, t, use_pse);
-            cand_d = dd;
+        if (cand_better(tc, cand)) {  // ascending t per thread: ties keep the lowest position
+            cand = tc;
+            cand_d = tc_d;
         }
     }
     // every block arrives here only after its own updates; the last arriver closes this iteration
@@ -3488,7 +3488,10 @@ void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_ds
     int t = g.m > g.n ? g.m : g.n;
     // inline_comb (primal iteration with the banded sweep): the update kernel sums the per-band partials itself
     // with_struct (dual iteration without PSE): the partition change rides in the tail blocks of this launch
-    const int n_upd = blocks_for(t);
+    // one position per thread: measured against 4 per thread (a quarter of the blocks and tickets) the longer per-thread
+    // chain of band-partial loads costs more than the tickets save (109.0 vs 104.3 us per pivot); the kernel strides
+    // only beyond 512 * 4 * 256 positions
+    const int n_upd = blocks_for(t) <= 2048 ? blocks_for(t) : 2048;
     hipLaunchKernelGGL(k_update_pivot, dim3(n_upd + (with_struct ? blocks_for(g.cap) : 0)), dim3(BLK), 0, st, dv, phase, use_dse, use_pse,
                        inline_comb, n_upd);
 }
