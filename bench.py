@@ -197,6 +197,56 @@ def full_solve_record():
     return None
 
 
+def compact_line(out):
+    """The ONE JSON line printed on stdout: every contract field, numbers rounded, free text kept short (the driver
+    reads the tail of stdout: the round-1 line was 2.7 KB).  The full record (kernel descriptions, sampling notes, every
+    per-kernel figure) is written next to it as gpurun_out/bench_detail_n<N>.json."""
+    def r(x, n=4):
+        return round(x, n) if isinstance(x, float) else x
+
+    def kern(k):  # per-kernel digest: average launch time, GB/s, fraction of the HBM peak
+        return {n: {"us": r(v.get("avg_us"), 1), "gbs": r(v.get("gbs"), 0), "frac": r(v.get("frac"), 3)} if "gbs" in v
+                else {"us": r(v.get("avg_us"), 1)} for n, v in k.items()}
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data")}
+    line["value"] = r(line["value"], 2)
+    line["ms_per_step"] = r(line["ms_per_step"], 5)
+    c = out["config"]
+    line["config"] = dict(workload=c["workload"], parallelism=c["parallelism"], nucleus_size_at_end=c["nucleus_size_at_end"],
+                          completed_steps=c["completed_steps"], pricing_path_us_per_pivot=r(c["pricing_path_us_per_pivot"], 1))
+    rf = out.get("roofline")
+    if rf:
+        line["roofline"] = dict(bound=rf["bound"], kernel=rf["kernel"].split(" (")[0], achieved=r(rf["achieved"], 1), peak=rf["peak"],
+                                unit=rf["unit"], frac=r(rf["frac"], 4), traffic=r(rf["traffic"], 0) if rf["traffic"] else None,
+                                avg_launch_us=r(rf["avg_launch_us"], 2), launches=rf["launches"],
+                                algorithmic_bytes_per_launch=r(rf["algorithmic_bytes_per_launch"], 0))
+        ft = rf.get("ftran")
+        if ft:  # north_star's FTRAN entries: the column FTRAN and the k^2 stream that serves tau = B^-1 rho
+            col = ft.get("column") if "column" in ft else ft
+            line["roofline"]["ftran"] = dict(column=kern({"x": col})["x"] if col else None)
+            if "tau_late_window" in ft:
+                line["roofline"]["ftran"]["tau_stream_late_window"] = kern({"x": ft["tau_late_window"]})["x"]
+    w = out.get("windows")
+    if w:
+        line["windows"] = {}
+        for name, x in w.items():
+            if not x:
+                line["windows"][name] = None
+            elif "error" in x:
+                line["windows"][name] = dict(error=x["error"][:160])
+            else:
+                line["windows"][name] = dict(k=x["nucleus_size_at_start"], steps=x["steps"], pivots_per_s=r(x["pivots_per_s"], 1),
+                                             us_per_pivot=r(x["us_per_pivot"], 1), kernels=kern(x["kernels"]))
+    fs = out.get("full_solve")
+    if fs:
+        line["full_solve"] = dict(total_solve_wall_s=r(fs["total_solve_wall_s"], 1), pivots=fs["pivots"], source=fs["source"])
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = dict(value=r(cb["value"], 2), unit=cb["unit"], cores=cb["cores"], kind=cb["kind"],
+                                    sample="oracle (C++ restatement of minilp 0.2.2), 1 thread, same instance, its first pivots after the same warm-up")
+    return line
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -343,7 +393,13 @@ def main():
     if rank == 0:
         if late_sharded is not None:
             out.setdefault("windows", {})["late_sharded"] = late_sharded
-        print(json.dumps(out), flush=True)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", f"bench_detail_n{world}.json"), "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError:
+            pass
+        print(json.dumps(compact_line(out)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -18,6 +18,7 @@
 #include <math.h>
 
 #include <cstdlib>
+#include <string>
 
 namespace mlp {
 
@@ -840,7 +841,57 @@ __global__ void __launch_bounds__(BLK) k_push_stage1(DevView v, int which) {
     double* dst = v.push_part + (size_t)cc * v.m + row0;
     for (int t = tid; t < nrows; t += BLK) dst[t] = acc[t];
 }
-__global__ void __launch_bounds__(BLK) k_push_combine(DevView v, int which) {
+// The same product through the band-major copy of A (when the banded sweep keeps one): block (band b, chunk c) walks the
+// nucleus slots of its chunk and reads each column's segment inside the band — one 8-byte load for the (begin, end) pair,
+// a contiguous run of ~8 entries — instead of 25 row blocks each re-reading every column's offsets and ~4 entries out of
+// a 128-byte line (PMC: 196 MB of HBM traffic per launch for 27 MB of algorithmic bytes at k = 20 500).  8 192 rows of
+// accumulators (64 KB of LDS) per workgroup, 13 x 19 workgroups on config 4.
+constexpr int PBB_THREADS = 512, PBB_TILE = 512;
+__global__ void __launch_bounds__(PBB_THREADS) k_push_band(DevView v, int which, int chunks) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    extern __shared__ double s_pb[];
+    double* acc = s_pb;                                    // BAND_ROWS
+    double* s_x = s_pb + BAND_ROWS;                        // PBB_TILE
+    int* s_beg = reinterpret_cast<int*>(s_x + PBB_TILE);   // PBB_TILE
+    int* s_len = s_beg + PBB_TILE;                         // PBB_TILE
+    const int b = (int)blockIdx.x / chunks, cc = (int)blockIdx.x % chunks, tid = threadIdx.x;
+    const int row0 = b * BAND_ROWS;
+    const int nrows = min(BAND_ROWS, v.m - row0);
+    for (int t = tid; t < nrows; t += PBB_THREADS) acc[t] = 0.0;
+    const int k = c->k;
+    const int per = (k + chunks - 1) / chunks;
+    const int s_lo = cc * per, s_hi = min(k, s_lo + per);
+    const double* xK = which ? v.tauK : v.aK;
+    const int* bp = v.bptr + (size_t)b * (size_t)(v.m + v.n + 1);
+    const int lane = tid & 7, grp = tid >> 3;  // 8 lanes per slot, 64 slots side by side
+    for (int tile0 = s_lo; tile0 < s_hi; tile0 += PBB_TILE) {
+        const int nt = min(PBB_TILE, s_hi - tile0);
+        __syncthreads();
+        for (int t = tid; t < nt; t += PBB_THREADS) {  // phase A: one thread per slot fetches its descriptor
+            const int slot = tile0 + t;
+            const double x = xK[slot];
+            const int var = v.basic_vars[v.pos_of_kslot[slot]];
+            const int beg = bp[var], end = bp[var + 1];
+            s_x[t] = x;
+            s_beg[t] = beg;
+            s_len[t] = (x != 0.0) ? end - beg : 0;
+        }
+        __syncthreads();
+        for (int t = grp; t < nt; t += PBB_THREADS / 8) {  // phase B: 8 lanes walk the slot's segment
+            const int len = s_len[t], beg = s_beg[t];
+            const double x = s_x[t];
+            for (int o = lane; o < len; o += 8) {
+                const double a = v.bval[beg + o];
+                if (a != 0.0) unsafeAtomicAdd(&acc[v.brow[beg + o]], a * x);  // (pad entries carry 0)
+            }
+        }
+    }
+    __syncthreads();
+    double* dst = v.push_part + (size_t)cc * v.m + row0;
+    for (int t = tid; t < nrows; t += PBB_THREADS) dst[t] = acc[t];
+}
+__global__ void __launch_bounds__(BLK) k_push_combine(DevView v, int which, int nchunks) {
     const Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     const int i = blockIdx.x * BLK + threadIdx.x;
@@ -848,8 +899,7 @@ __global__ void __launch_bounds__(BLK) k_push_combine(DevView v, int which) {
     const RowInfo ri = v.rowinfo[i];
     if (ri.kslot >= 0) return;
     double s = 0.0;
-#pragma unroll
-    for (int cc = 0; cc < PB_CHUNKS; ++cc) s += v.push_part[(size_t)cc * v.m + i];
+    for (int cc = 0; cc < nchunks; ++cc) s += v.push_part[(size_t)cc * v.m + i];
     if (s != 0.0) {
         double* out = which ? v.tau : v.alpha_q;
         out[ri.pos] -= s / ri.diag;
@@ -891,8 +941,27 @@ static void launch_pull_F(const DevView& dv, const Geom& g, int which, hipStream
     else hipLaunchKernelGGL(k_pull_F<64>, dim3(blocks_for((long)dv.m * 64)), dim3(BLK), 0, st, dv, which);
 }
 static void launch_blocked_push(const DevView& dv, int which, hipStream_t st) {
+    // Measured (round 2, k = 20 500): the band form runs in 34.6 + 9.5 us against 34.8 + 6.4 us for the row-block form
+    // over the CSC — neither is bound by its traffic (the row-block form moves 196 MB for 27 MB of algorithmic bytes, PMC)
+    // but by the serial descriptor / entry chains of its slot tiles.  The row-block form stays the default;
+    // MLP_PUSH_BAND=1 selects the band form for experiments.
+    static const bool band_push = std::getenv("MLP_PUSH_BAND") != nullptr;
+    if (dv.banded && band_push) {
+        static bool attr_set = false;
+        const size_t lds = sizeof(double) * (BAND_ROWS + PBB_TILE) + sizeof(int) * 2 * PBB_TILE;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_push_band), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        int chunks = 256 / dv.nbands;  // about one workgroup per CU (two fit by LDS)
+        if (chunks < 1) chunks = 1;
+        if (chunks > PB_CHUNKS) chunks = PB_CHUNKS;  // push_part holds PB_CHUNKS x m partial sums
+        hipLaunchKernelGGL(k_push_band, dim3(dv.nbands * chunks), dim3(PBB_THREADS), lds, st, dv, which, chunks);
+        hipLaunchKernelGGL(k_push_combine, dim3((dv.m + BLK - 1) / BLK), dim3(BLK), 0, st, dv, which, chunks);
+        return;
+    }
     hipLaunchKernelGGL(k_push_stage1, dim3(dv.pb_rb, PB_CHUNKS), dim3(BLK), 0, st, dv, which);
-    hipLaunchKernelGGL(k_push_combine, dim3((dv.m + BLK - 1) / BLK), dim3(BLK), 0, st, dv, which);
+    hipLaunchKernelGGL(k_push_combine, dim3((dv.m + BLK - 1) / BLK), dim3(BLK), 0, st, dv, which, PB_CHUNKS);
 }
 
 // ------------------------------------------------------------------- K5: primal Harris ratio test
@@ -1583,7 +1652,13 @@ __global__ void __launch_bounds__(BLK) k_sweep(DevView v, int n_sweep) {
 // up in band order (fixed summation order, no atomics).
 typedef unsigned int uint4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
-template <int MODE>
+// VORD: the columns are visited in VARIABLE order (the storage order of the band-major copy) instead of non-basic
+// POSITION order.  After many pivots nb_vars is a random permutation, so position order turns the read of the copy into
+// 80-byte gathers out of 128-byte lines: the PMC counters show 521 MB of HBM traffic per launch at pivot 240 000 against
+// 150 MB at pivot 200, for the same 116 MB copy.  In variable order the copy is read front to back; basic variables are
+// skipped (var_loc >= 0) and the partials are scattered to band_part[b][position] (16-byte stores).  Unsharded solves
+// only: a rank of a sharded solve owns a range of POSITIONS, which in variable order would be a scattered subset.
+template <int MODE, bool VORD>
 __global__ void __launch_bounds__(BAND_THREADS) k_sweep_band(DevView v, int chunks) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
@@ -1598,19 +1673,33 @@ __global__ void __launch_bounds__(BAND_THREADS) k_sweep_band(DevView v, int chun
     const int nrows = min(BAND_ROWS, v.m - row0);
     for (int t = tid; t < nrows; t += BAND_THREADS) s_rv[t] = v.rv[row0 + t];
     __syncthreads();
-    const int span = v.nb_hi - v.nb_lo;
+    const int base = VORD ? 0 : v.nb_lo;
+    const int span = VORD ? v.m + v.n : v.nb_hi - v.nb_lo;  // variables, or this rank's non-basic positions
     const int per = (span + chunks - 1) / chunks;
-    const int c_lo = v.nb_lo + chunk * per;
-    const int c_hi = min(v.nb_hi, c_lo + per);
+    const int c_lo = base + chunk * per;
+    const int c_hi = min(base + span, c_lo + per);
     const int* bp = v.bptr + (size_t)b * (size_t)(v.m + v.n + 1);
     double2* out = v.band_part + (size_t)b * (size_t)v.n;
-    constexpr int CPT = 4;  // columns per thread resolved together: their three-deep index chains overlap
+    constexpr int CPT = 4;  // columns per thread resolved together: their index chains overlap
     for (int j0 = c_lo + tid; j0 < c_hi; j0 += CPT * BAND_THREADS) {
-    int vars[CPT], begs[CPT], ends[CPT];
+    int vars[CPT], poss[CPT], begs[CPT], ends[CPT];
 #pragma unroll
     for (int u = 0; u < CPT; ++u) {
-        const int j = j0 + u * BAND_THREADS;
-        vars[u] = j < c_hi ? v.nb_vars[j] : -1;
+        const int i = j0 + u * BAND_THREADS;
+        vars[u] = -1;
+        poss[u] = -1;
+        if (i < c_hi) {
+            if (VORD) {
+                const int loc = v.var_loc[i];
+                if (loc < 0) {  // non-basic: position -1 - loc
+                    vars[u] = i;
+                    poss[u] = -1 - loc;
+                }
+            } else {
+                vars[u] = v.nb_vars[i];
+                poss[u] = i;
+            }
+        }
     }
 #pragma unroll
     for (int u = 0; u < CPT; ++u) {
@@ -1619,8 +1708,8 @@ __global__ void __launch_bounds__(BAND_THREADS) k_sweep_band(DevView v, int chun
     }
 #pragma unroll
     for (int u = 0; u < CPT; ++u) {
-        const int j = j0 + u * BAND_THREADS;
-        if (j >= c_hi) break;
+        if (vars[u] < 0) continue;
+        const int j = poss[u];
         const int beg = begs[u], end = ends[u];
         double a1 = 0.0, a2 = 0.0;
         for (int e0 = beg; e0 < end; e0 += 8) {
@@ -3270,11 +3359,20 @@ static void launch_sweep_banded(const DevView& dv, const Geom& g, int mode, int 
     const size_t lds = sizeof(double2) * (size_t)BAND_ROWS;
     if (!attr_set) {  // more than the default 64 KB of LDS per workgroup
         // (a failure here makes the launches below fail, which Engine::pull_ctl reports through hipGetLastError)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_band<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_band<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_band<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_band<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_band<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_band<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_band<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_band<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_band<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
+    // column order of the pass
+    // Measured (round 2): variable order does NOT pay — late window 77.5 us against 73.4 us in position order, early window
+    // 112.4 against 103.9 us per pivot: the 16-byte partial stores scattered by position cost what the sequential read
+    // saves.  Position order stays the default; MLP_SWEEP_ORDER=var selects the other for experiments.
+    static const bool want_var = std::getenv("MLP_SWEEP_ORDER") && std::string(std::getenv("MLP_SWEEP_ORDER")) == "var";
+    const bool vord = dv.world <= 1 && want_var;
     // One workgroup per CU (LDS-bound): all blocks of the launch must fit the 256 CUs at once, or a second,
     // almost empty round of workgroups doubles the kernel time (260 workgroups: 43 us, 247: 36 us).  In the
     // primal iteration the per-band partials are summed by k_update_pivot itself (inline_combine) and the
@@ -3283,9 +3381,15 @@ static void launch_sweep_banded(const DevView& dv, const Geom& g, int mode, int 
     int chunks = (256 - struct_blocks) / dv.nbands;
     if (chunks < 1) chunks = 1;
     const dim3 gr(dv.nbands * chunks + struct_blocks), b(BAND_THREADS);
-    if (mode == 0) hipLaunchKernelGGL(k_sweep_band<0>, gr, b, lds, st, dv, chunks);
-    else if (mode == 1) hipLaunchKernelGGL(k_sweep_band<1>, gr, b, lds, st, dv, chunks);
-    else hipLaunchKernelGGL(k_sweep_band<2>, gr, b, lds, st, dv, chunks);
+    if (vord) {
+        if (mode == 0) hipLaunchKernelGGL((k_sweep_band<0, true>), gr, b, lds, st, dv, chunks);
+        else if (mode == 1) hipLaunchKernelGGL((k_sweep_band<1, true>), gr, b, lds, st, dv, chunks);
+        else hipLaunchKernelGGL((k_sweep_band<2, true>), gr, b, lds, st, dv, chunks);
+    } else {
+        if (mode == 0) hipLaunchKernelGGL((k_sweep_band<0, false>), gr, b, lds, st, dv, chunks);
+        else if (mode == 1) hipLaunchKernelGGL((k_sweep_band<1, false>), gr, b, lds, st, dv, chunks);
+        else hipLaunchKernelGGL((k_sweep_band<2, false>), gr, b, lds, st, dv, chunks);
+    }
     if (inline_combine) return;
     const int nc = blocks_for(dv.nb_hi - dv.nb_lo);
     const dim3 gc(nc + (with_struct ? blocks_for(g.cap) : 0));

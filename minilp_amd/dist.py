@@ -46,13 +46,9 @@ def remove_mailbox(name):
         pass
 
 
-def setup_sharding(solution, dist=None):
-    """Call on every rank after `Problem.solve(budget=0)`: agree on a mailbox and enable sharding.
-    `dist` is torch.distributed (initialised) or None for a single process.  Returns the mailbox name
-    (rank 0 should remove it at the end)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return None
-    rank, world = dist.get_rank(), dist.get_world_size()
+def _try_enable(solution, dist, rank, world):
+    """One collective attempt: rank 0 creates the rendezvous object, every rank enables sharding; returns
+    (box name, list of per-rank error strings)."""
     box = [create_mailbox(world) if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
     err = None
@@ -61,13 +57,35 @@ def setup_sharding(solution, dist=None):
     except Exception as e:  # every rank must leave through the same door
         err = f"rank {rank}: {e}"
     errs = [None] * world
-    dist.all_gather_object(errs, err)  # doubles as the barrier after which every slot is mapped
-    bad = [e for e in errs if e]
+    dist.all_gather_object(errs, err)  # doubles as the barrier after which every box is mapped
+    return box[0], [e for e in errs if e]
+
+
+def setup_sharding(solution, dist=None):
+    """Call on every rank after `Problem.solve(budget=0)`: agree on a rendezvous object and enable sharding.
+    `dist` is torch.distributed (initialised) or None for a single process.  Returns the object's name (rank 0
+    should remove it at the end).
+
+    Transport: device mailboxes written by the peers over xGMI (HIP IPC).  If ANY rank cannot set that up (IPC or peer
+    access unavailable on the node), all ranks together fall back ONCE to the host-memory mailbox — still the same
+    sharded solve of one LP, only the 64-byte exchanges take the PCIe route; `Solution.transport()` says which one is
+    in use.  If that fails too the call raises on every rank (never a silent change of what is being run)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return None
+    rank, world = dist.get_rank(), dist.get_world_size()
+    name, bad = _try_enable(solution, dist, rank, world)
+    if bad and os.environ.get("MLP_MAILBOX") != "host":
+        if rank == 0:
+            remove_mailbox(name)
+            print("[minilp_amd.dist] peer transport unavailable (" + "; ".join(bad) + "): falling back to the host-memory mailbox",
+                  flush=True)
+        os.environ["MLP_MAILBOX"] = "host"   # read by the engine at enable_sharding
+        name, bad = _try_enable(solution, dist, rank, world)
     if bad:
         if rank == 0:
-            remove_mailbox(box[0])
+            remove_mailbox(name)
         raise RuntimeError("sharding could not be enabled on every rank: " + "; ".join(bad))
-    return box[0]
+    return name
 
 
 def combine_candidates(cands):

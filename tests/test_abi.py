@@ -206,6 +206,18 @@ def test_bench_contract_pieces_that_need_no_gpu():
     assert t is not None and 1.0e8 < t < 3.0e8 and src.endswith(".json")   # HBM bytes per launch of the dominant kernel
     assert bench.pmc_traffic(types.SimpleNamespace(rows=10, cols=10, nnz_per_row=2, seed=1), "sweep")[0] is None
     assert bench.HBM_PEAK_GBS == 8000.0
+    # the printed line is a compact digest of the detailed record (the driver reads the tail of stdout)
+    import json
+    detail = json.load(open(os.path.join(root, "profiles", "r02k_bench.json")))
+    line = bench.compact_line(detail)
+    text = json.dumps(line)
+    assert len(text) < 3000, len(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "windows", "full_solve"):
+        assert key in line, key
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "ftran"}
+    assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert line["windows"]["late"]["kernels"]["fused"]["frac"] > 0.5 and line["config"]["workload"].startswith("config 4")
     rec = bench.full_solve_record()
     assert rec and rec["total_solve_wall_s"] > 0 and rec["pivots"] > 10 ** 6 and rec["source"].startswith("profiles/")
 
