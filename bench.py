@@ -319,7 +319,7 @@ def main():
         roofline = None
         if dom:
             which = ("sweep_band" if st.get("banded_sweep") else "sweep") if dom == "sweep" else dom
-            traffic, traffic_src = pmc_traffic(a, dom)
+            traffic, traffic_src = pmc_traffic(a, dom) if world == 1 else (None, None)  # the PMC figure is the unsharded kernel's
             roofline = dict(bound="hbm", kernel=KERNEL_NAMES[which], achieved=kern[dom]["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=kern[dom]["frac"], traffic=traffic,
                             traffic_unit=f"HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/{traffic_src})" if traffic else None,

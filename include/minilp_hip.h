@@ -103,7 +103,7 @@ int mlp_solution_reinvert(mlp_solution* s, double* max_diff);
 /* Column-block sharding of the pricing path across the GPUs of one node (one process per GPU,
  * DESIGN.md §6).  Every rank builds the SAME problem, calls mlp_problem_solve_ex(budget = 0), then
  * this function with its rank, the world size (<= 16) and the name of a POSIX shared-memory object of
- * 768 * world zeroed bytes created by the launcher (the rendezvous), and then the same sequence of
+ * 896 * world zeroed bytes created by the launcher (the rendezvous), and then the same sequence of
  * mlp_solution_continue calls.  Rank r owns non-basic positions [n*r/world, n*(r+1)/world): its
  * tableau-row sweep, d/gamma update and pricing scan cover only that block; candidates are exchanged once or
  * twice per pivot (primal: pricing all-gather + ratio decision; dual: leaving row, pass-1 minimum, pass-2

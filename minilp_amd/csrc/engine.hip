@@ -75,6 +75,9 @@ Engine::Engine() {
     const char* ng = std::getenv("MLP_NO_GRAPH");
     use_graph = !(ng && ng[0] == '1');
     const char* br = std::getenv("MLP_BRANCH");
+    // side branch of the graph for the tau push of the large-nucleus regime: measured (round 2) 902.6 vs 901.6 us per
+    // pivot at k = 20 500 and 367.7 vs 358.6 us at k = 10 000 — the two kernels do not overlap usefully with the sweep and
+    // the fork / join costs a little; off unless MLP_BRANCH=1
     use_branches = br && br[0] == '1';
     const char* rt = std::getenv("MLP_REFRESH_TOL");
     if (rt) refresh_tol = std::atof(rt);
@@ -543,8 +546,8 @@ void Engine::push_maps() {
 
 // ------------------------------------------------------------------ column-block sharding
 // Rendezvous: a POSIX shared-memory object created (zeroed) by the launcher, mapped by every rank:
-//   [0, 640 * world)                 host-transport mailbox (MLP_MAILBOX=host), registered with HIP
-//   [640 * world, 768 * world)       one 128-byte rendezvous record per rank: HIP IPC handle of its device box
+//   [0, 768 * world)                 host-transport mailbox (MLP_MAILBOX=host), registered with HIP
+//   [768 * world, 896 * world)       one 128-byte rendezvous record per rank: HIP IPC handle of its device box
 // Peer transport (default): every rank allocates its box in its OWN HBM (uncached, falling back to fine-grained),
 // publishes the IPC handle, opens the peers' handles (peer access is enabled lazily by hipIpcOpenMemHandle), and
 // the pivot kernels then write their 64-byte records straight into the peers' boxes over xGMI and poll locally.
@@ -556,7 +559,7 @@ struct Rendezvous {  // 128 bytes
     uint8_t pad[128 - 8 - 8 - sizeof(hipIpcMemHandle_t)];
 };
 static_assert(sizeof(Rendezvous) == 128, "rendezvous record layout");
-constexpr size_t kHostBoxBytesPerRank = sizeof(MailRec) * 2 * MAIL_KINDS;  // 640
+constexpr size_t kHostBoxBytesPerRank = sizeof(MailRec) * 2 * MAIL_KINDS;  // 768
 bool wait_flag(volatile uint64_t* f, uint64_t want, double seconds) {
     const double t0 = now_s();
     while (__atomic_load_n(f, __ATOMIC_ACQUIRE) < want) {
@@ -600,7 +603,7 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name) {
     struct stat sb;
     if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < bytes) {
         close(fd);
-        throw MlpError(-1, "enable_sharding: mailbox object too small (need 768 * world bytes)");
+        throw MlpError(-1, "enable_sharding: mailbox object too small (need 896 * world bytes)");
     }
     void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
@@ -676,6 +679,28 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name) {
     }
     shard_rank = rank; shard_world = world;
     view_dirty = true;
+    // Handshake: before any pivot depends on it, every rank posts one record to every box and waits for all of them
+    // with a short bound (~2 s).  A transport that maps but does not deliver (no peer-to-peer route, non-coherent
+    // mapping) is detected HERE — the caller can then fall back to the host mailbox — not as a 10-second stall
+    // inside the first sharded pivot.
+    try {
+        sync_view();
+        DevBuf<int> flag;
+        flag.ensure(2, 0, st);
+        HIPCHECK(hipMemsetAsync(flag.p, 0, 2 * sizeof(int), st));
+        launch_mail_handshake(hview, flag.p, st);
+        int hf[2] = {0, 0};
+        HIPCHECK(hipMemcpyAsync(hf, flag.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        if (hf[0] != 1)
+            throw MlpError(-3, "enable_sharding: the mailbox handshake did not complete (rank " + std::to_string(rank) + " heard from " +
+                                   std::to_string(hf[1]) + " of " + std::to_string(world) + " ranks): transport '" + transport + "' does not deliver");
+    } catch (...) {
+        release_mailboxes();
+        shard_rank = 0; shard_world = 1;
+        view_dirty = true;
+        throw;
+    }
 }
 
 // ------------------------------------------------------------------ Solver::try_new (solver.rs:108-369)
@@ -868,6 +893,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     // banded sweep, primal iteration: k_update_pivot sums the per-band partials itself (no combine launch);
     // the host-paced stepping API keeps the separate combine so that row_coeffs is readable after STAGE_ROW
     const int inl = (dv.banded && phase == 0 && !stepping) ? 1 : 0;
+    const bool tau_branch = use_branches && dv.pb_on && phase == 0 && !stepping && shard_world == 1;
     // The pricing decision (q for primal, r for dual) is already in Ctl: it was taken by the
     // previous iteration's update kernel, or by the standalone pricing kernel at batch start.
     switch (stage) {
@@ -901,12 +927,23 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         if (with_events) HIPCHECK(hipEventRecord(ev[2], st));
         launch_fused_w(dv, g, pse, st);                       // tauK / vK partials + eta update of W
         if (with_events) HIPCHECK(hipEventRecord(ev[3], st));
-        launch_post_fused(dv, g, pse, st);                    // tau by position (F push)  |  v reduce + scatter
+        if (tau_branch) {
+            // large-nucleus regime: the blocked push of -F tau_K (two kernels, ~40 us of serial chains) is needed by the
+            // update kernel only; it runs on a side branch of the graph next to the tableau-row sweep.  The partition
+            // change then rides in the update kernel instead of the sweep (the push reads the OLD slot maps).
+            launch_post_fused(dv, g, pse, st, 0, 1);
+            HIPCHECK(hipEventRecord(evFork[0], st));
+            HIPCHECK(hipStreamWaitEvent(st2, evFork[0], 0));
+            launch_push_tau(dv, st2);
+            HIPCHECK(hipEventRecord(evJoin[0], st2));
+        } else {
+            launch_post_fused(dv, g, pse, st);                // tau by position (F push)  |  v reduce + scatter
+        }
         break;
     case STAGE_ROW:
         if (phase == 0) {
             if (with_events) HIPCHECK(hipEventRecord(ev[0], st));
-            launch_sweep(dv, g, pse ? 1 : 0, 1, st, inl);     // K4 (+ PSE helper in the same pass)  |  partition change
+            launch_sweep(dv, g, pse ? 1 : 0, tau_branch ? 0 : 1, st, inl);  // K4 (+ PSE helper in the same pass)  |  partition change
             if (with_events) HIPCHECK(hipEventRecord(ev[1], st));
         } else {
             if (with_events) HIPCHECK(hipEventRecord(ev[0], st));
@@ -918,7 +955,8 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         if (phase == 1 && pse) launch_sweep(dv, g, 2, 1, st);  // dual path: PSE helper  |  partition change
         if (with_events) HIPCHECK(hipEventRecord(ev[4], st));
         // K8 + zero the work vectors + price the next iteration (dual path without PSE: | partition change)
-        launch_update_pivot(dv, g, phase, dse, pse, st, inl, (phase == 1 && !pse) ? 1 : 0);
+        if (tau_branch) HIPCHECK(hipStreamWaitEvent(st, evJoin[0], 0));  // the tau push has landed
+        launch_update_pivot(dv, g, phase, dse, pse, st, inl, ((phase == 1 && !pse) || tau_branch) ? 1 : 0);
         if (with_events) HIPCHECK(hipEventRecord(ev[5], st));
         break;
     default:

@@ -89,7 +89,7 @@ struct Ctl {
 
 // Sharded pricing: one 64-byte mailbox record per (kind, parity, rank) in host
 // memory mapped into every rank's GPU; a rank writes only its own slot and polls the others.
-constexpr int MAIL_KINDS = 5;
+constexpr int MAIL_KINDS = 6;  // 0-3 candidate exchanges, 4 vector-exchange flags, 5 transport handshake
 constexpr int MAX_WORLD = 16;  // ranks of one sharded solve (one node: 8 GPUs; test rigs oversubscribe one GPU)
 struct alignas(64) MailRec {
     unsigned long long epoch;
@@ -228,7 +228,9 @@ void launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, h
 void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st);                 // K7 p1, p2 (+FTRAN head)
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st);        // tauK/vK partials + eta update of W
-void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic = 0);  // tau push | v reduce+scatter (classic: partials of k_fused_w's tiling)
+void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic = 0, int skip_push = 0);
+void launch_push_tau(const DevView& dv, hipStream_t st);  // blocked push of -F tau_K alone (runs on a side branch of the graph)  // tau push | v reduce+scatter (classic: partials of k_fused_w's tiling)
+void launch_mail_handshake(const DevView& dv, int* out, hipStream_t st);  // transport self-test at enable_sharding
 bool stream_strips_enabled();  // large-nucleus streaming pass in strip form (MLP_STREAM_STRIPS=0 disables)
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_dse, int use_pse, hipStream_t st, int inline_comb = 0,

@@ -445,6 +445,41 @@ __device__ bool adopt_rank0_candidate(const DevView& v, Ctl* c, Cand& best) {
     return true;
 }
 
+// Transport handshake (Engine::enable_sharding): one wave posts a record of the handshake kind (MAIL_KINDS - 1, used
+// by nothing else) with epoch 1 to every box and waits for every rank's record with a short bound; out[0] = 1 on
+// success, out[1] = number of ranks heard from.
+__global__ void __launch_bounds__(64) k_mail_handshake(DevView v, int* out) {
+    const int lane = threadIdx.x;
+    const unsigned long long ep = 1ull;
+    double f[7] = {(double)v.rank, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    mail_post_wave(v, MAIL_KINDS - 1, ep, f, lane);
+    bool ok = true;
+    int heard = 0;
+    for (int r = lane; r < v.world; r += 64) {
+        MailRec* slot = mail_slot(v, MAIL_KINDS - 1, ep, r);
+        bool got = false;
+        for (long spins = 0; spins < 12000000L; ++spins) {  // ~2 s
+            if (__hip_atomic_load(&slot->epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == ep) {
+                got = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (got && __hip_atomic_load(&slot->f[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == (double)r) heard += 1;
+        else ok = false;
+    }
+    ok = __all(ok);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) heard += __shfl_down(heard, o, 64);
+    if (lane == 0) {
+        out[1] = heard;
+        out[0] = ok ? 1 : 0;
+    }
+}
+void launch_mail_handshake(const DevView& dv, int* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_mail_handshake, dim3(1), dim3(64), 0, st, dv, out);
+}
+
 // Partition-change plan, run by ONE thread once q, r and the final alpha_q are
 // known.  The host never needs (q, r): this is what makes the iteration graph-replayable.
 __device__ void plan_update(const DevView& v, Ctl* c, int phase) {
@@ -3547,7 +3582,7 @@ void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st
         else hipLaunchKernelGGL((k_fused_w<16, true, false, true, true, false, FW_RL, true>), dim3(nb), b, 0, st, dv);
     }
 }
-void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic) {
+void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic, int skip_push) {
     if (!classic && dv.lrJ && fw_rows(g) != 8 && FW_RL == 1 && stream_strips()) {  // partials of k_stream_w's strips
 #define POSTX(RB, CH)                                                                                             \
     if (sw_rb() == RB && sw_ch() == CH) hipLaunchKernelGGL((k_post_exchange<RB, CH>), dim3(blocks_for(g.cap)), dim3(BLK), 0, st, dv, with_v);
@@ -3568,7 +3603,7 @@ void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t
         LANES_SWITCH(g.lanes, POSTS(4), POSTS(16), POSTS(64));
 #undef POSTS
 #undef POSTS2
-        if (dv.pb_on) launch_blocked_push(dv, 1, st);
+        if (dv.pb_on && !skip_push) launch_blocked_push(dv, 1, st);
         else if (dv.det_pull) launch_pull_F(dv, g, 1, st);
         return;
     }
@@ -3581,9 +3616,10 @@ void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t
     } while (0)
     LANES_SWITCH(g.lanes, POSTF(4), POSTF(16), POSTF(64));
 #undef POSTF
-    if (dv.pb_on) launch_blocked_push(dv, 1, st);
+    if (dv.pb_on && !skip_push) launch_blocked_push(dv, 1, st);
     else if (dv.det_pull) launch_pull_F(dv, g, 1, st);
 }
+void launch_push_tau(const DevView& dv, hipStream_t st) { launch_blocked_push(dv, 1, st); }  // the tau push alone (side branch)
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st) {
     hipLaunchKernelGGL(k_struct_update, dim3(blocks_for(g.cap)), dim3(BLK), 0, st, dv);
 }

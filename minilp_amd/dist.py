@@ -10,7 +10,7 @@ import os
 import uuid
 
 MAILREC_BYTES = 64
-KINDS, PARITIES = 5, 2  # kernels.h: MAIL_KINDS (pricing, primal ratio decision, dual ratio min, dual ratio candidate, W-stream vectors)
+KINDS, PARITIES = 6, 2  # kernels.h: MAIL_KINDS (pricing, primal ratio decision, dual ratio min, dual ratio candidate, W-stream flags, handshake)
 
 
 RENDEZVOUS_BYTES = 128  # engine.hip: one record per rank (ready flag, device, pid, 64-byte HIP IPC handle)
@@ -21,7 +21,7 @@ def host_box_bytes(world):
 
 
 def mailbox_bytes(world):
-    """Size of the shared-memory object: host-transport mailbox + the rendezvous records (768 bytes per rank)."""
+    """Size of the shared-memory object: host-transport mailbox + the rendezvous records (896 bytes per rank)."""
     return host_box_bytes(world) + RENDEZVOUS_BYTES * world
 
 

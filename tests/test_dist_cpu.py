@@ -74,7 +74,7 @@ def _worker(rank, world, port, q):
             vals.append(struct.unpack("<d", bytes(mm[o2 + 8: o2 + 16]))[0])
         results.append(("min", min(vals)))
         assert min(vals) == 2.0 * epoch / 7.0  # rank 0 holds the smallest ratio
-    assert slot(4, 1, world - 1) + rec <= md.host_box_bytes(world) <= md.mailbox_bytes(world) and md.KINDS == 5
+    assert slot(5, 1, world - 1) + rec <= md.host_box_bytes(world) <= md.mailbox_bytes(world) and md.KINDS == 6
     gathered = [None] * world
     dist.all_gather_object(gathered, results)
     if rank == 0:
