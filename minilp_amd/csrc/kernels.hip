@@ -1158,15 +1158,20 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_fused(DevView v, int use_p
         ca[u] = 0.0;
         stp[u] = 0.0;
         if (p >= v.m) continue;
+        // every input of the element is loaded up front (independent loads in flight together) instead of behind the
+        // branches that use it: one dependent memory round trip less on the critical path of the iteration
         const double coeff = v.alpha_q[p];
+        const int ks = v.kslot_of_pos[p], sr = v.srow_of_pos[p];
+        const double sd = v.sdiag_of_pos[p];
+        const double xb = v.xB[p], lob = v.loB[p], hib = v.hiB[p];
         if (use_pse) {
             sq += coeff * coeff;
-            if (v.kslot_of_pos[p] < 0) v.rv[v.srow_of_pos[p]].y = coeff / v.sdiag_of_pos[p];
+            if (ks < 0) v.rv[sr].y = coeff / sd;
         }
         const double a = fabs(coeff);
         if (a < EPS) continue;
-        bool tm;
-        const double st = leaving_step(v, p, coeff, sign, tm);
+        const bool tm = (sign && coeff < 0.0) || (!sign && coeff > 0.0);  // solver.rs:752-771 (as leaving_step)
+        const double st = tm ? (xb < hib ? hib - xb : 0.0) : (xb > lob ? xb - lob : 0.0);
         pos[u] = p;
         ca[u] = a;
         stp[u] = st;
@@ -2825,6 +2830,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
         if (t < v.m) {
             double a = v.alpha_q[t];
             double xb = v.xB[t], lo = v.loB[t], hi = v.hiB[t], bt = use_dse ? v.beta[t] : 1.0;
+            const double tau_t = (use_dse && !flip) ? v.tau[t] : 0.0;  // loaded with the others, not behind `a != 0`
             if (t == r) {
                 int ev = it->entering_var;
                 xb = it->entering_new_val;
@@ -2844,7 +2850,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                 xb -= it->entering_diff * a;
                 v.xB[t] = xb;
                 if (use_dse && !flip) {
-                    bt += -2.0 * a * v.tau[t] / pc + it->rho_sq * a * a / (pc * pc);
+                    bt += -2.0 * a * tau_t / pc + it->rho_sq * a * a / (pc * pc);
                     v.beta[t] = bt;
                 }
             }
@@ -2896,13 +2902,13 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                 double ar, hp = 0.0;
                 if (inline_comb) {  // banded sweep: sum the per-band partials here (band order) instead of a combine launch
                     double s1 = 0.0, s2 = 0.0;
-                    for (int b0 = 0; b0 < v.nbands; b0 += 8) {  // eight independent loads in flight, summed in band order
-                        double2 pb[8];
-    #pragma unroll
-                        for (int u = 0; u < 8; ++u)
+                    for (int b0 = 0; b0 < v.nbands; b0 += 16) {  // sixteen independent loads in flight (all 13 bands of
+                        double2 pb[16];                            // config 4 in one round), summed in band order
+#pragma unroll
+                        for (int u = 0; u < 16; ++u)
                             pb[u] = (b0 + u < v.nbands) ? v.band_part[(size_t)(b0 + u) * (size_t)v.n + t] : make_double2(0.0, 0.0);
-    #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) {
                             s1 += pb[u].x;
                             s2 += pb[u].y;
                         }
