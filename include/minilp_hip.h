@@ -132,6 +132,8 @@ typedef struct mlp_stats {
      * algorithmic bytes 8 k |list| + 12 nnz(nucleus columns) + 12 nnz(a_q), HIP-event time of sampled iterations */
     double ftran_bytes, ftran_ms; uint64_t ftran_launches;
     double iter_ms; uint64_t iter_samples; /* whole sampled iterations, first kernel to last (HIP events) */
+    uint64_t beta_rebuilds; /* lazy dual steepest edge: exact rebuilds of the dual edge norms from the basis inverse (the primal
+                               loop skips their per-pivot recurrence, solver.rs:1153-1174, because nothing reads them there) */
 } mlp_stats;
 void mlp_solution_stats(const mlp_solution* s, mlp_stats* out);
 void mlp_solution_reset_stats(mlp_solution* s);

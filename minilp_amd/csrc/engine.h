@@ -129,6 +129,7 @@ struct Stats {
     uint64_t update_launches = 0;
     double solve_wall_s = 0;
     double max_pivot_err = 0;
+    uint64_t beta_rebuilds = 0;  // lazy dual steepest edge: exact rebuilds of beta from the basis inverse
     uint64_t kase[5] = {0, 0, 0, 0, 0};  // partition-change cases: nuc->nuc, grow, shrink, col swap, same-row
 };
 
@@ -188,6 +189,13 @@ private:
     std::vector<double> h_cval;
     int max_col_nnz_ = 0, max_row_nnz_ = 0;   // longest column / row of A (in-kernel stage heads need them to fit an LDS list)
     bool no_head_fusion = false;             // MLP_NO_HEAD_FUSION: keep the stage heads as launches of their own
+    // Lazy dual steepest edge: the primal loop never reads beta, so its iterations skip tau = B^-1 rho (solver.rs:1157)
+    // and the beta recurrence; beta is rebuilt exactly from the basis inverse (k_exact_beta) when something next needs it
+    bool lazy_dse = true;                    // MLP_LAZY_DSE=0: maintain beta in every pivot like the reference
+    bool beta_stale = false;
+    bool batch_lazy = false;                 // the iterations being recorded skip the beta recurrence
+    bool lazy_now(int phase) const { return lazy_dse && enable_dse && phase == 0 && !stepping && max_row_nnz_ <= HEAD_LIST_CAP; }
+    void ensure_beta();
     std::vector<int> h_colnnz, h_single_row;
     std::vector<double> h_single_val;
     std::vector<int> h_basic_vars, h_nb_vars, h_var_loc;

@@ -97,6 +97,8 @@ Engine::Engine() {
     if (fr) final_refresh_pivots = std::atol(fr);
     const char* nbp = std::getenv("MLP_NO_BLOCKED_PUSH");
     pb_disable = nbp && std::atoi(nbp) != 0;
+    const char* lz = std::getenv("MLP_LAZY_DSE");
+    lazy_dse = !(lz && lz[0] == '0');
     const char* nhf = std::getenv("MLP_NO_HEAD_FUSION");
     no_head_fusion = nhf && std::atoi(nhf) != 0;
     const char* nws = std::getenv("MLP_NO_WSHARD");
@@ -889,11 +891,14 @@ static const int kStageOrder[2][6] = {{STAGE_FTRAN, STAGE_RATIO, STAGE_BTRAN, ST
 void Engine::launch_stage(int phase, int stage, bool with_events) {
     const DevView& dv = hview;
     const Geom g = geom();
-    const int pse = enable_pse ? 1 : 0, dse = enable_dse ? 1 : 0;
+    const int pse = enable_pse ? 1 : 0;
+    const bool lazy = lazy_now(phase);                       // primal iteration: no tau, no beta update (ensure_beta() later)
+    const int dse = (enable_dse && !lazy) ? 1 : 0;
+    const int wtau = lazy ? 0 : 1;
     // banded sweep, primal iteration: k_update_pivot sums the per-band partials itself (no combine launch);
     // the host-paced stepping API keeps the separate combine so that row_coeffs is readable after STAGE_ROW
     const int inl = (dv.banded && phase == 0 && !stepping) ? 1 : 0;
-    const bool tau_branch = use_branches && dv.pb_on && phase == 0 && !stepping && shard_world == 1;
+    const bool tau_branch = use_branches && dv.pb_on && phase == 0 && !stepping && shard_world == 1 && !lazy_now(phase);
     // The pricing decision (q for primal, r for dual) is already in Ctl: it was taken by the
     // previous iteration's update kernel, or by the standalone pricing kernel at batch start.
     switch (stage) {
@@ -925,19 +930,19 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         break;
     case STAGE_BASIS:
         if (with_events) HIPCHECK(hipEventRecord(ev[2], st));
-        launch_fused_w(dv, g, pse, st);                       // tauK / vK partials + eta update of W
+        launch_fused_w(dv, g, pse, st, wtau);                 // tauK / vK partials + eta update of W
         if (with_events) HIPCHECK(hipEventRecord(ev[3], st));
         if (tau_branch) {
             // large-nucleus regime: the blocked push of -F tau_K (two kernels, ~40 us of serial chains) is needed by the
             // update kernel only; it runs on a side branch of the graph next to the tableau-row sweep.  The partition
             // change then rides in the update kernel instead of the sweep (the push reads the OLD slot maps).
-            launch_post_fused(dv, g, pse, st, 0, 1);
+            launch_post_fused(dv, g, pse, st, 0, 1, wtau);
             HIPCHECK(hipEventRecord(evFork[0], st));
             HIPCHECK(hipStreamWaitEvent(st2, evFork[0], 0));
             launch_push_tau(dv, st2);
             HIPCHECK(hipEventRecord(evJoin[0], st2));
         } else {
-            launch_post_fused(dv, g, pse, st);                // tau by position (F push)  |  v reduce + scatter
+            launch_post_fused(dv, g, pse, st, 0, 0, wtau);    // tau by position (F push)  |  v reduce + scatter
         }
         break;
     case STAGE_ROW:
@@ -1020,6 +1025,7 @@ int Engine::step_open(StepInfo* out) {
         return ITER_OPTIMAL;
     }
     step_phase = phase;
+    ensure_beta();  // stepped iterations maintain beta by the recurrence, from an exact base
     pivot_budget = -1;
     budget_exhausted = false;
     sync_view();
@@ -1051,7 +1057,8 @@ int Engine::step_stage(int stage, StepInfo* out) {
         sync_view();
         launch_reset_ring(hview, st);  // one record per stepped iteration
     }
-    stepping = true;
+    stepping = true;   // (stepped iterations keep the beta recurrence: every stage's vector is inspectable, tau included)
+    batch_lazy = false;
     launch_stage(phase, stage, false);
     stepping = false;
     pull_ctl();
@@ -1120,8 +1127,12 @@ int Engine::process_records(int phase, int launched) {
             stats.iterations += 1;
             iters_since_recalc += 1;
             iters_since_polish += 1;
-            if (r.phase == 0) stats.primal_iters += 1;
-            else stats.dual_iters += 1;
+            if (r.phase == 0) {
+                stats.primal_iters += 1;
+                if (r.status == ITER_PIVOT && batch_lazy) beta_stale = true;  // that pivot skipped the beta recurrence
+            } else {
+                stats.dual_iters += 1;
+            }
             values_dirty = true;
             if (r.status == ITER_FLIP) {
                 stats.bound_flips += 1;
@@ -1147,6 +1158,8 @@ int Engine::process_records(int phase, int launched) {
 }
 
 int Engine::run_loop(int phase) {
+    if (phase == 1) ensure_beta();  // the dual pricing reads beta
+    batch_lazy = lazy_now(phase);
     for (;;) {
         if (pivot_budget == 0) {
             budget_exhausted = true;
@@ -1242,6 +1255,18 @@ int Engine::run_loop(int phase) {
         if (res == ITER_PIVOT && !(h_ctl->max_pivot_err <= refresh_tol) && k_ > 0) rebuild_inverse();
         if (res != ITER_PIVOT) return res;
     }
+}
+
+// Lazy dual steepest edge: rebuild beta_p = ||e_p^T B^-1||^2 exactly from the basis inverse after primal pivots that
+// skipped the recurrence (solver.rs:1153-1174 maintains the same quantity pivot by pivot).
+void Engine::ensure_beta() {
+    if (!beta_stale) return;
+    flush_lowrank();  // W0 must be the whole inverse
+    sync_view();
+    launch_exact_beta(hview, st);
+    HIPCHECK(hipStreamSynchronize(st));
+    beta_stale = false;
+    stats.beta_rebuilds += 1;
 }
 
 // ------------------------------------------------------------------ loops (solver.rs:470-547)
@@ -1366,6 +1391,7 @@ void Engine::recalc_basic_vals() {
 
 void Engine::fix_var(int var, double val) {  // solver.rs:378-415
     double t0 = now_s();
+    ensure_beta();
     if (val < h_lo[var] || val > h_hi[var]) throw LpFail{1};
     int col;
     if (h_var_loc[var] >= 0) {
@@ -1377,6 +1403,7 @@ void Engine::fix_var(int var, double val) {  // solver.rs:378-415
         launch_reset_ring(dv, st);
         launch_clear_work(dv, st);
         launch_set_iter(dv, ITER_PIVOT, -1, row, val, 1, st);
+        batch_lazy = false;
         record_iteration(1, false);
         pull_ctl();
         int64_t keep = pivot_budget;
@@ -1502,6 +1529,7 @@ void Engine::append_row_on_device(const Constraint& c, int slack, int row) {
 void Engine::add_constraint(Constraint c) {
     double t0 = now_s();
     if (!primal_feasible || !dual_feasible) throw MlpError(-1, "add_constraint: model not solved (solver.rs:555-556)");
+    ensure_beta();
     if (c.idx.empty()) {
         bool taut = c.op == 0 ? (0.0 == c.rhs) : c.op == 1 ? (0.0 <= c.rhs) : (0.0 >= c.rhs);
         if (taut) return;
@@ -1742,6 +1770,7 @@ std::vector<uint8_t> Engine::save_basis(int mode) {
     if (mode < 0 || mode > 2) throw MlpError(-1, "save_basis: mode must be 0, 1 or 2");
     if (shard_world > 1) throw MlpError(-1, "save_basis: not available on a sharded solution");
     HIPCHECK(hipStreamSynchronize(st));
+    if (mode >= 1) ensure_beta();
     pull_ctl();
     const size_t mm = (size_t)m_, nn = (size_t)num_vars;
     std::vector<uint8_t> out(basis_blob_size(mode, mm, nn), 0);
@@ -1874,6 +1903,7 @@ void Engine::load_basis(const uint8_t* blob, size_t len) {
     iters_since_polish = 0;
     values_dirty = true;
     budget_exhausted = false;
+    beta_stale = false;  // the weights came from the blob (or were reset to 1)
     HIPCHECK(hipStreamSynchronize(st));
 }
 
@@ -1889,6 +1919,7 @@ Engine* Engine::clone() {
     e->h_rptr = h_rptr; e->h_rcol = h_rcol; e->h_rval = h_rval;
     e->h_colnnz = h_colnnz; e->h_single_row = h_single_row; e->h_single_val = h_single_val;
     e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->no_head_fusion = no_head_fusion;
+    e->lazy_dse = lazy_dse; e->beta_stale = beta_stale;
     e->h_basic_vars = h_basic_vars; e->h_nb_vars = h_nb_vars; e->h_var_loc = h_var_loc;
     e->h_kslot_of_pos = h_kslot_of_pos; e->h_srow_of_pos = h_srow_of_pos; e->h_kslot_of_row = h_kslot_of_row;
     e->h_pos_of_srow = h_pos_of_srow; e->h_sdiag_of_pos = h_sdiag_of_pos; e->h_nb_fixed = h_nb_fixed;
@@ -1947,6 +1978,7 @@ Engine* Engine::clone() {
 uint64_t Engine::state(const char* what, double* out, uint64_t cap) {
     HIPCHECK(hipStreamSynchronize(st));
     std::string w(what);
+    if (w == "dual_edge_sq_norms") ensure_beta();
     std::vector<double> tmp;
     auto from_dev_d = [&](const double* b, size_t n) {
         tmp.resize(n);

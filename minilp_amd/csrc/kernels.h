@@ -227,8 +227,9 @@ void launch_btran_rhs(const DevView& dv, const Geom& g, hipStream_t st);        
 void launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, hipStream_t st, int inline_combine = 0);  // K4 [| partition change]
 void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st);                 // K7 p1, p2 (+FTRAN head)
-void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st);        // tauK/vK partials + eta update of W
-void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic = 0, int skip_push = 0);
+void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int with_tau = 1);  // tauK/vK partials + eta update of W
+void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic = 0, int skip_push = 0, int with_tau = 1);
+void launch_exact_beta(const DevView& dv, hipStream_t st);  // beta_p = ||e_p^T B^-1||^2 for every basic position (lazy dual steepest edge)
 void launch_push_tau(const DevView& dv, hipStream_t st);  // blocked push of -F tau_K alone (runs on a side branch of the graph)  // tau push | v reduce+scatter (classic: partials of k_fused_w's tiling)
 void launch_mail_handshake(const DevView& dv, int* out, hipStream_t st);  // transport self-test at enable_sharding
 bool stream_strips_enabled();  // large-nucleus streaming pass in strip form (MLP_STREAM_STRIPS=0 disables)

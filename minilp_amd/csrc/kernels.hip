@@ -2445,7 +2445,7 @@ __global__ void __launch_bounds__(BLK) k_fused_lr16(DevView v, int fold_only) {
 // reads the folded matrix.
 constexpr int SW_MAX_BLOCKS = 8192;
 template <bool WITH_V, int SW_CH, int SW_RB, int SW_RS>
-__global__ void __launch_bounds__(BLK, 4) k_stream_w(DevView v) {  // 4 waves per SIMD: keep the double buffer within 128 VGPRs
+__global__ void __launch_bounds__(BLK, 4) k_stream_w(DevView v, int with_tau) {  // 4 waves per SIMD: keep the double buffer within 128 VGPRs
     static_assert(SW_CH == 2 * BLK || SW_CH == 4 * BLK, "one or two column pairs per thread");
     constexpr int NP = SW_CH / (2 * BLK);
     Ctl* c = v.ctl;
@@ -2531,20 +2531,23 @@ __global__ void __launch_bounds__(BLK, 4) k_stream_w(DevView v) {  // 4 waves pe
                         vacc1[p] += w[a][p].y * t;
                     }
                 }
-                s_t[buf][a][tid] = sacc;
+                if (with_tau) s_t[buf][a][tid] = sacc;
             }
-            __syncthreads();  // one barrier per step: the two LDS buffers alternate
-            double sum = 0.0;
+            if (with_tau) {  // (uniform) lazy dual steepest edge: the primal loop skips tau = B^-1 rho altogether — no
+                             // row sums, no barrier: the pass is then a pure accumulation of v in registers
+                __syncthreads();  // one barrier per step: the two LDS buffers alternate
+                double sum = 0.0;
 #pragma unroll
-            for (int j = 0; j < BLK / G; ++j) sum += s_t[buf][rrow][gl + j * G];
-            sum = group_sum<G>(sum);
-            if (gl == 0 && r0 + rrow < rend) v.part_tau[(size_t)chunk * ld + r0 + rrow] = sum;
+                for (int j = 0; j < BLK / G; ++j) sum += s_t[buf][rrow][gl + j * G];
+                sum = group_sum<G>(sum);
+                if (gl == 0 && r0 + rrow < rend) v.part_tau[(size_t)chunk * ld + r0 + rrow] = sum;
+            }
 #pragma unroll
             for (int a = 0; a < SW_RS; ++a)
 #pragma unroll
                 for (int p = 0; p < NP; ++p) w[a][p] = wn[a][p];
         }
-        __syncthreads();  // the next tile's first step may reuse the buffer the slowest wave is still reducing
+        if (with_tau) __syncthreads();  // the next tile's first step may reuse the buffer the slowest wave is still reducing
         if (WITH_V) {
             double* pv = v.part_v + (size_t)strip * ld;
 #pragma unroll
@@ -2655,7 +2658,7 @@ __global__ void k_reset_nlow(DevView v) {
 // exchange buffer; the last block to finish makes the stores visible system-wide and raises this rank's flag (mailbox
 // kind 4) in every box.  k_post_fused then waits for all flags and reads only local memory.
 template <int TR, int TC>
-__global__ void __launch_bounds__(BLK) k_post_exchange(DevView v, int with_v) {
+__global__ void __launch_bounds__(BLK) k_post_exchange(DevView v, int with_v, int with_tau) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     const int k = c->k, ld = v.ld;
@@ -2664,7 +2667,7 @@ __global__ void __launch_bounds__(BLK) k_post_exchange(DevView v, int with_v) {
     const int i = blockIdx.x * BLK + threadIdx.x;
     if (i < k) {
         const int strip = i / TR;
-        const bool mine = strip % v.world == v.rank;
+        const bool mine = with_tau && strip % v.world == v.rank;
         double x = 0.0;
         if (mine) {
             const int nchunks = (k + TC - 1) / TC;
@@ -3097,6 +3100,78 @@ __global__ void __launch_bounds__(BLK) k_gj_eliminate(double* Kd, double* Wv, in
 }
 
 
+
+// Exact dual steepest-edge weights from the basis inverse: beta_p = || e_p^T B^-1 ||^2 (the quantity the recurrence of
+// solver.rs:1153-1174 maintains).  One block per basic position: the BTRAN head builds the position's list of rows of W
+// (no side effects), the block forms rho_K = sum_j a_j W[s_j, :] column by column and sums its squares; a singleton
+// position adds 1 / diag^2 for its own row.  Used by the LAZY dual steepest edge: the primal loop never reads beta, so it
+// skips tau = B^-1 rho (the second FTRAN of every pivot and its push) and beta is rebuilt here when the dual simplex,
+// a checkpoint or the white-box state next needs it.  Requires W0 to be the whole inverse (pending terms folded).
+__global__ void __launch_bounds__(BLK) k_exact_beta(DevView v) {
+    const int p = blockIdx.x;
+    if (p >= v.m) return;
+    __shared__ int s_ls[HEAD_CAP];
+    __shared__ double s_la[HEAD_CAP];
+    __shared__ int s_n;
+    __shared__ double s_inv2;
+    const int k = v.ctl->k, ld = v.ld;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const int sr = v.kslot_of_pos[p];
+        if (sr >= 0) {
+            if (lane == 0) {
+                s_ls[0] = sr;
+                s_la[0] = 1.0;
+                s_n = 1;
+                s_inv2 = 0.0;
+            }
+        } else {
+            const int i_r = v.srow_of_pos[p];
+            const double inv = 1.0 / v.sdiag_of_pos[p];
+            const int base = v.csr_ptr[i_r], end = v.csr_ptr[i_r + 1];
+            int cnt = 0;
+            for (int e0 = base; e0 < end; e0 += 64) {
+                const int e = e0 + lane;
+                const bool valid = e < end;
+                int s = -1;
+                double a = 0.0;
+                if (valid) {
+                    const int loc = v.var_loc[v.csr_col[e]];
+                    a = v.csr_val[e];
+                    if (loc >= 0) s = v.kslot_of_pos[loc];
+                }
+                const bool isk = valid && s >= 0;
+                const unsigned long long mask = __ballot(isk);
+                if (isk) {
+                    const int off = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (off < HEAD_CAP) {
+                        s_ls[off] = s;
+                        s_la[off] = -a * inv;
+                    }
+                }
+                cnt += __popcll(mask);
+            }
+            if (lane == 0) {
+                s_n = cnt < HEAD_CAP ? cnt : HEAD_CAP;
+                s_inv2 = inv * inv;
+            }
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    double sq = 0.0;
+    for (int s = threadIdx.x; s < k; s += BLK) {
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc += s_la[j] * v.W[(size_t)s_ls[j] * ld + s];
+        sq += acc * acc;
+    }
+    sq = block_sum(sq);
+    if (threadIdx.x == 0) v.beta[p] = sq + s_inv2;
+}
+void launch_exact_beta(const DevView& dv, hipStream_t st) {
+    if (dv.m > 0) hipLaunchKernelGGL(k_exact_beta, dim3(dv.m), dim3(BLK), 0, st, dv);
+}
+
 // ------------------------------------------------------------------- device-side matrix maintenance
 // Solution::add_constraint appends ONE row (solver.rs:597-613 rebuilds CSR and CSC on the host, O(nnz)).  Here the
 // matrix stays on the device: the CSR row is appended in place (capacity-doubling buffers), the CSC is re-laid out by
@@ -3502,7 +3577,7 @@ bool stream_strips_enabled() {
     static const bool on = !(std::getenv("MLP_STREAM_STRIPS") && std::atoi(std::getenv("MLP_STREAM_STRIPS")) == 0);
     return on;
 }
-static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fold_only, hipStream_t st) {
+static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fold_only, hipStream_t st, int with_tau = 1) {
     const int rows = fw_rows(g);
     int nstripes = (g.cap + rows - 1) / rows, nchunks = (g.cap + FW_TC - 1) / FW_TC;
     dim3 b(BLK);
@@ -3534,8 +3609,8 @@ static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fo
                 const int nt = (int)(tiles < SW_MAX_BLOCKS ? tiles : SW_MAX_BLOCKS);
 #define SW_LAUNCH(CH, RB, RS)                                                                                     \
     do {                                                                                                          \
-        if (with_v) hipLaunchKernelGGL((k_stream_w<true, CH, RB, RS>), dim3(nt + LR_MAX), b, 0, st, dv);          \
-        else hipLaunchKernelGGL((k_stream_w<false, CH, RB, RS>), dim3(nt + LR_MAX), b, 0, st, dv);                \
+        if (with_v) hipLaunchKernelGGL((k_stream_w<true, CH, RB, RS>), dim3(nt + LR_MAX), b, 0, st, dv, with_tau); \
+        else if (with_tau) hipLaunchKernelGGL((k_stream_w<false, CH, RB, RS>), dim3(nt + LR_MAX), b, 0, st, dv, 1);  \
     } while (0)
                 switch (stream_variant()) {
                 case 0: SW_LAUNCH(512, 512, 8); break;
@@ -3569,29 +3644,35 @@ void launch_fold_lowrank(const DevView& dv, const Geom& g, hipStream_t st) {
     launch_fused_lr(dv, g, 0, 1, st);
     hipLaunchKernelGGL(k_reset_nlow, dim3(1), dim3(1), 0, st, dv);
 }
-void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st) {
+void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int with_tau) {
     if (g.cap <= 0) return;  // a model without kept rows has no nucleus: nothing to stream (and no valid grid)
     if (dv.lrJ) {
-        launch_fused_lr(dv, g, with_v, 0, st);
+        launch_fused_lr(dv, g, with_v, 0, st, with_tau);
         return;
     }
     const int rows = fw_rows(g);
     int nstripes = (g.cap + rows - 1) / rows, nchunks = (g.cap + FW_TC - 1) / FW_TC;
     dim3 gr(nstripes, nchunks), b(BLK);
     if (rows == 8) {
-        if (with_v) hipLaunchKernelGGL((k_fused_w<8, true, true, true>), gr, b, 0, st, dv);
-        else hipLaunchKernelGGL((k_fused_w<8, true, false, true>), gr, b, 0, st, dv);
+        if (with_v && with_tau) hipLaunchKernelGGL((k_fused_w<8, true, true, true>), gr, b, 0, st, dv);
+        else if (with_v) hipLaunchKernelGGL((k_fused_w<8, false, true, true>), gr, b, 0, st, dv);
+        else if (with_tau) hipLaunchKernelGGL((k_fused_w<8, true, false, true>), gr, b, 0, st, dv);
+        else hipLaunchKernelGGL((k_fused_w<8, false, false, true>), gr, b, 0, st, dv);
     } else {
         const long tiles_cap = (long)nstripes * nchunks;
         const int nb = (int)(tiles_cap < FW_TILE_BLOCKS ? tiles_cap : FW_TILE_BLOCKS);
-        if (with_v) hipLaunchKernelGGL((k_fused_w<16, true, true, true, true, false, FW_RL, true>), dim3(nb), b, 0, st, dv);
-        else hipLaunchKernelGGL((k_fused_w<16, true, false, true, true, false, FW_RL, true>), dim3(nb), b, 0, st, dv);
+        if (with_v && with_tau) hipLaunchKernelGGL((k_fused_w<16, true, true, true, true, false, FW_RL, true>), dim3(nb), b, 0, st, dv);
+        else if (with_v) hipLaunchKernelGGL((k_fused_w<16, false, true, true, true, false, FW_RL, true>), dim3(nb), b, 0, st, dv);
+        else if (with_tau) hipLaunchKernelGGL((k_fused_w<16, true, false, true, true, false, FW_RL, true>), dim3(nb), b, 0, st, dv);
+        else hipLaunchKernelGGL((k_fused_w<16, false, false, true, true, false, FW_RL, true>), dim3(nb), b, 0, st, dv);
     }
 }
-void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic, int skip_push) {
+void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic, int skip_push, int with_tau) {
+    if (!with_tau) skip_push = 1;  // lazy dual steepest edge: no tau, hence no push of -F tau_K
+    if (!with_tau && !with_v) return;
     if (!classic && dv.lrJ && fw_rows(g) != 8 && FW_RL == 1 && stream_strips()) {  // partials of k_stream_w's strips
 #define POSTX(RB, CH)                                                                                             \
-    if (sw_rb() == RB && sw_ch() == CH) hipLaunchKernelGGL((k_post_exchange<RB, CH>), dim3(blocks_for(g.cap)), dim3(BLK), 0, st, dv, with_v);
+    if (sw_rb() == RB && sw_ch() == CH) hipLaunchKernelGGL((k_post_exchange<RB, CH>), dim3(blocks_for(g.cap)), dim3(BLK), 0, st, dv, with_v, with_tau);
         if (dv.wshard) {  // row-sharded pass: exchange the partials first (k_post_fused then reads the exchange buffer)
             POSTX(512, 512) POSTX(256, 1024) POSTX(128, 1024) POSTX(256, 512) POSTX(128, 512) POSTX(64, 1024)
         }
@@ -3603,19 +3684,19 @@ void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t
     }
 #define POSTS(G)                                                                                                  \
     do {                                                                                                          \
-        int n_push = blocks_for((long)g.cap * G);                                                                 \
+        int n_push = with_tau ? blocks_for((long)g.cap * G) : 0;                                                  \
         POSTS2(G, 512, 512); POSTS2(G, 256, 1024); POSTS2(G, 128, 1024); POSTS2(G, 256, 512); POSTS2(G, 128, 512); POSTS2(G, 64, 1024);  \
     } while (0)
         LANES_SWITCH(g.lanes, POSTS(4), POSTS(16), POSTS(64));
 #undef POSTS
 #undef POSTS2
         if (dv.pb_on && !skip_push) launch_blocked_push(dv, 1, st);
-        else if (dv.det_pull) launch_pull_F(dv, g, 1, st);
+        else if (dv.det_pull && with_tau) launch_pull_F(dv, g, 1, st);
         return;
     }
 #define POSTF(G)                                                                                                  \
     do {                                                                                                          \
-        int n_push = blocks_for((long)g.cap * G);                                                                 \
+        int n_push = with_tau ? blocks_for((long)g.cap * G) : 0;                                                  \
         if (with_v && fw_rows(g) == 8) hipLaunchKernelGGL((k_post_fused<G, true, 8>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push); \
         else if (with_v) hipLaunchKernelGGL((k_post_fused<G, true, 16 * FW_RL>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push); \
         else hipLaunchKernelGGL((k_post_fused<G, false, 16>), dim3(n_push), dim3(BLK), 0, st, dv, n_push);        \
@@ -3623,7 +3704,7 @@ void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t
     LANES_SWITCH(g.lanes, POSTF(4), POSTF(16), POSTF(64));
 #undef POSTF
     if (dv.pb_on && !skip_push) launch_blocked_push(dv, 1, st);
-    else if (dv.det_pull) launch_pull_F(dv, g, 1, st);
+    else if (dv.det_pull && with_tau) launch_pull_F(dv, g, 1, st);
 }
 void launch_push_tau(const DevView& dv, hipStream_t st) { launch_blocked_push(dv, 1, st); }  // the tau push alone (side branch)
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st) {

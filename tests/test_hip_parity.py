@@ -642,3 +642,34 @@ def test_rows_appended_on_the_device_match_the_oracle_step_by_step(monkeypatch, 
     so2 = so.clone().add_constraint(expr, O.LE, rhs)
     assert obj_close(c.objective(), so2.objective())
     assert obj_close(sg.objective(), so.objective())   # the original is untouched by its clone's cut
+
+
+def test_lazy_dual_steepest_edge_rebuilds_the_norms_the_recurrence_would_hold(monkeypatch):
+    """The primal loop never reads the dual steepest-edge norms, so it skips their recurrence (solver.rs:1153-1174) and
+    the second FTRAN behind it; they are rebuilt exactly from the basis inverse when next needed.  The rebuilt norms
+    must be the recurrence's (oracle) values, the pivot sequence must not change, and a dual re-solve after the primal
+    phase (add_constraint) must go on from them like the eager engine does."""
+    lp = GEN["sparse"](m=260, n=240, k=10, seed=71)
+    so = lpgen.build_problem(O.Problem, lp).solve(trace=True)
+    lazy = lpgen.build_problem(M.Problem, lp).solve(trace=True)
+    assert [t[:5] for t in lazy.trace()] == [t[:5] for t in so.trace()]
+    st = lazy.stats()
+    assert st["primal_iters"] > 30 and st["beta_rebuilds"] == 0            # nothing has asked for beta yet
+    beta = lazy.state("dual_edge_sq_norms")                                # ... now something does
+    assert lazy.stats()["beta_rebuilds"] == 1
+    ref = np.asarray(so.state("dual_edge_sq_norms"))
+    assert np.abs(beta - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    monkeypatch.setenv("MLP_LAZY_DSE", "0")
+    eager = lpgen.build_problem(M.Problem, lp).solve(trace=True)
+    monkeypatch.delenv("MLP_LAZY_DSE")
+    assert eager.stats()["beta_rebuilds"] == 0
+    assert [t[:5] for t in eager.trace()] == [t[:5] for t in lazy.trace()]
+    assert np.abs(eager.state("dual_edge_sq_norms") - beta).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    # warm start: the dual loop starts from the rebuilt norms
+    x = np.asarray(so.values())
+    top = [int(j) for j in np.argsort(-x)[:3]]                              # three variables that are positive at the optimum
+    expr = [(j, 1.0) for j in sorted(top)]
+    rhs = float(x[top].sum()) * 0.8
+    a, b, c = lazy.add_constraint(expr, M.LE, rhs), eager.add_constraint(expr, M.LE, rhs), so.add_constraint(expr, O.LE, rhs)
+    assert obj_close(a.objective(), c.objective()) and obj_close(b.objective(), c.objective())
+    assert np.abs(np.asarray(a.values()) - np.asarray(c.values())).max() <= X_ATOL
