@@ -223,6 +223,17 @@ private:
     DevBuf<double> d_bval;
     DevBuf<double2> d_band_part;
     bool banded_dirty = true;
+    // Locality order of the banded sweep: after many pivots nb_vars is a random permutation and the pass over the
+    // band-major copy degenerates into 80-byte gathers (PMC: 521 MB per launch at pivot 240 000 against 150 MB at pivot
+    // 200).  The pass therefore visits the positions sorted by the variable they hold; the host rebuilds that order from
+    // its mirror of var_loc (O(N)) every `order_every` pivots — a stale order only costs locality, never correctness.
+    DevBuf<int> d_nb_order;
+    bool use_order = true;          // MLP_SWEEP_LOCALITY=0: plain position order
+    uint64_t order_built_at = 0;    // lifetime pivot count at the last rebuild
+    uint64_t lifetime_pivots = 0;   // (stats can be reset by the caller)
+    uint64_t order_every = 2048;
+    bool order_valid = false;
+    void refresh_nb_order(bool force);
     int det_mode = -1;              // MLP_DETERMINISTIC: 1 force the pulled F products, 0 never, -1 auto (<= 2^21 non-zeros)
     int banded_mode = -1;           // MLP_BANDED: 1 force on, 0 off, -1 auto (m >= 4 bands and >= 2^22 non-zeros)
     bool use_banded() const;

@@ -97,6 +97,8 @@ Engine::Engine() {
     if (fr) final_refresh_pivots = std::atol(fr);
     const char* nbp = std::getenv("MLP_NO_BLOCKED_PUSH");
     pb_disable = nbp && std::atoi(nbp) != 0;
+    const char* sl = std::getenv("MLP_SWEEP_LOCALITY");
+    use_order = !(sl && sl[0] == '0');
     const char* lz = std::getenv("MLP_LAZY_DSE");
     lazy_dse = !(lz && lz[0] == '0');
     const char* nhf = std::getenv("MLP_NO_HEAD_FUSION");
@@ -325,6 +327,20 @@ void Engine::ensure_banded() {
     banded_dirty = false;
 }
 
+void Engine::refresh_nb_order(bool force) {
+    if (!force && (!order_valid || lifetime_pivots - order_built_at < order_every)) return;
+    std::vector<int> ord;
+    ord.reserve((size_t)num_vars);
+    for (int var = 0; var < N_; ++var)  // ascending variables = storage order of the band-major copy
+        if (h_var_loc[var] < 0) ord.push_back(-1 - h_var_loc[var]);
+    if ((int)ord.size() != num_vars) throw MlpError(-3, "refresh_nb_order: host mirror of var_loc is inconsistent");
+    d_nb_order.ensure((size_t)num_vars, 0, st);
+    HIPCHECK(hipMemcpyAsync(d_nb_order.p, ord.data(), sizeof(int) * (size_t)num_vars, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipStreamSynchronize(st));  // `ord` is a local staging buffer
+    order_built_at = lifetime_pivots;
+    order_valid = true;
+}
+
 // Row-block offsets of every column for the blocked F push: colblk[var][b] = first CSC index of column
 // var whose row is >= b * PB_ROWS (columns hold ascending rows), colblk[var][RB] = end of the column.
 void Engine::ensure_colblk() {
@@ -362,6 +378,12 @@ DevView* Engine::sync_view() {
     v.bval = v.banded ? d_bval.p : nullptr;
     v.band_part = v.banded ? d_band_part.p : nullptr;
     v.nbands = (m_ + BAND_ROWS - 1) / BAND_ROWS;
+    if (v.banded && use_order && shard_world == 1) {
+        if (!order_valid) refresh_nb_order(true);
+        v.nb_order = d_nb_order.p;
+    } else {
+        v.nb_order = nullptr;
+    }
     v.pos_of_kslot = d_pos_of_kslot.p; v.row_of_kslot = d_row_of_kslot.p; v.W = d_W.p;
     v.U = d_U.p; v.V = d_V.p; v.pad1 = 0;
     // delayed-update period: 16 from capacity 8192, 32 from 32768 (the fold's k^2 cost outgrows the O(k J) overheads)
@@ -1125,6 +1147,7 @@ int Engine::process_records(int phase, int launched) {
         if (pivot_budget > 0) pivot_budget -= 1;
         if (r.status == ITER_PIVOT || r.status == ITER_FLIP) {
             stats.iterations += 1;
+            lifetime_pivots += 1;
             iters_since_recalc += 1;
             iters_since_polish += 1;
             if (r.phase == 0) {
@@ -1174,6 +1197,7 @@ int Engine::run_loop(int phase) {
         // so short warm-start re-solves run eagerly; the graph is captured once the same geometry has
         // survived a few iterations.
         sync_view();
+        if (hview.nb_order) refresh_nb_order(false);  // every `order_every` pivots (same buffer: captured graphs stay valid)
         const bool have_graph = gexec[phase][enable_pse ? 1 : 0][0] != nullptr;
         const bool graph_now = use_graph && !sample && (have_graph || eager_iters_in_geom >= 4);
         if (!have_graph) eager_iters_in_geom += 1;
@@ -1858,6 +1882,8 @@ void Engine::load_basis(const uint8_t* blob, size_t len) {
     }
     d_basic_vars.upload(h_basic_vars, st); d_nb_vars.upload(h_nb_vars, st); d_var_loc.upload(h_var_loc, st);
     d_loB.upload(loB, st); d_hiB.upload(hiB, st);
+    order_valid = false;  // the locality order of the banded sweep belongs to the old non-basic set
+    view_dirty = true;
     d_nbflags.upload(flags, st); d_xN.upload(xN, st);
     HIPCHECK(hipStreamSynchronize(st));  // local staging buffers
     sync_view();
@@ -1919,7 +1945,7 @@ Engine* Engine::clone() {
     e->h_rptr = h_rptr; e->h_rcol = h_rcol; e->h_rval = h_rval;
     e->h_colnnz = h_colnnz; e->h_single_row = h_single_row; e->h_single_val = h_single_val;
     e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->no_head_fusion = no_head_fusion;
-    e->lazy_dse = lazy_dse; e->beta_stale = beta_stale;
+    e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order;
     e->h_basic_vars = h_basic_vars; e->h_nb_vars = h_nb_vars; e->h_var_loc = h_var_loc;
     e->h_kslot_of_pos = h_kslot_of_pos; e->h_srow_of_pos = h_srow_of_pos; e->h_kslot_of_row = h_kslot_of_row;
     e->h_pos_of_srow = h_pos_of_srow; e->h_sdiag_of_pos = h_sdiag_of_pos; e->h_nb_fixed = h_nb_fixed;

@@ -123,6 +123,7 @@ struct DevView {
     // non-basic side, by nb position (solver.rs:44-49)
     int* nb_vars; double* d; double* xN; double* gamma; uint8_t* nbflags;
     int2* nb_rng;  // n: CSC [begin, end) of the column at each non-basic position (cache of csc_ptr[nb_vars[c]])
+    const int* nb_order;  // n or null: locality order of the banded sweep (positions sorted by the variable they hold)
     // basis inverse: singleton split + dense nucleus inverse W
     int* kslot_of_pos;     // m: row slot of W for a nucleus position, -1 for a singleton position
     int* srow_of_pos;      // m: the row of the single entry of a singleton basic column

@@ -1736,7 +1736,9 @@ __global__ void __launch_bounds__(BAND_THREADS) k_sweep_band(DevView v, int chun
                     poss[u] = -1 - loc;
                 }
             } else {
-                vars[u] = v.nb_vars[i];
+                // locality order: index i of the pass serves position nb_order[i] (positions sorted by the variable
+                // they hold, refreshed by the host now and then), and the partials are indexed by i
+                vars[u] = v.nb_vars[v.nb_order ? v.nb_order[i] : i];
                 poss[u] = i;
             }
         }
@@ -1788,11 +1790,12 @@ __global__ void __launch_bounds__(BLK) k_band_combine(DevView v, int n_comb) {
         struct_update_body(v, c, ((int)blockIdx.x - n_comb) * BLK + threadIdx.x);
         return;
     }
-    const int j = v.nb_lo + blockIdx.x * BLK + threadIdx.x;
-    if (j >= v.nb_hi) return;
+    const int i = v.nb_lo + blockIdx.x * BLK + threadIdx.x;  // index of the pass (= position without a locality order)
+    if (i >= v.nb_hi) return;
+    const int j = v.nb_order ? v.nb_order[i] : i;
     double a1 = 0.0, a2 = 0.0;
     for (int b = 0; b < v.nbands; ++b) {
-        const double2 t = v.band_part[(size_t)b * (size_t)v.n + j];
+        const double2 t = v.band_part[(size_t)b * (size_t)v.n + i];
         a1 += t.x;
         a2 += t.y;
     }
@@ -2863,9 +2866,12 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
             if (phase == 1 && !c->forced) tc = price_dual_one(xb, lo, hi, bt, t, use_dse);
         }
         if (t < v.n) {
-            double dd = v.d[t], gm = use_pse ? v.gamma[t] : 1.0;
-            uint8_t f = v.nbflags[t];
-            if (t == q) {
+            // non-basic side: thread t serves position tn = nb_order[t] (locality order of the banded sweep: its partials
+            // are indexed by t), or position t itself without an order
+            const int tn = v.nb_order ? v.nb_order[t] : t;
+            double dd = v.d[tn], gm = use_pse ? v.gamma[tn] : 1.0;
+            uint8_t f = v.nbflags[tn];
+            if (tn == q) {
                 if (flip) {
                     int ev = it->entering_var;
                     double nv = it->entering_new_val;
@@ -2880,7 +2886,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                         double ba;
                         if (inline_comb) {
                             ba = 0.0;
-                            for (int b = 0; b < v.nbands; ++b) ba += v.band_part[(size_t)b * (size_t)v.n + q].x;
+                            for (int b = 0; b < v.nbands; ++b) ba += v.band_part[(size_t)b * (size_t)v.n + t].x;
                             v.alpha_r[q] = ba;
                         } else {
                             ba = v.alpha_r[q];
@@ -2901,7 +2907,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                     f = (uint8_t)((lnv == v.var_lo[lv] ? NB_AT_MIN : 0) | (lnv == v.var_hi[lv] ? NB_AT_MAX : 0));
                     v.nbflags[q] = f;
                 }
-            } else if (!flip && t >= v.nb_lo && t < v.nb_hi) {
+            } else if (!flip && tn >= v.nb_lo && tn < v.nb_hi) {
                 double ar, hp = 0.0;
                 if (inline_comb) {  // banded sweep: sum the per-band partials here (band order) instead of a combine launch
                     double s1 = 0.0, s2 = 0.0;
@@ -2918,27 +2924,27 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                     }
                     ar = s1;
                     hp = s2;
-                    v.alpha_r[t] = ar;
-                    if (use_pse) v.helper[t] = hp;
+                    v.alpha_r[tn] = ar;
+                    if (use_pse) v.helper[tn] = hp;
                 } else {
-                    ar = v.alpha_r[t];
-                    if (use_pse) hp = v.helper[t];
+                    ar = v.alpha_r[tn];
+                    if (use_pse) hp = v.helper[tn];
                 }
                 if (ar != 0.0) {
                     dd -= it->pivot_obj * ar;
-                    v.d[t] = dd;
+                    v.d[tn] = dd;
                     if (use_pse) {
                         gm += -2.0 * ar * hp / pc + it->alpha_sq * ar * ar / (pc * pc);
-                        v.gamma[t] = gm;
+                        v.gamma[tn] = gm;
                     }
                 }
             }
-            if (phase == 0 && t >= v.nb_lo && t < v.nb_hi) {
-                tc = price_primal_one(dd, gm, f, t, use_pse);
+            if (phase == 0 && tn >= v.nb_lo && tn < v.nb_hi) {
+                tc = price_primal_one(dd, gm, f, tn, use_pse);
                 tc_d = dd;
             }
         }
-        if (cand_better(tc, cand)) {  // ascending t per thread: ties keep the lowest position
+        if (cand_better(tc, cand)) {  // (ties keep the lowest position whatever the visiting order)
             cand = tc;
             cand_d = tc_d;
         }
@@ -3488,7 +3494,7 @@ static void launch_sweep_banded(const DevView& dv, const Geom& g, int mode, int 
     // 112.4 against 103.9 us per pivot: the 16-byte partial stores scattered by position cost what the sequential read
     // saves.  Position order stays the default; MLP_SWEEP_ORDER=var selects the other for experiments.
     static const bool want_var = std::getenv("MLP_SWEEP_ORDER") && std::string(std::getenv("MLP_SWEEP_ORDER")) == "var";
-    const bool vord = dv.world <= 1 && want_var;
+    const bool vord = dv.world <= 1 && want_var && dv.nb_order == nullptr;  // (the two orders exclude each other)
     // One workgroup per CU (LDS-bound): all blocks of the launch must fit the 256 CUs at once, or a second,
     // almost empty round of workgroups doubles the kernel time (260 workgroups: 43 us, 247: 36 us).  In the
     // primal iteration the per-band partials are summed by k_update_pivot itself (inline_combine) and the

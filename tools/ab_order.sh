@@ -1,0 +1,11 @@
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+for w in late mid; do
+  python tools/window_profile.py $w 512 2>&1 | grep pivots/s
+  MLP_SWEEP_LOCALITY=0 python tools/window_profile.py $w 512 2>&1 | grep pivots/s | sed "s/^/position order: /"
+done
+python tools/window_profile.py early 2000 200 2>&1 | grep pivots/s
+MLP_SWEEP_LOCALITY=0 python tools/window_profile.py early 2000 200 2>&1 | grep pivots/s | sed "s/^/position order: /"
+MLP_LOWRANK=32 python tools/window_profile.py mid 512 2>&1 | grep pivots/s | sed "s/^/J=32: /"
+cd /tmp && export TMPDIR=/tmp
+for w in late mid; do rm -rf /tmp/prof_$w; MLP_IMPORT_TORCH=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$w -o t -- python $GRAFT_REPO_ROOT/tools/window_profile.py $w 512 > /dev/null 2>&1; python $GRAFT_REPO_ROOT/tools/prof_summary.py /tmp/prof_$w $GRAFT_REPO_ROOT/gpurun_out/r02A_${w}_kernel_stats.csv 200 > /dev/null; done
+cd $GRAFT_REPO_ROOT; grep -v "rocsolver\|Cijk\|rocblas" gpurun_out/r02A_late_kernel_stats.csv | head -12; grep -v "rocsolver\|Cijk\|rocblas" gpurun_out/r02A_mid_kernel_stats.csv | head -12
