@@ -233,6 +233,8 @@ private:
     uint64_t lifetime_pivots = 0;   // (stats can be reset by the caller)
     uint64_t order_every = 2048;
     bool order_valid = false;
+    uint64_t order_from = 4096;     // pivots after which the order is switched on
+    bool order_force = false;       // (loaded bases: from the start)
     void refresh_nb_order(bool force);
     int det_mode = -1;              // MLP_DETERMINISTIC: 1 force the pulled F products, 0 never, -1 auto (<= 2^21 non-zeros)
     int banded_mode = -1;           // MLP_BANDED: 1 force on, 0 off, -1 auto (m >= 4 bands and >= 2^22 non-zeros)

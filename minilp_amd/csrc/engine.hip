@@ -293,7 +293,7 @@ Geom Engine::geom() const {
     g.lanes = avg >= 40.0 ? 64 : (avg >= 6.0 ? 16 : 4);
     g.sweep_variant = sweep_variant;
     g.big = (cap_ > 4096 || force_big_tiles) ? 1 : 0;
-    const int lr = lr_force >= 0 ? lr_force : (cap_ >= 32768 ? 32 : (cap_ >= 8192 ? 16 : 0));  // as in sync_view
+    const int lr = lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 32 : 0);  // as in sync_view
     g.head_fused = (!no_head_fusion && lr == 0 && max_col_nnz_ <= HEAD_LIST_CAP && max_row_nnz_ <= HEAD_LIST_CAP) ? 1 : 0;
     return g;
 }
@@ -378,7 +378,9 @@ DevView* Engine::sync_view() {
     v.bval = v.banded ? d_bval.p : nullptr;
     v.band_part = v.banded ? d_band_part.p : nullptr;
     v.nbands = (m_ + BAND_ROWS - 1) / BAND_ROWS;
-    if (v.banded && use_order && shard_world == 1) {
+    // (while the non-basic positions still hold their original variables the plain position order IS the locality
+    // order and the indirection only costs: 96.9 vs 95.1 us per pivot in the benchmark window)
+    if (v.banded && use_order && shard_world == 1 && (lifetime_pivots >= order_from || order_force)) {
         if (!order_valid) refresh_nb_order(true);
         v.nb_order = d_nb_order.p;
     } else {
@@ -386,8 +388,8 @@ DevView* Engine::sync_view() {
     }
     v.pos_of_kslot = d_pos_of_kslot.p; v.row_of_kslot = d_row_of_kslot.p; v.W = d_W.p;
     v.U = d_U.p; v.V = d_V.p; v.pad1 = 0;
-    // delayed-update period: 16 from capacity 8192, 32 from 32768 (the fold's k^2 cost outgrows the O(k J) overheads)
-    v.lrJ = lr_force >= 0 ? lr_force : (cap_ >= 32768 ? 32 : (cap_ >= 8192 ? 16 : 0));
+    // delayed-update period: 32 from capacity 8192 on (the fold's k^2 cost outgrows the O(k J) overheads)
+    v.lrJ = lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 32 : 0);  // (16 up to cap 16 384 in round 1: 304 vs 296 us per pivot at k = 10 000)
     v.alpha_q = d_work.p;
     v.tau = d_work.p + (size_t)m_;
     v.rv = reinterpret_cast<double2*>(d_work.p + 2 * (size_t)m_);
@@ -1196,6 +1198,7 @@ int Engine::run_loop(int phase) {
         // Capturing a graph costs milliseconds and is invalidated by every add_constraint (m changes),
         // so short warm-start re-solves run eagerly; the graph is captured once the same geometry has
         // survived a few iterations.
+        if (!hview.nb_order && use_order && lifetime_pivots >= order_from) view_dirty = true;  // time to switch the order on
         sync_view();
         if (hview.nb_order) refresh_nb_order(false);  // every `order_every` pivots (same buffer: captured graphs stay valid)
         const bool have_graph = gexec[phase][enable_pse ? 1 : 0][0] != nullptr;
@@ -1883,6 +1886,7 @@ void Engine::load_basis(const uint8_t* blob, size_t len) {
     d_basic_vars.upload(h_basic_vars, st); d_nb_vars.upload(h_nb_vars, st); d_var_loc.upload(h_var_loc, st);
     d_loB.upload(loB, st); d_hiB.upload(hiB, st);
     order_valid = false;  // the locality order of the banded sweep belongs to the old non-basic set
+    order_force = true;   // a loaded basis is a scrambled one: use the order from the first pivot
     view_dirty = true;
     d_nbflags.upload(flags, st); d_xN.upload(xN, st);
     HIPCHECK(hipStreamSynchronize(st));  // local staging buffers
@@ -1945,7 +1949,7 @@ Engine* Engine::clone() {
     e->h_rptr = h_rptr; e->h_rcol = h_rcol; e->h_rval = h_rval;
     e->h_colnnz = h_colnnz; e->h_single_row = h_single_row; e->h_single_val = h_single_val;
     e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->no_head_fusion = no_head_fusion;
-    e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order;
+    e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
     e->h_basic_vars = h_basic_vars; e->h_nb_vars = h_nb_vars; e->h_var_loc = h_var_loc;
     e->h_kslot_of_pos = h_kslot_of_pos; e->h_srow_of_pos = h_srow_of_pos; e->h_kslot_of_row = h_kslot_of_row;
     e->h_pos_of_srow = h_pos_of_srow; e->h_sdiag_of_pos = h_sdiag_of_pos; e->h_nb_fixed = h_nb_fixed;
