@@ -35,7 +35,8 @@ class MlpStats(C.Structure):
                 + [("solve_wall_s", C.c_double), ("kase", C.c_uint64 * 5), ("update_ms", C.c_double),
                    ("update_launches", C.c_uint64), ("banded_sweep", C.c_uint64), ("final_refreshes", C.c_uint64), ("max_pivot_err", C.c_double),
                    ("ftran_bytes", C.c_double), ("ftran_ms", C.c_double), ("ftran_launches", C.c_uint64),
-                   ("iter_ms", C.c_double), ("iter_samples", C.c_uint64), ("beta_rebuilds", C.c_uint64)])
+                   ("iter_ms", C.c_double), ("iter_samples", C.c_uint64), ("beta_rebuilds", C.c_uint64),
+                   ("gram_rebuilds", C.c_uint64), ("gram_pivots", C.c_uint64), ("gram_err", C.c_double)])
 
 
 class MlpIterInfo(C.Structure):  # include/minilp_hip.h: mlp_iter_info

@@ -294,6 +294,7 @@ void mlp_solution_stats(const mlp_solution* s, mlp_stats* o) {
     o->ftran_bytes = t.ftran_bytes; o->ftran_ms = t.ftran_ms; o->ftran_launches = t.ftran_launches;
     o->iter_ms = t.iter_ms; o->iter_samples = t.iter_samples;
     o->beta_rebuilds = t.beta_rebuilds;
+    o->gram_rebuilds = t.gram_rebuilds; o->gram_pivots = t.gram_pivots; o->gram_err = t.gram_err;
     for (int i = 0; i < 5; ++i) o->kase[i] = t.kase[i];
 }
 void mlp_solution_reset_stats(mlp_solution* s) {

@@ -130,6 +130,9 @@ struct Stats {
     double solve_wall_s = 0;
     double max_pivot_err = 0;
     uint64_t beta_rebuilds = 0;  // lazy dual steepest edge: exact rebuilds of beta from the basis inverse
+    uint64_t gram_rebuilds = 0;  // Gram mode: builds of M = W^T (I + F^T D^-2 F) W from the basis inverse
+    uint64_t gram_pivots = 0;    // pivots whose v = B^-T alpha_q came from the Gram path
+    double gram_err = 0;         // Gram mode drift monitor: max |a_q.v - ||alpha_q||^2| / (1 + ||alpha_q||^2)
     uint64_t kase[5] = {0, 0, 0, 0, 0};  // partition-change cases: nuc->nuc, grow, shrink, col swap, same-row
 };
 
@@ -196,6 +199,17 @@ private:
     bool batch_lazy = false;                 // the iterations being recorded skip the beta recurrence
     bool lazy_now(int phase) const { return lazy_dse && enable_dse && phase == 0 && !stepping && max_row_nnz_ <= HEAD_LIST_CAP; }
     void ensure_beta();
+    // Gram mode: the primal steepest-edge solve v = B^-T alpha_q reads a few rows of the resident
+    // M = [(B B^T)^-1]_KK and the few rows of W0 that F^T D^-2 a_S touches, instead of all of W0 every pivot.
+    // Large-nucleus delayed-update mode, one GPU, lazy dual steepest edge (no tau) only.
+    bool gram_enable = true;                 // MLP_GRAM=0: every primal PSE pivot streams W0 (the round-2 path)
+    bool gram_phase = false;                 // the loop being run is the primal one
+    bool gram_valid = false;                 // M matches the current basis
+    bool gram_oom = false;                   // M did not fit next to W: the mode stays off
+    double gram_tol = 1e-3;                  // MLP_GRAM_TOL: monitor value of a batch above which M is rebuilt (a fresh M reads 5e-6 at k = 20 000)
+    DevBuf<double> d_M, d_MU, d_MV, d_mK;
+    bool gram_wanted() const;
+    void gram_rebuild();
     std::vector<int> h_colnnz, h_single_row;
     std::vector<double> h_single_val;
     std::vector<int> h_basic_vars, h_nb_vars, h_var_loc;
@@ -254,10 +268,11 @@ private:
     int pad_for(int cap) const { return (cap >= 8192 || force_big_tiles) ? ld_pad : 0; }
     int ld() const { return cap_ + pad_for(cap_); }
     int lr_force = -1;  // MLP_LOWRANK: force the delayed-update period (0 = off); default: 16 from cap 8192, 32 from 32768
-    DevBuf<double> d_work;  // alpha_q | tau | rv (2m)  — one memset per pivot
+    DevBuf<double> d_work;  // alpha_q | tau | rv (2m) | hS  — one memset per batch
     DevBuf<double> d_alpha_r, d_helper;
     DevBuf<int2> d_nb_rng;
     int sweep_variant = 0;
+    int lanes_force = 0;  // MLP_LANES: lanes per column / slot in the gather kernels (4, 16, 64)
     int rt_device = 0;
     void acquire_runtime();  // streams, events, pinned Ctl mirror: recycled across Solutions
     void release_runtime();

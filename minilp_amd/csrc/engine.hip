@@ -97,10 +97,14 @@ Engine::Engine() {
     if (fr) final_refresh_pivots = std::atol(fr);
     const char* nbp = std::getenv("MLP_NO_BLOCKED_PUSH");
     pb_disable = nbp && std::atoi(nbp) != 0;
+    const char* ln = std::getenv("MLP_LANES");
+    if (ln) lanes_force = std::atoi(ln);
     const char* sl = std::getenv("MLP_SWEEP_LOCALITY");
     use_order = !(sl && sl[0] == '0');
     const char* lz = std::getenv("MLP_LAZY_DSE");
     lazy_dse = !(lz && lz[0] == '0');
+    if (const char* gm = std::getenv("MLP_GRAM")) gram_enable = gm[0] != '0';
+    if (const char* gt = std::getenv("MLP_GRAM_TOL")) gram_tol = std::atof(gt);
     const char* nhf = std::getenv("MLP_NO_HEAD_FUSION");
     no_head_fusion = nhf && std::atoi(nhf) != 0;
     const char* nws = std::getenv("MLP_NO_WSHARD");
@@ -291,6 +295,7 @@ Geom Engine::geom() const {
     g.cap = cap_;
     double avg = num_vars > 0 ? (double)(h_rcol.size() - (size_t)m_) / (double)num_vars : 1.0;  // structural columns
     g.lanes = avg >= 40.0 ? 64 : (avg >= 6.0 ? 16 : 4);
+    if (lanes_force > 0) g.lanes = lanes_force;  // MLP_LANES (A/B runs)
     g.sweep_variant = sweep_variant;
     g.big = (cap_ > 4096 || force_big_tiles) ? 1 : 0;
     const int lr = lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 32 : 0);  // as in sync_view
@@ -387,12 +392,28 @@ DevView* Engine::sync_view() {
         v.nb_order = nullptr;
     }
     v.pos_of_kslot = d_pos_of_kslot.p; v.row_of_kslot = d_row_of_kslot.p; v.W = d_W.p;
-    v.U = d_U.p; v.V = d_V.p; v.pad1 = 0;
+    v.U = d_U.p; v.V = d_V.p;
     // delayed-update period: 32 from capacity 8192 on (the fold's k^2 cost outgrows the O(k J) overheads)
     v.lrJ = lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 32 : 0);  // (16 up to cap 16 384 in round 1: 304 vs 296 us per pivot at k = 10 000)
     v.alpha_q = d_work.p;
     v.tau = d_work.p + (size_t)m_;
     v.rv = reinterpret_cast<double2*>(d_work.p + 2 * (size_t)m_);
+    v.hS = d_work.p + 4 * (size_t)m_;
+    v.gram = 0;
+    if (v.lrJ > 0 && gram_wanted()) {  // M next to W (same shape); without the memory for it the mode simply stays off
+        try {
+            d_M.ensure((size_t)cap_ * (size_t)ld(), 0, st);
+            d_MU.ensure((size_t)LR_MAX * ld(), 0, st);
+            d_MV.ensure((size_t)LR_MAX * ld(), 0, st);
+            d_mK.ensure((size_t)cap_, 0, st);
+            v.gram = 1;
+        } catch (MlpError&) {
+            (void)hipGetLastError();
+            gram_oom = true;
+        }
+    }
+    v.M = v.gram ? d_M.p : nullptr; v.MU = v.gram ? d_MU.p : nullptr; v.MV = v.gram ? d_MV.p : nullptr;
+    v.mK = v.gram ? d_mK.p : nullptr;
     v.alpha_r = d_alpha_r.p; v.helper = d_helper.p;
     v.aK = d_aK.p; v.rK = d_rK.p; v.tK = d_tK.p; v.tauK = d_tauK.p; v.vK = d_vK.p;
     v.klist_s = d_klist_s.p; v.klist_a = d_klist_a.p; v.blist_s = d_blist_s.p; v.blist_a = d_blist_a.p;
@@ -467,7 +488,7 @@ void Engine::alloc_row_buffers(int m_new) {
     d_hiB.ensure(mm, keep, st); d_beta.ensure(mm, keep, st);
     d_kslot_of_pos.ensure(mm, keep, st); d_srow_of_pos.ensure(mm, keep, st); d_sdiag_of_pos.ensure(mm, keep, st);
     d_kslot_of_row.ensure(mm, keep, st); d_pos_of_srow.ensure(mm, keep, st); d_rowinfo.ensure(mm, keep, st);
-    d_work.ensure(4 * mm + 8, 0, st);
+    d_work.ensure(5 * mm + 8, 0, st);
     d_klist_s.ensure(mm, 0, st); d_klist_a.ensure(mm, 0, st);
     d_blist_s.ensure(mm + num_vars + 64, 0, st); d_blist_a.ensure(mm + num_vars + 64, 0, st);
     d_var_loc.ensure((size_t)num_vars + mm, (size_t)num_vars + keep, st);
@@ -515,6 +536,8 @@ void Engine::ensure_nucleus_cap(int need) {
     d_V.ensure((size_t)LR_MAX * nld, 0, st);
     cap_ = ncap;
     view_dirty = true;
+    gram_valid = false;  // M is re-allocated with the new pitch and rebuilt from W
+    d_M.release(); d_MU.release(); d_MV.release(); d_mK.release();
 }
 
 void Engine::ensure_red() {
@@ -954,6 +977,11 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         break;
     case STAGE_BASIS:
         if (with_events) HIPCHECK(hipEventRecord(ev[2], st));
+        if (dv.gram && phase == 0 && pse) {
+            launch_gram_basis(dv, g, st);                     // Gram path: folds when due, sparse pass over W0, v_K assembly
+            if (with_events) HIPCHECK(hipEventRecord(ev[3], st));
+            break;
+        }
         launch_fused_w(dv, g, pse, st, wtau);                 // tauK / vK partials + eta update of W
         if (with_events) HIPCHECK(hipEventRecord(ev[3], st));
         if (tau_branch) {
@@ -1171,6 +1199,8 @@ int Engine::process_records(int phase, int launched) {
                 nnz_nonbasic += (size_t)col_nnz(lv);
                 nnz_nonbasic -= (size_t)col_nnz(ev_);
                 stats.basis_changes += 1;
+                if (hview.gram && r.phase == 0) stats.gram_pivots += 1;
+                else gram_valid = false;  // a basis change that did not carry M along
                 if (r.kase >= 0 && r.kase < 5) stats.kase[r.kase] += 1;
                 if (trace) trace_log.push_back({r.phase, r.q, r.r, ev_, lv, r.pivot_coeff, r.obj});
             }
@@ -1185,6 +1215,11 @@ int Engine::process_records(int phase, int launched) {
 int Engine::run_loop(int phase) {
     if (phase == 1) ensure_beta();  // the dual pricing reads beta
     batch_lazy = lazy_now(phase);
+    if (gram_phase != (phase == 0)) {  // the Gram path belongs to the primal loop (DevView.gram is baked into its graphs)
+        gram_phase = phase == 0;
+        view_dirty = true;
+    }
+    if (phase == 1) gram_valid = false;  // dual pivots do not maintain M
     for (;;) {
         if (pivot_budget == 0) {
             budget_exhausted = true;
@@ -1221,6 +1256,7 @@ int Engine::run_loop(int phase) {
         const bool graph_batch = graph_now;
         ensure_nucleus_cap(k_ + B + 1);
         sync_view();
+        if (hview.gram && !gram_valid) gram_rebuild();
         const DevView& dv = hview;
         launch_reset_ring(dv, st);
         launch_clear_work(dv, st);
@@ -1277,11 +1313,57 @@ int Engine::run_loop(int phase) {
             }
             (void)hipGetLastError();  // an event pair that was not recorded this iteration is not an error
         }
+        if (hview.gram && phase == 0) {  // drift monitor of M: a_q . v against ||alpha_q||^2 (k_gram_reset clears it per rebuild)
+            if (h_ctl->gram_err > stats.gram_err || h_ctl->gram_err != h_ctl->gram_err) stats.gram_err = h_ctl->gram_err;
+            if (!(h_ctl->gram_err <= gram_tol)) gram_valid = false;  // rebuilt before the next batch
+        }
         // drift monitor: the pivot element from FTRAN and from the tableau row must agree
         if (h_ctl->max_pivot_err > stats.max_pivot_err) stats.max_pivot_err = h_ctl->max_pivot_err;
         if (res == ITER_PIVOT && !(h_ctl->max_pivot_err <= refresh_tol) && k_ > 0) rebuild_inverse();
         if (res != ITER_PIVOT) return res;
     }
+}
+
+// Gram mode.  Conditions: primal loop with steepest-edge pricing, the large-nucleus delayed-update
+// mode with its strip kernels, lazy dual steepest edge (no tau = B^-1 rho, which would need the full pass anyway), one GPU
+// (a sharded solve splits the full pass by rows instead).
+bool Engine::gram_wanted() const {
+    return gram_enable && !gram_oom && gram_phase && enable_pse && shard_world == 1 && lazy_now(0) && geom().big &&
+           stream_strips_enabled();
+}
+// M = W^T C W with C = I + F^T D^-2 F, from the folded inverse: C is accumulated on the device from the CSC / CSR,
+// the two k x k x k products are rocBLAS dgemm calls (plain library GEMMs; the buffers are row-major, i.e. their
+// column-major readings are W^T, C and M, both symmetric).  2 x 2 k^3 flops: 0.01 s at k = 4 096, 0.6 s at k = 20 000.
+void Engine::gram_rebuild() {
+    flush_lowrank();
+    sync_view();
+    if (!hview.gram) return;
+    const int k = k_, l = ld();
+    if (k > 0) {
+        DevBuf<double> C, T;
+        C.alloc_exact((size_t)k * l);
+        T.alloc_exact((size_t)k * l);
+        HIPCHECK(hipMemsetAsync(C.p, 0, sizeof(double) * (size_t)k * l, st));
+        launch_gram_build_c(hview, geom(), C.p, k, st);
+        if (!blas) {
+            if (rocblas_create_handle(reinterpret_cast<rocblas_handle*>(&blas)) != rocblas_status_success)
+                throw MlpError(-3, "rocblas_create_handle failed");
+        }
+        rocblas_handle h = reinterpret_cast<rocblas_handle>(blas);
+        rocblas_set_stream(h, st);
+        const double one = 1.0, zero = 0.0;
+        // column-major: T^T = W^T C  (row-major T = C W), then M = T^T (W^T)^T  (row-major M = W^T T)
+        if (rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, k, k, k, &one, d_W.p, l, C.p, l, &zero, T.p, l) !=
+                rocblas_status_success ||
+            rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_transpose, k, k, k, &one, T.p, l, d_W.p, l, &zero, d_M.p, l) !=
+                rocblas_status_success)
+            throw MlpError(-3, "rocblas_dgemm failed (Gram matrix build)");
+        HIPCHECK(hipStreamSynchronize(st));
+    }
+    launch_gram_reset(hview, st);
+    HIPCHECK(hipStreamSynchronize(st));
+    gram_valid = true;
+    stats.gram_rebuilds += 1;
 }
 
 // Lazy dual steepest edge: rebuild beta_p = ||e_p^T B^-1||^2 exactly from the basis inverse after primal pivots that
@@ -1554,6 +1636,7 @@ void Engine::append_row_on_device(const Constraint& c, int slack, int row) {
 // solver.rs:549-634.  The new slack is a singleton basic column on the new row, so the nucleus
 // inverse is unchanged unless the new row touches a basic singleton column (then: rebuild).
 void Engine::add_constraint(Constraint c) {
+    gram_valid = false;  // (Gram mode: M no longer matches the basis)
     double t0 = now_s();
     if (!primal_feasible || !dual_feasible) throw MlpError(-1, "add_constraint: model not solved (solver.rs:555-556)");
     ensure_beta();
@@ -1635,6 +1718,7 @@ void Engine::add_constraint(Constraint c) {
 // Counterpart of BasisSolver::reset (solver.rs:1286-1303): classify the basic columns (singleton vs
 // nucleus), build K = B[R_K, P_K] densely from the CSC and invert it on the device.
 void Engine::rebuild_inverse() {
+    gram_valid = false;  // (Gram mode: M no longer matches the basis)
     HIPCHECK(hipStreamSynchronize(st));
     HIPCHECK(hipMemsetAsync(&d_ctl.p->nlow, 0, 2 * sizeof(int), st));  // a fresh inverse has no pending terms
     std::vector<int> claimed(m_, -1);
@@ -1840,6 +1924,7 @@ std::vector<uint8_t> Engine::save_basis(int mode) {
     return out;
 }
 void Engine::load_basis(const uint8_t* blob, size_t len) {
+    gram_valid = false;  // (Gram mode: M no longer matches the basis)
     if (shard_world > 1) throw MlpError(-1, "load_basis: not available on a sharded solution");
     if (!blob || len < sizeof(BasisHeader)) throw MlpError(-1, "load_basis: blob too short");
     BasisHeader h;
@@ -1949,7 +2034,7 @@ Engine* Engine::clone() {
     e->h_rptr = h_rptr; e->h_rcol = h_rcol; e->h_rval = h_rval;
     e->h_colnnz = h_colnnz; e->h_single_row = h_single_row; e->h_single_val = h_single_val;
     e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->no_head_fusion = no_head_fusion;
-    e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
+    e->gram_enable = gram_enable; e->gram_tol = gram_tol; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
     e->h_basic_vars = h_basic_vars; e->h_nb_vars = h_nb_vars; e->h_var_loc = h_var_loc;
     e->h_kslot_of_pos = h_kslot_of_pos; e->h_srow_of_pos = h_srow_of_pos; e->h_kslot_of_row = h_kslot_of_row;
     e->h_pos_of_srow = h_pos_of_srow; e->h_sdiag_of_pos = h_sdiag_of_pos; e->h_nb_fixed = h_nb_fixed;

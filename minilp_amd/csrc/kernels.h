@@ -54,6 +54,8 @@ struct StructUpdate {  // how the (P_K, R_K) partition changes 
     int cq;    // col slot of i_q (cases 2, 3)
     int kold;  // nucleus size before the change
     int jn;    // delayed-update mode: index the new rank-1 term gets (0 after a fold)
+    int mjn;   // Gram mode: index the first of the pivot's two terms of M gets (0 after a fold of M)
+    int pad;
     double diag_q;      // value of the entering singleton's entry
     double inv_diag_r;  // rho[i_r] = 1/diag of the leaving singleton
 };
@@ -84,6 +86,11 @@ struct Ctl {
                                    // 2: dual ratio pass-1 minimum, 3: dual ratio pass-2 candidate,
                                    // 4: tau_K / v_K vectors of the row-sharded streaming pass)
     double max_pivot_err;  // max over the batch of |alpha_q[r] - alpha_r[q]| / max(1,|alpha_q[r]|): drift monitor of W
+    // Gram mode: M = M0 + sum_{t<mnlow} MU[t] MV[t]^T, two terms per pivot
+    int mnlow;             // number of pending rank-1 terms of M
+    int mfold;             // this pivot folds them into M0 first (set by the plan)
+    double lr_mc[LR_MAX];  // MV[t] . (listed entries of a_q on nucleus rows)
+    double gram_err;       // max over the batch of |a_q.v - ||alpha_q||^2| / (1 + ||alpha_q||^2): drift monitor of M
     PivotRec ring[RING];
 };
 
@@ -152,7 +159,17 @@ struct DevView {
     double* U;             // LR_MAX x ld: pending rank-1 terms, row-slot side   (delayed-update mode)
     double* V;             // LR_MAX x ld: pending rank-1 terms, col-slot side
     int lrJ;               // 0: every pivot updates W in place; J > 0: fold every J pivots
-    int pad1;
+    // Gram mode of the primal steepest-edge solve v = B^-T alpha_q = (B B^T)^-1 a_q: with
+    // M = [(B B^T)^-1] restricted to the nucleus rows (cap x ld, symmetric, col slot x col slot) resident, v on the
+    // nucleus rows is a gather of a few rows of M plus a pass over the few rows of W that F^T D^-2 a_S touches —
+    // instead of one read of all of W per pivot.  M follows the basis by a symmetric rank-2 term per pivot (delayed
+    // like W's: LR_MAX pending rank-1 terms, i.e. a fold every LR_MAX / 2 pivots).
+    int gram;              // 1: the primal PSE iteration takes the Gram path (large-nucleus delayed-update mode only)
+    double* M;             // cap x ld: M0
+    double* MU;            // LR_MAX x ld: pending terms of M, left factors
+    double* MV;            // LR_MAX x ld: pending terms of M, right factors
+    double* hS;            // m by row: a_q[i] / D_i^2 on the singleton rows the entering column touches, 0 elsewhere
+    double* mK;            // cap: M0 rows . a_K (scratch of the v assembly)
     // per-pivot vectors
     double* alpha_q;  // m by position  (col_coeffs,            solver.rs:54)
     double* tau;      // m by position  (B^-1 rho,              solver.rs:1157)
@@ -248,6 +265,11 @@ void launch_sq_norms_add_row(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_copy_rho_sq_to_beta(const DevView& dv, int row, hipStream_t st);
 void launch_build_nucleus(const DevView& dv, const Geom& g, double* Kd, int k, hipStream_t st);
 void launch_fold_lowrank(const DevView& dv, const Geom& g, hipStream_t st);  // W0 += U^T V, nlow := 0 (host-requested flush)
+// Gram mode: the BASIS stage of a primal PSE pivot (folds of W0 and M0 when due, sparse pass over W0, assembly of v_K),
+// the build of C = I + F^T D^-2 F for the (re)build M = W^T C W, and the reset of the pending-term counters
+void launch_gram_basis(const DevView& dv, const Geom& g, hipStream_t st);
+void launch_gram_build_c(const DevView& dv, const Geom& g, double* C, int k, hipStream_t st);
+void launch_gram_reset(const DevView& dv, hipStream_t st);
 void launch_gauss_jordan(double* Kd, double* Winv, int k, int ld, int* d_flag, double* d_scratch, hipStream_t st);
 
 // device-side matrix maintenance (add_constraint without a host pass over the non-zeros; also the initial builds)

@@ -506,6 +506,9 @@ __device__ void plan_update(const DevView& v, Ctl* c, int phase) {
     c->it.inv_alpha = 1.0 / v.alpha_q[r];
     c->fold = (v.lrJ > 0 && c->nlow >= v.lrJ) ? 1 : 0;
     u.jn = c->fold ? 0 : c->nlow;
+    c->mfold = (v.gram && phase == 0 && c->mnlow + 2 > LR_MAX) ? 1 : 0;
+    u.mjn = c->mfold ? 0 : c->mnlow;
+    u.pad = 0;
     if (new_sing) {
         u.i_q = v.csc_row[cb];
         u.diag_q = v.csc_val[cb];
@@ -583,6 +586,10 @@ __device__ void ftran_prep_wave(const DevView& v, Ctl* c, int lane, int derive_p
     const int nlow = v.lrJ ? c->nlow : 0;
     const double* Vrow = v.V + (size_t)(lane < nlow ? lane : 0) * v.ld;
     double lr_acc = 0.0;
+    // Gram mode: the same dots against the pending terms of M (lane t serves term t), and h = D^-2 a_S by row
+    const int mnlow = (v.gram && derive_primal) ? c->mnlow : 0;
+    const double* MVrow = v.gram ? v.MV + (size_t)(lane < mnlow ? lane : 0) * v.ld : nullptr;
+    double mlr_acc = 0.0;
     for (int e0 = base; e0 < end; e0 += 64) {
         int e = e0 + lane;
         bool valid = e < end;
@@ -594,7 +601,9 @@ __device__ void ftran_prep_wave(const DevView& v, Ctl* c, int lane, int derive_p
             s = v.kslot_of_row[i];
             if (s < 0) {
                 int p = v.pos_of_srow[i];
-                v.alpha_q[p] = a / v.sdiag_of_pos[p];
+                const double dg = v.sdiag_of_pos[p];
+                v.alpha_q[p] = a / dg;
+                if (v.gram && derive_primal) v.hS[i] = a / (dg * dg);
             }
         }
         bool isk = valid && s >= 0;
@@ -606,9 +615,11 @@ __device__ void ftran_prep_wave(const DevView& v, Ctl* c, int lane, int derive_p
         }
         cnt += __popcll(mask);
         if (nlow > 0) lr_dot_listed(mask, s, a, Vrow, lane < nlow, lr_acc);
+        if (mnlow > 0) lr_dot_listed(mask, s, a, MVrow, lane < mnlow, mlr_acc);
     }
     if (lane == 0) it->klist_n = cnt;
     if (lane < nlow) c->lr_c[lane] = lr_acc;
+    if (lane < mnlow) c->lr_mc[lane] = mlr_acc;
 }
 // BTRAN head (one wave): rho = B^-T e_r (solver.rs:680-683) as a short list of rows of W.
 __device__ void btran_prep_wave(const DevView& v, Ctl* c, int lane, int r, int derive_dual, int plan_after, int phase) {
@@ -1295,6 +1306,15 @@ __global__ void __launch_bounds__(BLK) k_btran(DevView v, int n_gather) {
         int var = v.basic_vars[p];
         int end = v.csc_ptr[var + 1];
         double acc = 0.0;
+        if (v.gram) {  // Gram mode: t_K = -F^T D^-2 a_S (non-zero only for the columns that meet a singleton row of a_q)
+            for (int e = v.csc_ptr[var] + gl; e < end; e += G) {
+                int i = v.csc_row[e];
+                if (v.kslot_of_row[i] < 0) acc += v.csc_val[e] * v.hS[i];
+            }
+            acc = group_sum<G>(acc);
+            if (gl == 0) v.tK[slot] = -acc;
+            return;
+        }
         for (int e = v.csc_ptr[var] + gl; e < end; e += G) {
             int i = v.csc_row[e];
             if (v.kslot_of_row[i] < 0) acc += v.csc_val[e] * v.rv[i].y;
@@ -1556,10 +1576,106 @@ __device__ __forceinline__ void lowrank_append(const DevView& v, Ctl* c, const S
     }
     if (s == 0) c->nlow = jn + 1;
 }
+// Symmetric rank-2 term of this pivot and the slot changes of M (called by every thread of the partition-change
+// blocks, s = slot index; mirrors lowrank_append / struct_update_body for W).  In slot terms, with P = rho and
+// X = (v - rho) / alpha_r - (s / (2 alpha_r^2)) rho on the NEW nucleus rows:  M' = M - P X^T - X P^T, stored as the two
+// rank-1 terms (MU, MV) = (-P, X), (-X, P).  A row that joins the nucleus (it was covered by the leaving singleton
+// r) brings Z[., i_r] = rho_K / D_r, Z[i_r, i_r] = 1 / D_r^2 into M0 and zeros into the pending terms.
+__device__ __forceinline__ void gram_update(const DevView& v, Ctl* c, const StructUpdate& u, int s) {
+    __shared__ double s_sig[2];
+    const IterState* it = &c->it;
+    if (threadIdx.x < 64) {  // a_q . v and b . v over the two columns (wave 0 of every block, fixed order)
+        const int lane = threadIdx.x;
+        double av = 0.0, bv = 0.0;
+        const int ev = it->entering_var, lv = it->leaving_var;
+        for (int e = v.csc_ptr[ev] + lane; e < v.csc_ptr[ev + 1]; e += 64) av += v.csc_val[e] * v.rv[v.csc_row[e]].y;
+        for (int e = v.csc_ptr[lv] + lane; e < v.csc_ptr[lv + 1]; e += 64) bv += v.csc_val[e] * v.rv[v.csc_row[e]].y;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            av += __shfl_down(av, o, 64);
+            bv += __shfl_down(bv, o, 64);
+        }
+        if (lane == 0) {
+            s_sig[0] = av;
+            s_sig[1] = bv;
+        }
+    }
+    __syncthreads();
+    const double av = s_sig[0], bv = s_sig[1];
+    const double ia = it->inv_alpha;
+    const double sc = av - bv - 1.0 / ia + 1.0;
+    const double sigma = 0.5 * sc * ia * ia;
+    const int kold = u.kold, ld = v.ld, last = kold - 1;
+    const int jn = u.mjn;
+    double* U0 = v.MU + (size_t)jn * ld;
+    double* V0 = v.MV + (size_t)jn * ld;
+    double* U1 = U0 + ld;
+    double* V1 = V0 + ld;
+    if (s == 0) {
+        const double err = fabs(av + 1.0 - it->alpha_sq) / it->alpha_sq;
+        if (err > c->gram_err || err != err) c->gram_err = err;
+    }
+    auto put = [&](int slot, double P, double vv) {
+        const double X = (vv - P) * ia - sigma * P;
+        U0[slot] = -P; V0[slot] = X;
+        U1[slot] = -X; V1[slot] = P;
+    };
+    if (u.kase == 0 || u.kase == 4) {
+        if (s < kold) put(s, v.rK[s], v.vK[s]);
+    } else if (u.kase == 2) {
+        if (s < last) {
+            const int src = (s == u.cq) ? last : s;
+            put(s, v.rK[src], v.vK[src]);
+            if (u.cq != last) {  // (M0 is read through its upper triangle: src <= last)
+                const double z = v.M[(size_t)src * ld + last];
+                v.M[(size_t)u.cq * ld + s] = z;
+                v.M[(size_t)s * ld + u.cq] = z;
+            }
+        }
+        if (s < jn && u.cq != last) {
+            v.MU[(size_t)s * ld + u.cq] = v.MU[(size_t)s * ld + last];
+            v.MV[(size_t)s * ld + u.cq] = v.MV[(size_t)s * ld + last];
+        }
+    } else if (u.kase == 1) {
+        const double idr = u.inv_diag_r;
+        if (s < kold) {
+            put(s, v.rK[s], v.vK[s]);
+            const double z = v.rK[s] * idr;
+            v.M[(size_t)kold * ld + s] = z;
+            v.M[(size_t)s * ld + kold] = z;
+        } else if (s == kold) {
+            put(kold, idr, v.rv[u.i_r].y);
+            v.M[(size_t)kold * ld + kold] = idr * idr;
+        }
+        if (s < jn) {
+            v.MU[(size_t)s * ld + kold] = 0.0;
+            v.MV[(size_t)s * ld + kold] = 0.0;
+        }
+    } else if (u.kase == 3) {
+        const double idr = u.inv_diag_r;
+        if (s < kold) {
+            if (s == u.cq) {
+                put(s, idr, v.rv[u.i_r].y);
+                v.M[(size_t)s * ld + s] = idr * idr;
+            } else {
+                put(s, v.rK[s], v.vK[s]);
+                const double z = v.rK[s] * idr;
+                v.M[(size_t)u.cq * ld + s] = z;
+                v.M[(size_t)s * ld + u.cq] = z;
+            }
+        }
+        if (s < jn) {
+            v.MU[(size_t)s * ld + u.cq] = 0.0;
+            v.MV[(size_t)s * ld + u.cq] = 0.0;
+        }
+    }
+    if (s == 0) c->mnlow = jn + 2;
+}
 __device__ __forceinline__ void struct_update_body(const DevView& v, Ctl* c, int s) {
     const StructUpdate u = c->up;
     if (u.kase < 0) return;
     if (v.lrJ) lowrank_append(v, c, u, s);
+    if (v.gram) gram_update(v, c, u, s);
     if (u.kase == 0) return;
     const int kold = u.kold;
     const int ld = v.ld;
@@ -2575,13 +2691,14 @@ constexpr int FD_CH = 256, FD_RB = 256, FD_RS = 8;
 // The hot loop is branch-free: rows and columns beyond the edge are CLAMPED (the loads are unconditional, their
 // results masked or never stored).  With `cond ? load : 0` forms the loop breaks into ~20 basic blocks and the
 // register allocator spills the V values (measured: 1.8 KB of scratch per lane).
+// which = 1: the same fold for the Gram matrix, M0 += sum_t MU[t] MV[t]^T (Ctl.mnlow terms, flag Ctl.mfold).
 template <int JM>
-__global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : 3)) k_fold_w(DevView v, int mode) {
+__global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : 3)) k_fold_w(DevView v, int mode, int which) {
     Ctl* c = v.ctl;
     if (mode != 1 && (c->halt || c->it.status != ITER_PIVOT)) return;
-    if (!(mode == 1 || c->fold)) return;
+    if (!(mode == 1 || (which ? c->mfold : c->fold))) return;
     const int k = c->k, ld = v.ld;
-    const int nlow = min(c->nlow, JM);
+    const int nlow = min(which ? c->mnlow : c->nlow, JM);
     if (nlow <= 0 || k <= 0) return;
     const int tid = threadIdx.x;
     __shared__ __attribute__((aligned(16))) double s_u[2][FD_RS][JM];
@@ -2589,12 +2706,13 @@ __global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : 3)) k_fold_w(DevView v, i
     const int sa = tid / JM, sj = tid % JM;  // staging: thread -> (row of the step, term)
     const bool stager = sa < FD_RS;
     const int sjc = min(sj, nlow - 1);
-    double* __restrict__ Wp = v.W;
-    const double* __restrict__ Up = v.U;
-    const double* __restrict__ Vp = v.V;
+    double* __restrict__ Wp = which ? v.M : v.W;
+    const double* __restrict__ Up = which ? v.MU : v.U;
+    const double* __restrict__ Vp = which ? v.MV : v.V;
     for (int tile = blockIdx.x; tile < nstr * nch; tile += gridDim.x) {
         const int strip = tile / nch, chunk = tile % nch;
         const int rbeg = strip * FD_RB, rend = min(k, rbeg + FD_RB);
+        if (which && (chunk + 1) * FD_CH <= rbeg) continue;  // M is symmetric: only its upper triangle (col >= row) is kept current
         const int col = chunk * FD_CH + tid;
         const bool active = col < k;
         const int colc = active ? col : k - 1;
@@ -2654,6 +2772,190 @@ __global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : 3)) k_fold_w(DevView v, i
 __global__ void k_reset_nlow(DevView v) {
     v.ctl->nlow = 0;
     v.ctl->fold = 0;
+    v.ctl->mnlow = 0;  // (the host-requested flush folds the pending terms of M as well)
+    v.ctl->mfold = 0;
+}
+
+// ------------------------------------------------------------------- Gram mode
+// v = B^-T alpha_q = (B B^T)^-1 a_q.  With Z = (B B^T)^-1 in blocks over the rows (R_K, R_S),
+//   Z[R_K,R_K] = M = W^T (I + F^T D^-2 F) W,   Z[R_K,R_S] = -W^T F^T D^-2,   Z[R_S,R_S] = D^-2,
+// the nucleus part is v_K = M a_K - W^T (F^T D^-2 a_S): a_K has a handful of entries (a gather of rows of M) and
+// t_K = -F^T D^-2 a_S is non-zero only for the nucleus columns that meet one of the ~80 singleton rows of a_q (8 % of
+// them on config 4), so the pass over W reads only those rows.  M follows the basis change B' = B + (a_q - b) e_r^T:
+//   Z' = G^T Z G,  G = I - (a_q - b) rho^T / alpha_r   =>   Z' = Z - (rho w^T + w rho^T) / alpha_r + (s / alpha_r^2) rho rho^T
+// with w = Z (a_q - b) = v - rho (Z b = B^-T e_r = rho, taken from W) and s = (a_q - b) . w computed FROM the stored v
+// (with the exact value ||alpha||^2 - 2 alpha_r + 1 in its place the recursion is unstable: a numpy model of it gains
+// a factor 10^5 per 100 pivots; with s consistent the error of M stays where the pivots put it, 1e-12 ... 1e-8).
+// Sparse pass: a block owns GS_RB rows x GS_CH columns of W0; it first compacts the rows with t != 0 (ascending, so the
+// summation order is fixed), then walks them in steps of GS_RS like k_stream_w (register double buffer, non-temporal
+// 16-byte loads) and writes one row of partials per strip.  The last LR_MAX blocks compute h_j = U[j] . t_K.
+constexpr int GS_CH = 1024, GS_RB = 512, GS_RS = 4;
+__global__ void __launch_bounds__(BLK, 4) k_wt_sparse(DevView v) {
+    constexpr int NP = GS_CH / (2 * BLK);
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    const int k = c->k, ld = v.ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_tile_blocks = (int)gridDim.x - LR_MAX;
+    if ((int)blockIdx.x >= n_tile_blocks) {
+        const int j = (int)blockIdx.x - n_tile_blocks;
+        if (c->fold || j >= c->nlow) return;
+        const double* Uj = v.U + (size_t)j * ld;
+        double h = 0.0;
+        for (int s = tid; s < k; s += BLK) h += Uj[s] * v.tK[s];
+        h = block_sum(h);
+        if (tid == 0) c->lr_h[j] = h;
+        return;
+    }
+    __shared__ int s_cnt[2 * (BLK / 64)];
+    __shared__ int s_row[GS_RB];
+    __shared__ double s_tv[GS_RB];
+    static_assert(GS_RB == 2 * BLK, "two rows per thread in the compaction");
+    const int nch = (k + GS_CH - 1) / GS_CH, nstr = (k + GS_RB - 1) / GS_RB;
+    const double* __restrict__ Wp = v.W;
+    for (int tile = blockIdx.x; tile < nstr * nch; tile += n_tile_blocks) {
+        const int strip = tile / nch, chunk = tile % nch;
+        const int rbeg = strip * GS_RB, rend = min(k, rbeg + GS_RB);
+        __syncthreads();  // the previous tile's readers of the list are done
+        double tv[2];
+        unsigned long long mk[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = rbeg + h * BLK + tid;
+            tv[h] = row < rend ? v.tK[row] : 0.0;
+            mk[h] = __ballot(tv[h] != 0.0);
+            if (lane == 0) s_cnt[h * (BLK / 64) + wave] = __popcll(mk[h]);
+        }
+        __syncthreads();
+        int nnz = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int base = 0;
+            for (int w2 = 0; w2 < h * (BLK / 64) + wave; ++w2) base += s_cnt[w2];
+            if (tv[h] != 0.0) {
+                const int off = base + __popcll(mk[h] & ((1ull << lane) - 1ull));
+                s_row[off] = rbeg + h * BLK + tid;
+                s_tv[off] = tv[h];
+            }
+        }
+        for (int w2 = 0; w2 < 2 * (BLK / 64); ++w2) nnz += s_cnt[w2];
+        __syncthreads();
+        int c0[NP];
+        bool pair[NP], one[NP];
+        double vacc0[NP], vacc1[NP];
+        const double* wcol[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            c0[p] = chunk * GS_CH + p * 2 * BLK + 2 * tid;
+            pair[p] = c0[p] + 1 < k;
+            one[p] = c0[p] < k;
+            vacc0[p] = vacc1[p] = 0.0;
+            wcol[p] = Wp + (one[p] ? c0[p] : 0);
+        }
+        if (nnz > 0) {
+            dbl2_t w[GS_RS][NP], wn[GS_RS][NP];
+            auto load_step = [&](dbl2_t (&dst)[GS_RS][NP], int i0) {
+#pragma unroll
+                for (int a = 0; a < GS_RS; ++a) {
+                    const size_t roff = (size_t)s_row[min(i0 + a, nnz - 1)] * ld;  // (clamped: masked through t = 0 below)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const dbl2_t t = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t*>(wcol[p] + roff));
+                        dst[a][p].x = one[p] ? t.x : 0.0;
+                        dst[a][p].y = pair[p] ? t.y : 0.0;
+                    }
+                }
+            };
+            load_step(w, 0);
+            for (int i0 = 0; i0 < nnz; i0 += GS_RS) {
+                if (i0 + GS_RS < nnz) load_step(wn, i0 + GS_RS);  // (uniform branch)
+#pragma unroll
+                for (int a = 0; a < GS_RS; ++a) {
+                    const double t = (i0 + a < nnz) ? s_tv[i0 + a] : 0.0;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        vacc0[p] += w[a][p].x * t;
+                        vacc1[p] += w[a][p].y * t;
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < GS_RS; ++a)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) w[a][p] = wn[a][p];
+            }
+        }
+        double* pv = v.part_v + (size_t)strip * ld;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (one[p]) pv[c0[p]] = vacc0[p];
+            if (pair[p]) pv[c0[p] + 1] = vacc1[p];
+        }
+    }
+}
+// Assembly of v_K (GV_L lanes per col slot, fixed summation order):
+//   v_K = sum over strips of the W0^T t_K partials + sum_j V[j] h_j        (the -W^T F^T D^-2 a_S part)
+//       + sum over the listed entries of a_K of a_c M0[c][.] + sum_t MU[t] (MV[t] . a_K)        (the M a_K part)
+// then the scatter by row.  The pending terms are skipped when this pivot's fold has just applied them.  Only the upper
+// triangle of M0 is kept current by the fold, so entry (c, i) is read as M0[min][max].
+constexpr int GV_L = 4;
+__global__ void __launch_bounds__(BLK) k_gram_v(DevView v) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    const int k = c->k, ld = v.ld;
+    const int gid = blockIdx.x * BLK + threadIdx.x;
+    const int i = gid / GV_L, gl = gid % GV_L;
+    if (i >= k) return;  // (whole lane groups leave together)
+    const int nstr = (k + GS_RB - 1) / GS_RB;
+    double sv = 0.0;
+    for (int t = gl; t < nstr; t += GV_L) sv += v.part_v[(size_t)t * ld + i];
+    if (!c->fold) {
+        const int nlow = c->nlow;
+        for (int j = gl; j < nlow; j += GV_L) sv += v.V[(size_t)j * ld + i] * c->lr_h[j];
+    }
+    const int n = c->it.klist_n;
+    double mv = 0.0;
+    for (int j = gl; j < n; j += GV_L) {
+        const int cs = v.klist_s[j];
+        mv += v.klist_a[j] * v.M[(size_t)min(cs, i) * ld + max(cs, i)];
+    }
+    if (!c->mfold) {
+        const int mn = c->mnlow;
+        for (int j = gl; j < mn; j += GV_L) mv += v.MU[(size_t)j * ld + i] * c->lr_mc[j];
+    }
+    sv += mv;
+    sv += __shfl_xor(sv, 1, 64);
+    sv += __shfl_xor(sv, 2, 64);
+    if (gl == 0) {
+        v.vK[i] = sv;
+        v.rv[v.row_of_kslot[i]].y = sv;
+    }
+}
+// C = I + F^T D^-2 F (row-slot x row-slot, dense) for the (re)build M = W^T C W: one wave per nucleus column s walks
+// its entries on singleton rows in order; for each such row the lanes spread over the row's entries in other nucleus
+// columns.  (C is zeroed by the caller; the adds to one address are issued by one wave in program order.)
+__global__ void __launch_bounds__(BLK) k_gram_build_c(DevView v, double* C, int k) {
+    const int s = (blockIdx.x * BLK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (s >= k) return;
+    const int var = v.basic_vars[v.pos_of_kslot[s]];
+    double* Cs = C + (size_t)s * v.ld;
+    for (int e = v.csc_ptr[var]; e < v.csc_ptr[var + 1]; ++e) {
+        const int i = v.csc_row[e];
+        const RowInfo ri = v.rowinfo[i];
+        if (ri.kslot >= 0) continue;
+        const double coef = v.csc_val[e] / (ri.diag * ri.diag);
+        for (int f = v.csr_ptr[i] + lane; f < v.csr_ptr[i + 1]; f += 64) {
+            const int loc = v.var_loc[v.csr_col[f]];
+            if (loc < 0) continue;
+            const int s2 = v.kslot_of_pos[loc];
+            if (s2 >= 0) atomicAdd(Cs + s2, coef * v.csr_val[f]);
+        }
+    }
+    if (lane == 0) atomicAdd(Cs + s, 1.0);
+}
+__global__ void k_gram_reset(DevView v) {
+    v.ctl->mnlow = 0;
+    v.ctl->mfold = 0;
+    v.ctl->gram_err = 0.0;
 }
 
 // Row-sharded streaming pass, step 2 of 3 (k_stream_w -> k_post_exchange -> k_post_fused): reduce this rank's partials
@@ -2863,6 +3165,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
             v.alpha_q[t] = 0.0;
             v.tau[t] = 0.0;
             v.rv[t] = make_double2(0.0, 0.0);
+            if (v.gram) v.hS[t] = 0.0;
             if (phase == 1 && !c->forced) tc = price_dual_one(xb, lo, hi, bt, t, use_dse);
         }
         if (t < v.n) {
@@ -2977,6 +3280,7 @@ __global__ void k_reset_ring(DevView v) {
     c->halt = 0;
     c->forced = 0;
     c->max_pivot_err = 0.0;
+    c->gram_err = 0.0;
 }
 // K9: recalc reduced costs (solver.rs:1216-1231): d_c = c_c - a_c . y, then the objective from scratch
 __global__ void __launch_bounds__(BLK) k_gather_basic_obj(DevView v) {
@@ -3391,8 +3695,8 @@ void launch_build_colblk(const int* cptr, const int* crow, int N, int rb, int* c
     } while (0)
 
 void launch_clear_work(const DevView& hv, hipStream_t st) {
-    // alpha_q | tau | rv are carved from one allocation (engine): a single memset
-    (void)hipMemsetAsync(hv.alpha_q, 0, sizeof(double) * 4 * (size_t)hv.m, st);
+    // alpha_q | tau | rv | hS are carved from one allocation (engine): a single memset
+    (void)hipMemsetAsync(hv.alpha_q, 0, sizeof(double) * 5 * (size_t)hv.m, st);
 }
 void launch_price_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st) {
     hipLaunchKernelGGL(k_price_primal, dim3(grid_for(dv.nb_hi - dv.nb_lo)), dim3(BLK), 0, st, dv, use_pse);
@@ -3607,8 +3911,8 @@ static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fo
             } else {
                 const long ftiles = (long)((g.cap + FD_RB - 1) / FD_RB) * ((g.cap + FD_CH - 1) / FD_CH);
                 const int nf = (int)(ftiles < SW_MAX_BLOCKS ? ftiles : SW_MAX_BLOCKS);
-                if (dv.lrJ <= 16) hipLaunchKernelGGL(k_fold_w<16>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2);
-                else hipLaunchKernelGGL(k_fold_w<LR_MAX>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2);
+                if (dv.lrJ <= 16) hipLaunchKernelGGL(k_fold_w<16>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, 0);
+                else hipLaunchKernelGGL(k_fold_w<LR_MAX>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, 0);
             }
             if (!fold_only) {
                 const long tiles = (long)((g.cap + sw_rb() - 1) / sw_rb()) * ((g.cap + sw_ch() - 1) / sw_ch());
@@ -3645,11 +3949,36 @@ static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fo
         }
     }
 }
+static int fold_blocks(const Geom& g) {
+    const long ftiles = (long)((g.cap + FD_RB - 1) / FD_RB) * ((g.cap + FD_CH - 1) / FD_CH);
+    return (int)(ftiles < SW_MAX_BLOCKS ? ftiles : SW_MAX_BLOCKS);
+}
 void launch_fold_lowrank(const DevView& dv, const Geom& g, hipStream_t st) {
     if (!dv.lrJ || g.cap <= 0) return;
     launch_fused_lr(dv, g, 0, 1, st);
+    if (dv.gram) hipLaunchKernelGGL(k_fold_w<LR_MAX>, dim3(fold_blocks(g)), dim3(BLK), 0, st, dv, 1, 1);
     hipLaunchKernelGGL(k_reset_nlow, dim3(1), dim3(1), 0, st, dv);
 }
+// BASIS stage of a primal PSE pivot in Gram mode: folds when due (W0 first: the sparse pass reads the folded matrix),
+// the sparse pass over W0, the assembly of v_K.  No tau (lazy dual steepest edge), hence no F push.
+void launch_gram_basis(const DevView& dv, const Geom& g, hipStream_t st) {
+    if (g.cap <= 0) return;
+    const dim3 b(BLK);
+    const int nf = fold_blocks(g);
+    if (dv.lrJ <= 16) hipLaunchKernelGGL(k_fold_w<16>, dim3(nf), b, 0, st, dv, 2, 0);
+    else hipLaunchKernelGGL(k_fold_w<LR_MAX>, dim3(nf), b, 0, st, dv, 2, 0);
+    hipLaunchKernelGGL(k_fold_w<LR_MAX>, dim3(nf), b, 0, st, dv, 2, 1);
+    const long tiles = (long)((g.cap + GS_RB - 1) / GS_RB) * ((g.cap + GS_CH - 1) / GS_CH);
+    const int nt = (int)(tiles < SW_MAX_BLOCKS ? tiles : SW_MAX_BLOCKS);
+    hipLaunchKernelGGL(k_wt_sparse, dim3(nt + LR_MAX), b, 0, st, dv);
+    hipLaunchKernelGGL(k_gram_v, dim3(blocks_for((long)g.cap * GV_L)), b, 0, st, dv);
+}
+void launch_gram_build_c(const DevView& dv, const Geom& g, double* C, int k, hipStream_t st) {
+    (void)g;
+    if (k <= 0) return;
+    hipLaunchKernelGGL(k_gram_build_c, dim3(blocks_for((long)k * 64)), dim3(BLK), 0, st, dv, C, k);
+}
+void launch_gram_reset(const DevView& dv, hipStream_t st) { hipLaunchKernelGGL(k_gram_reset, dim3(1), dim3(1), 0, st, dv); }
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int with_tau) {
     if (g.cap <= 0) return;  // a model without kept rows has no nucleus: nothing to stream (and no valid grid)
     if (dv.lrJ) {

@@ -5,7 +5,8 @@ a CPU without any LP solver: a primal point x and a dual point y with
     c.x == b.y              (no duality gap)
 Weak duality then proves both optimal.  y comes from the reduced costs of the non-basic slack columns
 (d_slack_i = -pi_i, solver.rs:1199-1231); basic slacks have y_i = 0.  Writes gpurun_out/cfg4_certificate.npz.
-usage: certify_cfg4.py [rows cols nnz_per_row seed]"""
+usage: [CERTIFY_CHUNK=25000] certify_cfg4.py [rows cols nnz_per_row seed]   (CERTIFY_CHUNK: also write the
+wall-time curve of the solve, one point per chunk, to gpurun_out/cfg4_solve_curve.json)"""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -15,8 +16,19 @@ from minilp_amd import lpgen
 
 m, n, k, seed = (int(a) for a in (sys.argv[1:5] if len(sys.argv) >= 5 else (100000, 100000, 100, 4)))
 lp = lpgen.gen_sparse_lp(m, n, k, seed)
+chunk = int(os.environ.get("CERTIFY_CHUNK", "0"))  # > 0: solve in chunks of that many pivots and record the curve
+curve = []
 t = time.time()
-s = lpgen.build_problem(M.Problem, lp).solve()
+if chunk > 0:
+    s = lpgen.build_problem(M.Problem, lp).solve(budget=chunk)
+    while True:
+        st = s.stats()
+        curve.append((int(st["iterations"]), time.time() - t, int(st["nucleus_size"])))
+        if not s.budget_exhausted:
+            break
+        s.continue_solve(chunk)
+else:
+    s = lpgen.build_problem(M.Problem, lp).solve()
 wall = time.time() - t
 st = s.stats()
 x = np.asarray(s.values())
@@ -34,6 +46,14 @@ cert = dict(rows=m, cols=n, nnz_per_row=k, seed=seed, pivots=int(st["iterations"
             nucleus_size=int(st["nucleus_size"]), max_pivot_err=st["max_pivot_err"])
 cert["relative_gap"] = abs(cert["primal_objective"] - cert["dual_objective"]) / max(1.0, abs(cert["primal_objective"]))
 print(json.dumps(cert, indent=1), flush=True)
+if curve:  # (pivots, wall seconds, nucleus size) at every chunk boundary, and the chunk's microseconds per pivot
+    rows, prev = [], (0, 0.0, 0)
+    for c3 in curve:
+        dp = max(c3[0] - prev[0], 1)
+        rows.append(dict(pivots=c3[0], wall_s=round(c3[1], 3), nucleus=c3[2], us_per_pivot=round((c3[1] - prev[1]) / dp * 1e6, 1)))
+        prev = c3
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(dict(chunk=chunk, solve_wall_s=wall, curve=rows), open("gpurun_out/cfg4_solve_curve.json", "w"), indent=0)
 os.makedirs("gpurun_out", exist_ok=True)
 xi = np.nonzero(x)[0]; yi = np.nonzero(y)[0]
 np.savez_compressed("gpurun_out/cfg%d_certificate.npz" % (4 if m == 100000 else 0), x_idx=xi.astype(np.int32), x_val=x[xi], y_idx=yi.astype(np.int32), y_val=y[yi],
