@@ -96,7 +96,7 @@ def cpu_baseline(lp, warmup, sample):
 def kernel_report(st):
     """Per-kernel averages of the event-bracketed (sampled) iterations: algorithmic bytes, GB/s, roofline fraction."""
     out = {}
-    for name in ("fused", "sweep", "ftran"):
+    for name in ("fused", "sweep", "ftran", "fold"):
         n_l = st[name + "_launches"]
         if n_l and st[name + "_ms"] > 0:
             gbs = st[name + "_bytes"] / (st[name + "_ms"] * 1e-3) / 1e9
@@ -105,6 +105,9 @@ def kernel_report(st):
                              total_ms=st[name + "_ms"])
     if st["update_launches"]:
         out["update"] = dict(launches=int(st["update_launches"]), avg_us=st["update_ms"] * 1e3 / st["update_launches"])
+    if st.get("gram_pivots"):  # Gram path: `fused` is its BASIS stage (sparse pass + v assembly + the folds due)
+        out["gram"] = dict(pivots=int(st["gram_pivots"]), rows_of_W_per_pivot=st["gram_rows"] / st["gram_pivots"],
+                           monitor_max=st["gram_err"], rebuilds=int(st["gram_rebuilds"]))
     if st["iter_samples"]:
         out["iteration"] = dict(samples=int(st["iter_samples"]), avg_us=st["iter_ms"] * 1e3 / st["iter_samples"])
     return out
@@ -112,6 +115,9 @@ def kernel_report(st):
 
 KERNEL_NAMES = {
     "fused": "k_fused_w (tau = W rho [the second FTRAN, solver.rs:1157], v = W^T t, eta update / streaming pass of the nucleus inverse)",
+    "fused_gram": ("Gram path of v = B^-T alpha_q: k_wt_sparse (the rows of the nucleus inverse that F^T D^-2 a_S touches) + k_gram_v "
+                   "(rows of M = [(B B^T)^-1]_KK) + the folds of W0 / M0 that were due"),
+    "fold": "k_fold_w (fold of the pending rank-1 terms into W0, every 32 pivots, and into M0, every 16: read + write)",
     "sweep_band": ("k_sweep_band (tableau row rho^T N [+ PSE helper]: band-major copy of A, the band of (rho, v) held in "
                    "LDS; per-band partials summed in band order by k_update_pivot)"),
     "sweep": "k_sweep (tableau row rho^T N [+ PSE helper] as a CSC pull over A)",
@@ -206,7 +212,8 @@ def compact_line(out):
 
     def kern(k):  # per-kernel digest: average launch time, GB/s, fraction of the HBM peak
         return {n: {"us": r(v.get("avg_us"), 1), "gbs": r(v.get("gbs"), 0), "frac": r(v.get("frac"), 3)} if "gbs" in v
-                else {"us": r(v.get("avg_us"), 1)} for n, v in k.items()}
+                else ({"rows_of_W": r(v["rows_of_W_per_pivot"], 0), "monitor": float("%.1e" % v["monitor_max"]), "rebuilds": v["rebuilds"]}
+                      if "rows_of_W_per_pivot" in v else {"us": r(v.get("avg_us"), 1)}) for n, v in k.items()}
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                 "vs_baseline", "dtype", "data")}
     line["value"] = r(line["value"], 2)
@@ -361,13 +368,15 @@ def main():
                 if roofline and windows.get("late") and "fused" in windows["late"]["kernels"]:
                     roofline["ftran"] = dict(
                         column=roofline.get("ftran"),
-                        tau_late_window=dict(kernel=KERNEL_NAMES["fused"], window="late window (saved basis)",
-                                             **windows["late"]["kernels"]["fused"]),
+                        tau_late_window=dict(kernel=KERNEL_NAMES["fused_gram" if "gram" in windows["late"]["kernels"] else "fused"],
+                                             window="late window (saved basis)", **windows["late"]["kernels"]["fused"]),
                         column_late_window=dict(kernel=KERNEL_NAMES["ftran"], window="late window (saved basis)",
                                                 **windows["late"]["kernels"].get("ftran", {})),
                         note="north_star's FTRAN target: the solve against the basis factor.  Here B^-1 is the explicit nucleus "
-                             "inverse: the column FTRAN reads |list| columns of it (latency-bound, a few MB), the second FTRAN "
-                             "of every pivot (tau = B^-1 rho, solver.rs:1157) is the k^2 stream of k_fused_w")
+                             "inverse: the column FTRAN reads |list| columns of it (latency-bound, a few MB).  The two dense solves "
+                             "of steepest edge (tau = B^-1 rho, solver.rs:1157; v = B^-T alpha_q, solver.rs:1114) were the k^2 "
+                             "stream of k_fused_w / k_stream_w; in the primal loop tau is now skipped (lazy dual steepest edge) and "
+                             "v comes from the Gram path (DESIGN.md 2.4), whose BASIS stage is the `tau_late_window` entry")
             out["full_solve"] = full_solve_record()
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(lp, a.warmup, a.cpu_pivots)

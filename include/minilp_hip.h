@@ -134,10 +134,13 @@ typedef struct mlp_stats {
     double iter_ms; uint64_t iter_samples; /* whole sampled iterations, first kernel to last (HIP events) */
     uint64_t beta_rebuilds; /* lazy dual steepest edge: exact rebuilds of the dual edge norms from the basis inverse (the primal
                                loop skips their per-pivot recurrence, solver.rs:1153-1174, because nothing reads them there) */
-    /* Gram mode of the primal steepest-edge solve v = B^-T alpha_q (large nucleus, one GPU; MLP_GRAM=0 switches it off):
+    /* Gram mode of the primal steepest-edge solve v = B^-T alpha_q (opt-in: MLP_GRAM=1; large nucleus, one GPU):
      * builds of M = [(B B^T)^-1] on the nucleus rows from the basis inverse, pivots that took the path, and its drift
-     * monitor max |a_q.v - ||alpha_q||^2| / (1 + ||alpha_q||^2) (M is rebuilt when a batch exceeds MLP_GRAM_TOL, 1e-3) */
+     * monitor max |a_q.v - ||alpha_q||^2| / (1 + ||alpha_q||^2) (M is rebuilt when a batch exceeds MLP_GRAM_TOL, 1e-2) */
     uint64_t gram_rebuilds, gram_pivots; double gram_err;
+    double gram_rows;  /* rows of the nucleus inverse read by the sparse passes of the Gram path (8 k bytes each) */
+    double fold_bytes, fold_ms; uint64_t fold_launches; /* sampled folds of W0 / M0 on the Gram path (HIP events) */
+    uint64_t gram_backoffs; /* times the monitor tripped within 4096 pivots of a rebuild: the streaming pass then serves the next 16 384 pivots */
 } mlp_stats;
 void mlp_solution_stats(const mlp_solution* s, mlp_stats* out);
 void mlp_solution_reset_stats(mlp_solution* s);

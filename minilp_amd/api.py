@@ -36,7 +36,9 @@ class MlpStats(C.Structure):
                    ("update_launches", C.c_uint64), ("banded_sweep", C.c_uint64), ("final_refreshes", C.c_uint64), ("max_pivot_err", C.c_double),
                    ("ftran_bytes", C.c_double), ("ftran_ms", C.c_double), ("ftran_launches", C.c_uint64),
                    ("iter_ms", C.c_double), ("iter_samples", C.c_uint64), ("beta_rebuilds", C.c_uint64),
-                   ("gram_rebuilds", C.c_uint64), ("gram_pivots", C.c_uint64), ("gram_err", C.c_double)])
+                   ("gram_rebuilds", C.c_uint64), ("gram_pivots", C.c_uint64), ("gram_err", C.c_double),
+                   ("gram_rows", C.c_double), ("fold_bytes", C.c_double), ("fold_ms", C.c_double), ("fold_launches", C.c_uint64),
+                   ("gram_backoffs", C.c_uint64)])
 
 
 class MlpIterInfo(C.Structure):  # include/minilp_hip.h: mlp_iter_info

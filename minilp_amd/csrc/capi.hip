@@ -295,6 +295,8 @@ void mlp_solution_stats(const mlp_solution* s, mlp_stats* o) {
     o->iter_ms = t.iter_ms; o->iter_samples = t.iter_samples;
     o->beta_rebuilds = t.beta_rebuilds;
     o->gram_rebuilds = t.gram_rebuilds; o->gram_pivots = t.gram_pivots; o->gram_err = t.gram_err;
+    o->gram_backoffs = t.gram_backoffs;
+    o->gram_rows = t.gram_rows; o->fold_bytes = t.fold_bytes; o->fold_ms = t.fold_ms; o->fold_launches = t.fold_launches;
     for (int i = 0; i < 5; ++i) o->kase[i] = t.kase[i];
 }
 void mlp_solution_reset_stats(mlp_solution* s) {

@@ -132,7 +132,11 @@ struct Stats {
     uint64_t beta_rebuilds = 0;  // lazy dual steepest edge: exact rebuilds of beta from the basis inverse
     uint64_t gram_rebuilds = 0;  // Gram mode: builds of M = W^T (I + F^T D^-2 F) W from the basis inverse
     uint64_t gram_pivots = 0;    // pivots whose v = B^-T alpha_q came from the Gram path
+    uint64_t gram_backoffs = 0;  // times the monitor tripped right after a rebuild and the streaming pass took over for a while
     double gram_err = 0;         // Gram mode drift monitor: max |a_q.v - ||alpha_q||^2| / (1 + ||alpha_q||^2)
+    double gram_rows = 0;        // rows of W0 read by the sparse passes (8 k bytes each)
+    double fold_bytes = 0, fold_ms = 0;  // sampled folds of W0 / M0 in Gram mode (HIP events): read + write of the matrix
+    uint64_t fold_launches = 0;
     uint64_t kase[5] = {0, 0, 0, 0, 0};  // partition-change cases: nuc->nuc, grow, shrink, col swap, same-row
 };
 
@@ -202,11 +206,17 @@ private:
     // Gram mode: the primal steepest-edge solve v = B^-T alpha_q reads a few rows of the resident
     // M = [(B B^T)^-1]_KK and the few rows of W0 that F^T D^-2 a_S touches, instead of all of W0 every pivot.
     // Large-nucleus delayed-update mode, one GPU, lazy dual steepest edge (no tau) only.
-    bool gram_enable = true;                 // MLP_GRAM=0: every primal PSE pivot streams W0 (the round-2 path)
+    bool gram_enable = false;                // MLP_GRAM=1 switches the mode on (measured: pivots 2.2x faster, pricing weights too noisy: §2.4)
     bool gram_phase = false;                 // the loop being run is the primal one
     bool gram_valid = false;                 // M matches the current basis
     bool gram_oom = false;                   // M did not fit next to W: the mode stays off
-    double gram_tol = 1e-3;                  // MLP_GRAM_TOL: monitor value of a batch above which M is rebuilt (a fresh M reads 5e-6 at k = 20 000)
+    // A monitor that trips again within gram_min_gap pivots of a rebuild means M cannot be held that accurately on
+    // this basis (it carries cond(B)^2): the mode backs off to the streaming pass for gram_backoff pivots.
+    double gram_safe = 1e-3;                 // MLP_GRAM_SAFE: per-pivot monitor above which the weight update is safeguarded
+    bool gram_probe = false;                 // MLP_GRAM_PROBE: print the accuracy of a freshly built M
+    uint64_t gram_built_at = 0, gram_off_until = 0;
+    uint64_t gram_min_gap = 4096, gram_backoff = 16384;
+    double gram_tol = 1e-2;                  // MLP_GRAM_TOL: monitor value of a batch above which M is rebuilt (a fresh M reads 5e-6 at k = 20 000; v only feeds the pricing weights)
     DevBuf<double> d_M, d_MU, d_MV, d_mK;
     bool gram_wanted() const;
     void gram_rebuild();
@@ -319,7 +329,7 @@ private:
     hipGraph_t ggraph[2][2][2] = {};
     Geom ggeom[2][2][2];
     uint64_t graph_batches_in_geom = 0;
-    hipEvent_t ev[10] = {};  // sweep0/1, fused0/1, update0/1, ftran0/1, iteration0/1
+    hipEvent_t ev[11] = {};  // sweep0/1, fused0/1, update0/1, ftran0/1, iteration0/1, end of the folds (Gram mode)
     size_t nnz_nucleus_cols();  // non-zeros of the nucleus basic columns (algorithmic bytes of the F products)
     void drop_graphs();
     hipGraphExec_t get_graph(int phase, int multi);

@@ -105,6 +105,9 @@ Engine::Engine() {
     lazy_dse = !(lz && lz[0] == '0');
     if (const char* gm = std::getenv("MLP_GRAM")) gram_enable = gm[0] != '0';
     if (const char* gt = std::getenv("MLP_GRAM_TOL")) gram_tol = std::atof(gt);
+    if (const char* gs = std::getenv("MLP_GRAM_SAFE")) gram_safe = std::atof(gs);
+    gram_probe = std::getenv("MLP_GRAM_PROBE") != nullptr;
+    if (const char* gg = std::getenv("MLP_GRAM_MIN_GAP")) gram_min_gap = (uint64_t)std::atoll(gg);  // 0: never back off (tests)
     const char* nhf = std::getenv("MLP_NO_HEAD_FUSION");
     no_head_fusion = nhf && std::atoi(nhf) != 0;
     const char* nws = std::getenv("MLP_NO_WSHARD");
@@ -978,7 +981,9 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     case STAGE_BASIS:
         if (with_events) HIPCHECK(hipEventRecord(ev[2], st));
         if (dv.gram && phase == 0 && pse) {
-            launch_gram_basis(dv, g, st);                     // Gram path: folds when due, sparse pass over W0, v_K assembly
+            launch_gram_folds(dv, g, st);                     // Gram path: folds of W0 / M0 when due (empty launches otherwise),
+            if (with_events) HIPCHECK(hipEventRecord(ev[10], st));
+            launch_gram_basis(dv, g, st);                     // sparse pass over W0, v_K assembly
             if (with_events) HIPCHECK(hipEventRecord(ev[3], st));
             break;
         }
@@ -1234,6 +1239,10 @@ int Engine::run_loop(int phase) {
         // so short warm-start re-solves run eagerly; the graph is captured once the same geometry has
         // survived a few iterations.
         if (!hview.nb_order && use_order && lifetime_pivots >= order_from) view_dirty = true;  // time to switch the order on
+        if (gram_off_until && lifetime_pivots >= gram_off_until) {  // the back-off of the Gram mode is over
+            gram_off_until = 0;
+            view_dirty = true;
+        }
         sync_view();
         if (hview.nb_order) refresh_nb_order(false);  // every `order_every` pivots (same buffer: captured graphs stay valid)
         const bool have_graph = gexec[phase][enable_pse ? 1 : 0][0] != nullptr;
@@ -1276,6 +1285,7 @@ int Engine::run_loop(int phase) {
         const int k_before = k_;
         const size_t nnz_nuc_before = sample ? nnz_nucleus_cols() : 0;
         pull_ctl();
+        const uint64_t gram_pivots_before = stats.gram_pivots;
         int res = process_records(phase, B);
         if (sample && h_ctl->ring_n >= 1 && h_ctl->ring[0].status == ITER_PIVOT) {
             float ms = 0.f;
@@ -1285,7 +1295,23 @@ int Engine::run_loop(int phase) {
                 stats.sweep_bytes += sh * (12.0 * (double)nnz_before + 16.0 * num_vars) + 16.0 * m_;
                 stats.sweep_launches += 1;
             }
-            if (k_before > 1 && hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) {
+            if (k_before > 1 && hview.gram && phase == 0 && enable_pse) {
+                // Gram path: the rows of W0 the sparse pass read, the listed rows of M0, and the folds that were due
+                // (W0: read + write; M0: read + write of its upper triangle)
+                const double kk = (double)k_before;
+                float fms = 0.f;
+                const double fb = (h_ctl->fold ? 16.0 * kk * kk : 0.0) + (h_ctl->mfold ? 8.0 * kk * kk : 0.0);
+                if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) {
+                    stats.fused_ms += ms;
+                    stats.fused_bytes += 8.0 * kk * ((double)h_ctl->gram_rows + (double)h_ctl->ring[0].klist_n) + fb;
+                    stats.fused_launches += 1;
+                }
+                if (fb > 0.0 && hipEventElapsedTime(&fms, ev[2], ev[10]) == hipSuccess) {
+                    stats.fold_ms += fms;
+                    stats.fold_bytes += fb;
+                    stats.fold_launches += (h_ctl->fold ? 1 : 0) + (h_ctl->mfold ? 1 : 0);
+                }
+            } else if (k_before > 1 && hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) {
                 stats.fused_ms += ms;
                 // read + write of W; a non-folding pivot of the delayed-update mode only reads it
                 const bool read_only = hview.lrJ > 0 && !h_ctl->fold;
@@ -1313,9 +1339,21 @@ int Engine::run_loop(int phase) {
             }
             (void)hipGetLastError();  // an event pair that was not recorded this iteration is not an error
         }
+        if (hview.gram && phase == 0) stats.gram_rows += (double)h_ctl->gram_rows;
         if (hview.gram && phase == 0) {  // drift monitor of M: a_q . v against ||alpha_q||^2 (k_gram_reset clears it per rebuild)
             if (h_ctl->gram_err > stats.gram_err || h_ctl->gram_err != h_ctl->gram_err) stats.gram_err = h_ctl->gram_err;
-            if (!(h_ctl->gram_err <= gram_tol)) gram_valid = false;  // rebuilt before the next batch
+            // one poor pivot says little about M (the check depends on the entering column as well); a batch whose
+            // pivots are mostly poor does
+            const uint64_t piv = stats.gram_pivots - gram_pivots_before;
+            if (piv > 0 && (uint64_t)h_ctl->gram_bad * 2 > piv) {
+                gram_valid = false;  // rebuilt before the next batch ...
+                if (lifetime_pivots - gram_built_at < gram_min_gap) {  // ... unless the last rebuild did not last: back off
+                    gram_off_until = lifetime_pivots + gram_backoff;
+                    if (gram_backoff < (1u << 18)) gram_backoff *= 2;  // every failed attempt waits twice as long
+                    stats.gram_backoffs += 1;
+                    view_dirty = true;
+                }
+            }
         }
         // drift monitor: the pivot element from FTRAN and from the tableau row must agree
         if (h_ctl->max_pivot_err > stats.max_pivot_err) stats.max_pivot_err = h_ctl->max_pivot_err;
@@ -1324,12 +1362,12 @@ int Engine::run_loop(int phase) {
     }
 }
 
-// Gram mode.  Conditions: primal loop with steepest-edge pricing, the large-nucleus delayed-update
+// Gram mode (opt-in, MLP_GRAM=1).  Conditions: primal loop with steepest-edge pricing, the large-nucleus delayed-update
 // mode with its strip kernels, lazy dual steepest edge (no tau = B^-1 rho, which would need the full pass anyway), one GPU
 // (a sharded solve splits the full pass by rows instead).
 bool Engine::gram_wanted() const {
     return gram_enable && !gram_oom && gram_phase && enable_pse && shard_world == 1 && lazy_now(0) && geom().big &&
-           stream_strips_enabled();
+           stream_strips_enabled() && lifetime_pivots >= gram_off_until;
 }
 // M = W^T C W with C = I + F^T D^-2 F, from the folded inverse: C is accumulated on the device from the CSC / CSR,
 // the two k x k x k products are rocBLAS dgemm calls (plain library GEMMs; the buffers are row-major, i.e. their
@@ -1359,10 +1397,32 @@ void Engine::gram_rebuild() {
                 rocblas_status_success)
             throw MlpError(-3, "rocblas_dgemm failed (Gram matrix build)");
         HIPCHECK(hipStreamSynchronize(st));
+        if (gram_probe) {  // M y against W^T (C (W y)) by three matrix-vector products, y sparse: the rounding level of the build
+            std::vector<double> y((size_t)k, 0.0), r1((size_t)k), r2((size_t)k);
+            for (int j = 0; j < 20; ++j) y[(size_t)((1103515245u * (unsigned)(j + 1) + 12345u) % (unsigned)k)] = 0.1 + 0.05 * j;
+            DevBuf<double> dy, d1, d2, d3;
+            dy.alloc_exact((size_t)k); d1.alloc_exact((size_t)k); d2.alloc_exact((size_t)k); d3.alloc_exact((size_t)k);
+            HIPCHECK(hipMemcpy(dy.p, y.data(), sizeof(double) * (size_t)k, hipMemcpyHostToDevice));
+            // row-major X (ld l) is column-major X^T: W y = (W^T)^T y -> op T on the W buffer; C symmetric; W^T z -> op N
+            rocblas_dgemv(h, rocblas_operation_transpose, k, k, &one, d_W.p, l, dy.p, 1, &zero, d1.p, 1);
+            rocblas_dgemv(h, rocblas_operation_none, k, k, &one, C.p, l, d1.p, 1, &zero, d2.p, 1);
+            rocblas_dgemv(h, rocblas_operation_none, k, k, &one, d_W.p, l, d2.p, 1, &zero, d3.p, 1);
+            rocblas_dgemv(h, rocblas_operation_none, k, k, &one, d_M.p, l, dy.p, 1, &zero, d1.p, 1);
+            HIPCHECK(hipStreamSynchronize(st));
+            HIPCHECK(hipMemcpy(r1.data(), d3.p, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost));
+            HIPCHECK(hipMemcpy(r2.data(), d1.p, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost));
+            double dmax = 0.0, vmax = 0.0;
+            for (int i = 0; i < k; ++i) {
+                dmax = std::max(dmax, std::fabs(r1[(size_t)i] - r2[(size_t)i]));
+                vmax = std::max(vmax, std::fabs(r1[(size_t)i]));
+            }
+            std::fprintf(stderr, "[gram probe] k = %d: max |M y - W^T C W y| = %.3e, max |M y| = %.3e\n", k, dmax, vmax);
+        }
     }
-    launch_gram_reset(hview, st);
+    launch_gram_reset(hview, gram_tol, gram_safe, st);
     HIPCHECK(hipStreamSynchronize(st));
     gram_valid = true;
+    gram_built_at = lifetime_pivots;
     stats.gram_rebuilds += 1;
 }
 
@@ -2034,7 +2094,7 @@ Engine* Engine::clone() {
     e->h_rptr = h_rptr; e->h_rcol = h_rcol; e->h_rval = h_rval;
     e->h_colnnz = h_colnnz; e->h_single_row = h_single_row; e->h_single_val = h_single_val;
     e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->no_head_fusion = no_head_fusion;
-    e->gram_enable = gram_enable; e->gram_tol = gram_tol; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
+    e->gram_enable = gram_enable; e->gram_safe = gram_safe; e->gram_tol = gram_tol; e->gram_min_gap = gram_min_gap; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
     e->h_basic_vars = h_basic_vars; e->h_nb_vars = h_nb_vars; e->h_var_loc = h_var_loc;
     e->h_kslot_of_pos = h_kslot_of_pos; e->h_srow_of_pos = h_srow_of_pos; e->h_kslot_of_row = h_kslot_of_row;
     e->h_pos_of_srow = h_pos_of_srow; e->h_sdiag_of_pos = h_sdiag_of_pos; e->h_nb_fixed = h_nb_fixed;

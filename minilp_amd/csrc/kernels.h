@@ -91,6 +91,12 @@ struct Ctl {
     int mfold;             // this pivot folds them into M0 first (set by the plan)
     double lr_mc[LR_MAX];  // MV[t] . (listed entries of a_q on nucleus rows)
     double gram_err;       // max over the batch of |a_q.v - ||alpha_q||^2| / (1 + ||alpha_q||^2): drift monitor of M
+    unsigned long long gram_rows;  // rows of W0 read by the sparse passes of the batch (algorithmic bytes: 8 k each)
+    double gram_now;       // the monitor of the pivot being applied (k_update_pivot safeguards the weights when it is poor)
+    double gram_tol;       // set at every (re)build of M: monitor value that counts as poor
+    int gram_bad;          // pivots of the batch whose monitor was poor (a majority means M itself is off: rebuild)
+    int gram_pad;
+    double gram_safe;      // monitor value above which k_update_pivot keeps the updated weights above their lower bound
     PivotRec ring[RING];
 };
 
@@ -267,9 +273,10 @@ void launch_build_nucleus(const DevView& dv, const Geom& g, double* Kd, int k, h
 void launch_fold_lowrank(const DevView& dv, const Geom& g, hipStream_t st);  // W0 += U^T V, nlow := 0 (host-requested flush)
 // Gram mode: the BASIS stage of a primal PSE pivot (folds of W0 and M0 when due, sparse pass over W0, assembly of v_K),
 // the build of C = I + F^T D^-2 F for the (re)build M = W^T C W, and the reset of the pending-term counters
-void launch_gram_basis(const DevView& dv, const Geom& g, hipStream_t st);
+void launch_gram_folds(const DevView& dv, const Geom& g, hipStream_t st);  // folds of W0 and M0 (empty launches unless due)
+void launch_gram_basis(const DevView& dv, const Geom& g, hipStream_t st);  // sparse pass over W0 + assembly of v_K
 void launch_gram_build_c(const DevView& dv, const Geom& g, double* C, int k, hipStream_t st);
-void launch_gram_reset(const DevView& dv, hipStream_t st);
+void launch_gram_reset(const DevView& dv, double tol, double safe, hipStream_t st);
 void launch_gauss_jordan(double* Kd, double* Winv, int k, int ld, int* d_flag, double* d_scratch, hipStream_t st);
 
 // device-side matrix maintenance (add_constraint without a host pass over the non-zeros; also the initial builds)

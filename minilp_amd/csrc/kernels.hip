@@ -1614,6 +1614,8 @@ __device__ __forceinline__ void gram_update(const DevView& v, Ctl* c, const Stru
     if (s == 0) {
         const double err = fabs(av + 1.0 - it->alpha_sq) / it->alpha_sq;
         if (err > c->gram_err || err != err) c->gram_err = err;
+        c->gram_now = err;
+        if (!(err <= c->gram_tol)) c->gram_bad += 1;
     }
     auto put = [&](int slot, double P, double vv) {
         const double X = (vv - P) * ia - sigma * P;
@@ -2839,6 +2841,7 @@ __global__ void __launch_bounds__(BLK, 4) k_wt_sparse(DevView v) {
             }
         }
         for (int w2 = 0; w2 < 2 * (BLK / 64); ++w2) nnz += s_cnt[w2];
+        if (chunk == 0 && tid == 0 && nnz > 0) atomicAdd(&c->gram_rows, (unsigned long long)nnz);
         __syncthreads();
         int c0[NP];
         bool pair[NP], one[NP];
@@ -2952,10 +2955,14 @@ __global__ void __launch_bounds__(BLK) k_gram_build_c(DevView v, double* C, int 
     }
     if (lane == 0) atomicAdd(Cs + s, 1.0);
 }
-__global__ void k_gram_reset(DevView v) {
+__global__ void k_gram_reset(DevView v, double tol, double safe) {
+    v.ctl->gram_safe = safe;
     v.ctl->mnlow = 0;
     v.ctl->mfold = 0;
     v.ctl->gram_err = 0.0;
+    v.ctl->gram_now = 0.0;
+    v.ctl->gram_tol = tol;
+    v.ctl->gram_bad = 0;
 }
 
 // Row-sharded streaming pass, step 2 of 3 (k_stream_w -> k_post_exchange -> k_post_fused): reduce this rank's partials
@@ -3238,6 +3245,11 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                     v.d[tn] = dd;
                     if (use_pse) {
                         gm += -2.0 * ar * hp / pc + it->alpha_sq * ar * ar / (pc * pc);
+                        // Gram mode: when this pivot's v failed its check (a_q.v against ||alpha_q||^2), keep the weight
+                        // above its lower bound 1 + (alpha_rj / alpha_rq)^2 (Forrest & Goldfarb's safeguard); never let a
+                        // broken M poison the weights
+                        if (v.gram && !(c->gram_now <= c->gram_safe)) gm = fmax(gm, 1.0 + ar * ar / (pc * pc));
+                        if (v.gram && !(fabs(gm) < 1e300)) gm = 1.0 + ar * ar / (pc * pc);
                         v.gamma[tn] = gm;
                     }
                 }
@@ -3281,6 +3293,8 @@ __global__ void k_reset_ring(DevView v) {
     c->forced = 0;
     c->max_pivot_err = 0.0;
     c->gram_err = 0.0;
+    c->gram_rows = 0ull;
+    c->gram_bad = 0;
 }
 // K9: recalc reduced costs (solver.rs:1216-1231): d_c = c_c - a_c . y, then the objective from scratch
 __global__ void __launch_bounds__(BLK) k_gather_basic_obj(DevView v) {
@@ -3959,15 +3973,19 @@ void launch_fold_lowrank(const DevView& dv, const Geom& g, hipStream_t st) {
     if (dv.gram) hipLaunchKernelGGL(k_fold_w<LR_MAX>, dim3(fold_blocks(g)), dim3(BLK), 0, st, dv, 1, 1);
     hipLaunchKernelGGL(k_reset_nlow, dim3(1), dim3(1), 0, st, dv);
 }
-// BASIS stage of a primal PSE pivot in Gram mode: folds when due (W0 first: the sparse pass reads the folded matrix),
-// the sparse pass over W0, the assembly of v_K.  No tau (lazy dual steepest edge), hence no F push.
-void launch_gram_basis(const DevView& dv, const Geom& g, hipStream_t st) {
+// BASIS stage of a primal PSE pivot in Gram mode: folds when due (the sparse pass reads the folded W0), then
+// the sparse pass over W0 and the assembly of v_K.  No tau (lazy dual steepest edge), hence no F push.
+void launch_gram_folds(const DevView& dv, const Geom& g, hipStream_t st) {
     if (g.cap <= 0) return;
     const dim3 b(BLK);
     const int nf = fold_blocks(g);
     if (dv.lrJ <= 16) hipLaunchKernelGGL(k_fold_w<16>, dim3(nf), b, 0, st, dv, 2, 0);
     else hipLaunchKernelGGL(k_fold_w<LR_MAX>, dim3(nf), b, 0, st, dv, 2, 0);
     hipLaunchKernelGGL(k_fold_w<LR_MAX>, dim3(nf), b, 0, st, dv, 2, 1);
+}
+void launch_gram_basis(const DevView& dv, const Geom& g, hipStream_t st) {
+    if (g.cap <= 0) return;
+    const dim3 b(BLK);
     const long tiles = (long)((g.cap + GS_RB - 1) / GS_RB) * ((g.cap + GS_CH - 1) / GS_CH);
     const int nt = (int)(tiles < SW_MAX_BLOCKS ? tiles : SW_MAX_BLOCKS);
     hipLaunchKernelGGL(k_wt_sparse, dim3(nt + LR_MAX), b, 0, st, dv);
@@ -3978,7 +3996,9 @@ void launch_gram_build_c(const DevView& dv, const Geom& g, double* C, int k, hip
     if (k <= 0) return;
     hipLaunchKernelGGL(k_gram_build_c, dim3(blocks_for((long)k * 64)), dim3(BLK), 0, st, dv, C, k);
 }
-void launch_gram_reset(const DevView& dv, hipStream_t st) { hipLaunchKernelGGL(k_gram_reset, dim3(1), dim3(1), 0, st, dv); }
+void launch_gram_reset(const DevView& dv, double tol, double safe, hipStream_t st) {
+    hipLaunchKernelGGL(k_gram_reset, dim3(1), dim3(1), 0, st, dv, tol, safe);
+}
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int with_tau) {
     if (g.cap <= 0) return;  // a model without kept rows has no nucleus: nothing to stream (and no valid grid)
     if (dv.lrJ) {
