@@ -213,6 +213,8 @@ private:
     // A monitor that trips again within gram_min_gap pivots of a rebuild means M cannot be held that accurately on
     // this basis (it carries cond(B)^2): the mode backs off to the streaming pass for gram_backoff pivots.
     double gram_safe = 1e-3;                 // MLP_GRAM_SAFE: per-pivot monitor above which the weight update is safeguarded
+    int gram_shadow = 0;                     // MLP_GRAM_SHADOW=1|2: also run the streaming pass and report max |v_gram - v_stream| (2: continue with the streamed v)
+    double sh_diff_max = 0, sh_ref_max = 0, sh_rel_max = 0;
     bool gram_probe = false;                 // MLP_GRAM_PROBE: print the accuracy of a freshly built M
     uint64_t gram_built_at = 0, gram_off_until = 0;
     uint64_t gram_min_gap = 4096, gram_backoff = 16384;

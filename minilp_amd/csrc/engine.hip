@@ -107,6 +107,7 @@ Engine::Engine() {
     if (const char* gt = std::getenv("MLP_GRAM_TOL")) gram_tol = std::atof(gt);
     if (const char* gs = std::getenv("MLP_GRAM_SAFE")) gram_safe = std::atof(gs);
     gram_probe = std::getenv("MLP_GRAM_PROBE") != nullptr;
+    if (const char* sh = std::getenv("MLP_GRAM_SHADOW")) gram_shadow = std::atoi(sh);
     if (const char* gg = std::getenv("MLP_GRAM_MIN_GAP")) gram_min_gap = (uint64_t)std::atoll(gg);  // 0: never back off (tests)
     const char* nhf = std::getenv("MLP_NO_HEAD_FUSION");
     no_head_fusion = nhf && std::atoi(nhf) != 0;
@@ -984,6 +985,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
             launch_gram_folds(dv, g, st);                     // Gram path: folds of W0 / M0 when due (empty launches otherwise),
             if (with_events) HIPCHECK(hipEventRecord(ev[10], st));
             launch_gram_basis(dv, g, st);                     // sparse pass over W0, v_K assembly
+            if (gram_shadow) launch_gram_shadow(dv, g, gram_shadow, st);
             if (with_events) HIPCHECK(hipEventRecord(ev[3], st));
             break;
         }
@@ -1340,6 +1342,17 @@ int Engine::run_loop(int phase) {
             (void)hipGetLastError();  // an event pair that was not recorded this iteration is not an error
         }
         if (hview.gram && phase == 0) stats.gram_rows += (double)h_ctl->gram_rows;
+        if (hview.gram && phase == 0 && gram_shadow) {
+            double dd, rr;
+            std::memcpy(&dd, &h_ctl->sh_diff, sizeof(double));
+            std::memcpy(&rr, &h_ctl->sh_ref, sizeof(double));
+            sh_diff_max = std::max(sh_diff_max, dd);
+            sh_ref_max = std::max(sh_ref_max, rr);
+            if (rr > 0) sh_rel_max = std::max(sh_rel_max, dd / rr);
+            if ((batches_run & 63) == 0)
+                std::fprintf(stderr, "[gram shadow] batch: max |dv| %.3e, max |v| %.3e | so far: max |dv| %.3e, max |dv|/|v|max %.3e, monitor %.2e\n",
+                             dd, rr, sh_diff_max, sh_rel_max, h_ctl->gram_err);
+        }
         if (hview.gram && phase == 0) {  // drift monitor of M: a_q . v against ||alpha_q||^2 (k_gram_reset clears it per rebuild)
             if (h_ctl->gram_err > stats.gram_err || h_ctl->gram_err != h_ctl->gram_err) stats.gram_err = h_ctl->gram_err;
             // one poor pivot says little about M (the check depends on the entering column as well); a batch whose

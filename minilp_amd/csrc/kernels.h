@@ -97,6 +97,8 @@ struct Ctl {
     int gram_bad;          // pivots of the batch whose monitor was poor (a majority means M itself is off: rebuild)
     int gram_pad;
     double gram_safe;      // monitor value above which k_update_pivot keeps the updated weights above their lower bound
+    unsigned long long sh_diff, sh_ref, sh_hdiff;  // MLP_GRAM_SHADOW: max |v_gram - v_stream|, max |v_stream| (bit patterns of
+                                                   // non-negative doubles order like integers); spare
     PivotRec ring[RING];
 };
 
@@ -277,6 +279,8 @@ void launch_gram_folds(const DevView& dv, const Geom& g, hipStream_t st);  // fo
 void launch_gram_basis(const DevView& dv, const Geom& g, hipStream_t st);  // sparse pass over W0 + assembly of v_K
 void launch_gram_build_c(const DevView& dv, const Geom& g, double* C, int k, hipStream_t st);
 void launch_gram_reset(const DevView& dv, double tol, double safe, hipStream_t st);
+// diagnostic (MLP_GRAM_SHADOW): the streaming pass of the same pivot next to the Gram result; mode 2 continues with the streamed v
+void launch_gram_shadow(const DevView& dv, const Geom& g, int mode, hipStream_t st);
 void launch_gauss_jordan(double* Kd, double* Winv, int k, int ld, int* d_flag, double* d_scratch, hipStream_t st);
 
 // device-side matrix maintenance (add_constraint without a host pass over the non-zeros; also the initial builds)

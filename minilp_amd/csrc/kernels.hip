@@ -102,6 +102,19 @@ __device__ __forceinline__ double block_sum(double x) {  // thread 0, fixed tree
     return x;
 }
 
+__device__ __forceinline__ double block_max(double x) {  // thread 0 (diagnostics)
+    __shared__ double s[BLK / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_down(x, o, 64));
+    int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) s[w] = x;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int i = 1; i < BLK / 64; ++i) x = fmax(x, s[i]);
+    return x;
+}
+
 // Cross-workgroup hand-off without fences (cdna_hip_programming.md §6 G16, form "8-B agent atomics
 // both sides"): every partial is stored write-through (relaxed agent-scope atomic store = sc1), the
 // storing lane drains its stores (s_waitcnt vmcnt(0)) and takes a ticket; the last arriver re-reads
@@ -2955,6 +2968,36 @@ __global__ void __launch_bounds__(BLK) k_gram_build_c(DevView v, double* C, int 
     }
     if (lane == 0) atomicAdd(Cs + s, 1.0);
 }
+// MLP_GRAM_SHADOW: v_K of the streaming pass (partials of k_stream_w's strips + low-rank part) against the Gram result
+template <int TR>
+__global__ void __launch_bounds__(BLK) k_gram_shadow(DevView v, int mode) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    const int k = c->k, ld = v.ld;
+    const int i = blockIdx.x * BLK + threadIdx.x;
+    double diff = 0.0, ref = 0.0;
+    if (i < k) {
+        const int nstr = (k + TR - 1) / TR;
+        double sv = 0.0;
+        for (int t = 0; t < nstr; ++t) sv += v.part_v[(size_t)t * ld + i];
+        if (!c->fold) {
+            const int nlow = c->nlow;
+            for (int j = 0; j < nlow; ++j) sv += v.V[(size_t)j * ld + i] * c->lr_h[j];
+        }
+        diff = fabs(sv - v.vK[i]);
+        ref = fabs(sv);
+        if (mode == 2) {
+            v.vK[i] = sv;
+            v.rv[v.row_of_kslot[i]].y = sv;
+        }
+    }
+    diff = block_max(diff);
+    ref = block_max(ref);
+    if (threadIdx.x == 0) {
+        atomicMax(&c->sh_diff, (unsigned long long)__double_as_longlong(diff));
+        atomicMax(&c->sh_ref, (unsigned long long)__double_as_longlong(ref));
+    }
+}
 __global__ void k_gram_reset(DevView v, double tol, double safe) {
     v.ctl->gram_safe = safe;
     v.ctl->mnlow = 0;
@@ -3295,6 +3338,8 @@ __global__ void k_reset_ring(DevView v) {
     c->gram_err = 0.0;
     c->gram_rows = 0ull;
     c->gram_bad = 0;
+    c->sh_diff = 0ull;
+    c->sh_ref = 0ull;
 }
 // K9: recalc reduced costs (solver.rs:1216-1231): d_c = c_c - a_c . y, then the objective from scratch
 __global__ void __launch_bounds__(BLK) k_gather_basic_obj(DevView v) {
@@ -3995,6 +4040,16 @@ void launch_gram_build_c(const DevView& dv, const Geom& g, double* C, int k, hip
     (void)g;
     if (k <= 0) return;
     hipLaunchKernelGGL(k_gram_build_c, dim3(blocks_for((long)k * 64)), dim3(BLK), 0, st, dv, C, k);
+}
+void launch_gram_shadow(const DevView& dv, const Geom& g, int mode, hipStream_t st) {
+    if (g.cap <= 0) return;
+    launch_btran_rhs(dv, g, st);  // the dense t_K = alpha_K - F^T y_S of the streaming pass (overwrites the sparse one)
+    const dim3 b(BLK);
+    const long tiles = (long)((g.cap + sw_rb() - 1) / sw_rb()) * ((g.cap + sw_ch() - 1) / sw_ch());
+    const int nt = (int)(tiles < SW_MAX_BLOCKS ? tiles : SW_MAX_BLOCKS);
+    if (sw_rb() != 128 || sw_ch() != 1024) return;  // (default strip geometry only)
+    hipLaunchKernelGGL((k_stream_w<true, 1024, 128, 4>), dim3(nt + LR_MAX), b, 0, st, dv, 0);
+    hipLaunchKernelGGL(k_gram_shadow<128>, dim3(blocks_for(g.cap)), b, 0, st, dv, mode);
 }
 void launch_gram_reset(const DevView& dv, double tol, double safe, hipStream_t st) {
     hipLaunchKernelGGL(k_gram_reset, dim3(1), dim3(1), 0, st, dv, tol, safe);
