@@ -259,6 +259,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # The contract is ONE JSON line on stdout.  Native libraries (Gloo's "Rank 0 is connected ...", RCCL warnings, the HIP
+    # runtime) write to file descriptor 1 directly, so fd 1 is pointed at stderr for the whole run and the line goes to
+    # a private copy of the original stdout.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     oversub = world > 1 and torch.cuda.device_count() < world  # test rigs with fewer GPUs than ranks
@@ -408,7 +414,8 @@ def main():
                 json.dump(out, f, indent=1)
         except OSError:
             pass
-        print(json.dumps(compact_line(out)), flush=True)
+        real_stdout.write(json.dumps(compact_line(out)) + "\n")
+        real_stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -284,6 +284,7 @@ private:
     DevBuf<double> d_alpha_r, d_helper;
     DevBuf<int2> d_nb_rng;
     int sweep_variant = 0;
+    int sw_balanced = 1;  // MLP_STREAM_BALANCED=0: fixed 128-row strips in the streaming pass (A/B runs); N > 1: that many blocks
     int lanes_force = 0;  // MLP_LANES: lanes per column / slot in the gather kernels (4, 16, 64)
     int rt_device = 0;
     void acquire_runtime();  // streams, events, pinned Ctl mirror: recycled across Solutions

@@ -107,6 +107,7 @@ Engine::Engine() {
     if (const char* gt = std::getenv("MLP_GRAM_TOL")) gram_tol = std::atof(gt);
     if (const char* gs = std::getenv("MLP_GRAM_SAFE")) gram_safe = std::atof(gs);
     gram_probe = std::getenv("MLP_GRAM_PROBE") != nullptr;
+    if (const char* sb = std::getenv("MLP_STREAM_BALANCED")) sw_balanced = std::atoi(sb);
     if (const char* sh = std::getenv("MLP_GRAM_SHADOW")) gram_shadow = std::atoi(sh);
     if (const char* gg = std::getenv("MLP_GRAM_MIN_GAP")) gram_min_gap = (uint64_t)std::atoll(gg);  // 0: never back off (tests)
     const char* nhf = std::getenv("MLP_NO_HEAD_FUSION");
@@ -437,6 +438,9 @@ DevView* Engine::sync_view() {
             v.xbuf_peer[r] = peer_box[r] ? reinterpret_cast<double*>(static_cast<uint8_t*>(peer_box[r]) + mb) : nullptr;
         v.xb_cap = (int)xb_cap_; v.pad3 = 0;
     }
+    v.sw_nbal = 0; v.sw_pad = 0;
+    if (sw_balanced && v.lrJ > 0 && geom().big && stream_strips_enabled())
+        v.sw_nbal = sw_balanced > 1 ? sw_balanced : stream_coresident_blocks();
     v.nb_lo = shard_world > 1 ? (int)((long)num_vars * shard_rank / shard_world) : 0;
     v.nb_hi = shard_world > 1 ? (int)((long)num_vars * (shard_rank + 1) / shard_world) : num_vars;
     if (std::memcmp(&old, &hview, sizeof(DevView)) != 0) {
@@ -2107,7 +2111,7 @@ Engine* Engine::clone() {
     e->h_rptr = h_rptr; e->h_rcol = h_rcol; e->h_rval = h_rval;
     e->h_colnnz = h_colnnz; e->h_single_row = h_single_row; e->h_single_val = h_single_val;
     e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->no_head_fusion = no_head_fusion;
-    e->gram_enable = gram_enable; e->gram_safe = gram_safe; e->gram_tol = gram_tol; e->gram_min_gap = gram_min_gap; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
+    e->sw_balanced = sw_balanced; e->gram_enable = gram_enable; e->gram_safe = gram_safe; e->gram_tol = gram_tol; e->gram_min_gap = gram_min_gap; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
     e->h_basic_vars = h_basic_vars; e->h_nb_vars = h_nb_vars; e->h_var_loc = h_var_loc;
     e->h_kslot_of_pos = h_kslot_of_pos; e->h_srow_of_pos = h_srow_of_pos; e->h_kslot_of_row = h_kslot_of_row;
     e->h_pos_of_srow = h_pos_of_srow; e->h_sdiag_of_pos = h_sdiag_of_pos; e->h_nb_fixed = h_nb_fixed;

@@ -173,6 +173,10 @@ struct DevView {
     // instead of one read of all of W per pivot.  M follows the basis by a symmetric rank-2 term per pivot (delayed
     // like W's: LR_MAX pending rank-1 terms, i.e. a fold every LR_MAX / 2 pivots).
     int gram;              // 1: the primal PSE iteration takes the Gram path (large-nucleus delayed-update mode only)
+    // Balanced strips of the streaming pass: with sw_nbal > 0 (the number of k_stream_w blocks the device holds at once)
+    // the strip height follows k so that every co-resident block gets ONE tile of equal size — the fixed 128-row strips
+    // leave 3 381 tiles for 1 024 slots at k = 20 500, i.e. some CUs stream four tiles while others stream three.
+    int sw_nbal, sw_pad;
     double* M;             // cap x ld: M0
     double* MU;            // LR_MAX x ld: pending terms of M, left factors
     double* MV;            // LR_MAX x ld: pending terms of M, right factors
@@ -258,7 +262,8 @@ void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t
 void launch_exact_beta(const DevView& dv, hipStream_t st);  // beta_p = ||e_p^T B^-1||^2 for every basic position (lazy dual steepest edge)
 void launch_push_tau(const DevView& dv, hipStream_t st);  // blocked push of -F tau_K alone (runs on a side branch of the graph)  // tau push | v reduce+scatter (classic: partials of k_fused_w's tiling)
 void launch_mail_handshake(const DevView& dv, int* out, hipStream_t st);  // transport self-test at enable_sharding
-bool stream_strips_enabled();  // large-nucleus streaming pass in strip form (MLP_STREAM_STRIPS=0 disables)
+bool stream_strips_enabled();
+int stream_coresident_blocks();  // blocks of the default k_stream_w instance the device holds at once (0: unknown)  // large-nucleus streaming pass in strip form (MLP_STREAM_STRIPS=0 disables)
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_dse, int use_pse, hipStream_t st, int inline_comb = 0,
                          int with_struct = 0);  // K8 + clear + next pricing

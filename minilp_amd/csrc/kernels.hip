@@ -2578,6 +2578,16 @@ __global__ void __launch_bounds__(BLK) k_fused_lr16(DevView v, int fold_only) {
 // pivot k_fused_lr16 (mode 2) has already applied the pending terms to W0, so the dots are skipped and the pass
 // reads the folded matrix.
 constexpr int SW_MAX_BLOCKS = 8192;
+// rows per strip of the streaming pass: fixed (template value) or balanced over the co-resident blocks (DevView.sw_nbal)
+__device__ __forceinline__ int sw_strip_rows(const DevView& v, int k, int ch, int rs, int rb_fixed) {
+    if (!v.sw_nbal || rb_fixed != 128) return rb_fixed;  // (only the partials of k_stream_w's default geometry are balanced)
+    const int nch = (k + ch - 1) / ch;
+    const int mult = v.wshard ? v.world : 1;     // row-sharded pass: every rank streams 1 / world of the strips
+    const int spc = max(1, (v.sw_nbal * mult) / nch);  // strips per column chunk
+    int rb = (k + spc - 1) / spc;
+    rb = ((rb + rs - 1) / rs) * rs;
+    return max(rb, 32);  // (part_v holds cap / 8 rows of partials)
+}
 template <bool WITH_V, int SW_CH, int SW_RB, int SW_RS>
 __global__ void __launch_bounds__(BLK, 4) k_stream_w(DevView v, int with_tau) {  // 4 waves per SIMD: keep the double buffer within 128 VGPRs
     static_assert(SW_CH == 2 * BLK || SW_CH == 4 * BLK, "one or two column pairs per thread");
@@ -2608,7 +2618,8 @@ __global__ void __launch_bounds__(BLK, 4) k_stream_w(DevView v, int with_tau) { 
     __shared__ double s_t[2][SW_RS][BLK + 1];
     constexpr int G = BLK / SW_RS;  // lanes that share a row in the reduction of a step (32)
     const int rrow = tid / G, gl = tid % G;
-    const int nch = (k + SW_CH - 1) / SW_CH, nstr_all = (k + SW_RB - 1) / SW_RB;
+    const int rb = sw_strip_rows(v, k, SW_CH, SW_RS, SW_RB);
+    const int nch = (k + SW_CH - 1) / SW_CH, nstr_all = (k + rb - 1) / rb;
     // row-sharded pass: this rank streams only the strips s with s % world == rank (k_post_exchange completes the products)
     const int sw = v.wshard ? v.world : 1, sr = v.wshard ? v.rank : 0;
     const int nstr = nstr_all > sr ? (nstr_all - sr + sw - 1) / sw : 0;
@@ -2616,7 +2627,7 @@ __global__ void __launch_bounds__(BLK, 4) k_stream_w(DevView v, int with_tau) { 
     const double* __restrict__ tKp = v.tK;
     for (int tile = blockIdx.x; tile < nstr * nch; tile += n_tile_blocks) {
         const int strip = (tile / nch) * sw + sr, chunk = tile % nch;
-        const int rbeg = strip * SW_RB, rend = min(k, rbeg + SW_RB);
+        const int rbeg = strip * rb, rend = min(k, rbeg + rb);
         int c0[NP];
         bool pair[NP], one[NP];
         double rk0[NP], rk1[NP], vacc0[NP], vacc1[NP];
@@ -2977,7 +2988,8 @@ __global__ void __launch_bounds__(BLK) k_gram_shadow(DevView v, int mode) {
     const int i = blockIdx.x * BLK + threadIdx.x;
     double diff = 0.0, ref = 0.0;
     if (i < k) {
-        const int nstr = (k + TR - 1) / TR;
+        const int tr = sw_strip_rows(v, k, 1024, 4, TR);
+        const int nstr = (k + tr - 1) / tr;
         double sv = 0.0;
         for (int t = 0; t < nstr; ++t) sv += v.part_v[(size_t)t * ld + i];
         if (!c->fold) {
@@ -3020,8 +3032,9 @@ __global__ void __launch_bounds__(BLK) k_post_exchange(DevView v, int with_v, in
     const unsigned long long ep = c->xepoch[4] + 1ull;
     const size_t par = (size_t)(ep & 1ull);
     const int i = blockIdx.x * BLK + threadIdx.x;
+    const int tr = sw_strip_rows(v, k, TC, 4, TR);
     if (i < k) {
-        const int strip = i / TR;
+        const int strip = i / tr;
         const bool mine = with_tau && strip % v.world == v.rank;
         double x = 0.0;
         if (mine) {
@@ -3030,7 +3043,7 @@ __global__ void __launch_bounds__(BLK) k_post_exchange(DevView v, int with_v, in
         }
         double sv = 0.0;
         if (with_v) {
-            const int nstripes = (k + TR - 1) / TR;
+            const int nstripes = (k + tr - 1) / tr;
             for (int t = v.rank; t < nstripes; t += v.world) sv += v.part_v[(size_t)t * ld + i];
         }
         const size_t off = ((par * v.world + v.rank) * 2) * (size_t)v.xb_cap + i;
@@ -3088,7 +3101,7 @@ __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push) {
         const int nchunks = (k + TC - 1) / TC;
         double x = 0.0;
         if (xsh) {
-            const int owner = (slot / TR) % v.world;
+            const int owner = (slot / sw_strip_rows(v, k, TC, 4, TR)) % v.world;
             x = __hip_atomic_load(xb + ((size_t)owner * 2) * v.xb_cap + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {
             for (int j = 0; j < nchunks; ++j) x += v.part_tau[(size_t)j * v.ld + slot];
@@ -3112,7 +3125,8 @@ __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push) {
     const int i = b * 32 + lane32;
     if (b * 32 >= k) return;
     __shared__ double s_part[8][33];
-    const int nstripes = (k + TR - 1) / TR;
+    const int tr = sw_strip_rows(v, k, TC, 4, TR);  // (balanced strips exist for the default geometry only: 4 rows per step)
+    const int nstripes = (k + tr - 1) / tr;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (xsh) {
         if (grp == 0 && i < k)  // rank order: every rank forms the identical sum
@@ -3942,6 +3956,19 @@ static int sw_ch() { return kSwGeoms[stream_variant()].ch; }
 static int sw_rb() { return kSwGeoms[stream_variant()].rb; }
 bool stream_strips_enabled();
 static bool stream_strips() { return stream_strips_enabled(); }
+int stream_coresident_blocks() {
+    static int n = -1;
+    if (n < 0) {
+        int dev = 0, per_cu = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_stream_w<true, 1024, 128, 4>), BLK, 0) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+            n = (per_cu < 3 ? per_cu : 3) * cus;  // measured: 3 per CU beats 4 (733 vs 740 us per pivot at k = 20 500); a
+        else                                      // count that is not a multiple of the CUs loads them unevenly (759 us)
+            n = 0;
+    }
+    return (stream_variant() == 2) ? n : 0;
+}
 bool stream_strips_enabled() {
     static const bool on = !(std::getenv("MLP_STREAM_STRIPS") && std::atoi(std::getenv("MLP_STREAM_STRIPS")) == 0);
     return on;
@@ -3974,7 +4001,8 @@ static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fo
                 else hipLaunchKernelGGL(k_fold_w<LR_MAX>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, 0);
             }
             if (!fold_only) {
-                const long tiles = (long)((g.cap + sw_rb() - 1) / sw_rb()) * ((g.cap + sw_ch() - 1) / sw_ch());
+                long tiles = (long)((g.cap + sw_rb() - 1) / sw_rb()) * ((g.cap + sw_ch() - 1) / sw_ch());
+                if (dv.sw_nbal > tiles) tiles = dv.sw_nbal;  // balanced strips: one tile per co-resident block
                 const int nt = (int)(tiles < SW_MAX_BLOCKS ? tiles : SW_MAX_BLOCKS);
 #define SW_LAUNCH(CH, RB, RS)                                                                                     \
     do {                                                                                                          \
