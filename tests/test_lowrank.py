@@ -93,3 +93,22 @@ def test_engine_level_stepping_with_the_large_model_machinery(lowrank):
     assert st == M.api.ITER_OPTIMAL and pivots == len(so.trace())
     assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
     assert obj_close(sg.objective(), so.objective())
+
+
+@pytest.mark.parametrize("balanced", ["0", "1", "5", "4096"])
+def test_stream_strip_geometry_does_not_change_the_pivots(balanced):
+    """k_stream_w: fixed 128-row strips (0), one equal tile per co-resident block (1, the default), and forced block
+    counts that make a block loop over several tiles (5) or leave most blocks without one (4096)."""
+    env = {"MLP_LOWRANK": "16", "MLP_BIGTILE": "1", "MLP_LDPAD": "16", "MLP_BANDED": "1", "MLP_STREAM_BALANCED": balanced}
+    os.environ.update(env)
+    try:
+        lp = lpgen.gen_sparse_lp(1500, 1500, 20, 2)   # a nucleus of several hundred slots
+        so = lpgen.build_problem(O.Problem, lp).solve(trace=True)
+        sg = lpgen.build_problem(M.Problem, lp).solve(trace=True)
+        assert sg.stats()["nucleus_size"] > 0
+        assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+        assert obj_close(sg.objective(), so.objective())
+        assert sg.reinvert() < 1e-8
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
