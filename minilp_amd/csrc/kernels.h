@@ -230,7 +230,8 @@ constexpr int FW_TC = 1024;  // columns per block (256 threads x 4)
 constexpr int BAND_ROWS = 8192;  // rows per band of the banded sweep: 128 KB of (rho, v) pairs in LDS
 constexpr int BAND_THREADS = 1024;
 constexpr int PB_ROWS = 4096;   // rows per LDS block of the blocked F push (32 KB of doubles)
-constexpr int PB_CHUNKS = 24;   // column chunks (slot ranges) of the blocked F push
+constexpr int PB_CHUNKS = 48;   // capacity of the partial-sum buffer of the blocked F push (column chunks = slot ranges)
+constexpr int PB_CHUNKS_DEFAULT = 24;  // chunks used (MLP_PB_CHUNKS overrides)
 
 struct Geom {
     int m, n, cap;

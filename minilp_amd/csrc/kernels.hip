@@ -846,7 +846,7 @@ __global__ void __launch_bounds__(BLK) k_push_stage1(DevView v, int which) {
     const int nrows = min(PB_ROWS, v.m - row0);
     for (int t = tid; t < nrows; t += BLK) acc[t] = 0.0;
     const int k = c->k;
-    const int per = (k + PB_CHUNKS - 1) / PB_CHUNKS;
+    const int per = (k + (int)gridDim.y - 1) / (int)gridDim.y;
     const int s_lo = cc * per, s_hi = min(k, s_lo + per);
     const double* xK = which ? v.tauK : v.aK;
     const int lane = tid & 7, grp = tid >> 3;  // 8 lanes per slot, 32 slots side by side
@@ -1019,8 +1019,12 @@ static void launch_blocked_push(const DevView& dv, int which, hipStream_t st) {
         hipLaunchKernelGGL(k_push_combine, dim3((dv.m + BLK - 1) / BLK), dim3(BLK), 0, st, dv, which, chunks);
         return;
     }
-    hipLaunchKernelGGL(k_push_stage1, dim3(dv.pb_rb, PB_CHUNKS), dim3(BLK), 0, st, dv, which);
-    hipLaunchKernelGGL(k_push_combine, dim3((dv.m + BLK - 1) / BLK), dim3(BLK), 0, st, dv, which, PB_CHUNKS);
+    // slot chunks: as many as keep (row blocks x chunks) within one round of workgroups (3 per CU by LDS), at most PB_CHUNKS
+    static const int want = std::getenv("MLP_PB_CHUNKS") ? std::atoi(std::getenv("MLP_PB_CHUNKS")) : 0;
+    int chunks = want > 0 ? want : PB_CHUNKS_DEFAULT;
+    if (chunks > PB_CHUNKS) chunks = PB_CHUNKS;
+    hipLaunchKernelGGL(k_push_stage1, dim3(dv.pb_rb, chunks), dim3(BLK), 0, st, dv, which);
+    hipLaunchKernelGGL(k_push_combine, dim3((dv.m + BLK - 1) / BLK), dim3(BLK), 0, st, dv, which, chunks);
 }
 
 // ------------------------------------------------------------------- K5: primal Harris ratio test
@@ -1291,13 +1295,27 @@ __global__ void __launch_bounds__(BLK) k_btran(DevView v, int n_gather) {
     if ((int)blockIdx.x < n_gather) {
         const int n = c->it.blist_n;
         double sq = 0.0;
+        if (v.lrJ) {
+            // delayed-update mode (large nucleus): four lanes share a slot — up to 20 listed rows plus 32 pending terms are
+            // 52 loads per slot, a serial chain for one lane (fixed summation order: lane-strided, then two shuffles)
+            const int nlow = c->nlow;
+            for (int g4 = blockIdx.x * BLK + threadIdx.x; g4 < 4 * k; g4 += n_gather * BLK) {  // (whole groups of 4 lanes)
+                const int s = g4 >> 2, gl = g4 & 3;
+                double acc = 0.0;
+                for (int j = gl; j < n; j += 4) acc += v.blist_a[j] * v.W[(size_t)v.blist_s[j] * v.ld + s];
+                for (int j = gl; j < nlow; j += 4) acc += c->lr_e[j] * v.V[(size_t)j * v.ld + s];
+                acc += __shfl_xor(acc, 1, 64);
+                acc += __shfl_xor(acc, 2, 64);
+                if (gl == 0) {
+                    v.rK[s] = acc;
+                    v.rv[v.row_of_kslot[s]].x = acc;
+                    sq += acc * acc;
+                }
+            }
+        } else
         for (int s = blockIdx.x * BLK + threadIdx.x; s < k; s += n_gather * BLK) {
             double acc = 0.0;
             for (int j = 0; j < n; ++j) acc += v.blist_a[j] * v.W[(size_t)v.blist_s[j] * v.ld + s];
-            if (v.lrJ) {
-                const int nlow = c->nlow;
-                for (int j = 0; j < nlow; ++j) acc += c->lr_e[j] * v.V[(size_t)j * v.ld + s];
-            }
             v.rK[s] = acc;
             v.rv[v.row_of_kslot[s]].x = acc;
             sq += acc * acc;
@@ -3837,8 +3855,8 @@ void launch_btran_prep(const DevView& dv, int derive_dual, int plan_after, hipSt
     hipLaunchKernelGGL(k_btran_prep, dim3(1), dim3(64), 0, st, dv, derive_dual, plan_after);
 }
 void launch_btran(const DevView& dv, const Geom& g, int with_rhs, hipStream_t st) {
-    int n_gather = blocks_for(g.cap);
-    if (n_gather > 512) n_gather = 512;
+    int n_gather = blocks_for(dv.lrJ ? (long)g.cap * 4 : (long)g.cap);  // delayed-update mode: 4 lanes per slot
+    if (n_gather > (dv.lrJ ? 1024 : 512)) n_gather = dv.lrJ ? 1024 : 512;  // (the reduction buffers hold >= 1024 partials)
 #define BTRAN(G)                                                                                           \
     do {                                                                                                   \
         int n_rhs = with_rhs ? blocks_for((long)g.cap * G) : 0;                                            \
