@@ -1346,10 +1346,9 @@ __global__ void __launch_bounds__(BLK) k_btran(DevView v, int n_gather) {
             if (gl == 0) v.tK[slot] = -acc;
             return;
         }
-        for (int e = v.csc_ptr[var] + gl; e < end; e += G) {
-            int i = v.csc_row[e];
-            if (v.kslot_of_row[i] < 0) acc += v.csc_val[e] * v.rv[i].y;
-        }
+        // (rv.y is zero on the nucleus rows at this point — the update kernel cleared it, v_K is scattered later — so the
+        // entries on nucleus rows add exact zeros and the row-map lookup that would skip them is not needed)
+        for (int e = v.csc_ptr[var] + gl; e < end; e += G) acc += v.csc_val[e] * v.rv[v.csc_row[e]].y;
         acc = group_sum<G>(acc);
         if (gl == 0) v.tK[slot] = v.alpha_q[p] - acc;
     }
@@ -2165,10 +2164,7 @@ __global__ void __launch_bounds__(BLK) k_btran_rhs(DevView v) {
     int var = v.basic_vars[p];
     int end = v.csc_ptr[var + 1];
     double acc = 0.0;
-    for (int e = v.csc_ptr[var] + gl; e < end; e += G) {
-        int i = v.csc_row[e];
-        if (v.kslot_of_row[i] < 0) acc += v.csc_val[e] * v.rv[i].y;
-    }
+    for (int e = v.csc_ptr[var] + gl; e < end; e += G) acc += v.csc_val[e] * v.rv[v.csc_row[e]].y;  // (zero on nucleus rows, see k_btran)
     acc = group_sum<G>(acc);
     if (gl == 0) v.tK[slot] = v.alpha_q[p] - acc;
 }
@@ -3160,16 +3156,16 @@ __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push) {
         }
         for (; t < nstripes; t += 8) s0 += v.part_v[(size_t)t * v.ld + i];
     }
+    if (i < k && v.lrJ && !c->fold) {  // low-rank part of W_eff^T * t_K, spread over the eight stripe groups as well
+        const int nlow = c->nlow;
+        for (int j = grp; j < nlow; j += 8) s1 += v.V[(size_t)j * v.ld + i] * c->lr_h[j];
+    }
     s_part[grp][lane32] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (grp == 0 && i < k) {
         double sv = s_part[0][lane32];
 #pragma unroll
         for (int g2 = 1; g2 < 8; ++g2) sv += s_part[g2][lane32];
-        if (v.lrJ && !c->fold) {  // low-rank part of W_eff^T * t_K
-            const int nlow = c->nlow;
-            for (int j = 0; j < nlow; ++j) sv += v.V[(size_t)j * v.ld + i] * c->lr_h[j];
-        }
         v.vK[i] = sv;
         v.rv[v.row_of_kslot[i]].y = sv;
     }
@@ -3379,7 +3375,9 @@ __global__ void __launch_bounds__(BLK) k_gather_basic_obj(DevView v) {
     if (p < v.m) {
         double cb = v.obj_c[v.basic_vars[p]];
         v.alpha_q[p] = cb;
-        if (v.kslot_of_pos[p] < 0) v.rv[v.srow_of_pos[p]].y = cb / v.sdiag_of_pos[p];
+        const int ks = v.kslot_of_pos[p];
+        if (ks < 0) v.rv[v.srow_of_pos[p]].y = cb / v.sdiag_of_pos[p];
+        else v.rv[v.row_of_kslot[ks]].y = 0.0;  // (the t_K pull adds every entry of a column times rv.y: zero on nucleus rows)
     }
     if (p == 0) {
         v.ctl->it.status = ITER_PIVOT;
