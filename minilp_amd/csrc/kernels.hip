@@ -958,7 +958,13 @@ __global__ void __launch_bounds__(BLK) k_push_combine(DevView v, int which, int 
     const RowInfo ri = v.rowinfo[i];
     if (ri.kslot >= 0) return;
     double s = 0.0;
-    for (int cc = 0; cc < nchunks; ++cc) s += v.push_part[(size_t)cc * v.m + i];
+    for (int c0 = 0; c0 < nchunks; c0 += 8) {  // eight independent loads in flight, summed in chunk order
+        double pp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pp[u] = (c0 + u < nchunks) ? v.push_part[(size_t)(c0 + u) * v.m + i] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += pp[u];
+    }
     if (s != 0.0) {
         double* out = which ? v.tau : v.alpha_q;
         out[ri.pos] -= s / ri.diag;
