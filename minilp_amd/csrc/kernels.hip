@@ -603,32 +603,49 @@ __device__ void ftran_prep_wave(const DevView& v, Ctl* c, int lane, int derive_p
     const int mnlow = (v.gram && derive_primal) ? c->mnlow : 0;
     const double* MVrow = v.gram ? v.MV + (size_t)(lane < mnlow ? lane : 0) * v.ld : nullptr;
     double mlr_acc = 0.0;
-    for (int e0 = base; e0 < end; e0 += 64) {
-        int e = e0 + lane;
-        bool valid = e < end;
-        int s = -1;
-        double a = 0.0;
-        if (valid) {
-            int i = v.csc_row[e];
-            a = v.csc_val[e];
-            s = v.kslot_of_row[i];
-            if (s < 0) {
-                int p = v.pos_of_srow[i];
-                const double dg = v.sdiag_of_pos[p];
-                v.alpha_q[p] = a / dg;
-                if (v.gram && derive_primal) v.hS[i] = a / (dg * dg);
+    // Two chunks of 64 entries per trip, their loads issued together: a 100-entry column is ONE round of the dependent
+    // chain entry -> row -> packed row map (diag, position, slot) instead of two rounds of a four-deep one.
+    for (int e0 = base; e0 < end; e0 += 128) {
+        int sx[2] = {-1, -1};
+        double ax[2] = {0.0, 0.0};
+        int ix[2];
+        bool vx[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = e0 + 64 * h + lane;
+            vx[h] = e < end;
+            ix[h] = vx[h] ? v.csc_row[e] : 0;
+            ax[h] = vx[h] ? v.csc_val[e] : 0.0;
+        }
+        RowInfo rx[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) rx[h] = v.rowinfo[ix[h]];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (vx[h]) {
+                sx[h] = rx[h].kslot;
+                if (sx[h] < 0) {
+                    v.alpha_q[rx[h].pos] = ax[h] / rx[h].diag;
+                    if (v.gram && derive_primal) v.hS[ix[h]] = ax[h] / (rx[h].diag * rx[h].diag);
+                }
             }
         }
-        bool isk = valid && s >= 0;
-        unsigned long long mask = __ballot(isk);
-        if (isk) {
-            int off = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-            v.klist_s[off] = s;
-            v.klist_a[off] = a;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && e0 + 64 >= end) break;  // (uniform)
+            const int s = sx[h];
+            const double a = ax[h];
+            bool isk = vx[h] && s >= 0;
+            unsigned long long mask = __ballot(isk);
+            if (isk) {
+                int off = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+                v.klist_s[off] = s;
+                v.klist_a[off] = a;
+            }
+            cnt += __popcll(mask);
+            if (nlow > 0) lr_dot_listed(mask, s, a, Vrow, lane < nlow, lr_acc);
+            if (mnlow > 0) lr_dot_listed(mask, s, a, MVrow, lane < mnlow, mlr_acc);
         }
-        cnt += __popcll(mask);
-        if (nlow > 0) lr_dot_listed(mask, s, a, Vrow, lane < nlow, lr_acc);
-        if (mnlow > 0) lr_dot_listed(mask, s, a, MVrow, lane < mnlow, mlr_acc);
     }
     if (lane == 0) it->klist_n = cnt;
     if (lane < nlow) c->lr_c[lane] = lr_acc;
@@ -663,27 +680,40 @@ __device__ void btran_prep_wave(const DevView& v, Ctl* c, int lane, int r, int d
         }
         int base = v.csr_ptr[i_r], end = v.csr_ptr[i_r + 1];
         int cnt = 0;
-        for (int e0 = base; e0 < end; e0 += 64) {
-            int e = e0 + lane;
-            bool valid = e < end;
-            int s = -1;
-            double a = 0.0;
-            if (valid) {
-                int loc = v.var_loc[v.csr_col[e]];
-                a = v.csr_val[e];
-                if (loc >= 0) s = v.kslot_of_pos[loc];
+        for (int e0 = base; e0 < end; e0 += 128) {  // two chunks per trip, their three-deep load chains side by side
+            int sx[2] = {-1, -1}, cx[2], lx[2];
+            double ax[2];
+            bool vx[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = e0 + 64 * h + lane;
+                vx[h] = e < end;
+                cx[h] = vx[h] ? v.csr_col[e] : 0;
+                ax[h] = vx[h] ? v.csr_val[e] : 0.0;
             }
-            bool isk = valid && s >= 0;
-            unsigned long long mask = __ballot(isk);
-            const double coef = -a * inv;
-            if (isk) {
-                int off = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-                v.blist_s[off] = s;
-                v.blist_a[off] = coef;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) lx[h] = v.var_loc[cx[h]];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ks = v.kslot_of_pos[lx[h] >= 0 ? lx[h] : 0];
+                if (vx[h] && lx[h] >= 0) sx[h] = ks;
             }
-            cnt += __popcll(mask);
-            // e_j = U[j] . (listed rows): lane j serves pending term j, entries travel by shuffle in list order
-            if (nlow > 0) lr_dot_listed(mask, s, coef, Urow, lane < nlow, lr_acc);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h == 1 && e0 + 64 >= end) break;  // (uniform)
+                const int s = sx[h];
+                bool isk = vx[h] && s >= 0;
+                unsigned long long mask = __ballot(isk);
+                const double coef = -ax[h] * inv;
+                if (isk) {
+                    int off = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+                    v.blist_s[off] = s;
+                    v.blist_a[off] = coef;
+                }
+                cnt += __popcll(mask);
+                // e_j = U[j] . (listed rows): lane j serves pending term j, entries travel by shuffle in list order
+                if (nlow > 0) lr_dot_listed(mask, s, coef, Urow, lane < nlow, lr_acc);
+            }
         }
         if (lane == 0) it->blist_n = cnt;
     }
