@@ -262,6 +262,7 @@ def main():
     # The contract is ONE JSON line on stdout.  Native libraries (Gloo's "Rank 0 is connected ...", RCCL warnings, the HIP
     # runtime) write to file descriptor 1 directly, so fd 1 is pointed at stderr for the whole run and the line goes to
     # a private copy of the original stdout.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL and the peer mailboxes need it on this driver
     sys.stdout.flush()
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)

@@ -7,6 +7,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libminilp_hip.so")
+# the sharded solve maps peer mailboxes through HIP IPC: this driver stack only supports the dmabuf flavour
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 MINIMIZE, MAXIMIZE = 0, 1          # lib.rs:61-68 OptimizationDirection
 EQ, LE, GE = 0, 1, 2               # lib.rs:160-169 ComparisonOp
