@@ -11,7 +11,10 @@ from tests.common import check_feasible, obj_close
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(12345)
 ENVS = [{}, {"MLP_LOWRANK": "3", "MLP_BIGTILE": "1", "MLP_LDPAD": "16", "MLP_BANDED": "1"}, {"MLP_BANDED": "1"},
-        {"MLP_LOWRANK": "16", "MLP_BIGTILE": "1"}, {"MLP_GRAPH_ITERS": "1"}, {"MLP_NO_GRAPH": "1"}]
+        {"MLP_LOWRANK": "16", "MLP_BIGTILE": "1"}, {"MLP_GRAPH_ITERS": "1"}, {"MLP_NO_GRAPH": "1"},
+        {"MLP_LOWRANK": "16", "MLP_BIGTILE": "1", "MLP_LDPAD": "16", "MLP_STREAM_BALANCED": "5"},
+        {"MLP_LOWRANK": "8", "MLP_BIGTILE": "1", "MLP_STREAM_BALANCED": "0"},
+        {"MLP_LOWRANK": "16", "MLP_BIGTILE": "1", "MLP_LDPAD": "16", "MLP_BANDED": "1", "MLP_GRAM": "1"}]
 bad = 0
 t0 = time.time()
 for case in range(n_cases):
