@@ -135,7 +135,7 @@ struct Stats {
     uint64_t gram_backoffs = 0;  // times the monitor tripped right after a rebuild and the streaming pass took over for a while
     double gram_err = 0;         // Gram mode drift monitor: max |a_q.v - ||alpha_q||^2| / (1 + ||alpha_q||^2)
     double gram_rows = 0;        // rows of W0 read by the sparse passes (8 k bytes each)
-    double fold_bytes = 0, fold_ms = 0;  // sampled folds of W0 / M0 in Gram mode (HIP events): read + write of the matrix
+    double fold_bytes = 0, fold_ms = 0;  // sampled folds of W0 (HIP events stamped by the kernel): read + write of the matrix
     uint64_t fold_launches = 0;
     uint64_t kase[5] = {0, 0, 0, 0, 0};  // partition-change cases: nuc->nuc, grow, shrink, col swap, same-row
 };
@@ -332,7 +332,7 @@ private:
     hipGraph_t ggraph[2][2][2] = {};
     Geom ggeom[2][2][2];
     uint64_t graph_batches_in_geom = 0;
-    hipEvent_t ev[11] = {};  // sweep0/1, fused0/1, update0/1, ftran0/1, iteration0/1, end of the folds (Gram mode)
+    hipEvent_t ev[12] = {};  // sweep0/1, W pass0/1, update0/1, ftran0/1, iteration0/1, fold0/1 (kernel-exact: arm_kernel_timing)
     size_t nnz_nucleus_cols();  // non-zeros of the nucleus basic columns (algorithmic bytes of the F products)
     void drop_graphs();
     hipGraphExec_t get_graph(int phase, int multi);

@@ -984,8 +984,8 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         }
         break;
     case STAGE_BASIS:
-        if (with_events) HIPCHECK(hipEventRecord(ev[2], st));
         if (dv.gram && phase == 0 && pse) {
+            if (with_events) HIPCHECK(hipEventRecord(ev[2], st));
             launch_gram_folds(dv, g, st);                     // Gram path: folds of W0 / M0 when due (empty launches otherwise),
             if (with_events) HIPCHECK(hipEventRecord(ev[10], st));
             launch_gram_basis(dv, g, st);                     // sparse pass over W0, v_K assembly
@@ -993,8 +993,15 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
             if (with_events) HIPCHECK(hipEventRecord(ev[3], st));
             break;
         }
+        if (with_events) {  // sampled iteration: the pass over the nucleus inverse and the fold are timed kernel-exactly
+            arm_kernel_timing(2, ev[2], ev[3]);
+            arm_kernel_timing(3, ev[10], ev[11]);
+        }
         launch_fused_w(dv, g, pse, st, wtau);                 // tauK / vK partials + eta update of W
-        if (with_events) HIPCHECK(hipEventRecord(ev[3], st));
+        if (with_events) {
+            arm_kernel_timing(2, nullptr, nullptr);
+            arm_kernel_timing(3, nullptr, nullptr);
+        }
         if (tau_branch) {
             // large-nucleus regime: the blocked push of -F tau_K (two kernels, ~40 us of serial chains) is needed by the
             // update kernel only; it runs on a side branch of the graph next to the tableau-row sweep.  The partition
@@ -1009,15 +1016,10 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         }
         break;
     case STAGE_ROW:
-        if (phase == 0) {
-            if (with_events) HIPCHECK(hipEventRecord(ev[0], st));
-            launch_sweep(dv, g, pse ? 1 : 0, tau_branch ? 0 : 1, st, inl);  // K4 (+ PSE helper in the same pass)  |  partition change
-            if (with_events) HIPCHECK(hipEventRecord(ev[1], st));
-        } else {
-            if (with_events) HIPCHECK(hipEventRecord(ev[0], st));
-            launch_sweep(dv, g, 0, 0, st);                    // K4: alpha_r = rho^T N
-            if (with_events) HIPCHECK(hipEventRecord(ev[1], st));
-        }
+        if (with_events) arm_kernel_timing(1, ev[0], ev[1]);  // sampled iteration: the sweep kernel is timed kernel-exactly
+        if (phase == 0) launch_sweep(dv, g, pse ? 1 : 0, tau_branch ? 0 : 1, st, inl);  // K4 (+ PSE helper in the same pass)  |  partition change
+        else launch_sweep(dv, g, 0, 0, st);                    // K4: alpha_r = rho^T N
+        if (with_events) arm_kernel_timing(1, nullptr, nullptr);
         break;
     case STAGE_APPLY:
         if (phase == 1 && pse) launch_sweep(dv, g, 2, 1, st);  // dual path: PSE helper  |  partition change
@@ -1318,14 +1320,18 @@ int Engine::run_loop(int phase) {
                     stats.fold_launches += (h_ctl->fold ? 1 : 0) + (h_ctl->mfold ? 1 : 0);
                 }
             } else if (k_before > 1 && hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) {
+                // the pass over the nucleus inverse, stamped by the kernel itself: in place it reads and writes W (16 k^2),
+                // in the delayed-update mode it only reads W0 (8 k^2; a rank of the row-sharded pass reads its strips only)
                 stats.fused_ms += ms;
-                // read + write of W; a non-folding pivot of the delayed-update mode only reads it
-                const bool read_only = hview.lrJ > 0 && !h_ctl->fold;
-                // a folding pivot of the large-nucleus mode reads and writes W0 (fold) and then streams it once more
-                const double fold_factor = (hview.lrJ > 0 && geom().big) ? 24.0 : 16.0;
-                const double stream_share = hview.wshard ? 1.0 / shard_world : 1.0;  // row-sharded pass: a rank streams its strips only
-                stats.fused_bytes += (read_only ? 8.0 * stream_share : fold_factor - 8.0 + 8.0 * stream_share) * (double)k_before * (double)k_before;
+                const double stream_share = hview.wshard ? 1.0 / shard_world : 1.0;
+                stats.fused_bytes += (hview.lrJ > 0 ? 8.0 * stream_share : 16.0) * (double)k_before * (double)k_before;
                 stats.fused_launches += 1;
+                float fms = 0.f;
+                if (hview.lrJ > 0 && h_ctl->fold && geom().big && hipEventElapsedTime(&fms, ev[10], ev[11]) == hipSuccess) {
+                    stats.fold_ms += fms;  // this pivot folded first: read + write of W0
+                    stats.fold_bytes += 16.0 * (double)k_before * (double)k_before;
+                    stats.fold_launches += 1;
+                }
             }
             if (hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) {
                 stats.update_ms += ms;

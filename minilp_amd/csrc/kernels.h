@@ -263,6 +263,9 @@ void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t
 void launch_exact_beta(const DevView& dv, hipStream_t st);  // beta_p = ||e_p^T B^-1||^2 for every basic position (lazy dual steepest edge)
 void launch_push_tau(const DevView& dv, hipStream_t st);  // blocked push of -F tau_K alone (runs on a side branch of the graph)  // tau push | v reduce+scatter (classic: partials of k_fused_w's tiling)
 void launch_mail_handshake(const DevView& dv, int* out, hipStream_t st);  // transport self-test at enable_sharding
+// sampled iterations: stamp (t0, t1) at the start / end of the next kernel of a slot (1 tableau-row sweep, 2 pass over the
+// nucleus inverse, 3 fold) instead of bracketing its launch; (nullptr, nullptr) disarms
+void arm_kernel_timing(int slot, hipEvent_t t0, hipEvent_t t1);
 bool stream_strips_enabled();
 int stream_coresident_blocks();  // blocks of the default k_stream_w instance the device holds at once (0: unknown)  // large-nucleus streaming pass in strip form (MLP_STREAM_STRIPS=0 disables)
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st);
