@@ -3321,7 +3321,6 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                         if (inline_comb) {
                             ba = 0.0;
                             for (int b = 0; b < v.nbands; ++b) ba += v.band_part[(size_t)b * (size_t)v.n + t].x;
-                            v.alpha_r[q] = ba;
                         } else {
                             ba = v.alpha_r[q];
                         }
@@ -3356,10 +3355,8 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                             s2 += pb[u].y;
                         }
                     }
-                    ar = s1;
-                    hp = s2;
-                    v.alpha_r[tn] = ar;
-                    if (use_pse) v.helper[tn] = hp;
+                    ar = s1;  // (row_coeffs / the PSE helper are not materialised on this path: nothing reads them — the
+                    hp = s2;  // host-paced stepping API, which exposes them, keeps the separate combine kernel)
                 } else {
                     ar = v.alpha_r[tn];
                     if (use_pse) hp = v.helper[tn];
