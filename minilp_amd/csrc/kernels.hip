@@ -888,7 +888,16 @@ __global__ void __launch_bounds__(BLK) k_push_stage1(DevView v, int which) {
     __shared__ double acc[PB_ROWS];
     __shared__ double s_x[PB_TILE];
     __shared__ int s_beg[PB_TILE], s_len[PB_TILE];
-    const int b = blockIdx.x, cc = blockIdx.y, tid = threadIdx.x;
+    // XCD-aware tile map (speed only): the row blocks of one slot chunk read the same columns — 25 workgroups, ~4 entries
+    // of every column each — so they are placed on ONE XCD (block L runs on XCD L % 8), where the second to 25th reader
+    // of a 128-byte line find it in that XCD's L2.  Needs the number of chunks to be a multiple of 8.
+    int b = blockIdx.x, cc = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {
+        const int L = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y, idx = L >> 3;
+        cc = (L & 7) + 8 * (idx / (int)gridDim.x);
+        b = idx % (int)gridDim.x;
+    }
+    const int tid = threadIdx.x;
     const int row0 = b * PB_ROWS;
     const int nrows = min(PB_ROWS, v.m - row0);
     for (int t = tid; t < nrows; t += BLK) acc[t] = 0.0;
