@@ -254,6 +254,14 @@ private:
     // 200).  The pass therefore visits the positions sorted by the variable they hold; the host rebuilds that order from
     // its mirror of var_loc (O(N)) every `order_every` pivots — a stale order only costs locality, never correctness.
     DevBuf<int> d_nb_order;
+    // packed non-basic copy of the band-major matrix in the locality order (DevView.pk_*), rebuilt with the order
+    DevBuf<int> d_pk_ptr;
+    DevBuf<unsigned short> d_pk_row;
+    DevBuf<double> d_pk_val;
+    DevBuf<unsigned char> d_pk_valid;
+    bool use_pack = true;           // MLP_SWEEP_PACKED=0: the sweep always takes the indirect path through the full copy
+    bool pack_built = false;
+    size_t band_total_ = 0;         // entries of the band-major copy (incl. pad entries)
     bool use_order = true;          // MLP_SWEEP_LOCALITY=0: plain position order
     uint64_t order_built_at = 0;    // lifetime pivot count at the last rebuild
     uint64_t lifetime_pivots = 0;   // (stats can be reset by the caller)

@@ -99,6 +99,9 @@ Engine::Engine() {
     pb_disable = nbp && std::atoi(nbp) != 0;
     const char* ln = std::getenv("MLP_LANES");
     if (ln) lanes_force = std::atoi(ln);
+    if (const char* sp = std::getenv("MLP_SWEEP_PACKED")) use_pack = sp[0] != '0';
+    if (const char* of = std::getenv("MLP_ORDER_FROM")) order_from = (uint64_t)std::atoll(of);    // (tests: locality order from pivot 0,
+    if (const char* oe = std::getenv("MLP_ORDER_EVERY")) order_every = (uint64_t)std::atoll(oe);  //  rebuilt every few pivots)
     const char* sl = std::getenv("MLP_SWEEP_LOCALITY");
     use_order = !(sl && sl[0] == '0');
     const char* lz = std::getenv("MLP_LAZY_DSE");
@@ -330,6 +333,8 @@ void Engine::ensure_banded() {
     HIPCHECK(hipStreamSynchronize(st));
     d_brow.ensure((size_t)total + 8, 0, st);  // + 8: the kernel reads whole groups of 8 entries
     d_bval.ensure((size_t)total + 8, 0, st);
+    band_total_ = (size_t)total;
+    pack_built = false;  // (the packed non-basic copy is derived from this one)
     HIPCHECK(hipMemsetAsync(d_brow.p + total, 0, 8 * sizeof(unsigned short), st));
     HIPCHECK(hipMemsetAsync(d_bval.p + total, 0, 8 * sizeof(double), st));
     launch_band_fill(d_cptr.p, d_crow.p, d_cval.p, N_, nb, d_bptr.p, d_brow.p, d_bval.p, st);
@@ -349,6 +354,32 @@ void Engine::refresh_nb_order(bool force) {
     HIPCHECK(hipStreamSynchronize(st));  // `ord` is a local staging buffer
     order_built_at = lifetime_pivots;
     order_valid = true;
+    // the packed copy of the current non-basic columns in that order (device: lengths -> exclusive scan -> copy)
+    pack_built = false;
+    if (use_pack && band_total_ > 0 && !banded_dirty) {
+        const int nb = (m_ + BAND_ROWS - 1) / BAND_ROWS;
+        const size_t np = (size_t)nb * ((size_t)num_vars + 1);
+        try {
+            d_pk_ptr.ensure(np, 0, st);
+            d_pk_row.ensure(band_total_ + 16, 0, st);
+            d_pk_val.ensure(band_total_ + 16, 0, st);
+            d_pk_valid.ensure((size_t)num_vars, 0, st);
+            d_scan_tmp.ensure(np / 4096 + 8, 0, st);
+        } catch (MlpError&) {  // no room for the second copy: the sweep keeps the indirect path
+            (void)hipGetLastError();
+            use_pack = false;
+            return;
+        }
+        DevView t{};
+        t.m = m_; t.n = num_vars; t.nbands = nb;
+        t.bptr = d_bptr.p; t.brow = d_brow.p; t.bval = d_bval.p;
+        t.nb_vars = d_nb_vars.p; t.nb_order = d_nb_order.p;
+        launch_pack_count(t, d_pk_ptr.p, st);
+        launch_exclusive_scan(d_pk_ptr.p, d_pk_ptr.p, (long)np, d_scan_tmp.p, st);
+        launch_pack_fill(t, d_pk_ptr.p, d_pk_row.p, d_pk_val.p, d_pk_valid.p, st);
+        HIPCHECK(hipStreamSynchronize(st));
+        pack_built = true;
+    }
 }
 
 // Row-block offsets of every column for the blocked F push: colblk[var][b] = first CSC index of column
@@ -391,11 +422,14 @@ DevView* Engine::sync_view() {
     // (while the non-basic positions still hold their original variables the plain position order IS the locality
     // order and the indirection only costs: 96.9 vs 95.1 us per pivot in the benchmark window)
     if (v.banded && use_order && shard_world == 1 && (lifetime_pivots >= order_from || order_force)) {
-        if (!order_valid) refresh_nb_order(true);
+        if (!order_valid || (use_pack && !pack_built)) refresh_nb_order(true);
         v.nb_order = d_nb_order.p;
     } else {
         v.nb_order = nullptr;
     }
+    const bool pk = v.nb_order && use_pack && pack_built;
+    v.pk_ptr = pk ? d_pk_ptr.p : nullptr; v.pk_row = pk ? d_pk_row.p : nullptr; v.pk_val = pk ? d_pk_val.p : nullptr;
+    v.pk_valid = pk ? d_pk_valid.p : nullptr;
     v.pos_of_kslot = d_pos_of_kslot.p; v.row_of_kslot = d_row_of_kslot.p; v.W = d_W.p;
     v.U = d_U.p; v.V = d_V.p;
     // delayed-update period: 32 from capacity 8192 on (the fold's k^2 cost outgrows the O(k J) overheads)
@@ -1253,6 +1287,10 @@ int Engine::run_loop(int phase) {
         }
         sync_view();
         if (hview.nb_order) refresh_nb_order(false);  // every `order_every` pivots (same buffer: captured graphs stay valid)
+        if (hview.nb_order && use_pack && pack_built != (hview.pk_ptr != nullptr)) {  // the packed copy came or went
+            view_dirty = true;
+            sync_view();
+        }
         const bool have_graph = gexec[phase][enable_pse ? 1 : 0][0] != nullptr;
         const bool graph_now = use_graph && !sample && (have_graph || eager_iters_in_geom >= 4);
         if (!have_graph) eager_iters_in_geom += 1;
@@ -2117,7 +2155,7 @@ Engine* Engine::clone() {
     e->h_rptr = h_rptr; e->h_rcol = h_rcol; e->h_rval = h_rval;
     e->h_colnnz = h_colnnz; e->h_single_row = h_single_row; e->h_single_val = h_single_val;
     e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->no_head_fusion = no_head_fusion;
-    e->sw_balanced = sw_balanced; e->gram_enable = gram_enable; e->gram_safe = gram_safe; e->gram_tol = gram_tol; e->gram_min_gap = gram_min_gap; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
+    e->sw_balanced = sw_balanced; e->gram_enable = gram_enable; e->gram_safe = gram_safe; e->gram_tol = gram_tol; e->gram_min_gap = gram_min_gap; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->use_pack = use_pack; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
     e->h_basic_vars = h_basic_vars; e->h_nb_vars = h_nb_vars; e->h_var_loc = h_var_loc;
     e->h_kslot_of_pos = h_kslot_of_pos; e->h_srow_of_pos = h_srow_of_pos; e->h_kslot_of_row = h_kslot_of_row;
     e->h_pos_of_srow = h_pos_of_srow; e->h_sdiag_of_pos = h_sdiag_of_pos; e->h_nb_fixed = h_nb_fixed;

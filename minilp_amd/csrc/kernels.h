@@ -139,6 +139,14 @@ struct DevView {
     int* nb_vars; double* d; double* xN; double* gamma; uint8_t* nbflags;
     int2* nb_rng;  // n: CSC [begin, end) of the column at each non-basic position (cache of csc_ptr[nb_vars[c]])
     const int* nb_order;  // n or null: locality order of the banded sweep (positions sorted by the variable they hold)
+    // Packed copy of the band-major matrix for the CURRENT non-basic set, in the locality order (rebuilt with it): index
+    // i of the pass reads its segments front to back — no holes where basic variables sit, no position -> variable ->
+    // offset chain.  pk_valid[i] is cleared by the update kernel when the position served by i changes its variable
+    // (at most one per pivot until the next rebuild); those indices take the indirect path.
+    const int* pk_ptr;             // nbands x (n + 1) offsets, or null
+    const unsigned short* pk_row;
+    const double* pk_val;
+    unsigned char* pk_valid;       // n
     // basis inverse: singleton split + dense nucleus inverse W
     int* kslot_of_pos;     // m: row slot of W for a nucleus position, -1 for a singleton position
     int* srow_of_pos;      // m: the row of the single entry of a singleton basic column
@@ -297,6 +305,9 @@ void launch_csc_append_row(const int* optr, const int* orow, const double* oval,
                            const double* nvals, int kn, int* nptr, int* nrow, double* nval, hipStream_t st);
 void launch_exclusive_scan(const int* in, int* out, long n, int* sums, hipStream_t st);  // sums: ceil(n / 4096) + 1 ints; sums[last] = total
 void launch_band_count(const int* cptr, const int* crow, int N, int nbands, int* cnt, hipStream_t st);
+// packed non-basic copy of the banded sweep: segment lengths by index of the pass (then an exclusive scan), then the copy
+void launch_pack_count(const DevView& dv, int* cnt, hipStream_t st);
+void launch_pack_fill(const DevView& dv, const int* pkptr, unsigned short* prow, double* pval, unsigned char* valid, hipStream_t st);
 void launch_band_fill(const int* cptr, const int* crow, const double* cval, int N, int nbands, const int* bptr, unsigned short* brow,
                       double* bval, hipStream_t st);
 void launch_build_colblk(const int* cptr, const int* crow, int N, int rb, int* colblk, hipStream_t st);

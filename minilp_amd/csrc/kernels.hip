@@ -1933,12 +1933,21 @@ __global__ void __launch_bounds__(BAND_THREADS) k_sweep_band(DevView v, int chun
     constexpr int CPT = 4;  // columns per thread resolved together: their index chains overlap
     for (int j0 = c_lo + tid; j0 < c_hi; j0 += CPT * BAND_THREADS) {
     int vars[CPT], poss[CPT], begs[CPT], ends[CPT];
+    bool pkd[CPT];
+    const int* pkp = (!VORD && v.pk_ptr) ? v.pk_ptr + (size_t)b * (size_t)(v.n + 1) : nullptr;
 #pragma unroll
     for (int u = 0; u < CPT; ++u) {
         const int i = j0 + u * BAND_THREADS;
         vars[u] = -1;
         poss[u] = -1;
+        pkd[u] = false;
         if (i < c_hi) {
+            if (!VORD && pkp && v.pk_valid[i]) {  // packed copy: the segment of index i, straight from its offsets
+                pkd[u] = true;
+                vars[u] = 0;
+                poss[u] = i;
+                continue;
+            }
             if (VORD) {
                 const int loc = v.var_loc[i];
                 if (loc < 0) {  // non-basic: position -1 - loc
@@ -1955,25 +1964,32 @@ __global__ void __launch_bounds__(BAND_THREADS) k_sweep_band(DevView v, int chun
     }
 #pragma unroll
     for (int u = 0; u < CPT; ++u) {
-        begs[u] = vars[u] >= 0 ? bp[vars[u]] : 0;
-        ends[u] = vars[u] >= 0 ? bp[vars[u] + 1] : 0;
+        if (pkd[u]) {
+            begs[u] = pkp[poss[u]];
+            ends[u] = pkp[poss[u] + 1];
+        } else {
+            begs[u] = vars[u] >= 0 ? bp[vars[u]] : 0;
+            ends[u] = vars[u] >= 0 ? bp[vars[u] + 1] : 0;
+        }
     }
 #pragma unroll
     for (int u = 0; u < CPT; ++u) {
         if (vars[u] < 0) continue;
         const int j = poss[u];
         const int beg = begs[u], end = ends[u];
+        const unsigned short* __restrict__ Rw = pkd[u] ? v.pk_row : v.brow;
+        const double* __restrict__ Vl = pkd[u] ? v.pk_val : v.bval;
         double a1 = 0.0, a2 = 0.0;
         for (int e0 = beg; e0 < end; e0 += 8) {
             // Eight entries per step as 1 + 4 sixteen-byte loads per lane (a lane's entries are contiguous;
             // eight scalar loads each touch 64 different lines per wave and the kernel becomes bound by the
             // texture-address unit: 35.5 us).  Reading past `end` is harmless: the arrays carry 8 spare
             // entries, a neighbour's rows are valid indices of this band, and the values are masked.
-            const uint4u rr = *reinterpret_cast<const uint4u*>(v.brow + e0);  // eight 16-bit rows; e0 is even
-            const dbl2u x0 = *reinterpret_cast<const dbl2u*>(v.bval + e0);
-            const dbl2u x1 = *reinterpret_cast<const dbl2u*>(v.bval + e0 + 2);
-            const dbl2u x2 = *reinterpret_cast<const dbl2u*>(v.bval + e0 + 4);
-            const dbl2u x3 = *reinterpret_cast<const dbl2u*>(v.bval + e0 + 6);
+            const uint4u rr = *reinterpret_cast<const uint4u*>(Rw + e0);  // eight 16-bit rows; e0 is even
+            const dbl2u x0 = *reinterpret_cast<const dbl2u*>(Vl + e0);
+            const dbl2u x1 = *reinterpret_cast<const dbl2u*>(Vl + e0 + 2);
+            const dbl2u x2 = *reinterpret_cast<const dbl2u*>(Vl + e0 + 4);
+            const dbl2u x3 = *reinterpret_cast<const dbl2u*>(Vl + e0 + 6);
             const unsigned r[8] = {rr.x & 0xffffu, rr.x >> 16, rr.y & 0xffffu, rr.y >> 16,
                                    rr.z & 0xffffu, rr.z >> 16, rr.w & 0xffffu, rr.w >> 16};
             double a[8] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y, x3.x, x3.y};
@@ -3344,6 +3360,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                         v.gamma[q] = gm;
                     }
                     v.nb_vars[q] = lv;
+                    if (v.pk_valid) v.pk_valid[t] = 0;  // index t of the pass serves position q: its packed segment is stale now
                     v.nb_rng[q] = make_int2(v.csc_ptr[lv], v.csc_ptr[lv + 1]);
                     v.xN[q] = lnv;
                     f = (uint8_t)((lnv == v.var_lo[lv] ? NB_AT_MIN : 0) | (lnv == v.var_hi[lv] ? NB_AT_MAX : 0));
@@ -3813,6 +3830,41 @@ void launch_band_count(const int* cptr, const int* crow, int N, int nbands, int*
 void launch_band_fill(const int* cptr, const int* crow, const double* cval, int N, int nbands, const int* bptr, unsigned short* brow,
                       double* bval, hipStream_t st) {
     hipLaunchKernelGGL(k_band_fill, dim3(blocks_for(N)), dim3(BLK), 0, st, cptr, crow, cval, N, nbands, bptr, brow, bval);
+}
+// Packed non-basic copy (DevView.pk_*): one thread per (band, index of the pass)
+__global__ void __launch_bounds__(BLK) k_pack_count(DevView v, int* __restrict__ cnt) {
+    const long g = (long)blockIdx.x * BLK + threadIdx.x;
+    const int n1 = v.n + 1;
+    if (g >= (long)v.nbands * n1) return;
+    const int b = (int)(g / n1), i = (int)(g % n1);
+    int len = 0;
+    if (i < v.n) {
+        const int var = v.nb_vars[v.nb_order[i]];
+        const int* bp = v.bptr + (size_t)b * (size_t)(v.m + v.n + 1);
+        len = bp[var + 1] - bp[var];
+    }
+    cnt[g] = len;
+}
+__global__ void __launch_bounds__(BLK) k_pack_fill(DevView v, const int* __restrict__ pkptr, unsigned short* __restrict__ prow,
+                                                    double* __restrict__ pval, unsigned char* __restrict__ valid) {
+    const long g = (long)blockIdx.x * BLK + threadIdx.x;
+    if (g >= (long)v.nbands * v.n) return;
+    const int b = (int)(g / v.n), i = (int)(g % v.n);
+    const int var = v.nb_vars[v.nb_order[i]];
+    const int* bp = v.bptr + (size_t)b * (size_t)(v.m + v.n + 1);
+    const int beg = bp[var], end = bp[var + 1];
+    int dst = pkptr[(size_t)b * (size_t)(v.n + 1) + i];
+    for (int e = beg; e < end; ++e, ++dst) {
+        prow[dst] = v.brow[e];
+        pval[dst] = v.bval[e];
+    }
+    if (b == 0) valid[i] = 1;
+}
+void launch_pack_count(const DevView& dv, int* cnt, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_count, dim3(blocks_for((long)dv.nbands * (dv.n + 1))), dim3(BLK), 0, st, dv, cnt);
+}
+void launch_pack_fill(const DevView& dv, const int* pkptr, unsigned short* prow, double* pval, unsigned char* valid, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_fill, dim3(blocks_for((long)dv.nbands * dv.n)), dim3(BLK), 0, st, dv, pkptr, prow, pval, valid);
 }
 // Row-block offsets of every column for the blocked F push: colblk[var][b] = first CSC index of column var whose row is
 // >= b * PB_ROWS, colblk[var][rb] = end of the column.
