@@ -259,15 +259,6 @@ private:
     DevBuf<unsigned short> d_pk_row;
     DevBuf<double> d_pk_val;
     DevBuf<unsigned char> d_pk_valid;
-    // packed copy of the nucleus columns for the blocked F push (DevView.pf_*), rebuilt every pf_every pivots
-    DevBuf<int> d_pf_ptr;
-    DevBuf<unsigned short> d_pf_row;
-    DevBuf<double> d_pf_val;
-    DevBuf<unsigned char> d_pf_valid;
-    bool use_pushpack = true;       // MLP_PUSH_PACKED=0: the push always chases slot -> position -> variable -> offsets
-    bool pf_built = false;
-    uint64_t pf_built_at = 0, pf_every = 2048;
-    void rebuild_pushpack();
     bool use_pack = true;           // MLP_SWEEP_PACKED=0: the sweep always takes the indirect path through the full copy
     bool pack_built = false;
     size_t band_total_ = 0;         // entries of the band-major copy (incl. pad entries)

@@ -100,8 +100,6 @@ Engine::Engine() {
     const char* ln = std::getenv("MLP_LANES");
     if (ln) lanes_force = std::atoi(ln);
     if (const char* sp = std::getenv("MLP_SWEEP_PACKED")) use_pack = sp[0] != '0';
-    if (const char* pp = std::getenv("MLP_PUSH_PACKED")) use_pushpack = pp[0] != '0';
-    if (const char* pe = std::getenv("MLP_PUSH_PACK_EVERY")) pf_every = (uint64_t)std::atoll(pe);
     if (const char* of = std::getenv("MLP_ORDER_FROM")) order_from = (uint64_t)std::atoll(of);    // (tests: locality order from pivot 0,
     if (const char* oe = std::getenv("MLP_ORDER_EVERY")) order_every = (uint64_t)std::atoll(oe);  //  rebuilt every few pivots)
     const char* sl = std::getenv("MLP_SWEEP_LOCALITY");
@@ -393,35 +391,6 @@ void Engine::ensure_colblk() {
     launch_build_colblk(d_cptr.p, d_crow.p, N_, rb, d_colblk.p, st);  // on the device, from the CSC
     d_push_part.ensure((size_t)PB_CHUNKS * (size_t)m_, 0, st);
     colblk_dirty = false;
-    pf_built = false;  // (the packed copy of the push is derived from this table)
-}
-// Packed copy of the current nucleus columns for the blocked F push: lengths per (row block, slot) from the row-block
-// table -> exclusive scan -> copy, all on the device; < 0.3 ms at k = 20 000.
-void Engine::rebuild_pushpack() {
-    pf_built = false;
-    if (!use_pushpack || !hview.pb_on || cap_ <= 0 || colblk_dirty) return;
-    const int rb = (m_ + PB_ROWS - 1) / PB_ROWS;
-    const size_t np = (size_t)rb * ((size_t)cap_ + 1);
-    const size_t total = nnz_nucleus_cols() + 16;
-    try {
-        d_pf_ptr.ensure(np, 0, st);
-        d_pf_row.ensure(total, 0, st);
-        d_pf_val.ensure(total, 0, st);
-        d_pf_valid.ensure((size_t)cap_, 0, st);
-        d_scan_tmp.ensure(np / 4096 + 8, 0, st);
-    } catch (MlpError&) {
-        (void)hipGetLastError();
-        use_pushpack = false;
-        return;
-    }
-    DevView t = hview;
-    t.pf_ld = cap_ + 1;
-    launch_pushpack_count(t, d_pf_ptr.p, st);
-    launch_exclusive_scan(d_pf_ptr.p, d_pf_ptr.p, (long)np, d_scan_tmp.p, st);
-    launch_pushpack_fill(t, d_pf_ptr.p, d_pf_row.p, d_pf_val.p, d_pf_valid.p, st);
-    HIPCHECK(hipStreamSynchronize(st));
-    pf_built = true;
-    pf_built_at = lifetime_pivots;
 }
 
 DevView* Engine::sync_view() {
@@ -442,12 +411,6 @@ DevView* Engine::sync_view() {
     v.colblk = v.pb_on ? d_colblk.p : nullptr;
     v.push_part = v.pb_on ? d_push_part.p : nullptr;
     v.pb_rb = (m_ + PB_ROWS - 1) / PB_ROWS;
-    {
-        const bool pf = v.pb_on && use_pushpack && pf_built && d_pf_valid.cap >= (size_t)cap_;
-        v.pf_ptr = pf ? d_pf_ptr.p : nullptr; v.pf_row = pf ? d_pf_row.p : nullptr; v.pf_val = pf ? d_pf_val.p : nullptr;
-        v.pf_valid = pf ? d_pf_valid.p : nullptr;
-        v.pf_ld = pf ? cap_ + 1 : 0; v.pf_pad = 0;
-    }
     v.det_pull = (!v.pb_on && (det_mode == 1 || (det_mode < 0 && h_rcol.size() <= ((size_t)1 << 21)))) ? 1 : 0;
     v.banded = use_banded() ? 1 : 0;
     if (v.banded) ensure_banded();
@@ -615,7 +578,6 @@ void Engine::ensure_nucleus_cap(int need) {
     d_V.ensure((size_t)LR_MAX * nld, 0, st);
     cap_ = ncap;
     view_dirty = true;
-    pf_built = false;    // (offset table of the packed push copy has a row pitch of cap + 1)
     gram_valid = false;  // M is re-allocated with the new pitch and rebuilt from W
     d_M.release(); d_MU.release(); d_MV.release(); d_mK.release();
 }
@@ -655,8 +617,6 @@ void Engine::pull_maps() {
     HIPCHECK(hipStreamSynchronize(st));
 }
 void Engine::push_maps() {
-    pf_built = false;  // slots are renumbered: the packed copy of the push is stale
-    view_dirty = true;
     d_kslot_of_pos.upload(h_kslot_of_pos, st); d_srow_of_pos.upload(h_srow_of_pos, st);
     d_sdiag_of_pos.upload(h_sdiag_of_pos, st);
     d_kslot_of_row.upload(h_kslot_of_row, st); d_pos_of_srow.upload(h_pos_of_srow, st);
@@ -1352,13 +1312,6 @@ int Engine::run_loop(int phase) {
         ensure_nucleus_cap(k_ + B + 1);
         sync_view();
         if (hview.gram && !gram_valid) gram_rebuild();
-        if (hview.pb_on && use_pushpack && (!pf_built || lifetime_pivots - pf_built_at >= pf_every)) {
-            rebuild_pushpack();
-            if (pf_built != (hview.pf_ptr != nullptr) ||
-                (pf_built && (hview.pf_ptr != d_pf_ptr.p || hview.pf_row != d_pf_row.p || hview.pf_val != d_pf_val.p)))
-                view_dirty = true;
-            if (view_dirty) sync_view();
-        }
         const DevView& dv = hview;
         launch_reset_ring(dv, st);
         launch_clear_work(dv, st);
@@ -2202,7 +2155,7 @@ Engine* Engine::clone() {
     e->h_rptr = h_rptr; e->h_rcol = h_rcol; e->h_rval = h_rval;
     e->h_colnnz = h_colnnz; e->h_single_row = h_single_row; e->h_single_val = h_single_val;
     e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->no_head_fusion = no_head_fusion;
-    e->sw_balanced = sw_balanced; e->gram_enable = gram_enable; e->gram_safe = gram_safe; e->gram_tol = gram_tol; e->gram_min_gap = gram_min_gap; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->use_pack = use_pack; e->use_pushpack = use_pushpack; e->pf_every = pf_every; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
+    e->sw_balanced = sw_balanced; e->gram_enable = gram_enable; e->gram_safe = gram_safe; e->gram_tol = gram_tol; e->gram_min_gap = gram_min_gap; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->use_pack = use_pack; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
     e->h_basic_vars = h_basic_vars; e->h_nb_vars = h_nb_vars; e->h_var_loc = h_var_loc;
     e->h_kslot_of_pos = h_kslot_of_pos; e->h_srow_of_pos = h_srow_of_pos; e->h_kslot_of_row = h_kslot_of_row;
     e->h_pos_of_srow = h_pos_of_srow; e->h_sdiag_of_pos = h_sdiag_of_pos; e->h_nb_fixed = h_nb_fixed;

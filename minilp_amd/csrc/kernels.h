@@ -158,15 +158,6 @@ struct DevView {
     // PB_ROWS rows starts (N x (pb_rb + 1)), and PB_CHUNKS x m partial sums
     int* colblk;
     double* push_part;
-    // Packed copy of the nucleus columns for the blocked F push, (row block, slot)-major: the workgroup of (block b, slot
-    // chunk) reads ONE contiguous run of offsets and entries instead of chasing slot -> position -> variable -> offsets
-    // into 25 scattered pieces of every column.  Rebuilt every few thousand pivots; a slot whose column has changed
-    // since (struct_update_body clears pf_valid) takes the indirect path.
-    const int* pf_ptr;             // pb_rb x pf_ld offsets, or null
-    const unsigned short* pf_row;  // row inside the block (PB_ROWS <= 65 536)
-    const double* pf_val;
-    unsigned char* pf_valid;       // cap
-    int pf_ld, pf_pad;
     int pb_rb, pb_on;
     // banded tableau-row sweep (large m): a second copy of A in band-major order (bands of BAND_ROWS rows;
     // per band a CSC with 16-bit local row indices), so that a workgroup can hold its band of (rho, v) in LDS
@@ -315,8 +306,6 @@ void launch_csc_append_row(const int* optr, const int* orow, const double* oval,
 void launch_exclusive_scan(const int* in, int* out, long n, int* sums, hipStream_t st);  // sums: ceil(n / 4096) + 1 ints; sums[last] = total
 void launch_band_count(const int* cptr, const int* crow, int N, int nbands, int* cnt, hipStream_t st);
 // packed non-basic copy of the banded sweep: segment lengths by index of the pass (then an exclusive scan), then the copy
-void launch_pushpack_count(const DevView& dv, int* cnt, hipStream_t st);   // packed copy of the blocked F push (DevView.pf_*)
-void launch_pushpack_fill(const DevView& dv, const int* ptr, unsigned short* prow, double* pval, unsigned char* valid, hipStream_t st);
 void launch_pack_count(const DevView& dv, int* cnt, hipStream_t st);
 void launch_pack_fill(const DevView& dv, const int* pkptr, unsigned short* prow, double* pval, unsigned char* valid, hipStream_t st);
 void launch_band_fill(const int* cptr, const int* crow, const double* cval, int N, int nbands, const int* bptr, unsigned short* brow,

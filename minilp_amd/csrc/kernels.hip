@@ -887,7 +887,7 @@ __global__ void __launch_bounds__(BLK) k_push_stage1(DevView v, int which) {
     if (c->halt || c->it.status != ITER_PIVOT) return;
     __shared__ double acc[PB_ROWS];
     __shared__ double s_x[PB_TILE];
-    __shared__ int s_beg[PB_TILE], s_len[PB_TILE];  // (s_len < 0: -len - 1 of a segment of the PACKED copy)
+    __shared__ int s_beg[PB_TILE], s_len[PB_TILE];
     // XCD-aware tile map (speed only): the row blocks of one slot chunk read the same columns — 25 workgroups, ~4 entries
     // of every column each — so they are placed on ONE XCD (block L runs on XCD L % 8), where the second to 25th reader
     // of a 128-byte line find it in that XCD's L2.  Needs the number of chunks to be a multiple of 8.
@@ -915,18 +915,11 @@ __global__ void __launch_bounds__(BLK) k_push_stage1(DevView v, int which) {
         for (int t = tid; t < nt; t += BLK) {
             const int slot = tile0 + t;
             const double x = xK[slot];
+            const int var = v.basic_vars[v.pos_of_kslot[slot]];
+            const int beg = v.colblk[(size_t)var * stride + b], end = v.colblk[(size_t)var * stride + b + 1];
             s_x[t] = x;
-            if (v.pf_ptr && v.pf_valid[slot]) {  // packed copy: offsets of (block b, slot) lie side by side
-                const int* pp = v.pf_ptr + (size_t)b * (size_t)v.pf_ld + slot;
-                const int beg = pp[0], end = pp[1];
-                s_beg[t] = beg;
-                s_len[t] = (x != 0.0) ? -(end - beg) - 1 : 0;
-            } else {
-                const int var = v.basic_vars[v.pos_of_kslot[slot]];
-                const int beg = v.colblk[(size_t)var * stride + b], end = v.colblk[(size_t)var * stride + b + 1];
-                s_beg[t] = beg;
-                s_len[t] = (x != 0.0) ? end - beg : 0;
-            }
+            s_beg[t] = beg;
+            s_len[t] = (x != 0.0) ? end - beg : 0;
         }
         __syncthreads();
         // phase B: four slots per 8-lane group in flight (independent loads), then the LDS atomics
@@ -936,15 +929,13 @@ __global__ void __launch_bounds__(BLK) k_push_stage1(DevView v, int which) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int t = base + j;
-                const int sl = t < nt ? s_len[t] : 0;
-                const bool pk = sl < 0;
-                const int len = pk ? -sl - 1 : sl;
+                const int len = t < nt ? s_len[t] : 0;
                 r[j] = -1;
                 a[j] = 0.0;
                 if (lane < len) {
                     const int e = s_beg[t] + lane;
-                    r[j] = pk ? (int)v.pf_row[e] : v.csc_row[e] - row0;
-                    a[j] = (pk ? v.pf_val[e] : v.csc_val[e]) * s_x[t];
+                    r[j] = v.csc_row[e] - row0;
+                    a[j] = v.csc_val[e] * s_x[t];
                 }
             }
 #pragma unroll
@@ -953,13 +944,10 @@ __global__ void __launch_bounds__(BLK) k_push_stage1(DevView v, int which) {
 #pragma unroll 1
             for (int j = 0; j < 4; ++j) {  // segments longer than 8 entries (rare)
                 const int t = base + j;
-                const int sl = t < nt ? s_len[t] : 0;
-                const bool pk = sl < 0;
-                const int len = pk ? -sl - 1 : sl;
+                const int len = t < nt ? s_len[t] : 0;
                 for (int o = 8 + lane; o < len; o += 8) {
                     const int e = s_beg[t] + o;
-                    if (pk) unsafeAtomicAdd(&acc[v.pf_row[e]], v.pf_val[e] * s_x[t]);
-                    else unsafeAtomicAdd(&acc[v.csc_row[e] - row0], v.csc_val[e] * s_x[t]);
+                    unsafeAtomicAdd(&acc[v.csc_row[e] - row0], v.csc_val[e] * s_x[t]);
                 }
             }
         }
@@ -1782,11 +1770,6 @@ __device__ __forceinline__ void struct_update_body(const DevView& v, Ctl* c, int
     if (u.kase < 0) return;
     if (v.lrJ) lowrank_append(v, c, u, s);
     if (v.gram) gram_update(v, c, u, s);
-    if (v.pf_valid && s == 0) {  // packed copy of the F push: the slots whose column changes at this pivot go stale
-        if (u.kase == 0 || u.kase == 2) v.pf_valid[u.sr] = 0;  // replaced column / the last slot's column moves in
-        if (u.kase == 1) v.pf_valid[u.kold] = 0;                // new slot (may have been in use at the last rebuild)
-        if (u.kase == 2) v.pf_valid[u.kold - 1] = 0;
-    }
     if (u.kase == 0) return;
     const int kold = u.kold;
     const int ld = v.ld;
@@ -3847,43 +3830,6 @@ void launch_band_count(const int* cptr, const int* crow, int N, int nbands, int*
 void launch_band_fill(const int* cptr, const int* crow, const double* cval, int N, int nbands, const int* bptr, unsigned short* brow,
                       double* bval, hipStream_t st) {
     hipLaunchKernelGGL(k_band_fill, dim3(blocks_for(N)), dim3(BLK), 0, st, cptr, crow, cval, N, nbands, bptr, brow, bval);
-}
-// Packed copy of the nucleus columns for the blocked F push (DevView.pf_*): one thread per (row block, slot)
-__global__ void __launch_bounds__(BLK) k_pushpack_count(DevView v, int* __restrict__ cnt) {
-    const long g = (long)blockIdx.x * BLK + threadIdx.x;
-    if (g >= (long)v.pb_rb * v.pf_ld) return;
-    const int b = (int)(g / v.pf_ld), s = (int)(g % v.pf_ld);
-    int len = 0;
-    if (s < v.ctl->k) {
-        const int var = v.basic_vars[v.pos_of_kslot[s]];
-        const int* cb = v.colblk + (size_t)var * (size_t)(v.pb_rb + 1) + b;
-        len = cb[1] - cb[0];
-    }
-    cnt[g] = len;
-}
-__global__ void __launch_bounds__(BLK) k_pushpack_fill(DevView v, const int* __restrict__ ptr, unsigned short* __restrict__ prow,
-                                                        double* __restrict__ pval, unsigned char* __restrict__ valid) {
-    const long g = (long)blockIdx.x * BLK + threadIdx.x;
-    if (g >= (long)v.pb_rb * v.pf_ld) return;
-    const int b = (int)(g / v.pf_ld), s = (int)(g % v.pf_ld);
-    if (s >= v.pf_ld - 1) return;  // (the last column of the offset table is the end marker)
-    const bool live = s < v.ctl->k;
-    if (b == 0) valid[s] = live ? 1 : 0;
-    if (!live) return;
-    const int var = v.basic_vars[v.pos_of_kslot[s]];
-    const int* cb = v.colblk + (size_t)var * (size_t)(v.pb_rb + 1) + b;
-    const int row0 = b * PB_ROWS;
-    int dst = ptr[g];
-    for (int e = cb[0]; e < cb[1]; ++e, ++dst) {
-        prow[dst] = (unsigned short)(v.csc_row[e] - row0);
-        pval[dst] = v.csc_val[e];
-    }
-}
-void launch_pushpack_count(const DevView& dv, int* cnt, hipStream_t st) {
-    hipLaunchKernelGGL(k_pushpack_count, dim3(blocks_for((long)dv.pb_rb * dv.pf_ld)), dim3(BLK), 0, st, dv, cnt);
-}
-void launch_pushpack_fill(const DevView& dv, const int* ptr, unsigned short* prow, double* pval, unsigned char* valid, hipStream_t st) {
-    hipLaunchKernelGGL(k_pushpack_fill, dim3(blocks_for((long)dv.pb_rb * dv.pf_ld)), dim3(BLK), 0, st, dv, ptr, prow, pval, valid);
 }
 // Packed non-basic copy (DevView.pk_*): one thread per (band, index of the pass)
 __global__ void __launch_bounds__(BLK) k_pack_count(DevView v, int* __restrict__ cnt) {

@@ -112,27 +112,3 @@ def test_stream_strip_geometry_does_not_change_the_pivots(balanced):
     finally:
         for k in env:
             os.environ.pop(k, None)
-
-
-@pytest.mark.parametrize("every", ["1", "7", "100000"])
-def test_packed_copy_of_the_blocked_push_keeps_the_pivots(every):
-    """Blocked F push of the large-nucleus regime: the packed (row block, slot)-major copy of the nucleus columns is
-    rebuilt after every batch (1), every 7 pivots, or only once (slots that change afterwards take the indirect path)."""
-    env = {"MLP_LOWRANK": "16", "MLP_BIGTILE": "1", "MLP_LDPAD": "16", "MLP_BANDED": "1", "MLP_PUSH_PACK_EVERY": every}
-    os.environ.update(env)
-    try:
-        for fam, kw in (("sparse", dict(m=700, n=600, k=12, seed=6)), ("mixed", dict(m=300, n=400, k=8, seed=4)),
-                        ("twophase", dict(m=400, n=400, k=14, seed=35))):
-            lp = GEN[fam](**kw)
-            so = lpgen.build_problem(O.Problem, lp).solve(trace=True)
-            sg = lpgen.build_problem(M.Problem, lp).solve(trace=True)
-            assert obj_close(sg.objective(), so.objective())
-            if fam != "mixed":   # (degenerate family: ties may break differently with the LDS atomics of the push)
-                assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
-            assert sg.reinvert() < 1e-8
-        os.environ["MLP_PUSH_PACKED"] = "0"
-        s0 = lpgen.build_problem(M.Problem, lp).solve(trace=True)
-        assert obj_close(s0.objective(), so.objective())
-    finally:
-        for k in list(env) + ["MLP_PUSH_PACKED"]:
-            os.environ.pop(k, None)

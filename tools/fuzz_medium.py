@@ -17,9 +17,7 @@ ENVS = [{}, {"MLP_LOWRANK": "3", "MLP_BIGTILE": "1", "MLP_LDPAD": "16", "MLP_BAN
         {"MLP_LOWRANK": "16", "MLP_BIGTILE": "1", "MLP_LDPAD": "16", "MLP_BANDED": "1", "MLP_GRAM": "1"},
         {"MLP_BANDED": "1", "MLP_ORDER_FROM": "0", "MLP_ORDER_EVERY": "5"},
         {"MLP_BANDED": "1", "MLP_ORDER_FROM": "0", "MLP_ORDER_EVERY": "64", "MLP_LOWRANK": "8", "MLP_BIGTILE": "1"},
-        {"MLP_BANDED": "1", "MLP_ORDER_FROM": "3", "MLP_ORDER_EVERY": "11", "MLP_SWEEP_PACKED": "0"},
-        {"MLP_LOWRANK": "16", "MLP_BIGTILE": "1", "MLP_PUSH_PACK_EVERY": "3"},
-        {"MLP_BIGTILE": "1", "MLP_PUSH_PACK_EVERY": "1", "MLP_BANDED": "1", "MLP_ORDER_FROM": "0", "MLP_ORDER_EVERY": "9"}]
+        {"MLP_BANDED": "1", "MLP_ORDER_FROM": "3", "MLP_ORDER_EVERY": "11", "MLP_SWEEP_PACKED": "0"}]
 bad = 0
 t0 = time.time()
 for case in range(n_cases):
