@@ -7,13 +7,19 @@ basis-inverse update -> x_B/d/gamma/beta updates) of the device-resident solver.
 
 `value` (the driver-timed figure): W warm-up pivots from the slack basis, then exactly K timed pivots
 bracketed by barrier + synchronize.  That window is the cheapest stretch of a 1.09 M-pivot solve, so the
-same JSON line also carries (N = 1, rank 0, outside the timed region):
-  * `windows.mid` / `windows.late`: a fixed number of pivots from the two committed MID-SOLVE bases of the same
+same JSON line also carries (N = 1, rank 0, outside the timed region; every object says whether it was measured
+LIVE by this run or read from a COMMITTED file):
+  * `windows.mid` / `windows.late` (live): a fixed number of pivots from the two committed MID-SOLVE bases of the same
     instance (tests/golden/cfg4_basis_p*.bin.gz, nucleus ~10 000 and ~20 000: where the solve spends its time),
     each with pivots/s, us per pivot and per-kernel bytes / GB/s / fraction of the HBM roofline;
-  * `roofline.ftran`: the FTRAN entries north_star asks for;
-  * `full_solve`: total solve wall time of the last full run of config 4 (profiles/, with its commit);
-  * `cpu_baseline`: the oracle timed on the host cores.
+  * `roofline.ftran` (live): the column FTRAN alpha_q = B^-1 a_q in us and bytes touched (a latency-bound gather of a few
+    columns of the explicit nucleus inverse: a bandwidth fraction is the wrong yardstick for it), and the one
+    FTRAN-shaped solve that IS a stream: the dense-rhs x_B = B^-1 (b - N x_N) of the polish step
+    (mlp_solution_recompute_basic_values), one read of the nucleus inverse through k_stream_w's tau side;
+  * `full_solve` (live): BASELINE.json's "total solve wall-time" — the timed solve is continued to optimality in chunks
+    of 50 000 pivots under a wall guard, and the optimum is certified on the box by weak duality (scipy mat-vecs);
+  * `cpu_baseline` (live): the oracle timed on the host cores over the SAME pivots as `value` (and over pivots
+    200..700, its fastest sustained stretch).
 N > 1: one process per GPU (torch.distributed, RCCL); ONE LP, pricing path sharded; a failure of
 the sharded set-up is an error, never a silent fall-back to replicas.
 
@@ -49,6 +55,10 @@ def parse():
     ap.add_argument("--no-windows", action="store_true", help="skip the mid / late windows from the saved bases")
     ap.add_argument("--window-steps", type=int, nargs=2, default=[512, 256], metavar=("MID", "LATE"))
     ap.add_argument("--samples", type=int, default=32, help="pivots of the event-bracketed sampling pass after a timed region")
+    ap.add_argument("--no-full-solve", action="store_true", help="do not continue the timed solve to optimality (total solve wall time)")
+    ap.add_argument("--wall-guard", type=float, default=1300.0,
+                    help="full solve: stop (complete = false) once the whole bench run has lasted this many seconds")
+    ap.add_argument("--chunk", type=int, default=50000, help="full solve: pivots per continue call")
     ap.add_argument("--independent", action="store_true",
                     help="N > 1: one independent LP per rank (weak scaling) instead of column-block sharded pricing of ONE LP")
     return ap.parse_args()
@@ -60,7 +70,7 @@ def pmc_traffic(a, which):
     MI355X_MICROARCH.md prescribes and as tools/pmc_calib.sh confirms).  PMC counters cannot be
     collected from inside the timed run, so the figure is the committed per-launch average; null when
     the workload differs from the profiled one."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             doc = json.load(open(os.path.join(ROOT, "profiles", name)))
         except OSError:
@@ -73,24 +83,37 @@ def pmc_traffic(a, which):
     return None, None
 
 
-def cpu_baseline(lp, warmup, sample):
-    """The oracle (single-threaded C++ restatement of minilp 0.2.2) timed on this box's host cores:
-    same instance, same warm-up, then `sample` timed pivots.  kind = "port" (the Rust reference
-    cannot be built here)."""
+def cpu_baseline(lp, warmup, steps, cap):
+    """The oracle (single-threaded C++ restatement of minilp 0.2.2) timed on this box's host cores on the same
+    instance.  `value`: exactly the pivots the GPU figure was timed on, warmup..warmup+steps (bounded by `cap` pivots so
+    that a long timed region costs ~20 s of CPU at most); `window_200_700`: pivots 200..700, its fastest sustained
+    stretch (it slows to ~7 pivots/s by pivot 2 500).  kind = "port" (the Rust reference cannot be built here)."""
     from minilp_amd import lpgen
     from oracle import minilp_oracle as O
+
+    def count(st):
+        return st["primal_iters"] + st["dual_iters"]
     s = lpgen.build_problem(O.Problem, lp).solve(budget=warmup)
-    it0 = s.stats()
+    n_same = min(steps, cap)
+    it0 = count(s.stats())
     t0 = time.perf_counter()
-    s.continue_solve(sample)
+    s.continue_solve(n_same)
     dt = time.perf_counter() - t0
-    it1 = s.stats()
-    n = (it1["primal_iters"] + it1["dual_iters"]) - (it0["primal_iters"] + it0["dual_iters"])
-    return dict(value=n / dt, unit="pivots/s", cores=1, kind="port",
-                sample=f"oracle (C++ restatement of minilp 0.2.2, 1 thread) on the same instance: pivots "
-                       f"{warmup}..{warmup + n} from the slack basis in {dt:.2f}s (its fastest stretch; it slows to "
-                       f"~7 pivots/s by pivot 2 500 and cannot reach the mid / late windows in hours)",
-                host_cpus=os.cpu_count())
+    n = count(s.stats()) - it0
+    out = dict(value=n / dt, unit="pivots/s", cores=1, kind="port", measured="live",
+               sample=f"oracle (C++ restatement of minilp 0.2.2, 1 thread), same instance, pivots {warmup}..{warmup + n} from the slack "
+                      f"basis in {dt:.2f}s" + ("" if n_same == steps else f" (the first {n_same} of the {steps} timed pivots)"),
+               host_cpus=os.cpu_count())
+    done = warmup + n
+    if done <= 200:   # the 200..700 figure quoted in DESIGN.md, separately
+        s.continue_solve(200 - done)
+        it0 = count(s.stats())
+        t0 = time.perf_counter()
+        s.continue_solve(500)
+        dt2 = time.perf_counter() - t0
+        n2 = count(s.stats()) - it0
+        out["window_200_700"] = dict(value=n2 / dt2, pivots=int(n2), seconds=dt2)
+    return out
 
 
 def kernel_report(st):
@@ -105,19 +128,18 @@ def kernel_report(st):
                              total_ms=st[name + "_ms"])
     if st["update_launches"]:
         out["update"] = dict(launches=int(st["update_launches"]), avg_us=st["update_ms"] * 1e3 / st["update_launches"])
-    if st.get("gram_pivots"):  # Gram path: `fused` is its BASIS stage (sparse pass + v assembly + the folds due)
-        out["gram"] = dict(pivots=int(st["gram_pivots"]), rows_of_W_per_pivot=st["gram_rows"] / st["gram_pivots"],
-                           monitor_max=st["gram_err"], rebuilds=int(st["gram_rebuilds"]))
     if st["iter_samples"]:
         out["iteration"] = dict(samples=int(st["iter_samples"]), avg_us=st["iter_ms"] * 1e3 / st["iter_samples"])
     return out
 
 
 KERNEL_NAMES = {
-    "fused": "k_fused_w (tau = W rho [the second FTRAN, solver.rs:1157], v = W^T t, eta update / streaming pass of the nucleus inverse)",
-    "fused_gram": ("Gram path of v = B^-T alpha_q: k_wt_sparse (the rows of the nucleus inverse that F^T D^-2 a_S touches) + k_gram_v "
-                   "(rows of M = [(B B^T)^-1]_KK) + the folds of W0 / M0 that were due"),
-    "fold": "k_fold_w (fold of the pending rank-1 terms into W0, every 32 pivots, and into M0, every 16: read + write)",
+    "fused": ("pass over the nucleus inverse of a primal pivot: v_K = W^T t_K, the BTRAN-shaped dense solve v = B^-T alpha_q of primal "
+              "steepest edge (solver.rs:1114).  Small nucleus: k_fused_w (one read + one write, the eta update rides along); large "
+              "nucleus: k_stream_w (read-only).  tau = B^-1 rho (solver.rs:1157) is skipped in primal pivots (lazy dual steepest edge)"),
+    "fold": "k_fold_w (fold of the pending rank-1 terms into the nucleus inverse, every 32 pivots: read + write)",
+    "dense_ftran": ("dense-rhs FTRAN x_B = B^-1 (b - N x_N) of the polish step (solver.rs:1177-1197): one streaming read of the nucleus "
+                    "inverse through k_stream_w's tau side, x_K = W r_K"),
     "sweep_band": ("k_sweep_band (tableau row rho^T N [+ PSE helper]: band-major copy of A, the band of (rho, v) held in "
                    "LDS; per-band partials summed in band order by k_update_pivot)"),
     "sweep": "k_sweep (tableau row rho^T N [+ PSE helper] as a CSC pull over A)",
@@ -125,7 +147,7 @@ KERNEL_NAMES = {
 }
 
 
-def window_from_basis(M, prob, path, warm, steps, samples, shard=None):
+def window_from_basis(M, prob, path, warm, steps, samples, shard=None, dense_ftran=True):
     """`steps` timed pivots from a committed mid-solve basis (after `warm` untimed ones), then an event-bracketed
     sampling pass of `samples` pivots for the per-kernel figures.  shard = (dist, mdist, barrier, max_over_ranks): every
     rank loads the same basis and the solve continues SHARDED (pricing path over column blocks, streaming pass of the
@@ -175,7 +197,16 @@ def window_from_basis(M, prob, path, warm, steps, samples, shard=None):
     st2 = s.stats()
     kern = kernel_report(st2)
     k1 = int(st2["nucleus_size"])
-    out = dict(basis=os.path.basename(path), nucleus_size_at_start=k0, nucleus_size_at_end=k1, warmup=warm, steps=done,
+    if not shard and dense_ftran:
+        # the FTRAN-shaped stream: x_B = B^-1 (b - N x_N), three dense-rhs solves (the solve + two refinement steps)
+        s.recompute_basic_values()
+        st3 = s.stats()
+        if st3["dense_ftran_launches"]:
+            ms, nl, by = st3["dense_ftran_ms"], st3["dense_ftran_launches"], st3["dense_ftran_bytes"]
+            gbs = by / (ms * 1e-3) / 1e9
+            kern["dense_ftran"] = dict(launches=int(nl), avg_us=ms * 1e3 / nl, algorithmic_bytes_per_launch=by / nl, gbs=gbs,
+                                       frac=gbs / HBM_PEAK_GBS, total_ms=ms)
+    out = dict(measured="live", basis=os.path.basename(path), nucleus_size_at_start=k0, nucleus_size_at_end=k1, warmup=warm, steps=done,
                pivots_per_s=done / dt, us_per_pivot=dt * 1e6 / max(done, 1), load_basis_s=load_s,
                objective_at_end=s.objective(), max_pivot_err=st2["max_pivot_err"], kernels=kern,
                sampling=f"{samples}-pivot event-bracketed pass right after the timed pivots (eager launches, "
@@ -189,18 +220,58 @@ def window_from_basis(M, prob, path, warm, steps, samples, shard=None):
     return out
 
 
-def full_solve_record():
-    """Total solve wall time of the last full run of config 4 (1 GPU, slack basis to certified optimum)."""
-    for name in ("r02_config4_full_solve.json", "r01_config4_certificate.json"):
-        try:
-            doc = json.load(open(os.path.join(ROOT, "profiles", name)))
-        except OSError:
-            continue
-        return dict(total_solve_wall_s=doc["solve_wall_s"], pivots=doc["pivots"], avg_pivots_per_s=doc["pivots"] / doc["solve_wall_s"],
-                    objective=doc.get("primal_objective", doc.get("objective_accumulated")), relative_gap=doc.get("relative_gap"),
-                    source="profiles/" + name, commit=doc.get("commit"),
-                    note="measured by tools/certify_cfg4.py on one MI355X (too long for the default bench run)")
-    return None
+def full_solve_live(s, lp, a, t_start, spent_s, pivots_done):
+    """BASELINE.json's `total solve wall-time`, measured live: the solve that was just timed (slack basis, warm-up, K timed
+    pivots, sampling pass: `spent_s` seconds, `pivots_done` pivots) is continued to optimality in chunks of a.chunk pivots.
+    A wall guard stops it (complete = false) once the whole bench run has lasted a.wall_guard seconds.  When it completes,
+    the optimum is certified on the box without a solver: x and the dual point y read off the reduced costs of the
+    non-basic slacks must satisfy A x <= b, x >= 0, A^T y >= c, y >= 0 and c.x = b.y (weak duality)."""
+    import numpy as np
+    import scipy.sparse as sp
+    wall = spent_s
+    curve = []
+    complete = False
+    error = None
+    try:
+        while True:
+            if not s.budget_exhausted:
+                complete = True
+                break
+            if time.perf_counter() - t_start > a.wall_guard:
+                break
+            t0 = time.perf_counter()
+            s.continue_solve(a.chunk)
+            wall += time.perf_counter() - t0
+            st = s.stats()
+            curve.append((pivots_done + int(st["iterations"]), round(wall, 2), int(st["nucleus_size"])))
+    except Exception as e:  # a failed solve is reported, it does not void the timed figure
+        error = str(e)
+    st = s.stats()
+    pivots = pivots_done + int(st["iterations"])
+    out = dict(measured="live", complete=bool(complete), pivots=pivots, total_solve_wall_s=wall, avg_pivots_per_s=pivots / max(wall, 1e-9),
+               objective=s.objective(), nucleus_size_at_end=int(st["nucleus_size"]), max_pivot_err=st["max_pivot_err"],
+               final_refreshes=int(st["final_refreshes"]), reinversions=int(st["reinversions"]), wall_guard_s=a.wall_guard, chunk=a.chunk,
+               wall_definition="seconds inside mlp_problem_solve_ex / mlp_solution_continue from the slack basis (set-up of the device "
+                               "state included, problem assembly through add_var / add_constraint excluded), incl. the event-bracketed sampling pass",
+               curve=[dict(pivots=p, wall_s=w, nucleus=k) for p, w, k in curve])
+    if error:
+        out["error"] = error[:300]
+    if complete and not error:
+        m, n = lp["m"], lp["n"]
+        x = np.asarray(s.values())
+        nb_vars = s.state("nb_vars").astype(np.int64)
+        d = s.state("nb_var_obj_coeffs")
+        y = np.zeros(m)
+        slack = nb_vars >= n
+        y[nb_vars[slack] - n] = d[slack]   # d_slack_i = -pi_i for the minimised form of Max c'x (solver.rs:1199-1231)
+        A = sp.csr_matrix((lp["data"], lp["indices"], lp["indptr"]), shape=(m, n))
+        c, b = lp["obj"], lp["rhs"]
+        po, do = float(c @ x), float(b @ y)
+        out["certificate"] = dict(primal_objective=po, dual_objective=do, relative_gap=abs(po - do) / max(1.0, abs(po)),
+                                  max_primal_violation=float(max((A @ x - b).max(), (-x).max(), 0.0)),
+                                  max_dual_violation=float(max((c - A.T @ y).max(), (-y).max(), 0.0)),
+                                  checked="on the box with scipy mat-vecs (weak duality), no solver")
+    return out
 
 
 def compact_line(out):
@@ -210,10 +281,11 @@ def compact_line(out):
     def r(x, n=4):
         return round(x, n) if isinstance(x, float) else x
 
+    NAMES = {"fused": "w_pass_v"}  # the pass over the nucleus inverse of a primal pivot computes v = B^-T alpha_q (BTRAN-shaped)
+
     def kern(k):  # per-kernel digest: average launch time, GB/s, fraction of the HBM peak
-        return {n: {"us": r(v.get("avg_us"), 1), "gbs": r(v.get("gbs"), 0), "frac": r(v.get("frac"), 3)} if "gbs" in v
-                else ({"rows_of_W": r(v["rows_of_W_per_pivot"], 0), "monitor": float("%.1e" % v["monitor_max"]), "rebuilds": v["rebuilds"]}
-                      if "rows_of_W_per_pivot" in v else {"us": r(v.get("avg_us"), 1)}) for n, v in k.items()}
+        return {NAMES.get(n, n): {"us": r(v.get("avg_us"), 1), "gbs": r(v.get("gbs"), 0), "frac": r(v.get("frac"), 3)} if "gbs" in v
+                else {"us": r(v.get("avg_us"), 1)} for n, v in k.items()}
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                 "vs_baseline", "dtype", "data")}
     line["value"] = r(line["value"], 2)
@@ -227,12 +299,14 @@ def compact_line(out):
                                 unit=rf["unit"], frac=r(rf["frac"], 4), traffic=r(rf["traffic"], 0) if rf["traffic"] else None,
                                 avg_launch_us=r(rf["avg_launch_us"], 2), launches=rf["launches"],
                                 algorithmic_bytes_per_launch=r(rf["algorithmic_bytes_per_launch"], 0))
+        line["roofline"]["measured"] = dict(achieved="live", traffic=rf.get("traffic_measured"))
         ft = rf.get("ftran")
-        if ft:  # north_star's FTRAN entries: the column FTRAN and the k^2 stream that serves tau = B^-1 rho
-            col = ft.get("column") if "column" in ft else ft
-            line["roofline"]["ftran"] = dict(column=kern({"x": col})["x"] if col else None)
-            if "tau_late_window" in ft:
-                line["roofline"]["ftran"]["tau_stream_late_window"] = kern({"x": ft["tau_late_window"]})["x"]
+        if ft:  # north_star's FTRAN entries: us and bytes touched of the column FTRAN per window; the dense-rhs FTRAN as a stream
+            def colft(x):
+                return dict(us=r(x["avg_us"], 1), bytes=r(x["algorithmic_bytes_per_launch"], 0)) if x and "avg_us" in x else None
+            line["roofline"]["ftran"] = dict(column={w: colft(x) for w, x in ft.get("column", {}).items()})
+            if ft.get("dense_rhs_late"):
+                line["roofline"]["ftran"]["dense_rhs_late"] = kern({"x": ft["dense_rhs_late"]})["x"]
     w = out.get("windows")
     if w:
         line["windows"] = {}
@@ -242,19 +316,30 @@ def compact_line(out):
             elif "error" in x:
                 line["windows"][name] = dict(error=x["error"][:160])
             else:
-                line["windows"][name] = dict(k=x["nucleus_size_at_start"], steps=x["steps"], pivots_per_s=r(x["pivots_per_s"], 1),
+                line["windows"][name] = dict(measured=x.get("measured", "live"), k=x["nucleus_size_at_start"], steps=x["steps"], pivots_per_s=r(x["pivots_per_s"], 1),
                                              us_per_pivot=r(x["us_per_pivot"], 1), kernels=kern(x["kernels"]))
     fs = out.get("full_solve")
     if fs:
-        line["full_solve"] = dict(total_solve_wall_s=r(fs["total_solve_wall_s"], 1), pivots=fs["pivots"], source=fs["source"])
+        line["full_solve"] = dict(measured=fs["measured"], complete=fs["complete"], total_solve_wall_s=r(fs["total_solve_wall_s"], 1),
+                                  pivots=fs["pivots"], avg_pivots_per_s=r(fs["avg_pivots_per_s"], 1), objective=r(fs["objective"], 6))
+        if fs.get("certificate"):
+            ce = fs["certificate"]
+            line["full_solve"]["certificate"] = dict(relative_gap=float("%.1e" % ce["relative_gap"]),
+                                                     primal_violation=float("%.1e" % ce["max_primal_violation"]),
+                                                     dual_violation=float("%.1e" % ce["max_dual_violation"]))
+        if fs.get("error"):
+            line["full_solve"]["error"] = fs["error"][:160]
     cb = out.get("cpu_baseline")
     if cb:
-        line["cpu_baseline"] = dict(value=r(cb["value"], 2), unit=cb["unit"], cores=cb["cores"], kind=cb["kind"],
-                                    sample="oracle (C++ restatement of minilp 0.2.2), 1 thread, same instance, its first pivots after the same warm-up")
+        line["cpu_baseline"] = dict(value=r(cb["value"], 2), unit=cb["unit"], cores=cb["cores"], kind=cb["kind"], measured=cb.get("measured", "live"),
+                                    sample=cb["sample"][:200])
+        if cb.get("window_200_700"):
+            line["cpu_baseline"]["pivots_200_700"] = r(cb["window_200_700"]["value"], 2)
     return line
 
 
 def main():
+    T_START = time.perf_counter()
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -293,19 +378,26 @@ def main():
     sharded = world > 1 and not a.independent
     lp = lpgen.gen_sparse_lp(a.rows, a.cols, a.nnz_per_row, a.seed + (0 if sharded or world == 1 else rank))
     prob = lpgen.build_problem(M.Problem, lp)
+    solve_s = 0.0   # seconds inside solve / continue calls of THIS solve (total solve wall time, N = 1)
+    t0 = time.perf_counter()
     s = prob.solve(budget=0, profile=True)
+    solve_s += time.perf_counter() - t0
     mailbox = None
     if sharded:
         # raises on EVERY rank when any rank cannot join (setup_sharding all-gathers the errors): a sharded run
         # that cannot be set up is a failed run, not a run of something else
         mailbox = mdist.setup_sharding(s, dist)
+    t0 = time.perf_counter()
     s.continue_solve(a.warmup)       # W untimed warm-up pivots
+    solve_s += time.perf_counter() - t0
+    pivots_before = int(s.stats()["iterations"])
     s.reset_stats()
     barrier()
     t0 = time.perf_counter()
     s.continue_solve(a.steps)        # exactly K timed pivots
     barrier()
     dt = time.perf_counter() - t0
+    solve_s += dt
     st_timed = s.stats()
     done = st_timed["iterations"]
     if world > 1:
@@ -321,7 +413,10 @@ def main():
     # of every kernel whatever K is; all ranks run it (the sharded exchange needs every rank)
     samples_in_region = int(st_timed["sweep_launches"])
     s.set_sampling(True)
+    t0 = time.perf_counter()
     s.continue_solve(a.samples)
+    solve_s += time.perf_counter() - t0
+    s.set_sampling(False)
     st = s.stats()
     if rank == 0:
         kern = kernel_report(st)
@@ -335,14 +430,14 @@ def main():
             which = ("sweep_band" if st.get("banded_sweep") else "sweep") if dom == "sweep" else dom
             traffic, traffic_src = pmc_traffic(a, dom) if world == 1 else (None, None)  # the PMC figure is the unsharded kernel's
             roofline = dict(bound="hbm", kernel=KERNEL_NAMES[which], achieved=kern[dom]["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=kern[dom]["frac"], traffic=traffic,
+                            frac=kern[dom]["frac"], traffic=traffic, traffic_measured=("committed:profiles/" + traffic_src) if traffic else None,
                             traffic_unit=f"HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/{traffic_src})" if traffic else None,
                             avg_launch_us=kern[dom]["avg_us"], launches=kern[dom]["launches"],
                             algorithmic_bytes_per_launch=kern[dom]["algorithmic_bytes_per_launch"],
                             samples=f"{samples_in_region} sampled iterations inside the timed region + a {a.samples}-pivot "
                                     f"event-bracketed pass right after it (HIP events on the launch stream)",
                             other_kernels={k: v for k, v in kern.items() if k not in (dom, "ftran")},
-                            ftran=dict(kernel=KERNEL_NAMES["ftran"], window="slack-basis window", **kern["ftran"]) if "ftran" in kern else None)
+                            ftran=dict(kernel=KERNEL_NAMES["ftran"], column=dict(early=kern.get("ftran"))))
         out = dict(metric="simplex pivots/sec", value=total / dt, unit="pivots/s", n_gpus=world, steps=a.steps,
                    warmup=a.warmup, ms_per_step=dt * 1e3 / max(done, 1), higher_is_better=True,
                    scaling=("weak" if (world > 1 and not sharded) else "strong"),
@@ -361,32 +456,39 @@ def main():
                                pricing_path_us_per_pivot=pricing_us,
                                vs_baseline_note="BASELINE.md §1: the reference publishes no number for this metric"),
                    roofline=roofline)
+        out["provenance"] = dict(value="live", roofline_achieved="live (HIP events stamped by the kernels, this run)",
+                                 roofline_traffic="committed (PMC passes cannot run inside the timed run)", windows="live",
+                                 full_solve="live", cpu_baseline="live")
         if world == 1:
-            del s
-            s = None
+            cfg4 = (a.rows, a.cols, a.nnz_per_row, a.seed) == (100000, 100000, 100, 4)
             if not a.no_windows:
                 windows = {}
                 for name, path, warm, steps in (("mid", MID_BASIS, 64, a.window_steps[0]), ("late", LATE_BASIS, 32, a.window_steps[1])):
-                    if (a.rows, a.cols, a.nnz_per_row, a.seed) != (100000, 100000, 100, 4) or not os.path.exists(path):
+                    if not cfg4 or not os.path.exists(path):
                         windows[name] = None
                         continue
                     windows[name] = window_from_basis(M, prob, path, warm, steps, min(a.samples, 16))
                 out["windows"] = windows
-                if roofline and windows.get("late") and "fused" in windows["late"]["kernels"]:
-                    roofline["ftran"] = dict(
-                        column=roofline.get("ftran"),
-                        tau_late_window=dict(kernel=KERNEL_NAMES["fused_gram" if "gram" in windows["late"]["kernels"] else "fused"],
-                                             window="late window (saved basis)", **windows["late"]["kernels"]["fused"]),
-                        column_late_window=dict(kernel=KERNEL_NAMES["ftran"], window="late window (saved basis)",
-                                                **windows["late"]["kernels"].get("ftran", {})),
-                        note="north_star's FTRAN target: the solve against the basis factor.  Here B^-1 is the explicit nucleus "
-                             "inverse: the column FTRAN reads |list| columns of it (latency-bound, a few MB).  The two dense solves "
-                             "of steepest edge (tau = B^-1 rho, solver.rs:1157; v = B^-T alpha_q, solver.rs:1114) were the k^2 "
-                             "stream of k_fused_w / k_stream_w; in the primal loop tau is now skipped (lazy dual steepest edge) and "
-                             "v comes from the Gram path (DESIGN.md 2.4), whose BASIS stage is the `tau_late_window` entry")
-            out["full_solve"] = full_solve_record()
+                if roofline:
+                    for name in ("mid", "late"):
+                        if windows.get(name) and "ftran" in windows[name].get("kernels", {}):
+                            roofline["ftran"]["column"][name] = windows[name]["kernels"]["ftran"]
+                    if windows.get("late") and "dense_ftran" in windows["late"].get("kernels", {}):
+                        roofline["ftran"]["dense_rhs_late"] = dict(kernel=KERNEL_NAMES["dense_ftran"], window="late window (saved basis)",
+                                                                   **windows["late"]["kernels"]["dense_ftran"])
+                    roofline["ftran"]["note"] = (
+                        "north_star's FTRAN target names the solve against the basis factor.  Here B^-1 is the explicit nucleus inverse: "
+                        "the column FTRAN alpha_q = B^-1 a_q reads |list| columns of it plus the nucleus columns of A (a latency-bound "
+                        "gather: reported in us and bytes, a bandwidth fraction says nothing about it).  The FTRAN that is a stream is "
+                        "the dense-rhs one, x_B = B^-1 (b - N x_N) (`dense_rhs_late`, k_stream_w's tau side).  The pass of every primal "
+                        "pivot (`w_pass_v` in the windows) computes v = B^-T alpha_q: BTRAN-shaped, not an FTRAN")
             if not a.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(lp, a.warmup, a.cpu_pivots)
+                out["cpu_baseline"] = cpu_baseline(lp, a.warmup, a.steps, a.cpu_pivots)
+            if not a.no_full_solve:
+                s.set_sampling(None)   # no event-bracketed iterations in the long run
+                out["full_solve"] = full_solve_live(s, lp, a, T_START, solve_s, pivots_before)
+            del s
+            s = None
     # N > 1, sharded: the late window as well (all ranks take part): this is where the row-sharded streaming pass of
     # the nucleus inverse pays; a failure here is reported inside the line, it does not void the timed figure above
     late_sharded = None

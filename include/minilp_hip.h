@@ -93,12 +93,19 @@ int mlp_solution_continue(mlp_solution* s, int64_t budget);
 uint64_t mlp_solution_save_basis(const mlp_solution* s, int mode, void* buf, uint64_t cap);
 int mlp_problem_solve_from_basis(const mlp_problem* p, const void* blob, uint64_t len, mlp_solution** out, int64_t budget,
                                  uint32_t flags);
-/* flags bit1 (HIP-event timing): sample EVERY iteration as an eager, event-bracketed one (measurement passes) */
+/* flags bit1 (HIP-event timing): 1 = sample EVERY iteration as an eager, event-bracketed one (measurement passes),
+ * 0 = the default cadence (every 8th / 4th batch), < 0 = switch the sampling off for the rest of the solve */
 int mlp_solution_set_sampling(mlp_solution* s, int every_iteration);
 int mlp_solution_budget_exhausted(const mlp_solution* s);
 /* Recompute the dense nucleus inverse from A (the counterpart of BasisSolver::reset,
  * solver.rs:1286-1303); returns max |W_incremental - W_fresh| through *max_diff when non-NULL. */
 int mlp_solution_reinvert(mlp_solution* s, double* max_diff);
+
+/* x_B = B^-1 (b - N x_N) recomputed from the basis, with two steps of iterative refinement (the reference's
+ * recalc_basic_var_vals, solver.rs:1177-1197, which it leaves unused; here it is the polish step of long runs and is
+ * exported for hosts that want it after many warm-start pivots).  A dense-rhs FTRAN: with a large nucleus it is one
+ * streaming read of the nucleus inverse (8 k^2 bytes) per step; in profile mode mlp_stats.dense_ftran_* time it. */
+int mlp_solution_recompute_basic_values(mlp_solution* s);
 
 /* Column-block sharding of the pricing path across the GPUs of one node (one process per GPU,
  * DESIGN.md §6).  Every rank builds the SAME problem, calls mlp_problem_solve_ex(budget = 0), then
@@ -134,13 +141,11 @@ typedef struct mlp_stats {
     double iter_ms; uint64_t iter_samples; /* whole sampled iterations, first kernel to last (HIP events) */
     uint64_t beta_rebuilds; /* lazy dual steepest edge: exact rebuilds of the dual edge norms from the basis inverse (the primal
                                loop skips their per-pivot recurrence, solver.rs:1153-1174, because nothing reads them there) */
-    /* Gram mode of the primal steepest-edge solve v = B^-T alpha_q (opt-in: MLP_GRAM=1; large nucleus, one GPU):
-     * builds of M = [(B B^T)^-1] on the nucleus rows from the basis inverse, pivots that took the path, and its drift
-     * monitor max |a_q.v - ||alpha_q||^2| / (1 + ||alpha_q||^2) (M is rebuilt when a batch exceeds MLP_GRAM_TOL, 1e-2) */
-    uint64_t gram_rebuilds, gram_pivots; double gram_err;
-    double gram_rows;  /* rows of the nucleus inverse read by the sparse passes of the Gram path (8 k bytes each) */
-    double fold_bytes, fold_ms; uint64_t fold_launches; /* sampled folds of W0 / M0 on the Gram path (HIP events) */
-    uint64_t gram_backoffs; /* times the monitor tripped within 4096 pivots of a rebuild: the streaming pass then serves the next 16 384 pivots */
+    double fold_bytes, fold_ms; uint64_t fold_launches; /* sampled folds of the pending rank-1 terms into the nucleus inverse (HIP events) */
+    double dense_ftran_bytes, dense_ftran_ms; uint64_t dense_ftran_launches; /* dense-rhs FTRAN of mlp_solution_recompute_basic_values /
+                              the polish step: algorithmic bytes (8 k^2 per solve) and kernel-exact time of the pass over the nucleus inverse */
+    uint64_t ratio_stalls; /* in-kernel waits of the one-launch Harris tests that timed out (grid not co-resident); each one is
+                              retried with the two-launch form, which then stays selected */
 } mlp_stats;
 void mlp_solution_stats(const mlp_solution* s, mlp_stats* out);
 void mlp_solution_reset_stats(mlp_solution* s);

@@ -38,9 +38,9 @@ class MlpStats(C.Structure):
                    ("update_launches", C.c_uint64), ("banded_sweep", C.c_uint64), ("final_refreshes", C.c_uint64), ("max_pivot_err", C.c_double),
                    ("ftran_bytes", C.c_double), ("ftran_ms", C.c_double), ("ftran_launches", C.c_uint64),
                    ("iter_ms", C.c_double), ("iter_samples", C.c_uint64), ("beta_rebuilds", C.c_uint64),
-                   ("gram_rebuilds", C.c_uint64), ("gram_pivots", C.c_uint64), ("gram_err", C.c_double),
-                   ("gram_rows", C.c_double), ("fold_bytes", C.c_double), ("fold_ms", C.c_double), ("fold_launches", C.c_uint64),
-                   ("gram_backoffs", C.c_uint64)])
+                   ("fold_bytes", C.c_double), ("fold_ms", C.c_double), ("fold_launches", C.c_uint64),
+                   ("dense_ftran_bytes", C.c_double), ("dense_ftran_ms", C.c_double), ("dense_ftran_launches", C.c_uint64),
+                   ("ratio_stalls", C.c_uint64)])
 
 
 class MlpIterInfo(C.Structure):  # include/minilp_hip.h: mlp_iter_info
@@ -98,6 +98,7 @@ def lib():
     sig("mlp_solution_set_sampling", i32, vp, i32)
     sig("mlp_solution_budget_exhausted", i32, vp)
     sig("mlp_solution_reinvert", i32, vp, pdbl)
+    sig("mlp_solution_recompute_basic_values", i32, vp)
     sig("mlp_solution_enable_sharding", i32, vp, i32, i32, C.c_char_p)
     sig("mlp_solution_transport", C.c_char_p, vp)
     sig("mlp_solution_clone", vp, vp)
@@ -359,7 +360,8 @@ class Solution:
         return bytes(buf)
 
     def set_sampling(self, every_iteration):
-        _raise(lib().mlp_solution_set_sampling(self._h, 1 if every_iteration else 0))
+        """True: every iteration is an eager, event-bracketed one; False: default cadence; None: sampling off for good."""
+        _raise(lib().mlp_solution_set_sampling(self._h, -1 if every_iteration is None else (1 if every_iteration else 0)))
 
     # --- engine-level controls (fixed pivot budget, stats, trace)
     def continue_solve(self, budget):
@@ -397,6 +399,10 @@ class Solution:
         d = C.c_double()
         _raise(lib().mlp_solution_reinvert(self._h, C.byref(d)))
         return d.value
+
+    def recompute_basic_values(self):
+        """x_B = B^-1 (b - N x_N) from the basis, two refinement steps (solver.rs:1177-1197)."""
+        _raise(lib().mlp_solution_recompute_basic_values(self._h))
 
     def stats(self):
         s = MlpStats()

@@ -156,7 +156,12 @@ uint64_t mlp_solution_save_basis(const mlp_solution* s, int mode, void* buf, uin
 int mlp_solution_set_sampling(mlp_solution* s, int every_iteration) {
     return guarded([&] {
         if (!s) throw MlpError(MLP_EINVAL, "NULL solution");
-        s->eng->sample_every = every_iteration ? 1 : 0;
+        if (every_iteration < 0) {  // switch the HIP-event sampling off altogether (long runs after a measurement pass)
+            s->eng->profile = false;
+            s->eng->sample_every = 0;
+        } else {
+            s->eng->sample_every = every_iteration ? 1 : 0;
+        }
     });
 }
 int mlp_solution_continue(mlp_solution* s, int64_t budget) {
@@ -199,6 +204,10 @@ int mlp_solution_reinvert(mlp_solution* s, double* max_diff) {
         double d = s->eng->reinvert(true);
         if (max_diff) *max_diff = d;
     });
+}
+
+int mlp_solution_recompute_basic_values(mlp_solution* s) {
+    return guarded([&] { s->eng->recalc_basic_vals(); });
 }
 
 int mlp_solution_enable_sharding(mlp_solution* s, int rank, int world, const char* shm_name) {
@@ -294,9 +303,9 @@ void mlp_solution_stats(const mlp_solution* s, mlp_stats* o) {
     o->ftran_bytes = t.ftran_bytes; o->ftran_ms = t.ftran_ms; o->ftran_launches = t.ftran_launches;
     o->iter_ms = t.iter_ms; o->iter_samples = t.iter_samples;
     o->beta_rebuilds = t.beta_rebuilds;
-    o->gram_rebuilds = t.gram_rebuilds; o->gram_pivots = t.gram_pivots; o->gram_err = t.gram_err;
-    o->gram_backoffs = t.gram_backoffs;
-    o->gram_rows = t.gram_rows; o->fold_bytes = t.fold_bytes; o->fold_ms = t.fold_ms; o->fold_launches = t.fold_launches;
+    o->ratio_stalls = t.ratio_stalls;
+    o->dense_ftran_bytes = t.dense_ftran_bytes; o->dense_ftran_ms = t.dense_ftran_ms; o->dense_ftran_launches = t.dense_ftran_launches;
+    o->fold_bytes = t.fold_bytes; o->fold_ms = t.fold_ms; o->fold_launches = t.fold_launches;
     for (int i = 0; i < 5; ++i) o->kase[i] = t.kase[i];
 }
 void mlp_solution_reset_stats(mlp_solution* s) {

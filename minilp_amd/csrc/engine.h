@@ -129,12 +129,11 @@ struct Stats {
     uint64_t update_launches = 0;
     double solve_wall_s = 0;
     double max_pivot_err = 0;
+    uint64_t ratio_stalls = 0;   // in-kernel waits of the fused ratio test that timed out (each one retried with two launches)
     uint64_t beta_rebuilds = 0;  // lazy dual steepest edge: exact rebuilds of beta from the basis inverse
-    uint64_t gram_rebuilds = 0;  // Gram mode: builds of M = W^T (I + F^T D^-2 F) W from the basis inverse
-    uint64_t gram_pivots = 0;    // pivots whose v = B^-T alpha_q came from the Gram path
-    uint64_t gram_backoffs = 0;  // times the monitor tripped right after a rebuild and the streaming pass took over for a while
-    double gram_err = 0;         // Gram mode drift monitor: max |a_q.v - ||alpha_q||^2| / (1 + ||alpha_q||^2)
-    double gram_rows = 0;        // rows of W0 read by the sparse passes (8 k bytes each)
+    // dense-rhs FTRAN x_B = B^-1 (b - N x_N) (recalc_basic_vals): the streaming read of the nucleus inverse, kernel-exact
+    double dense_ftran_bytes = 0, dense_ftran_ms = 0;
+    uint64_t dense_ftran_launches = 0;
     double fold_bytes = 0, fold_ms = 0;  // sampled folds of W0 (HIP events stamped by the kernel): read + write of the matrix
     uint64_t fold_launches = 0;
     uint64_t kase[5] = {0, 0, 0, 0, 0};  // partition-change cases: nuc->nuc, grow, shrink, col swap, same-row
@@ -158,6 +157,7 @@ public:
     double cur_obj_val();                                                   // solver.rs:51
     Engine* clone();                                                        // #[derive(Clone)] solver.rs:14
     double reinvert(bool replace);  // from-scratch nucleus inversion; returns max |W - W_fresh|
+    double last_reinvert_scale = 0.0;  // max |W_fresh| of that comparison (state "reinvert_scale")
     // Basis checkpoint (include/minilp_hip.h: mlp_solution_save_basis / mlp_problem_solve_from_basis).
     // mode 0: basic / non-basic sets, flags and x_N; 1: + steepest-edge weights as f32; 2: + x_B, d, gamma,
     // beta, objective as f64 (a loaded solve continues pivot for pivot).
@@ -196,6 +196,9 @@ private:
     std::vector<double> h_cval;
     int max_col_nnz_ = 0, max_row_nnz_ = 0;   // longest column / row of A (in-kernel stage heads need them to fit an LDS list)
     bool no_head_fusion = false;             // MLP_NO_HEAD_FUSION: keep the stage heads as launches of their own
+    bool ratio_two = false;                  // MLP_RATIO_TWO_KERNELS, or latched by an ITER_STALL: two launches for the two Harris passes
+    long long ratio_spin_limit = 20000000LL; // MLP_RATIO_SPIN_LIMIT: polls before a fused ratio test gives up (0: the first launch stalls; tests)
+    bool ranks_share_device = false;         // sharded solve with another rank on this GPU (or unknown): same
     // Lazy dual steepest edge: the primal loop never reads beta, so its iterations skip tau = B^-1 rho (solver.rs:1157)
     // and the beta recurrence; beta is rebuilt exactly from the basis inverse (k_exact_beta) when something next needs it
     bool lazy_dse = true;                    // MLP_LAZY_DSE=0: maintain beta in every pivot like the reference
@@ -203,25 +206,6 @@ private:
     bool batch_lazy = false;                 // the iterations being recorded skip the beta recurrence
     bool lazy_now(int phase) const { return lazy_dse && enable_dse && phase == 0 && !stepping && max_row_nnz_ <= HEAD_LIST_CAP; }
     void ensure_beta();
-    // Gram mode: the primal steepest-edge solve v = B^-T alpha_q reads a few rows of the resident
-    // M = [(B B^T)^-1]_KK and the few rows of W0 that F^T D^-2 a_S touches, instead of all of W0 every pivot.
-    // Large-nucleus delayed-update mode, one GPU, lazy dual steepest edge (no tau) only.
-    bool gram_enable = false;                // MLP_GRAM=1 switches the mode on (measured: pivots 2.2x faster, pricing weights too noisy: §2.4)
-    bool gram_phase = false;                 // the loop being run is the primal one
-    bool gram_valid = false;                 // M matches the current basis
-    bool gram_oom = false;                   // M did not fit next to W: the mode stays off
-    // A monitor that trips again within gram_min_gap pivots of a rebuild means M cannot be held that accurately on
-    // this basis (it carries cond(B)^2): the mode backs off to the streaming pass for gram_backoff pivots.
-    double gram_safe = 1e-3;                 // MLP_GRAM_SAFE: per-pivot monitor above which the weight update is safeguarded
-    int gram_shadow = 0;                     // MLP_GRAM_SHADOW=1|2: also run the streaming pass and report max |v_gram - v_stream| (2: continue with the streamed v)
-    double sh_diff_max = 0, sh_ref_max = 0, sh_rel_max = 0;
-    bool gram_probe = false;                 // MLP_GRAM_PROBE: print the accuracy of a freshly built M
-    uint64_t gram_built_at = 0, gram_off_until = 0;
-    uint64_t gram_min_gap = 4096, gram_backoff = 16384;
-    double gram_tol = 1e-2;                  // MLP_GRAM_TOL: monitor value of a batch above which M is rebuilt (a fresh M reads 5e-6 at k = 20 000; v only feeds the pricing weights)
-    DevBuf<double> d_M, d_MU, d_MV, d_mK;
-    bool gram_wanted() const;
-    void gram_rebuild();
     std::vector<int> h_colnnz, h_single_row;
     std::vector<double> h_single_val;
     std::vector<int> h_basic_vars, h_nb_vars, h_var_loc;

@@ -106,13 +106,9 @@ Engine::Engine() {
     use_order = !(sl && sl[0] == '0');
     const char* lz = std::getenv("MLP_LAZY_DSE");
     lazy_dse = !(lz && lz[0] == '0');
-    if (const char* gm = std::getenv("MLP_GRAM")) gram_enable = gm[0] != '0';
-    if (const char* gt = std::getenv("MLP_GRAM_TOL")) gram_tol = std::atof(gt);
-    if (const char* gs = std::getenv("MLP_GRAM_SAFE")) gram_safe = std::atof(gs);
-    gram_probe = std::getenv("MLP_GRAM_PROBE") != nullptr;
+    ratio_two = std::getenv("MLP_RATIO_TWO_KERNELS") != nullptr;
+    if (const char* rs = std::getenv("MLP_RATIO_SPIN_LIMIT")) ratio_spin_limit = std::atoll(rs);
     if (const char* sb = std::getenv("MLP_STREAM_BALANCED")) sw_balanced = std::atoi(sb);
-    if (const char* sh = std::getenv("MLP_GRAM_SHADOW")) gram_shadow = std::atoi(sh);
-    if (const char* gg = std::getenv("MLP_GRAM_MIN_GAP")) gram_min_gap = (uint64_t)std::atoll(gg);  // 0: never back off (tests)
     const char* nhf = std::getenv("MLP_NO_HEAD_FUSION");
     no_head_fusion = nhf && std::atoi(nhf) != 0;
     const char* nws = std::getenv("MLP_NO_WSHARD");
@@ -308,6 +304,9 @@ Geom Engine::geom() const {
     g.big = (cap_ > 4096 || force_big_tiles) ? 1 : 0;
     const int lr = lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 32 : 0);  // as in sync_view
     g.head_fused = (!no_head_fusion && lr == 0 && max_col_nnz_ <= HEAD_LIST_CAP && max_row_nnz_ <= HEAD_LIST_CAP) ? 1 : 0;
+    // in-kernel wait between the two Harris passes: never while the ranks of a sharded solve share a device (their grids
+    // compete for the same CUs), never again after a wait has timed out once
+    g.ratio_two = (ratio_two || (shard_world > 1 && ranks_share_device)) ? 1 : 0;
     return g;
 }
 
@@ -437,22 +436,6 @@ DevView* Engine::sync_view() {
     v.alpha_q = d_work.p;
     v.tau = d_work.p + (size_t)m_;
     v.rv = reinterpret_cast<double2*>(d_work.p + 2 * (size_t)m_);
-    v.hS = d_work.p + 4 * (size_t)m_;
-    v.gram = 0;
-    if (v.lrJ > 0 && gram_wanted()) {  // M next to W (same shape); without the memory for it the mode simply stays off
-        try {
-            d_M.ensure((size_t)cap_ * (size_t)ld(), 0, st);
-            d_MU.ensure((size_t)LR_MAX * ld(), 0, st);
-            d_MV.ensure((size_t)LR_MAX * ld(), 0, st);
-            d_mK.ensure((size_t)cap_, 0, st);
-            v.gram = 1;
-        } catch (MlpError&) {
-            (void)hipGetLastError();
-            gram_oom = true;
-        }
-    }
-    v.M = v.gram ? d_M.p : nullptr; v.MU = v.gram ? d_MU.p : nullptr; v.MV = v.gram ? d_MV.p : nullptr;
-    v.mK = v.gram ? d_mK.p : nullptr;
     v.alpha_r = d_alpha_r.p; v.helper = d_helper.p;
     v.aK = d_aK.p; v.rK = d_rK.p; v.tK = d_tK.p; v.tauK = d_tauK.p; v.vK = d_vK.p;
     v.klist_s = d_klist_s.p; v.klist_a = d_klist_a.p; v.blist_s = d_blist_s.p; v.blist_a = d_blist_a.p;
@@ -578,8 +561,6 @@ void Engine::ensure_nucleus_cap(int need) {
     d_V.ensure((size_t)LR_MAX * nld, 0, st);
     cap_ = ncap;
     view_dirty = true;
-    gram_valid = false;  // M is re-allocated with the new pitch and rebuilt from W
-    d_M.release(); d_MU.release(); d_MV.release(); d_mK.release();
 }
 
 void Engine::ensure_red() {
@@ -710,6 +691,7 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name) {
             d_mail = reinterpret_cast<MailRec*>(dp);
             for (int r = 0; r < world; ++r) peer_box[r] = nullptr;
             mail_fanout = 1;
+            ranks_share_device = true;  // unknown with this transport: take the form that needs no co-residency
             transport = "host-mapped shared-memory mailbox (PCIe)";
         } else {
             // one allocation: the mailbox ([kind][parity][rank] records) followed by the exchange buffer of the
@@ -731,7 +713,13 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name) {
             HIPCHECK(hipIpcGetMemHandle(&mine->handle, own_box));
             int dev = 0;
             HIPCHECK(hipGetDevice(&dev));
-            mine->device = dev;
+            {   // physical identity of the device (ordinals differ between processes with different visibility masks)
+                int dom = 0, bus = 0, did = 0;
+                (void)hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, dev);
+                (void)hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, dev);
+                (void)hipDeviceGetAttribute(&did, hipDeviceAttributePciDeviceId, dev);
+                mine->device = ((dom & 0xffff) << 16) | ((bus & 0xff) << 8) | (did & 0xff);
+            }
             mine->pid = (int32_t)getpid();
             __atomic_store_n(&mine->ready, (uint64_t)1, __ATOMIC_RELEASE);
             for (int r = 0; r < world; ++r) {
@@ -758,7 +746,11 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name) {
             d_mail = reinterpret_cast<MailRec*>(own_box);
             mail_fanout = world;
             bool same_dev = true;
-            for (int r = 0; r < world; ++r) same_dev = same_dev && rv[r].device == dev;
+            ranks_share_device = false;
+            for (int r = 0; r < world; ++r) {
+                same_dev = same_dev && rv[r].device == mine->device;
+                if (r != rank && rv[r].device == mine->device) ranks_share_device = true;
+            }
             transport = same_dev ? "device-resident mailboxes mapped through HIP IPC (all ranks on one GPU)"
                                  : "device-resident mailboxes in each GPU's HBM, written by the peers over xGMI (HIP IPC peer mappings)";
         }
@@ -934,6 +926,7 @@ void Engine::try_new(const ProblemData& pd) {
     h_ctl->it.obj = cur_obj;
     h_ctl->it.status = ITER_NONE;
     h_ctl->up.kase = -1;
+    h_ctl->ratio_spin_limit = ratio_spin_limit;
     HIPCHECK(hipMemcpyAsync(d_ctl.p, h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, st));
     ensure_nucleus_cap(256);
     push_maps();
@@ -1018,15 +1011,6 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         }
         break;
     case STAGE_BASIS:
-        if (dv.gram && phase == 0 && pse) {
-            if (with_events) HIPCHECK(hipEventRecord(ev[2], st));
-            launch_gram_folds(dv, g, st);                     // Gram path: folds of W0 / M0 when due (empty launches otherwise),
-            if (with_events) HIPCHECK(hipEventRecord(ev[10], st));
-            launch_gram_basis(dv, g, st);                     // sparse pass over W0, v_K assembly
-            if (gram_shadow) launch_gram_shadow(dv, g, gram_shadow, st);
-            if (with_events) HIPCHECK(hipEventRecord(ev[3], st));
-            break;
-        }
         if (with_events) {  // sampled iteration: the pass over the nucleus inverse and the fold are timed kernel-exactly
             arm_kernel_timing(2, ev[2], ev[3]);
             arm_kernel_timing(3, ev[10], ev[11]);
@@ -1246,8 +1230,6 @@ int Engine::process_records(int phase, int launched) {
                 nnz_nonbasic += (size_t)col_nnz(lv);
                 nnz_nonbasic -= (size_t)col_nnz(ev_);
                 stats.basis_changes += 1;
-                if (hview.gram && r.phase == 0) stats.gram_pivots += 1;
-                else gram_valid = false;  // a basis change that did not carry M along
                 if (r.kase >= 0 && r.kase < 5) stats.kase[r.kase] += 1;
                 if (trace) trace_log.push_back({r.phase, r.q, r.r, ev_, lv, r.pivot_coeff, r.obj});
             }
@@ -1262,11 +1244,6 @@ int Engine::process_records(int phase, int launched) {
 int Engine::run_loop(int phase) {
     if (phase == 1) ensure_beta();  // the dual pricing reads beta
     batch_lazy = lazy_now(phase);
-    if (gram_phase != (phase == 0)) {  // the Gram path belongs to the primal loop (DevView.gram is baked into its graphs)
-        gram_phase = phase == 0;
-        view_dirty = true;
-    }
-    if (phase == 1) gram_valid = false;  // dual pivots do not maintain M
     for (;;) {
         if (pivot_budget == 0) {
             budget_exhausted = true;
@@ -1281,10 +1258,6 @@ int Engine::run_loop(int phase) {
         // so short warm-start re-solves run eagerly; the graph is captured once the same geometry has
         // survived a few iterations.
         if (!hview.nb_order && use_order && lifetime_pivots >= order_from) view_dirty = true;  // time to switch the order on
-        if (gram_off_until && lifetime_pivots >= gram_off_until) {  // the back-off of the Gram mode is over
-            gram_off_until = 0;
-            view_dirty = true;
-        }
         sync_view();
         if (hview.nb_order) refresh_nb_order(false);  // every `order_every` pivots (same buffer: captured graphs stay valid)
         if (hview.nb_order && use_pack && pack_built != (hview.pk_ptr != nullptr)) {  // the packed copy came or went
@@ -1311,7 +1284,6 @@ int Engine::run_loop(int phase) {
         const bool graph_batch = graph_now;
         ensure_nucleus_cap(k_ + B + 1);
         sync_view();
-        if (hview.gram && !gram_valid) gram_rebuild();
         const DevView& dv = hview;
         launch_reset_ring(dv, st);
         launch_clear_work(dv, st);
@@ -1331,7 +1303,6 @@ int Engine::run_loop(int phase) {
         const int k_before = k_;
         const size_t nnz_nuc_before = sample ? nnz_nucleus_cols() : 0;
         pull_ctl();
-        const uint64_t gram_pivots_before = stats.gram_pivots;
         int res = process_records(phase, B);
         if (sample && h_ctl->ring_n >= 1 && h_ctl->ring[0].status == ITER_PIVOT) {
             float ms = 0.f;
@@ -1341,23 +1312,7 @@ int Engine::run_loop(int phase) {
                 stats.sweep_bytes += sh * (12.0 * (double)nnz_before + 16.0 * num_vars) + 16.0 * m_;
                 stats.sweep_launches += 1;
             }
-            if (k_before > 1 && hview.gram && phase == 0 && enable_pse) {
-                // Gram path: the rows of W0 the sparse pass read, the listed rows of M0, and the folds that were due
-                // (W0: read + write; M0: read + write of its upper triangle)
-                const double kk = (double)k_before;
-                float fms = 0.f;
-                const double fb = (h_ctl->fold ? 16.0 * kk * kk : 0.0) + (h_ctl->mfold ? 8.0 * kk * kk : 0.0);
-                if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) {
-                    stats.fused_ms += ms;
-                    stats.fused_bytes += 8.0 * kk * ((double)h_ctl->gram_rows + (double)h_ctl->ring[0].klist_n) + fb;
-                    stats.fused_launches += 1;
-                }
-                if (fb > 0.0 && hipEventElapsedTime(&fms, ev[2], ev[10]) == hipSuccess) {
-                    stats.fold_ms += fms;
-                    stats.fold_bytes += fb;
-                    stats.fold_launches += (h_ctl->fold ? 1 : 0) + (h_ctl->mfold ? 1 : 0);
-                }
-            } else if (k_before > 1 && hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) {
+            if (k_before > 1 && hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) {
                 // the pass over the nucleus inverse, stamped by the kernel itself: in place it reads and writes W (16 k^2),
                 // in the delayed-update mode it only reads W0 (8 k^2; a rank of the row-sharded pass reads its strips only)
                 stats.fused_ms += ms;
@@ -1389,106 +1344,25 @@ int Engine::run_loop(int phase) {
             }
             (void)hipGetLastError();  // an event pair that was not recorded this iteration is not an error
         }
-        if (hview.gram && phase == 0) stats.gram_rows += (double)h_ctl->gram_rows;
-        if (hview.gram && phase == 0 && gram_shadow) {
-            double dd, rr;
-            std::memcpy(&dd, &h_ctl->sh_diff, sizeof(double));
-            std::memcpy(&rr, &h_ctl->sh_ref, sizeof(double));
-            sh_diff_max = std::max(sh_diff_max, dd);
-            sh_ref_max = std::max(sh_ref_max, rr);
-            if (rr > 0) sh_rel_max = std::max(sh_rel_max, dd / rr);
-            if ((batches_run & 63) == 0)
-                std::fprintf(stderr, "[gram shadow] batch: max |dv| %.3e, max |v| %.3e | so far: max |dv| %.3e, max |dv|/|v|max %.3e, monitor %.2e\n",
-                             dd, rr, sh_diff_max, sh_rel_max, h_ctl->gram_err);
-        }
-        if (hview.gram && phase == 0) {  // drift monitor of M: a_q . v against ||alpha_q||^2 (k_gram_reset clears it per rebuild)
-            if (h_ctl->gram_err > stats.gram_err || h_ctl->gram_err != h_ctl->gram_err) stats.gram_err = h_ctl->gram_err;
-            // one poor pivot says little about M (the check depends on the entering column as well); a batch whose
-            // pivots are mostly poor does
-            const uint64_t piv = stats.gram_pivots - gram_pivots_before;
-            if (piv > 0 && (uint64_t)h_ctl->gram_bad * 2 > piv) {
-                gram_valid = false;  // rebuilt before the next batch ...
-                if (lifetime_pivots - gram_built_at < gram_min_gap) {  // ... unless the last rebuild did not last: back off
-                    gram_off_until = lifetime_pivots + gram_backoff;
-                    if (gram_backoff < (1u << 18)) gram_backoff *= 2;  // every failed attempt waits twice as long
-                    stats.gram_backoffs += 1;
-                    view_dirty = true;
-                }
-            }
-        }
         // drift monitor: the pivot element from FTRAN and from the tableau row must agree
         if (h_ctl->max_pivot_err > stats.max_pivot_err) stats.max_pivot_err = h_ctl->max_pivot_err;
         if (res == ITER_PIVOT && !(h_ctl->max_pivot_err <= refresh_tol) && k_ > 0) rebuild_inverse();
+        if (res == ITER_STALL && !ratio_two && shard_world == 1 && !(phase == 1 && h_ctl->forced)) {
+            // The in-kernel wait between the two Harris passes timed out: the grid was not co-resident (another process
+            // holds the CUs, or the occupancy estimate was wrong for this partition).  Nothing of the iteration has been
+            // applied — the stalled kernel only halted the batch — so switch to the two-launch form for good (the
+            // geometry changes: graphs are re-captured) and run the iteration again: the next batch clears the work
+            // vectors and re-takes the same pricing decision from the unchanged d / gamma / x_B / beta.
+            ratio_two = true;
+            stats.ratio_stalls += 1;
+            if (pivot_budget >= 0) pivot_budget += 1;  // the stalled record consumed one unit
+            HIPCHECK(hipMemsetAsync(d_ticket.p, 0, sizeof(unsigned) * std::min<size_t>(d_ticket.cap, 64), st));
+            continue;
+        }
         if (res != ITER_PIVOT) return res;
     }
 }
 
-// Gram mode (opt-in, MLP_GRAM=1).  Conditions: primal loop with steepest-edge pricing, the large-nucleus delayed-update
-// mode with its strip kernels, lazy dual steepest edge (no tau = B^-1 rho, which would need the full pass anyway), one GPU
-// (a sharded solve splits the full pass by rows instead).
-bool Engine::gram_wanted() const {
-    return gram_enable && !gram_oom && gram_phase && enable_pse && shard_world == 1 && lazy_now(0) && geom().big &&
-           stream_strips_enabled() && lifetime_pivots >= gram_off_until;
-}
-// M = W^T C W with C = I + F^T D^-2 F, from the folded inverse: C is accumulated on the device from the CSC / CSR,
-// the two k x k x k products are rocBLAS dgemm calls (plain library GEMMs; the buffers are row-major, i.e. their
-// column-major readings are W^T, C and M, both symmetric).  2 x 2 k^3 flops: 0.01 s at k = 4 096, 0.6 s at k = 20 000.
-void Engine::gram_rebuild() {
-    flush_lowrank();
-    sync_view();
-    if (!hview.gram) return;
-    const int k = k_, l = ld();
-    if (k > 0) {
-        DevBuf<double> C, T;
-        C.alloc_exact((size_t)k * l);
-        T.alloc_exact((size_t)k * l);
-        HIPCHECK(hipMemsetAsync(C.p, 0, sizeof(double) * (size_t)k * l, st));
-        launch_gram_build_c(hview, geom(), C.p, k, st);
-        if (!blas) {
-            if (rocblas_create_handle(reinterpret_cast<rocblas_handle*>(&blas)) != rocblas_status_success)
-                throw MlpError(-3, "rocblas_create_handle failed");
-        }
-        rocblas_handle h = reinterpret_cast<rocblas_handle>(blas);
-        rocblas_set_stream(h, st);
-        const double one = 1.0, zero = 0.0;
-        // column-major: T^T = W^T C  (row-major T = C W), then M = T^T (W^T)^T  (row-major M = W^T T)
-        if (rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, k, k, k, &one, d_W.p, l, C.p, l, &zero, T.p, l) !=
-                rocblas_status_success ||
-            rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_transpose, k, k, k, &one, T.p, l, d_W.p, l, &zero, d_M.p, l) !=
-                rocblas_status_success)
-            throw MlpError(-3, "rocblas_dgemm failed (Gram matrix build)");
-        HIPCHECK(hipStreamSynchronize(st));
-        if (gram_probe) {  // M y against W^T (C (W y)) by three matrix-vector products, y sparse: the rounding level of the build
-            std::vector<double> y((size_t)k, 0.0), r1((size_t)k), r2((size_t)k);
-            for (int j = 0; j < 20; ++j) y[(size_t)((1103515245u * (unsigned)(j + 1) + 12345u) % (unsigned)k)] = 0.1 + 0.05 * j;
-            DevBuf<double> dy, d1, d2, d3;
-            dy.alloc_exact((size_t)k); d1.alloc_exact((size_t)k); d2.alloc_exact((size_t)k); d3.alloc_exact((size_t)k);
-            HIPCHECK(hipMemcpy(dy.p, y.data(), sizeof(double) * (size_t)k, hipMemcpyHostToDevice));
-            // row-major X (ld l) is column-major X^T: W y = (W^T)^T y -> op T on the W buffer; C symmetric; W^T z -> op N
-            rocblas_dgemv(h, rocblas_operation_transpose, k, k, &one, d_W.p, l, dy.p, 1, &zero, d1.p, 1);
-            rocblas_dgemv(h, rocblas_operation_none, k, k, &one, C.p, l, d1.p, 1, &zero, d2.p, 1);
-            rocblas_dgemv(h, rocblas_operation_none, k, k, &one, d_W.p, l, d2.p, 1, &zero, d3.p, 1);
-            rocblas_dgemv(h, rocblas_operation_none, k, k, &one, d_M.p, l, dy.p, 1, &zero, d1.p, 1);
-            HIPCHECK(hipStreamSynchronize(st));
-            HIPCHECK(hipMemcpy(r1.data(), d3.p, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost));
-            HIPCHECK(hipMemcpy(r2.data(), d1.p, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost));
-            double dmax = 0.0, vmax = 0.0;
-            for (int i = 0; i < k; ++i) {
-                dmax = std::max(dmax, std::fabs(r1[(size_t)i] - r2[(size_t)i]));
-                vmax = std::max(vmax, std::fabs(r1[(size_t)i]));
-            }
-            std::fprintf(stderr, "[gram probe] k = %d: max |M y - W^T C W y| = %.3e, max |M y| = %.3e\n", k, dmax, vmax);
-        }
-    }
-    launch_gram_reset(hview, gram_tol, gram_safe, st);
-    HIPCHECK(hipStreamSynchronize(st));
-    gram_valid = true;
-    gram_built_at = lifetime_pivots;
-    stats.gram_rebuilds += 1;
-}
-
-// Lazy dual steepest edge: rebuild beta_p = ||e_p^T B^-1||^2 exactly from the basis inverse after primal pivots that
-// skipped the recurrence (solver.rs:1153-1174 maintains the same quantity pivot by pivot).
 void Engine::ensure_beta() {
     if (!beta_stale) return;
     flush_lowrank();  // W0 must be the whole inverse
@@ -1611,10 +1485,26 @@ void Engine::recalc_basic_vals() {
     DevBuf<double> rhs, r;
     rhs.upload(h_rhs, st);
     r.ensure((size_t)m_ + 8, 0, st);
-    launch_recalc_basic_vals(hview, geom(), rhs.p, r.p, 0, st);
-    // two steps of iterative refinement with the same inverse: x_B += B^-1 (b - A x)
-    launch_recalc_basic_vals(hview, geom(), rhs.p, r.p, 1, st);
-    launch_recalc_basic_vals(hview, geom(), rhs.p, r.p, 1, st);
+    // profile mode: the dense-rhs FTRAN of each step (one read of the nucleus inverse: x_K = W r_K) is timed kernel-exactly
+    for (int step = 0; step < 3; ++step) {  // the solve, then two steps of iterative refinement with the same inverse: x_B += B^-1 (b - A x)
+        if (profile) {
+            for (int e : {2, 3})
+                if (!ev[e]) HIPCHECK(hipEventCreate(&ev[e]));
+            arm_kernel_timing(2, ev[2], ev[3]);
+        }
+        launch_recalc_basic_vals(hview, geom(), rhs.p, r.p, step > 0 ? 1 : 0, st);
+        if (profile) {
+            arm_kernel_timing(2, nullptr, nullptr);
+            HIPCHECK(hipStreamSynchronize(st));
+            float ms = 0.f;
+            if (k_ > 1 && hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) {
+                stats.dense_ftran_ms += ms;
+                stats.dense_ftran_bytes += 8.0 * (double)k_ * (double)k_;
+                stats.dense_ftran_launches += 1;
+            }
+            (void)hipGetLastError();
+        }
+    }
     HIPCHECK(hipStreamSynchronize(st));
     values_dirty = true;
 }
@@ -1739,8 +1629,13 @@ void Engine::append_row_on_device(const Constraint& c, int slack, int row) {
     d_cptr.swap(d_cptr_alt); d_crow.swap(d_crow_alt); d_cval.swap(d_cval_alt);
     // --- host column summaries
     for (size_t p = 0; p < kn; ++p) {
-        h_colnnz[c.idx[p]] += 1;
-        max_col_nnz_ = std::max(max_col_nnz_, h_colnnz[c.idx[p]]);
+        const int var = c.idx[p];
+        h_colnnz[var] += 1;
+        if (h_colnnz[var] == 1) {  // a column that was empty so far (tsp.rs:226-235 has such variables) becomes a singleton
+            h_single_row[var] = row;
+            h_single_val[var] = c.val[p];
+        }
+        max_col_nnz_ = std::max(max_col_nnz_, h_colnnz[var]);
     }
     max_row_nnz_ = std::max(max_row_nnz_, (int)kn + 1);
     h_colnnz.push_back(1);
@@ -1757,7 +1652,6 @@ void Engine::append_row_on_device(const Constraint& c, int slack, int row) {
 // solver.rs:549-634.  The new slack is a singleton basic column on the new row, so the nucleus
 // inverse is unchanged unless the new row touches a basic singleton column (then: rebuild).
 void Engine::add_constraint(Constraint c) {
-    gram_valid = false;  // (Gram mode: M no longer matches the basis)
     double t0 = now_s();
     if (!primal_feasible || !dual_feasible) throw MlpError(-1, "add_constraint: model not solved (solver.rs:555-556)");
     ensure_beta();
@@ -1839,7 +1733,6 @@ void Engine::add_constraint(Constraint c) {
 // Counterpart of BasisSolver::reset (solver.rs:1286-1303): classify the basic columns (singleton vs
 // nucleus), build K = B[R_K, P_K] densely from the CSC and invert it on the device.
 void Engine::rebuild_inverse() {
-    gram_valid = false;  // (Gram mode: M no longer matches the basis)
     HIPCHECK(hipStreamSynchronize(st));
     HIPCHECK(hipMemsetAsync(&d_ctl.p->nlow, 0, 2 * sizeof(int), st));  // a fresh inverse has no pending terms
     std::vector<int> claimed(m_, -1);
@@ -1943,7 +1836,7 @@ double Engine::reinvert(bool replace) {
         HIPCHECK(hipMemcpy(oldW.p, d_W.p, sizeof(double) * (size_t)capold * ldold, hipMemcpyDeviceToDevice));
     }
     rebuild_inverse();
-    double diff = -1.0;
+    double diff = -1.0, scale = 0.0;
     if (k_ == kold) {
         std::vector<double> b((size_t)kold * kold);
         HIPCHECK(hipMemcpy2D(b.data(), (size_t)kold * sizeof(double), d_W.p, (size_t)ld() * sizeof(double),
@@ -1956,7 +1849,9 @@ double Engine::reinvert(bool replace) {
                 double y = b[(size_t)h_kslot_of_pos[p] * kold + h_kslot_of_row[i]];
                 double dlt = std::fabs(x - y);
                 if (!(dlt <= diff)) diff = dlt;
+                if (std::fabs(y) > scale) scale = std::fabs(y);
             }
+        last_reinvert_scale = scale;
     }
     if (!replace && cap_ == capold) {  // restore the incremental representation
         h_pos_of_kslot = hp; h_row_of_kslot = hr; h_kslot_of_pos = hkp; h_kslot_of_row = hkr;
@@ -2045,7 +1940,6 @@ std::vector<uint8_t> Engine::save_basis(int mode) {
     return out;
 }
 void Engine::load_basis(const uint8_t* blob, size_t len) {
-    gram_valid = false;  // (Gram mode: M no longer matches the basis)
     if (shard_world > 1) throw MlpError(-1, "load_basis: not available on a sharded solution");
     if (!blob || len < sizeof(BasisHeader)) throw MlpError(-1, "load_basis: blob too short");
     BasisHeader h;
@@ -2155,7 +2049,7 @@ Engine* Engine::clone() {
     e->h_rptr = h_rptr; e->h_rcol = h_rcol; e->h_rval = h_rval;
     e->h_colnnz = h_colnnz; e->h_single_row = h_single_row; e->h_single_val = h_single_val;
     e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->no_head_fusion = no_head_fusion;
-    e->sw_balanced = sw_balanced; e->gram_enable = gram_enable; e->gram_safe = gram_safe; e->gram_tol = gram_tol; e->gram_min_gap = gram_min_gap; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->use_pack = use_pack; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
+    e->sw_balanced = sw_balanced; e->ratio_two = ratio_two; e->ratio_spin_limit = ratio_spin_limit; e->ranks_share_device = false; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->use_pack = use_pack; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
     e->h_basic_vars = h_basic_vars; e->h_nb_vars = h_nb_vars; e->h_var_loc = h_var_loc;
     e->h_kslot_of_pos = h_kslot_of_pos; e->h_srow_of_pos = h_srow_of_pos; e->h_kslot_of_row = h_kslot_of_row;
     e->h_pos_of_srow = h_pos_of_srow; e->h_sdiag_of_pos = h_sdiag_of_pos; e->h_nb_fixed = h_nb_fixed;
@@ -2256,6 +2150,7 @@ uint64_t Engine::state(const char* what, double* out, uint64_t cap) {
     else if (w == "orig_var_maxs") tmp = h_hi;
     else if (w == "orig_rhs") tmp = h_rhs;
     else if (w == "flags") tmp = {(double)primal_feasible, (double)dual_feasible, (double)enable_pse, (double)enable_dse};
+    else if (w == "reinvert_scale") tmp = {last_reinvert_scale};  // max |entry| of the fresh nucleus inverse of the last reinvert()
     else if (w == "host_basic_vars") tmp.assign(h_basic_vars.begin(), h_basic_vars.end());
     else if (w == "host_nb_vars") tmp.assign(h_nb_vars.begin(), h_nb_vars.end());
     else return (uint64_t)-1;

@@ -54,7 +54,7 @@ struct StructUpdate {  // how the (P_K, R_K) partition changes 
     int cq;    // col slot of i_q (cases 2, 3)
     int kold;  // nucleus size before the change
     int jn;    // delayed-update mode: index the new rank-1 term gets (0 after a fold)
-    int mjn;   // Gram mode: index the first of the pivot's two terms of M gets (0 after a fold of M)
+    int pad0;
     int pad;
     double diag_q;      // value of the entering singleton's entry
     double inv_diag_r;  // rho[i_r] = 1/diag of the leaving singleton
@@ -86,19 +86,8 @@ struct Ctl {
                                    // 2: dual ratio pass-1 minimum, 3: dual ratio pass-2 candidate,
                                    // 4: tau_K / v_K vectors of the row-sharded streaming pass)
     double max_pivot_err;  // max over the batch of |alpha_q[r] - alpha_r[q]| / max(1,|alpha_q[r]|): drift monitor of W
-    // Gram mode: M = M0 + sum_{t<mnlow} MU[t] MV[t]^T, two terms per pivot
-    int mnlow;             // number of pending rank-1 terms of M
-    int mfold;             // this pivot folds them into M0 first (set by the plan)
-    double lr_mc[LR_MAX];  // MV[t] . (listed entries of a_q on nucleus rows)
-    double gram_err;       // max over the batch of |a_q.v - ||alpha_q||^2| / (1 + ||alpha_q||^2): drift monitor of M
-    unsigned long long gram_rows;  // rows of W0 read by the sparse passes of the batch (algorithmic bytes: 8 k each)
-    double gram_now;       // the monitor of the pivot being applied (k_update_pivot safeguards the weights when it is poor)
-    double gram_tol;       // set at every (re)build of M: monitor value that counts as poor
-    int gram_bad;          // pivots of the batch whose monitor was poor (a majority means M itself is off: rebuild)
-    int gram_pad;
-    double gram_safe;      // monitor value above which k_update_pivot keeps the updated weights above their lower bound
-    unsigned long long sh_diff, sh_ref, sh_hdiff;  // MLP_GRAM_SHADOW: max |v_gram - v_stream|, max |v_stream| (bit patterns of
-                                                   // non-negative doubles order like integers); spare
+    long long ratio_spin_limit;  // fused ratio tests: polls of the in-kernel wait before it gives up with ITER_STALL (set by the
+                                 // host: 20 M ~ seconds; MLP_RATIO_SPIN_LIMIT=0 makes the first launch stall, for the retry test)
     PivotRec ring[RING];
 };
 
@@ -175,21 +164,10 @@ struct DevView {
     double* U;             // LR_MAX x ld: pending rank-1 terms, row-slot side   (delayed-update mode)
     double* V;             // LR_MAX x ld: pending rank-1 terms, col-slot side
     int lrJ;               // 0: every pivot updates W in place; J > 0: fold every J pivots
-    // Gram mode of the primal steepest-edge solve v = B^-T alpha_q = (B B^T)^-1 a_q: with
-    // M = [(B B^T)^-1] restricted to the nucleus rows (cap x ld, symmetric, col slot x col slot) resident, v on the
-    // nucleus rows is a gather of a few rows of M plus a pass over the few rows of W that F^T D^-2 a_S touches —
-    // instead of one read of all of W per pivot.  M follows the basis by a symmetric rank-2 term per pivot (delayed
-    // like W's: LR_MAX pending rank-1 terms, i.e. a fold every LR_MAX / 2 pivots).
-    int gram;              // 1: the primal PSE iteration takes the Gram path (large-nucleus delayed-update mode only)
     // Balanced strips of the streaming pass: with sw_nbal > 0 (the number of k_stream_w blocks the device holds at once)
     // the strip height follows k so that every co-resident block gets ONE tile of equal size — the fixed 128-row strips
     // leave 3 381 tiles for 1 024 slots at k = 20 500, i.e. some CUs stream four tiles while others stream three.
     int sw_nbal, sw_pad;
-    double* M;             // cap x ld: M0
-    double* MU;            // LR_MAX x ld: pending terms of M, left factors
-    double* MV;            // LR_MAX x ld: pending terms of M, right factors
-    double* hS;            // m by row: a_q[i] / D_i^2 on the singleton rows the entering column touches, 0 elsewhere
-    double* mK;            // cap: M0 rows . a_K (scratch of the v assembly)
     // per-pivot vectors
     double* alpha_q;  // m by position  (col_coeffs,            solver.rs:54)
     double* tau;      // m by position  (B^-1 rho,              solver.rs:1157)
@@ -247,6 +225,7 @@ struct Geom {
     int sweep_variant;  // tuning knob (MLP_SWEEP): 0 default
     int big;            // fused W pass: 64-row x 1024-column blocks, non-temporal (cap > 4096, or forced by MLP_BIGTILE)
     int head_fused;     // stage heads run inside the consuming kernel (delayed-update mode off, every column / row fits the LDS list)
+    int ratio_two;      // the two Harris passes as two launches (no in-kernel wait): MLP_RATIO_TWO_KERNELS, ranks sharing a device, after an ITER_STALL
 };
 
 // ---- launch wrappers (all asynchronous on `st`; the DevView is passed to the kernels by value) ----
@@ -290,14 +269,6 @@ void launch_sq_norms_add_row(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_copy_rho_sq_to_beta(const DevView& dv, int row, hipStream_t st);
 void launch_build_nucleus(const DevView& dv, const Geom& g, double* Kd, int k, hipStream_t st);
 void launch_fold_lowrank(const DevView& dv, const Geom& g, hipStream_t st);  // W0 += U^T V, nlow := 0 (host-requested flush)
-// Gram mode: the BASIS stage of a primal PSE pivot (folds of W0 and M0 when due, sparse pass over W0, assembly of v_K),
-// the build of C = I + F^T D^-2 F for the (re)build M = W^T C W, and the reset of the pending-term counters
-void launch_gram_folds(const DevView& dv, const Geom& g, hipStream_t st);  // folds of W0 and M0 (empty launches unless due)
-void launch_gram_basis(const DevView& dv, const Geom& g, hipStream_t st);  // sparse pass over W0 + assembly of v_K
-void launch_gram_build_c(const DevView& dv, const Geom& g, double* C, int k, hipStream_t st);
-void launch_gram_reset(const DevView& dv, double tol, double safe, hipStream_t st);
-// diagnostic (MLP_GRAM_SHADOW): the streaming pass of the same pivot next to the Gram result; mode 2 continues with the streamed v
-void launch_gram_shadow(const DevView& dv, const Geom& g, int mode, hipStream_t st);
 void launch_gauss_jordan(double* Kd, double* Winv, int k, int ld, int* d_flag, double* d_scratch, hipStream_t st);
 
 // device-side matrix maintenance (add_constraint without a host pass over the non-zeros; also the initial builds)

@@ -263,7 +263,9 @@ static inline int grid_for(int n, int per_thread = 4, int max_blocks = 512) {
 // slot, the launch goes through hipExtLaunchKernelGGL, which stamps the events at the start and at the end of the
 // KERNEL — the figure rocprofv3 reports — instead of bracketing the launch with hipEventRecord (which adds the
 // dispatch gap of an eager launch: 27.5 against 23.9 us on the banded sweep).
-static hipEvent_t g_tev[4][2] = {};
+// thread_local: two Solutions in profile mode on different host threads must not stamp each other's events (a Solution is
+// driven by one thread at a time; arming and launching happen on that thread)
+static thread_local hipEvent_t g_tev[4][2] = {};
 void arm_kernel_timing(int slot, hipEvent_t t0, hipEvent_t t1) {
     if (slot > 0 && slot < 4) {
         g_tev[slot][0] = t0;
@@ -536,8 +538,7 @@ __device__ void plan_update(const DevView& v, Ctl* c, int phase) {
     c->it.inv_alpha = 1.0 / v.alpha_q[r];
     c->fold = (v.lrJ > 0 && c->nlow >= v.lrJ) ? 1 : 0;
     u.jn = c->fold ? 0 : c->nlow;
-    c->mfold = (v.gram && phase == 0 && c->mnlow + 2 > LR_MAX) ? 1 : 0;
-    u.mjn = c->mfold ? 0 : c->mnlow;
+    u.pad0 = 0;
     u.pad = 0;
     if (new_sing) {
         u.i_q = v.csc_row[cb];
@@ -616,10 +617,6 @@ __device__ void ftran_prep_wave(const DevView& v, Ctl* c, int lane, int derive_p
     const int nlow = v.lrJ ? c->nlow : 0;
     const double* Vrow = v.V + (size_t)(lane < nlow ? lane : 0) * v.ld;
     double lr_acc = 0.0;
-    // Gram mode: the same dots against the pending terms of M (lane t serves term t), and h = D^-2 a_S by row
-    const int mnlow = (v.gram && derive_primal) ? c->mnlow : 0;
-    const double* MVrow = v.gram ? v.MV + (size_t)(lane < mnlow ? lane : 0) * v.ld : nullptr;
-    double mlr_acc = 0.0;
     // Two chunks of 64 entries per trip, their loads issued together: a 100-entry column is ONE round of the dependent
     // chain entry -> row -> packed row map (diag, position, slot) instead of two rounds of a four-deep one.
     for (int e0 = base; e0 < end; e0 += 128) {
@@ -641,10 +638,7 @@ __device__ void ftran_prep_wave(const DevView& v, Ctl* c, int lane, int derive_p
         for (int h = 0; h < 2; ++h) {
             if (vx[h]) {
                 sx[h] = rx[h].kslot;
-                if (sx[h] < 0) {
-                    v.alpha_q[rx[h].pos] = ax[h] / rx[h].diag;
-                    if (v.gram && derive_primal) v.hS[ix[h]] = ax[h] / (rx[h].diag * rx[h].diag);
-                }
+                if (sx[h] < 0) v.alpha_q[rx[h].pos] = ax[h] / rx[h].diag;
             }
         }
 #pragma unroll
@@ -661,12 +655,10 @@ __device__ void ftran_prep_wave(const DevView& v, Ctl* c, int lane, int derive_p
             }
             cnt += __popcll(mask);
             if (nlow > 0) lr_dot_listed(mask, s, a, Vrow, lane < nlow, lr_acc);
-            if (mnlow > 0) lr_dot_listed(mask, s, a, MVrow, lane < mnlow, mlr_acc);
         }
     }
     if (lane == 0) it->klist_n = cnt;
     if (lane < nlow) c->lr_c[lane] = lr_acc;
-    if (lane < mnlow) c->lr_mc[lane] = mlr_acc;
 }
 // BTRAN head (one wave): rho = B^-T e_r (solver.rs:680-683) as a short list of rows of W.
 __device__ void btran_prep_wave(const DevView& v, Ctl* c, int lane, int r, int derive_dual, int plan_after, int phase) {
@@ -1289,7 +1281,7 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_fused(DevView v, int use_p
         long spins = 0;
         while (ld_agent(&c->ratio_epoch) != epoch0 + 1) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > 20000000L) {  // seconds: cannot happen while the grid is co-resident; never hang the GPU
+            if (++spins > c->ratio_spin_limit) {  // seconds: cannot happen while the grid is co-resident; never hang the GPU
                 s_gave_up = 1;
                 break;
             }
@@ -1399,15 +1391,6 @@ __global__ void __launch_bounds__(BLK) k_btran(DevView v, int n_gather) {
         int var = v.basic_vars[p];
         int end = v.csc_ptr[var + 1];
         double acc = 0.0;
-        if (v.gram) {  // Gram mode: t_K = -F^T D^-2 a_S (non-zero only for the columns that meet a singleton row of a_q)
-            for (int e = v.csc_ptr[var] + gl; e < end; e += G) {
-                int i = v.csc_row[e];
-                if (v.kslot_of_row[i] < 0) acc += v.csc_val[e] * v.hS[i];
-            }
-            acc = group_sum<G>(acc);
-            if (gl == 0) v.tK[slot] = -acc;
-            return;
-        }
         // (rv.y is zero on the nucleus rows at this point — the update kernel cleared it, v_K is scattered later — so the
         // entries on nucleus rows add exact zeros and the row-map lookup that would skip them is not needed)
         for (int e = v.csc_ptr[var] + gl; e < end; e += G) acc += v.csc_val[e] * v.rv[v.csc_row[e]].y;
@@ -1668,108 +1651,10 @@ __device__ __forceinline__ void lowrank_append(const DevView& v, Ctl* c, const S
     }
     if (s == 0) c->nlow = jn + 1;
 }
-// Symmetric rank-2 term of this pivot and the slot changes of M (called by every thread of the partition-change
-// blocks, s = slot index; mirrors lowrank_append / struct_update_body for W).  In slot terms, with P = rho and
-// X = (v - rho) / alpha_r - (s / (2 alpha_r^2)) rho on the NEW nucleus rows:  M' = M - P X^T - X P^T, stored as the two
-// rank-1 terms (MU, MV) = (-P, X), (-X, P).  A row that joins the nucleus (it was covered by the leaving singleton
-// r) brings Z[., i_r] = rho_K / D_r, Z[i_r, i_r] = 1 / D_r^2 into M0 and zeros into the pending terms.
-__device__ __forceinline__ void gram_update(const DevView& v, Ctl* c, const StructUpdate& u, int s) {
-    __shared__ double s_sig[2];
-    const IterState* it = &c->it;
-    if (threadIdx.x < 64) {  // a_q . v and b . v over the two columns (wave 0 of every block, fixed order)
-        const int lane = threadIdx.x;
-        double av = 0.0, bv = 0.0;
-        const int ev = it->entering_var, lv = it->leaving_var;
-        for (int e = v.csc_ptr[ev] + lane; e < v.csc_ptr[ev + 1]; e += 64) av += v.csc_val[e] * v.rv[v.csc_row[e]].y;
-        for (int e = v.csc_ptr[lv] + lane; e < v.csc_ptr[lv + 1]; e += 64) bv += v.csc_val[e] * v.rv[v.csc_row[e]].y;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            av += __shfl_down(av, o, 64);
-            bv += __shfl_down(bv, o, 64);
-        }
-        if (lane == 0) {
-            s_sig[0] = av;
-            s_sig[1] = bv;
-        }
-    }
-    __syncthreads();
-    const double av = s_sig[0], bv = s_sig[1];
-    const double ia = it->inv_alpha;
-    const double sc = av - bv - 1.0 / ia + 1.0;
-    const double sigma = 0.5 * sc * ia * ia;
-    const int kold = u.kold, ld = v.ld, last = kold - 1;
-    const int jn = u.mjn;
-    double* U0 = v.MU + (size_t)jn * ld;
-    double* V0 = v.MV + (size_t)jn * ld;
-    double* U1 = U0 + ld;
-    double* V1 = V0 + ld;
-    if (s == 0) {
-        const double err = fabs(av + 1.0 - it->alpha_sq) / it->alpha_sq;
-        if (err > c->gram_err || err != err) c->gram_err = err;
-        c->gram_now = err;
-        if (!(err <= c->gram_tol)) c->gram_bad += 1;
-    }
-    auto put = [&](int slot, double P, double vv) {
-        const double X = (vv - P) * ia - sigma * P;
-        U0[slot] = -P; V0[slot] = X;
-        U1[slot] = -X; V1[slot] = P;
-    };
-    if (u.kase == 0 || u.kase == 4) {
-        if (s < kold) put(s, v.rK[s], v.vK[s]);
-    } else if (u.kase == 2) {
-        if (s < last) {
-            const int src = (s == u.cq) ? last : s;
-            put(s, v.rK[src], v.vK[src]);
-            if (u.cq != last) {  // (M0 is read through its upper triangle: src <= last)
-                const double z = v.M[(size_t)src * ld + last];
-                v.M[(size_t)u.cq * ld + s] = z;
-                v.M[(size_t)s * ld + u.cq] = z;
-            }
-        }
-        if (s < jn && u.cq != last) {
-            v.MU[(size_t)s * ld + u.cq] = v.MU[(size_t)s * ld + last];
-            v.MV[(size_t)s * ld + u.cq] = v.MV[(size_t)s * ld + last];
-        }
-    } else if (u.kase == 1) {
-        const double idr = u.inv_diag_r;
-        if (s < kold) {
-            put(s, v.rK[s], v.vK[s]);
-            const double z = v.rK[s] * idr;
-            v.M[(size_t)kold * ld + s] = z;
-            v.M[(size_t)s * ld + kold] = z;
-        } else if (s == kold) {
-            put(kold, idr, v.rv[u.i_r].y);
-            v.M[(size_t)kold * ld + kold] = idr * idr;
-        }
-        if (s < jn) {
-            v.MU[(size_t)s * ld + kold] = 0.0;
-            v.MV[(size_t)s * ld + kold] = 0.0;
-        }
-    } else if (u.kase == 3) {
-        const double idr = u.inv_diag_r;
-        if (s < kold) {
-            if (s == u.cq) {
-                put(s, idr, v.rv[u.i_r].y);
-                v.M[(size_t)s * ld + s] = idr * idr;
-            } else {
-                put(s, v.rK[s], v.vK[s]);
-                const double z = v.rK[s] * idr;
-                v.M[(size_t)u.cq * ld + s] = z;
-                v.M[(size_t)s * ld + u.cq] = z;
-            }
-        }
-        if (s < jn) {
-            v.MU[(size_t)s * ld + u.cq] = 0.0;
-            v.MV[(size_t)s * ld + u.cq] = 0.0;
-        }
-    }
-    if (s == 0) c->mnlow = jn + 2;
-}
 __device__ __forceinline__ void struct_update_body(const DevView& v, Ctl* c, int s) {
     const StructUpdate u = c->up;
     if (u.kase < 0) return;
     if (v.lrJ) lowrank_append(v, c, u, s);
-    if (v.gram) gram_update(v, c, u, s);
     if (u.kase == 0) return;
     const int kold = u.kold;
     const int ld = v.ld;
@@ -2198,7 +2083,7 @@ __global__ void __launch_bounds__(BLK) k_ratio_dual_fused(DevView v) {
         long spins = 0;
         while (ld_agent(&c->ratio_epoch) != epoch0 + 1) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > 20000000L) {
+            if (++spins > c->ratio_spin_limit) {
                 state = 1;
                 break;
             }
@@ -2809,14 +2694,13 @@ constexpr int FD_CH = 256, FD_RB = 256, FD_RS = 8;
 // The hot loop is branch-free: rows and columns beyond the edge are CLAMPED (the loads are unconditional, their
 // results masked or never stored).  With `cond ? load : 0` forms the loop breaks into ~20 basic blocks and the
 // register allocator spills the V values (measured: 1.8 KB of scratch per lane).
-// which = 1: the same fold for the Gram matrix, M0 += sum_t MU[t] MV[t]^T (Ctl.mnlow terms, flag Ctl.mfold).
 template <int JM>
-__global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : 3)) k_fold_w(DevView v, int mode, int which) {
+__global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : 3)) k_fold_w(DevView v, int mode) {
     Ctl* c = v.ctl;
     if (mode != 1 && (c->halt || c->it.status != ITER_PIVOT)) return;
-    if (!(mode == 1 || (which ? c->mfold : c->fold))) return;
+    if (!(mode == 1 || c->fold)) return;
     const int k = c->k, ld = v.ld;
-    const int nlow = min(which ? c->mnlow : c->nlow, JM);
+    const int nlow = min(c->nlow, JM);
     if (nlow <= 0 || k <= 0) return;
     const int tid = threadIdx.x;
     __shared__ __attribute__((aligned(16))) double s_u[2][FD_RS][JM];
@@ -2824,13 +2708,12 @@ __global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : 3)) k_fold_w(DevView v, i
     const int sa = tid / JM, sj = tid % JM;  // staging: thread -> (row of the step, term)
     const bool stager = sa < FD_RS;
     const int sjc = min(sj, nlow - 1);
-    double* __restrict__ Wp = which ? v.M : v.W;
-    const double* __restrict__ Up = which ? v.MU : v.U;
-    const double* __restrict__ Vp = which ? v.MV : v.V;
+    double* __restrict__ Wp = v.W;
+    const double* __restrict__ Up = v.U;
+    const double* __restrict__ Vp = v.V;
     for (int tile = blockIdx.x; tile < nstr * nch; tile += gridDim.x) {
         const int strip = tile / nch, chunk = tile % nch;
         const int rbeg = strip * FD_RB, rend = min(k, rbeg + FD_RB);
-        if (which && (chunk + 1) * FD_CH <= rbeg) continue;  // M is symmetric: only its upper triangle (col >= row) is kept current
         const int col = chunk * FD_CH + tid;
         const bool active = col < k;
         const int colc = active ? col : k - 1;
@@ -2890,226 +2773,6 @@ __global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : 3)) k_fold_w(DevView v, i
 __global__ void k_reset_nlow(DevView v) {
     v.ctl->nlow = 0;
     v.ctl->fold = 0;
-    v.ctl->mnlow = 0;  // (the host-requested flush folds the pending terms of M as well)
-    v.ctl->mfold = 0;
-}
-
-// ------------------------------------------------------------------- Gram mode
-// v = B^-T alpha_q = (B B^T)^-1 a_q.  With Z = (B B^T)^-1 in blocks over the rows (R_K, R_S),
-//   Z[R_K,R_K] = M = W^T (I + F^T D^-2 F) W,   Z[R_K,R_S] = -W^T F^T D^-2,   Z[R_S,R_S] = D^-2,
-// the nucleus part is v_K = M a_K - W^T (F^T D^-2 a_S): a_K has a handful of entries (a gather of rows of M) and
-// t_K = -F^T D^-2 a_S is non-zero only for the nucleus columns that meet one of the ~80 singleton rows of a_q (8 % of
-// them on config 4), so the pass over W reads only those rows.  M follows the basis change B' = B + (a_q - b) e_r^T:
-//   Z' = G^T Z G,  G = I - (a_q - b) rho^T / alpha_r   =>   Z' = Z - (rho w^T + w rho^T) / alpha_r + (s / alpha_r^2) rho rho^T
-// with w = Z (a_q - b) = v - rho (Z b = B^-T e_r = rho, taken from W) and s = (a_q - b) . w computed FROM the stored v
-// (with the exact value ||alpha||^2 - 2 alpha_r + 1 in its place the recursion is unstable: a numpy model of it gains
-// a factor 10^5 per 100 pivots; with s consistent the error of M stays where the pivots put it, 1e-12 ... 1e-8).
-// Sparse pass: a block owns GS_RB rows x GS_CH columns of W0; it first compacts the rows with t != 0 (ascending, so the
-// summation order is fixed), then walks them in steps of GS_RS like k_stream_w (register double buffer, non-temporal
-// 16-byte loads) and writes one row of partials per strip.  The last LR_MAX blocks compute h_j = U[j] . t_K.
-constexpr int GS_CH = 1024, GS_RB = 512, GS_RS = 4;
-__global__ void __launch_bounds__(BLK, 4) k_wt_sparse(DevView v) {
-    constexpr int NP = GS_CH / (2 * BLK);
-    Ctl* c = v.ctl;
-    if (c->halt || c->it.status != ITER_PIVOT) return;
-    const int k = c->k, ld = v.ld;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_tile_blocks = (int)gridDim.x - LR_MAX;
-    if ((int)blockIdx.x >= n_tile_blocks) {
-        const int j = (int)blockIdx.x - n_tile_blocks;
-        if (c->fold || j >= c->nlow) return;
-        const double* Uj = v.U + (size_t)j * ld;
-        double h = 0.0;
-        for (int s = tid; s < k; s += BLK) h += Uj[s] * v.tK[s];
-        h = block_sum(h);
-        if (tid == 0) c->lr_h[j] = h;
-        return;
-    }
-    __shared__ int s_cnt[2 * (BLK / 64)];
-    __shared__ int s_row[GS_RB];
-    __shared__ double s_tv[GS_RB];
-    static_assert(GS_RB == 2 * BLK, "two rows per thread in the compaction");
-    const int nch = (k + GS_CH - 1) / GS_CH, nstr = (k + GS_RB - 1) / GS_RB;
-    const double* __restrict__ Wp = v.W;
-    for (int tile = blockIdx.x; tile < nstr * nch; tile += n_tile_blocks) {
-        const int strip = tile / nch, chunk = tile % nch;
-        const int rbeg = strip * GS_RB, rend = min(k, rbeg + GS_RB);
-        __syncthreads();  // the previous tile's readers of the list are done
-        double tv[2];
-        unsigned long long mk[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int row = rbeg + h * BLK + tid;
-            tv[h] = row < rend ? v.tK[row] : 0.0;
-            mk[h] = __ballot(tv[h] != 0.0);
-            if (lane == 0) s_cnt[h * (BLK / 64) + wave] = __popcll(mk[h]);
-        }
-        __syncthreads();
-        int nnz = 0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            int base = 0;
-            for (int w2 = 0; w2 < h * (BLK / 64) + wave; ++w2) base += s_cnt[w2];
-            if (tv[h] != 0.0) {
-                const int off = base + __popcll(mk[h] & ((1ull << lane) - 1ull));
-                s_row[off] = rbeg + h * BLK + tid;
-                s_tv[off] = tv[h];
-            }
-        }
-        for (int w2 = 0; w2 < 2 * (BLK / 64); ++w2) nnz += s_cnt[w2];
-        if (chunk == 0 && tid == 0 && nnz > 0) atomicAdd(&c->gram_rows, (unsigned long long)nnz);
-        __syncthreads();
-        int c0[NP];
-        bool pair[NP], one[NP];
-        double vacc0[NP], vacc1[NP];
-        const double* wcol[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            c0[p] = chunk * GS_CH + p * 2 * BLK + 2 * tid;
-            pair[p] = c0[p] + 1 < k;
-            one[p] = c0[p] < k;
-            vacc0[p] = vacc1[p] = 0.0;
-            wcol[p] = Wp + (one[p] ? c0[p] : 0);
-        }
-        if (nnz > 0) {
-            dbl2_t w[GS_RS][NP], wn[GS_RS][NP];
-            auto load_step = [&](dbl2_t (&dst)[GS_RS][NP], int i0) {
-#pragma unroll
-                for (int a = 0; a < GS_RS; ++a) {
-                    const size_t roff = (size_t)s_row[min(i0 + a, nnz - 1)] * ld;  // (clamped: masked through t = 0 below)
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) {
-                        const dbl2_t t = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t*>(wcol[p] + roff));
-                        dst[a][p].x = one[p] ? t.x : 0.0;
-                        dst[a][p].y = pair[p] ? t.y : 0.0;
-                    }
-                }
-            };
-            load_step(w, 0);
-            for (int i0 = 0; i0 < nnz; i0 += GS_RS) {
-                if (i0 + GS_RS < nnz) load_step(wn, i0 + GS_RS);  // (uniform branch)
-#pragma unroll
-                for (int a = 0; a < GS_RS; ++a) {
-                    const double t = (i0 + a < nnz) ? s_tv[i0 + a] : 0.0;
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) {
-                        vacc0[p] += w[a][p].x * t;
-                        vacc1[p] += w[a][p].y * t;
-                    }
-                }
-#pragma unroll
-                for (int a = 0; a < GS_RS; ++a)
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) w[a][p] = wn[a][p];
-            }
-        }
-        double* pv = v.part_v + (size_t)strip * ld;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            if (one[p]) pv[c0[p]] = vacc0[p];
-            if (pair[p]) pv[c0[p] + 1] = vacc1[p];
-        }
-    }
-}
-// Assembly of v_K (GV_L lanes per col slot, fixed summation order):
-//   v_K = sum over strips of the W0^T t_K partials + sum_j V[j] h_j        (the -W^T F^T D^-2 a_S part)
-//       + sum over the listed entries of a_K of a_c M0[c][.] + sum_t MU[t] (MV[t] . a_K)        (the M a_K part)
-// then the scatter by row.  The pending terms are skipped when this pivot's fold has just applied them.  Only the upper
-// triangle of M0 is kept current by the fold, so entry (c, i) is read as M0[min][max].
-constexpr int GV_L = 4;
-__global__ void __launch_bounds__(BLK) k_gram_v(DevView v) {
-    Ctl* c = v.ctl;
-    if (c->halt || c->it.status != ITER_PIVOT) return;
-    const int k = c->k, ld = v.ld;
-    const int gid = blockIdx.x * BLK + threadIdx.x;
-    const int i = gid / GV_L, gl = gid % GV_L;
-    if (i >= k) return;  // (whole lane groups leave together)
-    const int nstr = (k + GS_RB - 1) / GS_RB;
-    double sv = 0.0;
-    for (int t = gl; t < nstr; t += GV_L) sv += v.part_v[(size_t)t * ld + i];
-    if (!c->fold) {
-        const int nlow = c->nlow;
-        for (int j = gl; j < nlow; j += GV_L) sv += v.V[(size_t)j * ld + i] * c->lr_h[j];
-    }
-    const int n = c->it.klist_n;
-    double mv = 0.0;
-    for (int j = gl; j < n; j += GV_L) {
-        const int cs = v.klist_s[j];
-        mv += v.klist_a[j] * v.M[(size_t)min(cs, i) * ld + max(cs, i)];
-    }
-    if (!c->mfold) {
-        const int mn = c->mnlow;
-        for (int j = gl; j < mn; j += GV_L) mv += v.MU[(size_t)j * ld + i] * c->lr_mc[j];
-    }
-    sv += mv;
-    sv += __shfl_xor(sv, 1, 64);
-    sv += __shfl_xor(sv, 2, 64);
-    if (gl == 0) {
-        v.vK[i] = sv;
-        v.rv[v.row_of_kslot[i]].y = sv;
-    }
-}
-// C = I + F^T D^-2 F (row-slot x row-slot, dense) for the (re)build M = W^T C W: one wave per nucleus column s walks
-// its entries on singleton rows in order; for each such row the lanes spread over the row's entries in other nucleus
-// columns.  (C is zeroed by the caller; the adds to one address are issued by one wave in program order.)
-__global__ void __launch_bounds__(BLK) k_gram_build_c(DevView v, double* C, int k) {
-    const int s = (blockIdx.x * BLK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (s >= k) return;
-    const int var = v.basic_vars[v.pos_of_kslot[s]];
-    double* Cs = C + (size_t)s * v.ld;
-    for (int e = v.csc_ptr[var]; e < v.csc_ptr[var + 1]; ++e) {
-        const int i = v.csc_row[e];
-        const RowInfo ri = v.rowinfo[i];
-        if (ri.kslot >= 0) continue;
-        const double coef = v.csc_val[e] / (ri.diag * ri.diag);
-        for (int f = v.csr_ptr[i] + lane; f < v.csr_ptr[i + 1]; f += 64) {
-            const int loc = v.var_loc[v.csr_col[f]];
-            if (loc < 0) continue;
-            const int s2 = v.kslot_of_pos[loc];
-            if (s2 >= 0) atomicAdd(Cs + s2, coef * v.csr_val[f]);
-        }
-    }
-    if (lane == 0) atomicAdd(Cs + s, 1.0);
-}
-// MLP_GRAM_SHADOW: v_K of the streaming pass (partials of k_stream_w's strips + low-rank part) against the Gram result
-template <int TR>
-__global__ void __launch_bounds__(BLK) k_gram_shadow(DevView v, int mode) {
-    Ctl* c = v.ctl;
-    if (c->halt || c->it.status != ITER_PIVOT) return;
-    const int k = c->k, ld = v.ld;
-    const int i = blockIdx.x * BLK + threadIdx.x;
-    double diff = 0.0, ref = 0.0;
-    if (i < k) {
-        const int tr = sw_strip_rows(v, k, 1024, 4, TR);
-        const int nstr = (k + tr - 1) / tr;
-        double sv = 0.0;
-        for (int t = 0; t < nstr; ++t) sv += v.part_v[(size_t)t * ld + i];
-        if (!c->fold) {
-            const int nlow = c->nlow;
-            for (int j = 0; j < nlow; ++j) sv += v.V[(size_t)j * ld + i] * c->lr_h[j];
-        }
-        diff = fabs(sv - v.vK[i]);
-        ref = fabs(sv);
-        if (mode == 2) {
-            v.vK[i] = sv;
-            v.rv[v.row_of_kslot[i]].y = sv;
-        }
-    }
-    diff = block_max(diff);
-    ref = block_max(ref);
-    if (threadIdx.x == 0) {
-        atomicMax(&c->sh_diff, (unsigned long long)__double_as_longlong(diff));
-        atomicMax(&c->sh_ref, (unsigned long long)__double_as_longlong(ref));
-    }
-}
-__global__ void k_gram_reset(DevView v, double tol, double safe) {
-    v.ctl->gram_safe = safe;
-    v.ctl->mnlow = 0;
-    v.ctl->mfold = 0;
-    v.ctl->gram_err = 0.0;
-    v.ctl->gram_now = 0.0;
-    v.ctl->gram_tol = tol;
-    v.ctl->gram_bad = 0;
 }
 
 // Row-sharded streaming pass, step 2 of 3 (k_stream_w -> k_post_exchange -> k_post_fused): reduce this rank's partials
@@ -3321,7 +2984,6 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
             v.alpha_q[t] = 0.0;
             v.tau[t] = 0.0;
             v.rv[t] = make_double2(0.0, 0.0);
-            if (v.gram) v.hS[t] = 0.0;
             if (phase == 1 && !c->forced) tc = price_dual_one(xb, lo, hi, bt, t, use_dse);
         }
         if (t < v.n) {
@@ -3392,11 +3054,6 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                     v.d[tn] = dd;
                     if (use_pse) {
                         gm += -2.0 * ar * hp / pc + it->alpha_sq * ar * ar / (pc * pc);
-                        // Gram mode: when this pivot's v failed its check (a_q.v against ||alpha_q||^2), keep the weight
-                        // above its lower bound 1 + (alpha_rj / alpha_rq)^2 (Forrest & Goldfarb's safeguard); never let a
-                        // broken M poison the weights
-                        if (v.gram && !(c->gram_now <= c->gram_safe)) gm = fmax(gm, 1.0 + ar * ar / (pc * pc));
-                        if (v.gram && !(fabs(gm) < 1e300)) gm = 1.0 + ar * ar / (pc * pc);
                         v.gamma[tn] = gm;
                     }
                 }
@@ -3439,11 +3096,6 @@ __global__ void k_reset_ring(DevView v) {
     c->halt = 0;
     c->forced = 0;
     c->max_pivot_err = 0.0;
-    c->gram_err = 0.0;
-    c->gram_rows = 0ull;
-    c->gram_bad = 0;
-    c->sh_diff = 0ull;
-    c->sh_ref = 0ull;
 }
 // K9: recalc reduced costs (solver.rs:1216-1231): d_c = c_c - a_c . y, then the objective from scratch
 __global__ void __launch_bounds__(BLK) k_gather_basic_obj(DevView v) {
@@ -3934,23 +3586,33 @@ void launch_ftran_gather(const DevView& dv, const Geom& g, hipStream_t st) {
     if (dv.pb_on) launch_blocked_push(dv, 0, st);
     else if (dv.det_pull) launch_pull_F(dv, g, 0, st);
 }
+// Blocks of `fn` (BLK threads, no dynamic LDS) that the CURRENT device holds at once, halved as a margin for kernels of
+// other queues sharing the CUs; cached per device (mlp_set_device may move a process to another GPU or partition).
+static int coresident_half(const void* fn, int slot) {
+    static int cache[2][64];
+    static bool known[2][64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!known[slot][dev]) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, BLK, 0) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+            cache[slot][dev] = per_cu * cus / 2;
+        else
+            cache[slot][dev] = 0;  // unknown: always take the two-kernel path
+        known[slot][dev] = true;
+    }
+    return cache[slot][dev];
+}
 void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st) {
     const int nb = grid_for(g.m);
-    static const bool two_kernels = std::getenv("MLP_RATIO_TWO_KERNELS") != nullptr;
     // The fused kernel's blocks wait inside the launch for its last-arriving block, which is only safe while the
     // WHOLE grid is co-resident: bound the grid by what this device (or partition: CPX mode, CU mask) can hold at
-    // once, per the occupancy calculator, with a 2x margin for kernels of other queues sharing the CUs.
-    static int max_coresident = -1;
-    if (max_coresident < 0) {
-        int dev = 0, per_cu = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_ratio_primal_fused), BLK, 0) == hipSuccess &&
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
-            max_coresident = per_cu * cus / 2;
-        else
-            max_coresident = 0;  // unknown: always take the two-kernel path
-    }
-    if (!two_kernels && nb <= max_coresident && (long)nb * BLK * 4 >= (long)g.m) {  // every element fits the fused kernel's registers
+    // once, per the occupancy calculator, with a 2x margin for kernels of other queues sharing the CUs.  The engine
+    // selects the two-launch form (Geom.ratio_two) when MLP_RATIO_TWO_KERNELS is set, when the ranks of a sharded solve
+    // share one device, and for good after a wait has ever timed out (ITER_STALL).
+    const int max_coresident = g.ratio_two ? 0 : coresident_half(reinterpret_cast<const void*>(k_ratio_primal_fused), 0);
+    if (nb <= max_coresident && (long)nb * BLK * 4 >= (long)g.m) {  // every element fits the fused kernel's registers
         hipLaunchKernelGGL(k_ratio_primal_fused, dim3(nb), dim3(BLK), 0, st, dv, use_pse);  // both passes + BTRAN head + plan
         return;
     }
@@ -4046,18 +3708,8 @@ void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st) {
 }
 void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st) {
     const int nb = grid_for(dv.nb_hi - dv.nb_lo);
-    static const bool two_kernels = std::getenv("MLP_RATIO_TWO_KERNELS") != nullptr;
-    static int max_coresident = -1;  // see launch_ratio_primal
-    if (max_coresident < 0) {
-        int dev = 0, per_cu = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_ratio_dual_fused), BLK, 0) == hipSuccess &&
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
-            max_coresident = per_cu * cus / 2;
-        else
-            max_coresident = 0;
-    }
-    if (!two_kernels && nb <= max_coresident && (long)nb * BLK * 4 >= (long)(dv.nb_hi - dv.nb_lo)) {
+    const int max_coresident = g.ratio_two ? 0 : coresident_half(reinterpret_cast<const void*>(k_ratio_dual_fused), 1);  // see launch_ratio_primal
+    if (nb <= max_coresident && (long)nb * BLK * 4 >= (long)(dv.nb_hi - dv.nb_lo)) {
         hipLaunchKernelGGL(k_ratio_dual_fused, dim3(nb), dim3(BLK), 0, st, dv);  // both passes + FTRAN head
         return;
     }
@@ -4124,8 +3776,8 @@ static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fo
             } else {
                 const long ftiles = (long)((g.cap + FD_RB - 1) / FD_RB) * ((g.cap + FD_CH - 1) / FD_CH);
                 const int nf = (int)(ftiles < SW_MAX_BLOCKS ? ftiles : SW_MAX_BLOCKS);
-                if (dv.lrJ <= 16) LAUNCH_T(3, k_fold_w<16>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, 0);
-                else LAUNCH_T(3, k_fold_w<LR_MAX>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, 0);
+                if (dv.lrJ <= 16) LAUNCH_T(3, k_fold_w<16>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2);
+                else LAUNCH_T(3, k_fold_w<LR_MAX>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2);
             }
             if (!fold_only) {
                 long tiles = (long)((g.cap + sw_rb() - 1) / sw_rb()) * ((g.cap + sw_ch() - 1) / sw_ch());
@@ -4163,51 +3815,10 @@ static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fo
         }
     }
 }
-static int fold_blocks(const Geom& g) {
-    const long ftiles = (long)((g.cap + FD_RB - 1) / FD_RB) * ((g.cap + FD_CH - 1) / FD_CH);
-    return (int)(ftiles < SW_MAX_BLOCKS ? ftiles : SW_MAX_BLOCKS);
-}
 void launch_fold_lowrank(const DevView& dv, const Geom& g, hipStream_t st) {
     if (!dv.lrJ || g.cap <= 0) return;
     launch_fused_lr(dv, g, 0, 1, st);
-    if (dv.gram) hipLaunchKernelGGL(k_fold_w<LR_MAX>, dim3(fold_blocks(g)), dim3(BLK), 0, st, dv, 1, 1);
     hipLaunchKernelGGL(k_reset_nlow, dim3(1), dim3(1), 0, st, dv);
-}
-// BASIS stage of a primal PSE pivot in Gram mode: folds when due (the sparse pass reads the folded W0), then
-// the sparse pass over W0 and the assembly of v_K.  No tau (lazy dual steepest edge), hence no F push.
-void launch_gram_folds(const DevView& dv, const Geom& g, hipStream_t st) {
-    if (g.cap <= 0) return;
-    const dim3 b(BLK);
-    const int nf = fold_blocks(g);
-    if (dv.lrJ <= 16) hipLaunchKernelGGL(k_fold_w<16>, dim3(nf), b, 0, st, dv, 2, 0);
-    else hipLaunchKernelGGL(k_fold_w<LR_MAX>, dim3(nf), b, 0, st, dv, 2, 0);
-    hipLaunchKernelGGL(k_fold_w<LR_MAX>, dim3(nf), b, 0, st, dv, 2, 1);
-}
-void launch_gram_basis(const DevView& dv, const Geom& g, hipStream_t st) {
-    if (g.cap <= 0) return;
-    const dim3 b(BLK);
-    const long tiles = (long)((g.cap + GS_RB - 1) / GS_RB) * ((g.cap + GS_CH - 1) / GS_CH);
-    const int nt = (int)(tiles < SW_MAX_BLOCKS ? tiles : SW_MAX_BLOCKS);
-    hipLaunchKernelGGL(k_wt_sparse, dim3(nt + LR_MAX), b, 0, st, dv);
-    hipLaunchKernelGGL(k_gram_v, dim3(blocks_for((long)g.cap * GV_L)), b, 0, st, dv);
-}
-void launch_gram_build_c(const DevView& dv, const Geom& g, double* C, int k, hipStream_t st) {
-    (void)g;
-    if (k <= 0) return;
-    hipLaunchKernelGGL(k_gram_build_c, dim3(blocks_for((long)k * 64)), dim3(BLK), 0, st, dv, C, k);
-}
-void launch_gram_shadow(const DevView& dv, const Geom& g, int mode, hipStream_t st) {
-    if (g.cap <= 0) return;
-    launch_btran_rhs(dv, g, st);  // the dense t_K = alpha_K - F^T y_S of the streaming pass (overwrites the sparse one)
-    const dim3 b(BLK);
-    const long tiles = (long)((g.cap + sw_rb() - 1) / sw_rb()) * ((g.cap + sw_ch() - 1) / sw_ch());
-    const int nt = (int)(tiles < SW_MAX_BLOCKS ? tiles : SW_MAX_BLOCKS);
-    if (sw_rb() != 128 || sw_ch() != 1024) return;  // (default strip geometry only)
-    hipLaunchKernelGGL((k_stream_w<true, 1024, 128, 4>), dim3(nt + LR_MAX), b, 0, st, dv, 0);
-    hipLaunchKernelGGL(k_gram_shadow<128>, dim3(blocks_for(g.cap)), b, 0, st, dv, mode);
-}
-void launch_gram_reset(const DevView& dv, double tol, double safe, hipStream_t st) {
-    hipLaunchKernelGGL(k_gram_reset, dim3(1), dim3(1), 0, st, dv, tol, safe);
 }
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int with_tau) {
     if (g.cap <= 0) return;  // a model without kept rows has no nucleus: nothing to stream (and no valid grid)
@@ -4345,11 +3956,19 @@ void launch_recalc_basic_vals(const DevView& dv, const Geom& g, const double* rh
     launch_clear_work(dv, st);
     const int t = g.m > g.cap ? g.m : g.cap;
     hipLaunchKernelGGL(k_seed_dense_ftran, dim3(blocks_for(t)), dim3(BLK), 0, st, dv, (const double*)r_tmp);
+    // Large-nucleus regime: the dense-rhs FTRAN x_K = W0 r_K is ONE streaming read of the nucleus inverse through the
+    // strip kernel of the pivot loop (k_stream_w, tau side only; the caller has folded the pending terms).  A sharded
+    // solve keeps the replicated classic pass (no exchange outside the pivot loop).
+    const bool strips = dv.lrJ && fw_rows(g) != 8 && FW_RL == 1 && stream_strips() && !dv.wshard;
     if (g.cap > 0) {
-        const int nstripes = (g.cap + 16 - 1) / 16, nchunks = (g.cap + FW_TC - 1) / FW_TC;
-        hipLaunchKernelGGL((k_fused_w<16, true, false, false>), dim3(nstripes, nchunks), dim3(BLK), 0, st, dv);
+        if (strips) {
+            launch_fused_lr(dv, g, 0, 0, st, 1);
+        } else {
+            const int nstripes = (g.cap + 16 - 1) / 16, nchunks = (g.cap + FW_TC - 1) / FW_TC;
+            LAUNCH_T(2, (k_fused_w<16, true, false, false>), dim3(nstripes, nchunks), dim3(BLK), 0, st, dv);
+        }
     }
-    launch_post_fused(dv, g, 0, st, 1);  // partials in the classic 16 x 1024 tiling (k_fused_w above)
+    launch_post_fused(dv, g, 0, st, strips ? 0 : 1);  // partials in the strip tiling / in the classic 16 x 1024 tiling
     hipLaunchKernelGGL(k_copy_tau_to_xb, dim3(blocks_for(g.m)), dim3(BLK), 0, st, dv, refine);
     launch_clear_work(dv, st);
 }

@@ -60,3 +60,18 @@ def test_default_transport_is_device_resident():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "traces identical: True" in r.stdout and "device-resident mailboxes" in r.stdout
+
+
+LATE_BASIS = os.path.join(ROOT, "tests", "golden", "cfg4_basis_p240000.bin.gz")
+
+
+@pytest.mark.parametrize("world,pivots", [(2, 256), (8, 64)], ids=["2 ranks", "8 ranks (oversubscribed)"])
+def test_sharding_at_config4_size_from_the_late_basis(world, pivots):
+    """Config 4 itself (100 000 x 100 000), continued from the committed basis with a nucleus of 20 493 and the DEFAULT
+    machinery: column-block sharded sweep / update / pricing, ROW-SHARDED streaming pass of the 3.4 GB nucleus inverse
+    with the tau_K / v_K exchange through the peers' buffers, replicated fold.  All ranks share the one GPU of the test
+    box (so the Harris tests take their two-launch form); the sharded run must take the unsharded run's pivots."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_test.py"), str(world), "100000", "100000", "100", str(pivots),
+                        "basis=" + LATE_BASIS], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "traces identical: True" in r.stdout and "device-resident mailboxes" in r.stdout

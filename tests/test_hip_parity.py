@@ -673,3 +673,50 @@ def test_lazy_dual_steepest_edge_rebuilds_the_norms_the_recurrence_would_hold(mo
     a, b, c = lazy.add_constraint(expr, M.LE, rhs), eager.add_constraint(expr, M.LE, rhs), so.add_constraint(expr, O.LE, rhs)
     assert obj_close(a.objective(), c.objective()) and obj_close(b.objective(), c.objective())
     assert np.abs(np.asarray(a.values()) - np.asarray(c.values())).max() <= X_ATOL
+
+
+def test_first_entry_of_an_empty_column_arrives_with_a_cut():
+    """a variable that appears in no constraint at try_new (tsp.rs:226-235 has 130 of them) gets its first
+    entry from add_constraint; the host summary of singleton columns must follow, or the next re-inversion classifies
+    the column with a bogus row.  Oracle step by step; the re-inversions are the ones that read the summary."""
+    def build(B):
+        p = B.Problem(B.MINIMIZE)
+        x = p.add_var(1.0, (0.0, 10.0))
+        y = p.add_var(-1.0, (0.0, 5.0))      # empty column: sits at its upper bound
+        z = p.add_var(2.0, (0.0, 10.0))
+        w = p.add_var(-0.5, (0.0, 4.0))      # a second empty column
+        p.add_constraint([(x, 1.0), (z, 1.0)], B.GE, 2.0)
+        p.add_constraint([(x, 1.0), (z, -1.0)], B.LE, 3.0)
+        return p, (x, y, z, w)
+    (po, vo), (pg, vg) = both(build)
+    so, sg = po.solve(), pg.solve()
+    assert near(sg.objective(), so.objective()) and near(sg[vg[1]], 5.0)
+    steps = [([(1, 1.0), (0, 1.0)], "LE", 4.0),              # y + x <= 4: y = 5 violates it, y becomes a basic singleton
+             ([(1, 2.0), (2, 1.0)], "LE", 7.0),              # touches the basic singleton y: re-inversion from the summary
+             ([(3, 1.0), (1, 1.0), (0, 1.0)], "LE", 5.5),    # w's first entry, y's third
+             ([(3, 3.0), (2, 1.0)], "GE", 1.0)]
+    for i, (expr, op, rhs) in enumerate(steps):
+        so = so.add_constraint(expr, getattr(O, op), rhs)
+        sg = sg.add_constraint(expr, getattr(M, op), rhs)
+        assert near(sg.objective(), so.objective()), i
+        assert np.abs(sg.values() - so.values()).max() <= X_ATOL, i
+        assert sg.reinvert() < 1e-9                           # classification of the basis from the host summaries
+        c = sg.clone()                                        # the clone copies the summaries
+        assert c.reinvert() < 1e-9 and near(c.objective(), sg.objective())
+
+
+@pytest.mark.parametrize("fam,args", [("sparse", (4000, 3500, 12, 4)), ("cover", (3000, 3500, 12, 4))], ids=["primal", "dual"])
+def test_a_stalled_one_launch_ratio_test_is_retried_with_two_launches(monkeypatch, fam, args):
+    """the in-kernel wait between the two Harris passes must not abort the solve when the grid turns out not
+    to be co-resident.  MLP_RATIO_SPIN_LIMIT=0 makes the first multi-block launch give up for real (the blocks that
+    arrive before the last one see no published bound); the engine then latches the two-launch form, re-runs the
+    iteration, and the solve takes the oracle's pivots as if nothing had happened."""
+    monkeypatch.setenv("MLP_RATIO_SPIN_LIMIT", "0")
+    lp = GEN[fam](*args)
+    sg = lpgen.build_problem(M.Problem, lp).solve(budget=300, trace=True)
+    so = lpgen.build_problem(O.Problem, lp).solve(budget=300, trace=True)
+    st = sg.stats()
+    assert st["ratio_stalls"] == 1, st["ratio_stalls"]        # one stall, then the two-launch form for good
+    assert st["iterations"] == 300
+    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+    assert obj_close(sg.objective(), so.objective())

@@ -1,0 +1,132 @@
+"""GPU: the large-nucleus regime of config 4 at FULL SIZE with the DEFAULT machinery (nothing forced): the two committed
+mid-solve bases that bench.py times (tests/golden/cfg4_basis_p45000 / p240000: nucleus 9 999 / 20 493, capacity 16 384 /
+32 768) are loaded through mlp_problem_solve_from_basis and continued.  From capacity 8 192 on the engine runs the
+delayed-update mode (k_stream_w every pivot, k_fold_w every 32nd), the blocked F push, the banded sweep in locality order
+with the packed non-basic copy — the kernels the solve spends > 90 % of its wall time in.
+
+(a) size-independent properties after 256 pivots: primal feasibility, monotone objective, c.x == objective, a fresh
+    inverse agrees with the incrementally maintained one, the two-way pivot check stayed at rounding level;
+(b) 8 pivots stepped stage by stage (mlp_engine_stage): every solve the iteration performs is checked against the
+    constraint matrix ITSELF with scipy on the box — B alpha_q = a_q, B^T rho = e_r, B tau = rho, B^T v = alpha_q,
+    alpha_r = N^T rho — as a componentwise backward error.  Nothing of the engine (no W, no other mode) is on the
+    reference side.  solver.rs:671-693, 1106-1174;
+(c) sharding at config-4 size lives in tests/test_dist_gpu.py (2 ranks and 8 ranks on the one GPU, identical traces).
+"""
+import gzip
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import minilp_amd as M
+from minilp_amd import lpgen
+from tests.common import ROOT, check_feasible, objective_of
+
+pytestmark = pytest.mark.gpu
+A = M.api
+MID = os.path.join(ROOT, "tests", "golden", "cfg4_basis_p45000.bin.gz")
+LATE = os.path.join(ROOT, "tests", "golden", "cfg4_basis_p240000.bin.gz")
+
+
+@pytest.fixture(scope="module")
+def cfg4():
+    lp = lpgen.gen_sparse_lp(100000, 100000, 100, 4)
+    return lp, lpgen.build_problem(M.Problem, lp)
+
+
+def _load(prob, path, **kw):
+    with gzip.open(path, "rb") as f:
+        return prob.solve_from_basis(f.read(), budget=0, **kw)
+
+
+@pytest.mark.parametrize("path,k0,cap", [(MID, 9999, 16384), (LATE, 20493, 32768)], ids=["mid k=9999", "late k=20493"])
+def test_default_machinery_from_saved_basis_keeps_the_invariants(cfg4, path, k0, cap):
+    lp, prob = cfg4
+    s = _load(prob, path, trace=True)
+    st = s.stats()
+    assert st["nucleus_size"] == k0 and st["nucleus_capacity"] == cap and st["banded_sweep"] == 1
+    obj0 = s.objective()
+    s.continue_solve(256)
+    st = s.stats()
+    assert st["iterations"] == 256 and s.budget_exhausted
+    tr = s.trace()
+    assert len(tr) == 256 and all(t[0] == 0 for t in tr)                      # primal loop
+    objs = np.array([obj0] + [-t[6] for t in tr])                             # trace holds the minimised form (lib.rs:235-238)
+    assert (np.diff(objs) >= -1e-9 * np.abs(objs[:-1])).all()                 # Maximize: never decreases
+    assert objs[-1] > objs[0]
+    x = s.values()
+    check_feasible(lp, x, tol=1e-7)
+    assert abs(objective_of(lp, x) - s.objective()) <= 1e-9 * abs(s.objective())
+    assert abs(s.objective() - objs[-1]) <= 1e-9 * abs(objs[-1])
+    assert st["max_pivot_err"] < 1e-9, st["max_pivot_err"]                    # alpha_q[r] (FTRAN) against alpha_r[q] (tableau row)
+    assert sum(st["kase"]) == st["basis_changes"]
+    assert s.stats()["nucleus_size"] >= k0 - 256
+    drift = s.reinvert()                                                      # folds the pending terms, then max |W - W_fresh|
+    scale = float(s.state("reinvert_scale")[0])                               # max |W_fresh|: the inverse's entries are far from O(1) here
+    assert drift <= 1e-9 * max(1.0, scale), (drift, scale)
+    print(f"{os.path.basename(path)}: 256 pivots, objective {objs[0]:.6f} -> {objs[-1]:.6f}, max_pivot_err {st['max_pivot_err']:.2e}, "
+          f"max |W - W_fresh| {drift:.2e} (max |W| {scale:.2e}), cases {st['kase']}")
+
+
+def _backward_error(resid, *abs_terms):
+    den = sum(abs_terms)
+    den = np.where(den > 0, den, 1.0)
+    return float((np.abs(resid) / den).max())
+
+
+@pytest.mark.parametrize("path", [MID, LATE], ids=["mid", "late"])
+def test_stepped_stages_satisfy_the_defining_equations_against_the_matrix(cfg4, path):
+    lp, prob = cfg4
+    m, n = lp["m"], lp["n"]
+    Acsc = sp.csr_matrix((lp["data"], lp["indices"], lp["indptr"]), shape=(m, n)).tocsc()
+    Aext = sp.hstack([Acsc, sp.identity(m, format="csc")], format="csc")      # slack coefficient +1 (solver.rs:250)
+    Aabs = abs(Aext)
+    s = _load(prob, path)
+    st, info = s.engine_open()
+    assert st == A.ITER_PIVOT and info["phase"] == 0
+    worst = {}
+    done = 0
+    while done < 8:
+        bv = s.state("basic_vars").astype(np.int64)
+        nb = s.state("nb_vars").astype(np.int64)
+        B, Babs = Aext[:, bv], Aabs[:, bv]
+        q = int(info["col"])
+        aq = np.asarray(Aext[:, int(nb[q])].todense()).ravel()
+        got = {}
+        while True:
+            stage = info["next_stage"]
+            st, info = s.engine_stage(stage)
+            if stage == A.STAGE_FTRAN:
+                got["alpha"] = s.state("col_coeffs")
+            elif stage == A.STAGE_RATIO:
+                r = int(info["row"])
+            elif stage == A.STAGE_BTRAN:
+                got["rho"] = s.state("inv_basis_row_coeffs")
+            elif stage == A.STAGE_BASIS:
+                got["tau"], got["v"] = s.state("tau"), s.state("v")
+            elif stage == A.STAGE_ROW:
+                got["alpha_r"] = s.state("row_coeffs")
+            if stage == A.STAGE_APPLY or st not in (A.ITER_PIVOT, A.ITER_FLIP):
+                break
+        assert stage == A.STAGE_APPLY and st in (A.ITER_PIVOT, A.ITER_FLIP), (stage, st)
+        if r < 0:
+            continue  # bound flip: no BTRAN / basis update in this iteration
+        alpha, rho, tau, v, alpha_r = got["alpha"], got["rho"], got["tau"], got["v"], got["alpha_r"]
+        e_r = np.zeros(m)
+        e_r[r] = 1.0
+        errs = dict(
+            ftran=_backward_error(B @ alpha - aq, Babs @ np.abs(alpha), np.abs(aq)),               # B alpha_q = a_q
+            btran=_backward_error(B.T @ rho - e_r, Babs.T @ np.abs(rho), e_r),                     # B^T rho_r = e_r
+            tau=_backward_error(B @ tau - rho, Babs @ np.abs(tau), np.abs(rho)),                   # B tau = rho_r   (solver.rs:1157)
+            v=_backward_error(B.T @ v - alpha, Babs.T @ np.abs(v), np.abs(alpha)),                 # B^T v = alpha_q (solver.rs:1114)
+        )
+        N, Nabs = Aext[:, nb], Aabs[:, nb]
+        want = N.T @ rho
+        errs["row"] = float((np.abs(alpha_r - want) / np.maximum(Nabs.T @ np.abs(rho), 1e-300)).max())  # alpha_r = N^T rho
+        assert abs(alpha[r] - alpha_r[q]) <= 1e-9 * max(1.0, abs(alpha[r]))                        # the pivot element, both ways
+        for kname, e in errs.items():
+            worst[kname] = max(worst.get(kname, 0.0), e)
+            assert e < 1e-8, (kname, e, done)
+        done += 1
+    print(os.path.basename(path), "8 stepped pivots; worst componentwise backward errors:", {k: f"{e:.1e}" for k, e in worst.items()})

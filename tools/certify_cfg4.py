@@ -26,8 +26,7 @@ if chunk > 0:
         st = s.stats()
         curve.append((int(st["iterations"]), time.time() - t, int(st["nucleus_size"])))
         with open("gpurun_out/cfg4_solve_progress.log", "a") as f:  # survives a run that is cut short
-            f.write("pivots %d wall %.1f k %d gram_pivots %d rebuilds %d monitor %.2e obj %.9f\n" % (
-                curve[-1][0], curve[-1][1], curve[-1][2], st["gram_pivots"], st["gram_rebuilds"], st["gram_err"], s.objective()))
+            f.write("pivots %d wall %.1f k %d obj %.9f\n" % (curve[-1][0], curve[-1][1], curve[-1][2], s.objective()))
         if not s.budget_exhausted:
             break
         s.continue_solve(chunk)
@@ -47,8 +46,7 @@ cert = dict(rows=m, cols=n, nnz_per_row=k, seed=seed, pivots=int(st["iterations"
             objective_accumulated=s.objective(), primal_objective=float(c @ x), dual_objective=float(b @ y),
             max_primal_violation=float(max((A @ x - b).max(), (-x).max(), 0.0)),
             max_dual_violation=float(max((c - A.T @ y).max(), (-y).max(), 0.0)),
-            nucleus_size=int(st["nucleus_size"]), max_pivot_err=st["max_pivot_err"],
-            gram_pivots=int(st["gram_pivots"]), gram_rebuilds=int(st["gram_rebuilds"]), gram_monitor_max=st["gram_err"])
+            nucleus_size=int(st["nucleus_size"]), max_pivot_err=st["max_pivot_err"])
 cert["relative_gap"] = abs(cert["primal_objective"] - cert["dual_objective"]) / max(1.0, abs(cert["primal_objective"]))
 print(json.dumps(cert, indent=1), flush=True)
 if curve:  # (pivots, wall seconds, nucleus size) at every chunk boundary, and the chunk's microseconds per pivot

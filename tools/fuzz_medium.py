@@ -14,7 +14,7 @@ ENVS = [{}, {"MLP_LOWRANK": "3", "MLP_BIGTILE": "1", "MLP_LDPAD": "16", "MLP_BAN
         {"MLP_LOWRANK": "16", "MLP_BIGTILE": "1"}, {"MLP_GRAPH_ITERS": "1"}, {"MLP_NO_GRAPH": "1"},
         {"MLP_LOWRANK": "16", "MLP_BIGTILE": "1", "MLP_LDPAD": "16", "MLP_STREAM_BALANCED": "5"},
         {"MLP_LOWRANK": "8", "MLP_BIGTILE": "1", "MLP_STREAM_BALANCED": "0"},
-        {"MLP_LOWRANK": "16", "MLP_BIGTILE": "1", "MLP_LDPAD": "16", "MLP_BANDED": "1", "MLP_GRAM": "1"},
+        {"MLP_LOWRANK": "16", "MLP_BIGTILE": "1", "MLP_LDPAD": "16", "MLP_BANDED": "1"},
         {"MLP_BANDED": "1", "MLP_ORDER_FROM": "0", "MLP_ORDER_EVERY": "5"},
         {"MLP_BANDED": "1", "MLP_ORDER_FROM": "0", "MLP_ORDER_EVERY": "64", "MLP_LOWRANK": "8", "MLP_BIGTILE": "1"},
         {"MLP_BANDED": "1", "MLP_ORDER_FROM": "3", "MLP_ORDER_EVERY": "11", "MLP_SWEEP_PACKED": "0"}]

@@ -24,21 +24,32 @@ def worker(rank, world, port, m, n, k, pivots, out, family="sparse"):
     M.set_device(rank if ndev >= world else 0)   # distinct devices whenever the box has them
     lp = lpgen.gen_cover_lp(m, n, k, 4) if family == "cover" else lpgen.gen_sparse_lp(m, n, k, 4)
     p = lpgen.build_problem(M.Problem, lp)
-    s = p.solve(budget=0, trace=True)
+    blob = None
+    if family.startswith("basis="):   # continue from a committed mid-solve basis (config-4 size: tests/golden/cfg4_basis_p*.bin.gz)
+        import gzip
+        with gzip.open(family[6:], "rb") as f:
+            blob = f.read()
+    s = p.solve_from_basis(blob, budget=0, trace=True) if blob else p.solve(budget=0, trace=True)
     box = md.setup_sharding(s, dist)
     dist.barrier()
     t0 = time.time()
     s.continue_solve(pivots)
     dt = time.time() - t0
     tr = [t[:5] for t in s.trace()]
+    transport = s.transport()
     res = dict(rank=rank, n=len(tr), obj=s.objective(), dt=dt, trace=tr, done=not s.budget_exhausted)
     gathered = [None] * world
     dist.all_gather_object(gathered, res)
     if rank == 0:
-        ref = p.solve(budget=pivots, trace=True)
+        if blob:
+            del s   # (its copy of the nucleus inverse)
+            ref = p.solve_from_basis(blob, budget=0, trace=True)
+            ref.continue_solve(pivots)
+        else:
+            ref = p.solve(budget=pivots, trace=True)
         rtr = [t[:5] for t in ref.trace()]
         ok = all(g["trace"] == rtr for g in gathered)
-        print("transport:", s.transport(), "| devices visible:", ndev, flush=True)
+        print("transport:", transport, "| devices visible:", ndev, flush=True)
         print("sharded world=%d: pivots=%s obj=%s dt=%s | unsharded pivots=%d obj=%.12g | traces identical: %s" % (
             world, [g["n"] for g in gathered], ["%.12g" % g["obj"] for g in gathered], ["%.3f" % g["dt"] for g in gathered],
             len(rtr), ref.objective(), ok), flush=True)
@@ -63,6 +74,6 @@ if __name__ == "__main__":
     for p in procs:
         p.start()
     for p in procs:
-        p.join(600)
+        p.join(1500)
     ok = out.get(timeout=5) if not out.empty() else False
     sys.exit(0 if ok else 1)

@@ -33,5 +33,4 @@ t0 = time.perf_counter()
 s.continue_solve(pivots)
 dt = time.perf_counter() - t0
 st = s.stats()
-print(f"{which}: {pivots} pivots in {dt:.4f}s = {pivots / dt:.1f} pivots/s, {dt * 1e6 / pivots:.1f} us/pivot, k = {st['nucleus_size']}, cap = {st['nucleus_capacity']}, "
-      f"gram pivots {st['gram_pivots']} rebuilds {st['gram_rebuilds']} err {st['gram_err']:.1e}", flush=True)
+print(f"{which}: {pivots} pivots in {dt:.4f}s = {pivots / dt:.1f} pivots/s, {dt * 1e6 / pivots:.1f} us/pivot, k = {st['nucleus_size']}, cap = {st['nucleus_capacity']}", flush=True)
