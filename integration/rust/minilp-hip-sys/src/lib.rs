@@ -62,6 +62,10 @@ extern "C" {
                                 maxs: *const c_double) -> c_int;
     pub fn mlp_problem_add_constraints_csr(p: *mut mlp_problem, m: u64, indptr: *const u64, vars: *const u32,
                                            coeffs: *const c_double, cmp_ops: *const i32, rhs: *const c_double) -> c_int;
+    pub fn mlp_problem_num_constraints(p: *const mlp_problem) -> u64;
+    pub fn mlp_problem_var(p: *const mlp_problem, var: u32, obj_coeff: *mut c_double, min: *mut c_double, max: *mut c_double) -> c_int;
+    pub fn mlp_problem_constraint(p: *const mlp_problem, c: u64, vars: *mut u32, coeffs: *mut c_double, cap: u64,
+                                  cmp_op: *mut c_int, rhs: *mut c_double) -> u64;
     pub fn mlp_problem_solve(p: *const mlp_problem, out: *mut *mut mlp_solution) -> c_int;
     pub fn mlp_problem_solve_ex(p: *const mlp_problem, out: *mut *mut mlp_solution, pivot_budget: i64, flags: u32) -> c_int;
 
@@ -78,6 +82,13 @@ extern "C" {
     pub fn mlp_solution_add_gomory_cut(s: *mut *mut mlp_solution, var: u32) -> c_int;
     pub fn mlp_solution_continue(s: *mut mlp_solution, pivot_budget: i64) -> c_int;
     pub fn mlp_solution_budget_exhausted(s: *const mlp_solution) -> c_int;
+    pub fn mlp_solution_reinvert(s: *mut mlp_solution, max_diff: *mut c_double) -> c_int;
+    pub fn mlp_solution_recompute_basic_values(s: *mut mlp_solution) -> c_int;
+    pub fn mlp_solution_save_basis(s: *const mlp_solution, mode: c_int, buf: *mut std::os::raw::c_void, cap: u64) -> u64;
+    pub fn mlp_problem_solve_from_basis(p: *const mlp_problem, blob: *const std::os::raw::c_void, len: u64,
+                                        out: *mut *mut mlp_solution, pivot_budget: i64, flags: u32) -> c_int;
+    pub fn mlp_solution_enable_sharding(s: *mut mlp_solution, rank: c_int, world: c_int, shm_name: *const c_char) -> c_int;
+    pub fn mlp_solution_transport(s: *const mlp_solution) -> *const c_char;
 
     pub fn mlp_engine_open(s: *mut mlp_solution, out: *mut mlp_iter_info) -> c_int;
     pub fn mlp_engine_stage(s: *mut mlp_solution, stage: c_int, out: *mut mlp_iter_info) -> c_int;

@@ -129,6 +129,7 @@ struct Stats {
     uint64_t update_launches = 0;
     double solve_wall_s = 0;
     double max_pivot_err = 0;
+    uint64_t hyper_iters = 0, hyper_bails = 0;  // iterations taken by the hypersparse kernel; iterations it handed back
     uint64_t ratio_stalls = 0;   // in-kernel waits of the fused ratio test that timed out (each one retried with two launches)
     uint64_t beta_rebuilds = 0;  // lazy dual steepest edge: exact rebuilds of beta from the basis inverse
     // dense-rhs FTRAN x_B = B^-1 (b - N x_N) (recalc_basic_vals): the streaming read of the nucleus inverse, kernel-exact
@@ -198,7 +199,16 @@ private:
     bool no_head_fusion = false;             // MLP_NO_HEAD_FUSION: keep the stage heads as launches of their own
     bool ratio_two = false;                  // MLP_RATIO_TWO_KERNELS, or latched by an ITER_STALL: two launches for the two Harris passes
     long long ratio_spin_limit = 20000000LL; // MLP_RATIO_SPIN_LIMIT: polls before a fused ratio test gives up (0: the first launch stalls; tests)
-    bool ranks_share_device = false;         // sharded solve with another rank on this GPU (or unknown): same
+    bool ranks_share_device = false;
+    // hypersparse single-workgroup iteration (hyper.inc)
+    int hyper_mode = -1;                     // MLP_HYPER: 1 on wherever the kernel applies, 0 off, -1 auto (<= 16 non-zeros per row on average)
+    long hyper_heavy = 0;                    // MLP_HYPER_HEAVY: eta-update entries one workgroup takes on (0: the kernel's default)
+    uint64_t hyper_off_until = 0;            // lifetime pivot count until which the multi-kernel path runs (after bail-outs)
+    int hyper_bail_streak = 0;
+    DevBuf<int> d_hy_stamp;                  // n + m epoch stamps (alpha_r list / singleton part of the alpha_q list)
+    size_t hy_stamp_len = 0;
+    bool hyper_wanted(int phase) const;
+    void ensure_hyper();         // sharded solve with another rank on this GPU (or unknown): same
     // Lazy dual steepest edge: the primal loop never reads beta, so its iterations skip tau = B^-1 rho (solver.rs:1157)
     // and the beta recurrence; beta is rebuilt exactly from the basis inverse (k_exact_beta) when something next needs it
     bool lazy_dse = true;                    // MLP_LAZY_DSE=0: maintain beta in every pivot like the reference

@@ -107,6 +107,8 @@ Engine::Engine() {
     const char* lz = std::getenv("MLP_LAZY_DSE");
     lazy_dse = !(lz && lz[0] == '0');
     ratio_two = std::getenv("MLP_RATIO_TWO_KERNELS") != nullptr;
+    if (const char* hy = std::getenv("MLP_HYPER")) hyper_mode = std::atoi(hy) > 0 ? 1 : 0;  // 1: whenever the kernel applies, 0: never
+    if (const char* hh = std::getenv("MLP_HYPER_HEAVY")) hyper_heavy = std::atol(hh);        // work bound per iteration (tests force bail-outs)
     if (const char* rs = std::getenv("MLP_RATIO_SPIN_LIMIT")) ratio_spin_limit = std::atoll(rs);
     if (const char* sb = std::getenv("MLP_STREAM_BALANCED")) sw_balanced = std::atoi(sb);
     const char* nhf = std::getenv("MLP_NO_HEAD_FUSION");
@@ -443,6 +445,8 @@ DevView* Engine::sync_view() {
     v.red_key = d_red_key.p; v.red_key2 = d_red_key2.p; v.red_idx = d_red_idx.p; v.ticket = d_ticket.p;
     v.ctl = d_ctl.p;
     v.nb_rng = d_nb_rng.p;
+    v.hy_stamp_n = d_hy_stamp.p;
+    v.hy_stamp_p = d_hy_stamp.p ? d_hy_stamp.p + num_vars : nullptr;
     v.rank = shard_rank; v.world = shard_world; v.mail = d_mail;
     for (int r = 0; r < MAX_WORLD; ++r) v.mail_peer[r] = reinterpret_cast<MailRec*>(peer_box[r]);
     v.mail_fanout = shard_world > 1 ? mail_fanout : 0;
@@ -1264,6 +1268,36 @@ int Engine::run_loop(int phase) {
             view_dirty = true;
             sync_view();
         }
+        if (!sample && hyper_wanted(phase)) {
+            // Hypersparse iteration (hyper.inc): up to RING dual iterations in ONE launch of one workgroup doing only
+            // support-restricted work.  Same records, same device state: the two paths alternate freely.
+            int B = RING;
+            if (pivot_budget > 0 && (int64_t)B > pivot_budget) B = (int)pivot_budget;
+            ensure_nucleus_cap(k_ + B + 1);
+            ensure_hyper();
+            sync_view();
+            launch_reset_ring(hview, st);
+            launch_clear_work(hview, st);
+            launch_hyper_dual(hview, enable_dse ? 1 : 0, B, hyper_heavy, st);
+            pull_ctl();
+            const uint64_t before = stats.iterations;
+            int res = process_records(phase, B);
+            stats.hyper_iters += stats.iterations - before;
+            if (h_ctl->hyper_bail) {
+                // the kernel declined an iteration (a list did not fit its LDS capacities, or the update was too much work for
+                // one workgroup): nothing of it was applied; the multi-kernel path takes over for a while — the longer, the
+                // more often this happens in a row (a model that is not hypersparse settles on the multi-kernel path)
+                stats.hyper_bails += 1;
+                hyper_bail_streak = std::min(hyper_bail_streak + 1, 8);
+                hyper_off_until = lifetime_pivots + ((uint64_t)8 << hyper_bail_streak);
+            } else if (stats.iterations - before >= 8) {
+                hyper_bail_streak = 0;
+            }
+            if (h_ctl->max_pivot_err > stats.max_pivot_err) stats.max_pivot_err = h_ctl->max_pivot_err;
+            if (res == ITER_PIVOT && !(h_ctl->max_pivot_err <= refresh_tol) && k_ > 0) rebuild_inverse();
+            if (res != ITER_PIVOT) return res;
+            continue;
+        }
         const bool have_graph = gexec[phase][enable_pse ? 1 : 0][0] != nullptr;
         const bool graph_now = use_graph && !sample && (have_graph || eager_iters_in_geom >= 4);
         if (!have_graph) eager_iters_in_geom += 1;
@@ -1371,6 +1405,27 @@ void Engine::ensure_beta() {
     HIPCHECK(hipStreamSynchronize(st));
     beta_stale = false;
     stats.beta_rebuilds += 1;
+}
+
+// Hypersparse iteration (hyper.inc): the dual loop without primal steepest edge, one GPU, in-place nucleus inverse, every
+// row / column short enough for the in-kernel stage heads.  auto: models with few non-zeros per row (the regime where the
+// multi-kernel iteration loses to reach-restricted CPU work); MLP_HYPER=1 / 0 force it on (where it applies) / off.
+bool Engine::hyper_wanted(int phase) const {
+    if (hyper_mode == 0 || phase != 1 || enable_pse || shard_world != 1 || stepping) return false;
+    if (lifetime_pivots < hyper_off_until) return false;
+    if ((lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 32 : 0)) != 0 || use_banded()) return false;
+    if (max_col_nnz_ > HEAD_LIST_CAP || max_row_nnz_ > HEAD_LIST_CAP) return false;
+    if (hyper_mode == 1) return true;
+    return m_ > 0 && (double)h_rcol.size() <= 16.0 * (double)m_;
+}
+void Engine::ensure_hyper() {
+    const size_t need = (size_t)num_vars + (size_t)m_;
+    if (d_hy_stamp.p && hy_stamp_len == need) return;
+    HIPCHECK(hipStreamSynchronize(st));
+    d_hy_stamp.ensure(need + 64, 0, st);
+    HIPCHECK(hipMemsetAsync(d_hy_stamp.p, 0, sizeof(int) * d_hy_stamp.cap, st));  // the epoch only grows: zero is "never"
+    hy_stamp_len = need;
+    view_dirty = true;
 }
 
 // ------------------------------------------------------------------ loops (solver.rs:470-547)
@@ -2049,7 +2104,7 @@ Engine* Engine::clone() {
     e->h_rptr = h_rptr; e->h_rcol = h_rcol; e->h_rval = h_rval;
     e->h_colnnz = h_colnnz; e->h_single_row = h_single_row; e->h_single_val = h_single_val;
     e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->no_head_fusion = no_head_fusion;
-    e->sw_balanced = sw_balanced; e->ratio_two = ratio_two; e->ratio_spin_limit = ratio_spin_limit; e->ranks_share_device = false; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->use_pack = use_pack; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
+    e->sw_balanced = sw_balanced; e->hyper_mode = hyper_mode; e->hyper_heavy = hyper_heavy; e->ratio_two = ratio_two; e->ratio_spin_limit = ratio_spin_limit; e->ranks_share_device = false; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->use_pack = use_pack; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
     e->h_basic_vars = h_basic_vars; e->h_nb_vars = h_nb_vars; e->h_var_loc = h_var_loc;
     e->h_kslot_of_pos = h_kslot_of_pos; e->h_srow_of_pos = h_srow_of_pos; e->h_kslot_of_row = h_kslot_of_row;
     e->h_pos_of_srow = h_pos_of_srow; e->h_sdiag_of_pos = h_sdiag_of_pos; e->h_nb_fixed = h_nb_fixed;

@@ -88,6 +88,10 @@ struct Ctl {
     double max_pivot_err;  // max over the batch of |alpha_q[r] - alpha_r[q]| / max(1,|alpha_q[r]|): drift monitor of W
     long long ratio_spin_limit;  // fused ratio tests: polls of the in-kernel wait before it gives up with ITER_STALL (set by the
                                  // host: 20 M ~ seconds; MLP_RATIO_SPIN_LIMIT=0 makes the first launch stall, for the retry test)
+    // hypersparse single-workgroup iteration (hyper.inc): epoch of the per-position stamps, and the flag with which the
+    // kernel hands an iteration it will not take (list overflow / too much work for one workgroup) to the multi-kernel path
+    int hyper_epoch;
+    int hyper_bail;
     PivotRec ring[RING];
 };
 
@@ -168,6 +172,8 @@ struct DevView {
     // the strip height follows k so that every co-resident block gets ONE tile of equal size — the fixed 128-row strips
     // leave 3 381 tiles for 1 024 slots at k = 20 500, i.e. some CUs stream four tiles while others stream three.
     int sw_nbal, sw_pad;
+    int* hy_stamp_n;  // n: hypersparse iteration: epoch at which a non-basic position last entered the alpha_r list
+    int* hy_stamp_p;  // m: ... a singleton basic position last entered the alpha_q list
     // per-pivot vectors
     double* alpha_q;  // m by position  (col_coeffs,            solver.rs:54)
     double* tau;      // m by position  (B^-1 rho,              solver.rs:1157)
@@ -249,6 +255,8 @@ void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st
 void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic = 0, int skip_push = 0, int with_tau = 1);
 void launch_exact_beta(const DevView& dv, hipStream_t st);  // beta_p = ||e_p^T B^-1||^2 for every basic position (lazy dual steepest edge)
 void launch_push_tau(const DevView& dv, hipStream_t st);  // blocked push of -F tau_K alone (runs on a side branch of the graph)  // tau push | v reduce+scatter (classic: partials of k_fused_w's tiling)
+// hypersparse iteration (hyper.inc): up to max_iters dual iterations (no primal steepest edge) in ONE launch of one workgroup
+void launch_hyper_dual(const DevView& dv, int use_dse, int max_iters, long heavy, hipStream_t st);  // heavy <= 0: default work bound
 void launch_mail_handshake(const DevView& dv, int* out, hipStream_t st);  // transport self-test at enable_sharding
 // sampled iterations: stamp (t0, t1) at the start / end of the next kernel of a slot (1 tableau-row sweep, 2 pass over the
 // nucleus inverse, 3 fold) instead of bracketing its launch; (nullptr, nullptr) disarms

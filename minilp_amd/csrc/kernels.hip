@@ -3096,6 +3096,7 @@ __global__ void k_reset_ring(DevView v) {
     c->halt = 0;
     c->forced = 0;
     c->max_pivot_err = 0.0;
+    c->hyper_bail = 0;
 }
 // K9: recalc reduced costs (solver.rs:1216-1231): d_c = c_c - a_c . y, then the objective from scratch
 __global__ void __launch_bounds__(BLK) k_gather_basic_obj(DevView v) {
@@ -3538,6 +3539,8 @@ void launch_build_colblk(const int* cptr, const int* crow, int N, int rb, int* c
     hipLaunchKernelGGL(k_build_colblk, dim3(blocks_for(N)), dim3(BLK), 0, st, cptr, crow, N, rb, colblk);
 }
 
+#include "hyper.inc"  // the hypersparse single-workgroup iteration (uses the stage helpers above)
+
 // ===================================================================================== launchers
 #define LANES_SWITCH(L, STMT4, STMT16, STMT32) \
     do {                                        \
@@ -3546,6 +3549,14 @@ void launch_build_colblk(const int* cptr, const int* crow, int N, int rb, int* c
         else { STMT32; }                        \
     } while (0)
 
+void launch_hyper_dual(const DevView& dv, int use_dse, int max_iters, long heavy, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {  // 136 KB of LDS lists (more than the default 64 KB per workgroup)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_hyper_dual), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HY_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_hyper_dual, dim3(1), dim3(HB), HY_LDS_BYTES, st, dv, use_dse, max_iters, heavy > 0 ? heavy : HY_HEAVY);
+}
 void launch_clear_work(const DevView& hv, hipStream_t st) {
     // alpha_q | tau | rv | hS are carved from one allocation (engine): a single memset
     (void)hipMemsetAsync(hv.alpha_q, 0, sizeof(double) * 5 * (size_t)hv.m, st);
