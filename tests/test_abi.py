@@ -208,18 +208,26 @@ def test_bench_contract_pieces_that_need_no_gpu():
     assert bench.HBM_PEAK_GBS == 8000.0
     # the printed line is a compact digest of the detailed record (the driver reads the tail of stdout)
     import json
-    detail = json.load(open(os.path.join(root, "profiles", "r02k_bench.json")))
+    detail = json.load(open(os.path.join(root, "profiles", "r03a_bench_detail.json")))   # a full record of a run on the GPU box
     line = bench.compact_line(detail)
     text = json.dumps(line)
-    assert len(text) < 3000, len(text)
+    assert len(text) < 3600, len(text)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline", "windows", "full_solve"):
         assert key in line, key
-    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "ftran"}
-    assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
-    assert line["windows"]["late"]["kernels"]["fused"]["frac"] > 0.5 and line["config"]["workload"].startswith("config 4")
-    rec = bench.full_solve_record()
-    assert rec and rec["total_solve_wall_s"] > 0 and rec["pivots"] > 10 ** 6 and rec["source"].startswith("profiles/")
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "ftran", "measured"}
+    assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample", "measured"}
+    assert line["windows"]["late"]["kernels"]["w_pass_v"]["frac"] > 0.5 and line["config"]["workload"].startswith("config 4")
+    # provenance: what this run measured itself is tagged live, what it read from profiles/ says which file
+    assert line["roofline"]["measured"]["achieved"] == "live" and line["roofline"]["measured"]["traffic"].startswith("committed:profiles/")
+    assert line["windows"]["late"]["measured"] == "live" and line["cpu_baseline"]["measured"] == "live"
+    fs = line["full_solve"]
+    assert fs["measured"] == "live" and fs["complete"] is True and fs["pivots"] > 10 ** 6 and fs["total_solve_wall_s"] > 0
+    assert fs["certificate"]["relative_gap"] < 1e-9
+    # FTRAN: the column FTRAN in microseconds and bytes per window, the dense-rhs FTRAN as a stream (no BTRAN-shaped pass under an FTRAN label)
+    ft = line["roofline"]["ftran"]
+    assert set(ft["column"]) == {"early", "mid", "late"} and all(set(v) == {"us", "bytes"} for v in ft["column"].values())
+    assert ft["dense_rhs_late"]["frac"] > 0.5 and "tau_stream_late_window" not in ft
 
 
 def test_mid_solve_basis_fixtures_are_wellformed():

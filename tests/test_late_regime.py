@@ -64,7 +64,9 @@ def test_default_machinery_from_saved_basis_keeps_the_invariants(cfg4, path, k0,
     assert s.stats()["nucleus_size"] >= k0 - 256
     drift = s.reinvert()                                                      # folds the pending terms, then max |W - W_fresh|
     scale = float(s.state("reinvert_scale")[0])                               # max |W_fresh|: the inverse's entries are far from O(1) here
-    assert drift <= 1e-9 * max(1.0, scale), (drift, scale)
+    # two inversions of the same K agree to eps * cond(K) * max|W| at best (the nucleus of config 4 is ill-conditioned:
+    # measured 2.6e-8 of max|W| at k = 20 493); the check guards against a WRONG update, which shows up at O(1)
+    assert drift <= 5e-7 * max(1.0, scale), (drift, scale)
     print(f"{os.path.basename(path)}: 256 pivots, objective {objs[0]:.6f} -> {objs[-1]:.6f}, max_pivot_err {st['max_pivot_err']:.2e}, "
           f"max |W - W_fresh| {drift:.2e} (max |W| {scale:.2e}), cases {st['kase']}")
 
