@@ -129,6 +129,8 @@ struct Stats {
     uint64_t update_launches = 0;
     double solve_wall_s = 0;
     double max_pivot_err = 0;
+    uint64_t reinversion_fallbacks = 0;  // blocked (rocSOLVER) inversions that reported a zero pivot and were redone by the Gauss-Jordan kernels
+    uint64_t hyper_bail_reason[9] = {};  // by reason code of the kernel (hyper.inc)
     uint64_t hyper_iters = 0, hyper_bails = 0;  // iterations taken by the hypersparse kernel; iterations it handed back
     uint64_t ratio_stalls = 0;   // in-kernel waits of the fused ratio test that timed out (each one retried with two launches)
     uint64_t beta_rebuilds = 0;  // lazy dual steepest edge: exact rebuilds of beta from the basis inverse
@@ -205,9 +207,10 @@ private:
     long hyper_heavy = 0;                    // MLP_HYPER_HEAVY: eta-update entries one workgroup takes on (0: the kernel's default)
     uint64_t hyper_off_until = 0;            // lifetime pivot count until which the multi-kernel path runs (after bail-outs)
     int hyper_bail_streak = 0;
-    DevBuf<int> d_hy_stamp;                  // n + m epoch stamps (alpha_r list / singleton part of the alpha_q list)
+    DevBuf<int> d_hy_stamp;                  // n + m epoch stamps (alpha_r list / singleton part of the alpha_q list) + the kernel's derived maps
+    DevBuf<double> d_hy_score;               // m dual pricing scores (derived by the kernel at every launch)
     size_t hy_stamp_len = 0;
-    bool hyper_wanted(int phase) const;
+    bool hyper_capable(int phase) const;
     void ensure_hyper();         // sharded solve with another rank on this GPU (or unknown): same
     // Lazy dual steepest edge: the primal loop never reads beta, so its iterations skip tau = B^-1 rho (solver.rs:1157)
     // and the beta recurrence; beta is rebuilt exactly from the basis inverse (k_exact_beta) when something next needs it

@@ -447,6 +447,9 @@ DevView* Engine::sync_view() {
     v.nb_rng = d_nb_rng.p;
     v.hy_stamp_n = d_hy_stamp.p;
     v.hy_stamp_p = d_hy_stamp.p ? d_hy_stamp.p + num_vars : nullptr;
+    v.hy_var_slot = d_hy_stamp.p ? d_hy_stamp.p + num_vars + m_ : nullptr;
+    v.hy_brng = d_hy_stamp.p ? reinterpret_cast<int2*>(d_hy_stamp.p + ((2 * ((size_t)num_vars + m_) + 1) & ~(size_t)1)) : nullptr;
+    v.hy_score = d_hy_score.p;
     v.rank = shard_rank; v.world = shard_world; v.mail = d_mail;
     for (int r = 0; r < MAX_WORLD; ++r) v.mail_peer[r] = reinterpret_cast<MailRec*>(peer_box[r]);
     v.mail_fanout = shard_world > 1 ? mail_fanout : 0;
@@ -1268,7 +1271,11 @@ int Engine::run_loop(int phase) {
             view_dirty = true;
             sync_view();
         }
-        if (!sample && hyper_wanted(phase)) {
+        // pivots the multi-kernel path still has to take before the hypersparse kernel is tried again (after a bail-out)
+        int hyper_gap = 0;
+        if (hyper_off_until > lifetime_pivots && hyper_capable(phase))
+            hyper_gap = (int)std::min<uint64_t>(hyper_off_until - lifetime_pivots, (uint64_t)1 << 20);
+        if (!sample && hyper_gap == 0 && hyper_capable(phase)) {
             // Hypersparse iteration (hyper.inc): up to RING dual iterations in ONE launch of one workgroup doing only
             // support-restricted work.  Same records, same device state: the two paths alternate freely.
             int B = RING;
@@ -1288,9 +1295,18 @@ int Engine::run_loop(int phase) {
                 // one workgroup): nothing of it was applied; the multi-kernel path takes over for a while — the longer, the
                 // more often this happens in a row (a model that is not hypersparse settles on the multi-kernel path)
                 stats.hyper_bails += 1;
-                hyper_bail_streak = std::min(hyper_bail_streak + 1, 8);
-                hyper_off_until = lifetime_pivots + ((uint64_t)8 << hyper_bail_streak);
-            } else if (stats.iterations - before >= 8) {
+                if (h_ctl->hyper_bail > 0 && h_ctl->hyper_bail < 9) stats.hyper_bail_reason[h_ctl->hyper_bail] += 1;
+                // Dense iterations come in clusters (measured on config 3: handing over one pivot at a time costs 173 bail-outs
+                // and 185 ms against 28 and 172 ms with a back-off): after a run of >= 16 hypersparse iterations the multi-kernel
+                // path takes that one pivot only; after a short run it keeps going for 4, 8, ... 512 pivots before the next attempt
+                if (stats.iterations - before >= 16) {
+                    hyper_bail_streak = 0;
+                    hyper_off_until = lifetime_pivots + 1;
+                } else {
+                    hyper_bail_streak = std::min(hyper_bail_streak + 1, 8);
+                    hyper_off_until = lifetime_pivots + ((uint64_t)2 << hyper_bail_streak);
+                }
+            } else if (stats.iterations - before >= 16) {
                 hyper_bail_streak = 0;
             }
             if (h_ctl->max_pivot_err > stats.max_pivot_err) stats.max_pivot_err = h_ctl->max_pivot_err;
@@ -1299,19 +1315,23 @@ int Engine::run_loop(int phase) {
             continue;
         }
         const bool have_graph = gexec[phase][enable_pse ? 1 : 0][0] != nullptr;
-        const bool graph_now = use_graph && !sample && (have_graph || eager_iters_in_geom >= 4);
-        if (!have_graph) eager_iters_in_geom += 1;
+        // (the one or two iterations handed over by the hypersparse kernel run eagerly: no graph is captured for them)
+        const bool brief = hyper_gap > 0 && hyper_gap <= 4;
+        const bool graph_now = use_graph && !sample && !brief && (have_graph || eager_iters_in_geom >= 4);
+        if (!have_graph && !brief) eager_iters_in_geom += 1;
         // long runs move on to graphs of several iterations and batches of a full record ring: one
         // launch and one host round trip cover more pivots (6 990 -> 7 300 pivots/s on config 4); short
         // warm-start re-solves never pay for capturing the longer graph
         const bool multi = graph_now && long_run;
         int B = graph_now ? (multi ? RING : batch) : 1;
         if (pivot_budget > 0 && (int64_t)B > pivot_budget) B = (int)pivot_budget;
+        if (hyper_gap > 0 && B > hyper_gap) B = hyper_gap;
         bool use_multi = multi;
         if (use_multi) {  // whole graphs only; a short tail falls back to the one-iteration graph
             B -= B % graph_iters;
             if (B == 0) {
                 B = (pivot_budget > 0 && pivot_budget < batch) ? (int)pivot_budget : batch;
+                if (hyper_gap > 0 && B > hyper_gap) B = hyper_gap;
                 use_multi = false;
             }
         }
@@ -1410,10 +1430,10 @@ void Engine::ensure_beta() {
 // Hypersparse iteration (hyper.inc): the dual loop without primal steepest edge, one GPU, in-place nucleus inverse, every
 // row / column short enough for the in-kernel stage heads.  auto: models with few non-zeros per row (the regime where the
 // multi-kernel iteration loses to reach-restricted CPU work); MLP_HYPER=1 / 0 force it on (where it applies) / off.
-bool Engine::hyper_wanted(int phase) const {
+bool Engine::hyper_capable(int phase) const {
     if (hyper_mode == 0 || phase != 1 || enable_pse || shard_world != 1 || stepping) return false;
-    if (lifetime_pivots < hyper_off_until) return false;
     if ((lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 32 : 0)) != 0 || use_banded()) return false;
+    if (cap_ > 4096) return false;  // (the kernel's dense passes over the nucleus slots hold 4 elements per thread)
     if (max_col_nnz_ > HEAD_LIST_CAP || max_row_nnz_ > HEAD_LIST_CAP) return false;
     if (hyper_mode == 1) return true;
     return m_ > 0 && (double)h_rcol.size() <= 16.0 * (double)m_;
@@ -1422,7 +1442,9 @@ void Engine::ensure_hyper() {
     const size_t need = (size_t)num_vars + (size_t)m_;
     if (d_hy_stamp.p && hy_stamp_len == need) return;
     HIPCHECK(hipStreamSynchronize(st));
-    d_hy_stamp.ensure(need + 64, 0, st);
+    // [stamps: n + m | variable -> slot: n + m | (8-byte aligned) column ranges: 2 m] ints, scores: m doubles
+    d_hy_stamp.ensure(2 * need + 2 + 2 * (size_t)m_ + 64, 0, st);
+    d_hy_score.ensure((size_t)m_ + 8, 0, st);
     HIPCHECK(hipMemsetAsync(d_hy_stamp.p, 0, sizeof(int) * d_hy_stamp.cap, st));  // the epoch only grows: zero is "never"
     hy_stamp_len = need;
     view_dirty = true;
@@ -1838,7 +1860,10 @@ void Engine::rebuild_inverse() {
         flag.ensure(2, 0, st);
         HIPCHECK(hipMemsetAsync(flag.p, 0, 2 * sizeof(int), st));
         int hflag = 0;
-        if (k >= 384) {
+        static const bool force_gj = std::getenv("MLP_REINVERT_GJ") != nullptr;  // (debugging: the hand-written Gauss-Jordan at any size)
+        bool blocked_failed = false;
+        int hf[2] = {0, 0};
+        if (k >= 384 && !force_gj) {
             // Large nucleus: blocked LU + inverse from rocSOLVER (GEMM-based, O(k^3) flops at library
             // speed).  K is assembled row-major straight into W; a row-major matrix handed over as
             // column-major is its transpose, and (K^T)^-1 read back row-major is K^-1, so no transposes.
@@ -1855,12 +1880,20 @@ void Engine::rebuild_inverse() {
                 throw MlpError(-3, "rocsolver_dgetrf failed");
             if (rocsolver_dgetri(h, k, d_W.p, ld(), ipiv.p, flag.p + 1) != rocblas_status_success)
                 throw MlpError(-3, "rocsolver_dgetri failed");
-            int hf[2] = {0, 0};
             HIPCHECK(hipMemcpyAsync(hf, flag.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHECK(hipStreamSynchronize(st));
-            hflag = hf[0] | hf[1];
-        } else {
-            // Small nucleus: hand-written Gauss-Jordan with partial pivoting
+            // Observed (round 3, covering LPs with 3 non-zeros per row, k = 564 ... 2 254): the library reports a zero pivot
+            // (info > 0) on nuclei that are well conditioned (numpy: cond 82, min |U_ii| 0.05) and that the Gauss-Jordan below
+            // inverts to 3e-14.  A reported zero pivot is therefore re-examined by the hand-written kernel before it
+            // counts as a singular basis.
+            blocked_failed = (hf[0] | hf[1]) != 0;
+            if (blocked_failed) {
+                stats.reinversion_fallbacks += 1;
+                HIPCHECK(hipMemsetAsync(flag.p, 0, 2 * sizeof(int), st));
+            }
+        }
+        if (k < 384 || force_gj || blocked_failed) {
+            // Small nucleus (or a blocked inversion that reported a zero pivot): hand-written Gauss-Jordan with partial pivoting
             DevBuf<double> Kd, scratch;
             Kd.ensure((size_t)k * ld(), 0, st);
             scratch.ensure((size_t)k + 8, 0, st);
@@ -1869,7 +1902,9 @@ void Engine::rebuild_inverse() {
             HIPCHECK(hipMemcpyAsync(&hflag, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHECK(hipStreamSynchronize(st));
         }
-        if (hflag) throw MlpError(-2, "singular basis matrix (solver.rs:1301)");
+        if (hflag)
+            throw MlpError(-2, "singular basis matrix (solver.rs:1301)" +
+                                   (blocked_failed ? " (getrf info " + std::to_string(hf[0]) + ", getri info " + std::to_string(hf[1]) + ")" : std::string()));
     }
     stats.reinversions += 1;
 }
@@ -2205,7 +2240,17 @@ uint64_t Engine::state(const char* what, double* out, uint64_t cap) {
     else if (w == "orig_var_maxs") tmp = h_hi;
     else if (w == "orig_rhs") tmp = h_rhs;
     else if (w == "flags") tmp = {(double)primal_feasible, (double)dual_feasible, (double)enable_pse, (double)enable_dse};
-    else if (w == "reinvert_scale") tmp = {last_reinvert_scale};  // max |entry| of the fresh nucleus inverse of the last reinvert()
+    else if (w == "hyper_profile") {  // microseconds per stage of the hypersparse iteration, accumulated since try_new
+        pull_ctl();
+        for (int i = 0; i < 13; ++i) tmp.push_back((double)h_ctl->hy_prof[i] * 0.01);
+        tmp.push_back((double)h_ctl->hy_prof[13]);  // shader-clock cycles of the launches (with slot 12: the clock the kernel ran at)
+        tmp.push_back((double)h_ctl->hy_prof[14] * 0.01);  // prologues
+        tmp.push_back(0.0);
+        for (int i = 16; i < 24; ++i) tmp.push_back((double)h_ctl->hy_prof[i] * 0.01);  // sub-stage marks (experiments)
+    }
+    else if (w == "hyper_bail_reasons") {
+        for (int i = 0; i < 9; ++i) tmp.push_back((double)stats.hyper_bail_reason[i]);
+    } else if (w == "reinvert_scale") tmp = {last_reinvert_scale};  // max |entry| of the fresh nucleus inverse of the last reinvert()
     else if (w == "host_basic_vars") tmp.assign(h_basic_vars.begin(), h_basic_vars.end());
     else if (w == "host_nb_vars") tmp.assign(h_nb_vars.begin(), h_nb_vars.end());
     else return (uint64_t)-1;

@@ -92,6 +92,7 @@ struct Ctl {
     // kernel hands an iteration it will not take (list overflow / too much work for one workgroup) to the multi-kernel path
     int hyper_epoch;
     int hyper_bail;
+    unsigned long long hy_prof[24];  // ticks of the 100 MHz wall clock per stage of the hypersparse iteration (diagnostics)
     PivotRec ring[RING];
 };
 
@@ -174,6 +175,9 @@ struct DevView {
     int sw_nbal, sw_pad;
     int* hy_stamp_n;  // n: hypersparse iteration: epoch at which a non-basic position last entered the alpha_r list
     int* hy_stamp_p;  // m: ... a singleton basic position last entered the alpha_q list
+    int* hy_var_slot; // n + m: nucleus slot of a variable (-1: non-basic or singleton basic); rebuilt at every launch of the kernel
+    int2* hy_brng;    // m: CSC range of the basic column at each position (same)
+    double* hy_score; // m: dual pricing score infeasibility^2 / beta of each row, -inf when feasible (same)
     // per-pivot vectors
     double* alpha_q;  // m by position  (col_coeffs,            solver.rs:54)
     double* tau;      // m by position  (B^-1 rho,              solver.rs:1157)

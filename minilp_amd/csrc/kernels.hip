@@ -3550,12 +3550,13 @@ void launch_build_colblk(const int* cptr, const int* crow, int N, int rb, int* c
     } while (0)
 
 void launch_hyper_dual(const DevView& dv, int use_dse, int max_iters, long heavy, hipStream_t st) {
+    const int prof_on = std::getenv("MLP_HYPER_PROF") != nullptr ? 1 : 0;  // per-stage wall-clock marks (each costs a timer read)
     static bool attr_set = false;
     if (!attr_set) {  // 136 KB of LDS lists (more than the default 64 KB per workgroup)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_hyper_dual), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HY_LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_hyper_dual, dim3(1), dim3(HB), HY_LDS_BYTES, st, dv, use_dse, max_iters, heavy > 0 ? heavy : HY_HEAVY);
+    hipLaunchKernelGGL(k_hyper_dual, dim3(1), dim3(HB), HY_LDS_BYTES, st, dv, use_dse, max_iters, heavy > 0 ? heavy : HY_HEAVY, prof_on);
 }
 void launch_clear_work(const DevView& hv, hipStream_t st) {
     // alpha_q | tau | rv | hS are carved from one allocation (engine): a single memset
