@@ -1436,7 +1436,8 @@ bool Engine::hyper_capable(int phase) const {
     if (cap_ > 4096) return false;  // (the kernel's dense passes over the nucleus slots hold 4 elements per thread)
     if (max_col_nnz_ > HEAD_LIST_CAP || max_row_nnz_ > HEAD_LIST_CAP) return false;
     if (hyper_mode == 1) return true;
-    return m_ > 0 && (double)h_rcol.size() <= 16.0 * (double)m_;
+    // few non-zeros per row OR per column (the TSP relaxations of config 5: 129 per degree row, 2 + cuts per column)
+    return m_ > 0 && (double)h_rcol.size() <= 16.0 * (double)std::max(m_, num_vars);
 }
 void Engine::ensure_hyper() {
     const size_t need = (size_t)num_vars + (size_t)m_;
