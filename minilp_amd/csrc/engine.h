@@ -202,6 +202,10 @@ private:
     bool ratio_two = false;                  // MLP_RATIO_TWO_KERNELS, or latched by an ITER_STALL: two launches for the two Harris passes
     long long ratio_spin_limit = 20000000LL; // MLP_RATIO_SPIN_LIMIT: polls before a fused ratio test gives up (0: the first launch stalls; tests)
     bool ranks_share_device = false;
+    // sparse tableau row (k_row_touch / k_row_pull) while the nucleus is small
+    int str_kmax = 192;                      // MLP_STR_K: largest nucleus the sparse form is used for (0: never)
+    bool str_now = false, str_clean = false; // geometry of the batch being run; alpha_r / helper are zero outside touched entries
+    DevBuf<int> d_str_list;
     // hypersparse single-workgroup iteration (hyper.inc)
     int hyper_mode = -1;                     // MLP_HYPER: 1 on wherever the kernel applies, 0 off, -1 auto (<= 16 non-zeros per row on average)
     long hyper_heavy = 0;                    // MLP_HYPER_HEAVY: eta-update entries one workgroup takes on (0: the kernel's default)

@@ -108,6 +108,7 @@ Engine::Engine() {
     lazy_dse = !(lz && lz[0] == '0');
     ratio_two = std::getenv("MLP_RATIO_TWO_KERNELS") != nullptr;
     if (const char* hy = std::getenv("MLP_HYPER")) hyper_mode = std::atoi(hy) > 0 ? 1 : 0;  // 1: whenever the kernel applies, 0: never
+    if (const char* sk = std::getenv("MLP_STR_K")) str_kmax = std::atoi(sk);  // sparse tableau row up to this nucleus size (0: never)
     if (const char* hh = std::getenv("MLP_HYPER_HEAVY")) hyper_heavy = std::atol(hh);        // work bound per iteration (tests force bail-outs)
     if (const char* rs = std::getenv("MLP_RATIO_SPIN_LIMIT")) ratio_spin_limit = std::atoll(rs);
     if (const char* sb = std::getenv("MLP_STREAM_BALANCED")) sw_balanced = std::atoi(sb);
@@ -309,6 +310,7 @@ Geom Engine::geom() const {
     // in-kernel wait between the two Harris passes: never while the ranks of a sharded solve share a device (their grids
     // compete for the same CUs), never again after a wait has timed out once
     g.ratio_two = (ratio_two || (shard_world > 1 && ranks_share_device)) ? 1 : 0;
+    g.str = (str_now && !stepping) ? 1 : 0;
     return g;
 }
 
@@ -450,6 +452,9 @@ DevView* Engine::sync_view() {
     v.hy_var_slot = d_hy_stamp.p ? d_hy_stamp.p + num_vars + m_ : nullptr;
     v.hy_brng = d_hy_stamp.p ? reinterpret_cast<int2*>(d_hy_stamp.p + ((2 * ((size_t)num_vars + m_) + 1) & ~(size_t)1)) : nullptr;
     v.hy_score = d_hy_score.p;
+    v.str_on = (str_now && !stepping) ? 1 : 0;
+    v.pad4 = 0;
+    v.str_list = d_str_list.p;
     v.rank = shard_rank; v.world = shard_world; v.mail = d_mail;
     for (int r = 0; r < MAX_WORLD; ++r) v.mail_peer[r] = reinterpret_cast<MailRec*>(peer_box[r]);
     v.mail_fanout = shard_world > 1 ? mail_fanout : 0;
@@ -986,7 +991,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     const int wtau = lazy ? 0 : 1;
     // banded sweep, primal iteration: k_update_pivot sums the per-band partials itself (no combine launch);
     // the host-paced stepping API keeps the separate combine so that row_coeffs is readable after STAGE_ROW
-    const int inl = (dv.banded && phase == 0 && !stepping) ? 1 : 0;
+    const int inl = (dv.banded && phase == 0 && !stepping && !g.str) ? 1 : 0;
     const bool tau_branch = use_branches && dv.pb_on && phase == 0 && !stepping && shard_world == 1 && !lazy_now(phase);
     // The pricing decision (q for primal, r for dual) is already in Ctl: it was taken by the
     // previous iteration's update kernel, or by the standalone pricing kernel at batch start.
@@ -1041,13 +1046,21 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         }
         break;
     case STAGE_ROW:
+        if (g.str) {  // small nucleus: the columns that meet supp(rho) only (k_row_touch + k_row_pull)
+            if (phase == 0) launch_row_sparse(dv, g, pse ? 1 : 0, tau_branch ? 0 : 1, 1, st);
+            else launch_row_sparse(dv, g, 0, 0, 1, st);
+            break;
+        }
         if (with_events) arm_kernel_timing(1, ev[0], ev[1]);  // sampled iteration: the sweep kernel is timed kernel-exactly
         if (phase == 0) launch_sweep(dv, g, pse ? 1 : 0, tau_branch ? 0 : 1, st, inl);  // K4 (+ PSE helper in the same pass)  |  partition change
         else launch_sweep(dv, g, 0, 0, st);                    // K4: alpha_r = rho^T N
         if (with_events) arm_kernel_timing(1, nullptr, nullptr);
         break;
     case STAGE_APPLY:
-        if (phase == 1 && pse) launch_sweep(dv, g, 2, 1, st);  // dual path: PSE helper  |  partition change
+        if (phase == 1 && pse) {  // dual path: PSE helper  |  partition change
+            if (g.str) launch_row_sparse(dv, g, 2, 1, 0, st);  // (on the columns the ROW stage listed)
+            else launch_sweep(dv, g, 2, 1, st);
+        }
         if (with_events) HIPCHECK(hipEventRecord(ev[4], st));
         // K8 + zero the work vectors + price the next iteration (dual path without PSE: | partition change)
         if (tau_branch) HIPCHECK(hipStreamWaitEvent(st, evJoin[0], 0));  // the tau push has landed
@@ -1115,6 +1128,10 @@ int Engine::step_open(StepInfo* out) {
         return ITER_OPTIMAL;
     }
     step_phase = phase;
+    if (str_now) {  // stepped iterations use the dense tableau row (row_coeffs is inspectable in full)
+        str_now = false;
+        view_dirty = true;
+    }
     ensure_beta();  // stepped iterations maintain beta by the recurrence, from an exact base
     pivot_budget = -1;
     budget_exhausted = false;
@@ -1250,6 +1267,7 @@ int Engine::process_records(int phase, int launched) {
 
 int Engine::run_loop(int phase) {
     if (phase == 1) ensure_beta();  // the dual pricing reads beta
+    str_clean = false;  // (whatever ran since the last loop may have written alpha_r / helper densely)
     batch_lazy = lazy_now(phase);
     for (;;) {
         if (pivot_budget == 0) {
@@ -1286,6 +1304,7 @@ int Engine::run_loop(int phase) {
             launch_reset_ring(hview, st);
             launch_clear_work(hview, st);
             launch_hyper_dual(hview, enable_dse ? 1 : 0, B, hyper_heavy, st);
+            str_clean = false;  // (the kernel writes alpha_r on its touched columns without zeroing them)
             pull_ctl();
             const uint64_t before = stats.iterations;
             int res = process_records(phase, B);
@@ -1313,6 +1332,30 @@ int Engine::run_loop(int phase) {
             if (res == ITER_PIVOT && !(h_ctl->max_pivot_err <= refresh_tol) && k_ > 0) rebuild_inverse();
             if (res != ITER_PIVOT) return res;
             continue;
+        }
+        // Sparse tableau row (small nucleus, one GPU): decided per batch — the geometry is baked into the graphs.  alpha_r /
+        // helper must be zero outside the touched entries when such a batch starts: any dense sweep (or the hypersparse
+        // kernel) in between leaves them dirty.
+        {
+            const bool want = str_kmax > 0 && shard_world == 1 && !stepping && k_ + RING + 1 <= str_kmax && max_row_nnz_ <= 4096;
+            if (want != str_now) {
+                str_now = want;
+                view_dirty = true;
+            }
+            if (str_now) {
+                ensure_hyper();  // the epoch stamps
+                d_str_list.ensure((size_t)num_vars + 64, 0, st);
+                if (!hview.str_list || hview.str_list != d_str_list.p) view_dirty = true;
+                sync_view();
+                if (!str_clean) {
+                    HIPCHECK(hipMemsetAsync(d_alpha_r.p, 0, sizeof(double) * (size_t)num_vars, st));
+                    HIPCHECK(hipMemsetAsync(d_helper.p, 0, sizeof(double) * (size_t)num_vars, st));
+                    HIPCHECK(hipMemsetAsync(&d_ctl.p->str_n, 0, sizeof(int), st));
+                    str_clean = true;
+                }
+            } else {
+                str_clean = false;
+            }
         }
         const bool have_graph = gexec[phase][enable_pse ? 1 : 0][0] != nullptr;
         // (the one or two iterations handed over by the hypersparse kernel run eagerly: no graph is captured for them)
@@ -1360,7 +1403,7 @@ int Engine::run_loop(int phase) {
         int res = process_records(phase, B);
         if (sample && h_ctl->ring_n >= 1 && h_ctl->ring[0].status == ITER_PIVOT) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) {
+            if (!geom().str && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) {
                 stats.sweep_ms += ms;
                 const double sh = shard_world > 1 ? 1.0 / shard_world : 1.0;  // a rank sweeps its own column block
                 stats.sweep_bytes += sh * (12.0 * (double)nnz_before + 16.0 * num_vars) + 16.0 * m_;
@@ -1596,6 +1639,10 @@ void Engine::fix_var(int var, double val) {  // solver.rs:378-415
         // basic: one forced dual pivot towards `val` (solver.rs:384-391)
         int row = h_var_loc[var];
         ensure_nucleus_cap(k_ + 2);
+        if (str_now) {  // (the forced iteration runs outside run_loop: dense tableau row, whatever the last batch used)
+            str_now = false;
+            view_dirty = true;
+        }
         sync_view();
         const DevView& dv = hview;
         launch_reset_ring(dv, st);
@@ -2140,7 +2187,7 @@ Engine* Engine::clone() {
     e->h_rptr = h_rptr; e->h_rcol = h_rcol; e->h_rval = h_rval;
     e->h_colnnz = h_colnnz; e->h_single_row = h_single_row; e->h_single_val = h_single_val;
     e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->no_head_fusion = no_head_fusion;
-    e->sw_balanced = sw_balanced; e->hyper_mode = hyper_mode; e->hyper_heavy = hyper_heavy; e->ratio_two = ratio_two; e->ratio_spin_limit = ratio_spin_limit; e->ranks_share_device = false; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->use_pack = use_pack; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
+    e->sw_balanced = sw_balanced; e->str_kmax = str_kmax; e->hyper_mode = hyper_mode; e->hyper_heavy = hyper_heavy; e->ratio_two = ratio_two; e->ratio_spin_limit = ratio_spin_limit; e->ranks_share_device = false; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->use_pack = use_pack; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
     e->h_basic_vars = h_basic_vars; e->h_nb_vars = h_nb_vars; e->h_var_loc = h_var_loc;
     e->h_kslot_of_pos = h_kslot_of_pos; e->h_srow_of_pos = h_srow_of_pos; e->h_kslot_of_row = h_kslot_of_row;
     e->h_pos_of_srow = h_pos_of_srow; e->h_sdiag_of_pos = h_sdiag_of_pos; e->h_nb_fixed = h_nb_fixed;

@@ -92,6 +92,8 @@ struct Ctl {
     // kernel hands an iteration it will not take (list overflow / too much work for one workgroup) to the multi-kernel path
     int hyper_epoch;
     int hyper_bail;
+    int str_n;       // sparse tableau row (k_row_touch / k_row_pull): non-basic columns touched by the rows of supp(rho) this iteration
+    int str_pad;
     unsigned long long hy_prof[24];  // ticks of the 100 MHz wall clock per stage of the hypersparse iteration (diagnostics)
     PivotRec ring[RING];
 };
@@ -216,6 +218,12 @@ struct DevView {
     double* xbuf;                    // this rank's exchange buffer (polled / read locally)
     double* xbuf_peer[MAX_WORLD];    // rank r's exchange buffer as mapped into this process
     int xb_cap, pad3;
+    // Sparse tableau row (str_on; small nucleus, one GPU): alpha_r = rho^T N (and the PSE helper N^T v on the same columns)
+    // over the columns that meet a row of supp(rho) only, listed in str_list through the epoch stamps hy_stamp_n, instead of
+    // a pass over all of A.  alpha_r / helper are then kept ZERO outside the touched entries (the update kernel zeroes what it
+    // used).
+    int* str_list;   // n
+    int str_on, pad4;
 };
 
 // fused pass tiling
@@ -235,6 +243,7 @@ struct Geom {
     int sweep_variant;  // tuning knob (MLP_SWEEP): 0 default
     int big;            // fused W pass: 64-row x 1024-column blocks, non-temporal (cap > 4096, or forced by MLP_BIGTILE)
     int head_fused;     // stage heads run inside the consuming kernel (delayed-update mode off, every column / row fits the LDS list)
+    int str;            // sparse tableau row instead of the sweep over all of A (nucleus of at most MLP_STR_K columns, one GPU)
     int ratio_two;      // the two Harris passes as two launches (no in-kernel wait): MLP_RATIO_TWO_KERNELS, ranks sharing a device, after an ITER_STALL
 };
 
@@ -253,6 +262,8 @@ void launch_btran_prep(const DevView& dv, int derive_dual, int plan_after, hipSt
 void launch_btran(const DevView& dv, const Geom& g, int with_rhs, hipStream_t st);        // rho, rK, rho_sq [| tK]
 void launch_btran_rhs(const DevView& dv, const Geom& g, hipStream_t st);                  // tK alone
 void launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, hipStream_t st, int inline_combine = 0);  // K4 [| partition change]
+// sparse tableau row: touched-column list, then the pull of alpha_r / helper on the listed columns (| partition change)
+void launch_row_sparse(const DevView& dv, const Geom& g, int mode, int with_struct, int touch, hipStream_t st);
 void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st);                 // K7 p1, p2 (+FTRAN head)
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int with_tau = 1);  // tauK/vK partials + eta update of W

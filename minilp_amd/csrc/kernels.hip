@@ -778,6 +778,10 @@ __device__ __forceinline__ void close_and_open(const DevView& v, Ctl* c, int pha
     __shared__ int s_idx, s_go;
     if (threadIdx.x == 0) {
         if (close_current) push_rec(c, phase);
+        if (close_current && v.str_on) {  // sparse tableau row: a new epoch for the stamps, an empty list
+            c->hyper_epoch += 1;
+            c->str_n = 0;
+        }
         s_go = 1;
         if (close_current && c->forced) {
             c->halt = 1;  // a host-forced iteration (fix_var) is a single step
@@ -3015,6 +3019,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                         double err = fabs(fa - ba) / fmax(1.0, fabs(fa));
                         if (err > c->max_pivot_err || err != err) c->max_pivot_err = err;
                     }
+                    if (v.str_on) v.alpha_r[q] = 0.0;
                     dd = -it->pivot_obj;
                     v.d[q] = dd;
                     if (use_pse) {
@@ -3056,6 +3061,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                         gm += -2.0 * ar * hp / pc + it->alpha_sq * ar * ar / (pc * pc);
                         v.gamma[tn] = gm;
                     }
+                    if (v.str_on) v.alpha_r[tn] = 0.0;  // sparse tableau row: the vector stays zero outside this iteration's touched entries
                 }
             }
             if (phase == 0 && tn >= v.nb_lo && tn < v.nb_hi) {
@@ -3539,6 +3545,79 @@ void launch_build_colblk(const int* cptr, const int* crow, int N, int rb, int* c
     hipLaunchKernelGGL(k_build_colblk, dim3(blocks_for(N)), dim3(BLK), 0, st, cptr, crow, N, rb, colblk);
 }
 
+// ------------------------------------------------------------------- K4, sparse form (small nucleus)
+// rho = B^-T e_r is non-zero on the nucleus rows (k col slots) and on the leaving singleton's own row only, so while the
+// nucleus is small the tableau row alpha_r = rho^T N (solver.rs:685-692) touches just the columns that meet those few rows —
+// the reference's loop over the rows of supp(rho), and SURVEY §8(d)'s 16 * sum_{i in supp rho} nnz(A_i) bytes — instead
+// of all of A (123 MB on config 4, of which < 6 % lies in the support while k <= 57).  With primal steepest edge the
+// helper N^T v (solver.rs:1126-1132) is needed on the columns with alpha_rj != 0 only, i.e. on the same list.
+//   k_row_touch: one wave per row of supp(rho): its CSR entries -> non-basic positions, each listed once (epoch stamp);
+//   k_row_pull : G lanes per listed column pull alpha_rj (and helper_j) from the CSC in storage order (no float atomics).
+__global__ void __launch_bounds__(BLK) k_row_touch(DevView v) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    const int k = c->k;
+    const int w = (int)((blockIdx.x * BLK + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (w > k) return;
+    int row;
+    if (w < k) {
+        if (v.rK[w] == 0.0) return;
+        row = v.row_of_kslot[w];
+    } else {  // the leaving singleton's own row (rho there is 1 / its diagonal entry)
+        const int r = c->it.r;
+        if (v.kslot_of_pos[r] >= 0) return;
+        row = v.srow_of_pos[r];
+    }
+    const int ep = c->hyper_epoch + 1;  // (advanced by the update kernel's finaliser)
+    const int end = v.csr_ptr[row + 1];
+    for (int e0 = v.csr_ptr[row]; e0 < end; e0 += 64) {
+        const int e = e0 + lane;
+        int j = -1;
+        if (e < end) {
+            const int loc = v.var_loc[v.csr_col[e]];
+            if (loc < 0) {
+                j = -1 - loc;
+                if (j < v.nb_lo || j >= v.nb_hi || atomicExch(&v.hy_stamp_n[j], ep) == ep) j = -1;
+            }
+        }
+        const unsigned long long mask = __ballot(j >= 0);  // one counter update per wave and trip
+        if (mask) {
+            int base = 0;
+            if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(&c->str_n, __popcll(mask));
+            base = __shfl(base, __ffsll((long long)mask) - 1, 64);
+            if (j >= 0) v.str_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = j;
+        }
+    }
+}
+template <int G, int MODE>  // MODE 0: alpha_r, 1: alpha_r + helper, 2: helper
+__global__ void __launch_bounds__(BLK) k_row_pull(DevView v, int n_pull) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    if ((int)blockIdx.x >= n_pull) {
+        struct_update_body(v, c, ((int)blockIdx.x - n_pull) * BLK + threadIdx.x);
+        return;
+    }
+    const int n_t = c->str_n;
+    const int gl = threadIdx.x & (G - 1);
+    for (int idx = (int)(blockIdx.x * BLK + threadIdx.x) / G; idx < n_t; idx += n_pull * (BLK / G)) {
+        const int col = v.str_list[idx];
+        const int2 rg = v.nb_rng[col];
+        double a1 = 0.0, a2 = 0.0;
+        for (int e = rg.x + gl; e < rg.y; e += G) {
+            const double a = v.csc_val[e];
+            const double2 t = v.rv[v.csc_row[e]];
+            if (MODE != 2) a1 += a * t.x;
+            if (MODE != 0) a2 += a * t.y;
+        }
+        if (MODE != 2) a1 = group_sum<G>(a1);
+        if (MODE != 0) a2 = group_sum<G>(a2);
+        if (gl == 0) {
+            if (MODE != 2) v.alpha_r[col] = a1;
+            if (MODE != 0) v.helper[col] = a2;
+        }
+    }
+}
+
 #include "hyper.inc"  // the hypersparse single-workgroup iteration (uses the stage helpers above)
 
 // ===================================================================================== launchers
@@ -3714,6 +3793,19 @@ void launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, h
     else if (g.sweep_variant == 2) { LANES_SWITCH(g.lanes, SWEEP(4, 8), SWEEP(8, 8), SWEEP(32, 8)); }
     else { LANES_SWITCH(g.lanes, SWEEP(4, 4), SWEEP(16, 4), SWEEP(16, 8)); }
 #undef SWEEP
+}
+void launch_row_sparse(const DevView& dv, const Geom& g, int mode, int with_struct, int touch, hipStream_t st) {
+    if (touch) hipLaunchKernelGGL(k_row_touch, dim3(blocks_for((long)(g.cap + 1) * 64)), dim3(BLK), 0, st, dv);
+    const int n_pull = 256;
+    const dim3 gr(n_pull + (with_struct ? blocks_for(g.cap) : 0));
+#define ROWPULL(G)                                                                                   \
+    do {                                                                                             \
+        if (mode == 0) hipLaunchKernelGGL((k_row_pull<G, 0>), gr, dim3(BLK), 0, st, dv, n_pull);      \
+        else if (mode == 1) hipLaunchKernelGGL((k_row_pull<G, 1>), gr, dim3(BLK), 0, st, dv, n_pull); \
+        else hipLaunchKernelGGL((k_row_pull<G, 2>), gr, dim3(BLK), 0, st, dv, n_pull);                \
+    } while (0)
+    LANES_SWITCH(g.lanes, ROWPULL(4), ROWPULL(16), ROWPULL(32));
+#undef ROWPULL
 }
 void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st) {
     hipLaunchKernelGGL(k_init_nb_rng, dim3(blocks_for(g.n)), dim3(BLK), 0, st, dv);
