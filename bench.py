@@ -126,6 +126,8 @@ def kernel_report(st):
             out[name] = dict(launches=int(n_l), avg_us=st[name + "_ms"] * 1e3 / n_l,
                              algorithmic_bytes_per_launch=st[name + "_bytes"] / n_l, gbs=gbs, frac=gbs / HBM_PEAK_GBS,
                              total_ms=st[name + "_ms"])
+    if st.get("str_launches"):
+        out["row_sparse"] = dict(launches=int(st["str_launches"]), avg_us=st["str_ms"] * 1e3 / st["str_launches"])
     if st["update_launches"]:
         out["update"] = dict(launches=int(st["update_launches"]), avg_us=st["update_ms"] * 1e3 / st["update_launches"])
     if st["iter_samples"]:
@@ -300,6 +302,11 @@ def compact_line(out):
                                 avg_launch_us=r(rf["avg_launch_us"], 2), launches=rf["launches"],
                                 algorithmic_bytes_per_launch=r(rf["algorithmic_bytes_per_launch"], 0))
         line["roofline"]["measured"] = dict(achieved="live", traffic=rf.get("traffic_measured"))
+        if rf.get("window"):
+            line["roofline"]["window"] = rf["window"][:120]
+        tw = rf.get("timed_window")
+        if tw:  # the driver-timed window's own largest kernel (no bandwidth-bound kernel there: a latency chain)
+            line["roofline"]["timed_window"] = dict(kernel=tw["kernel"].split(" (")[0][:40], us=r(tw["avg_launch_us"], 1), frac=r(tw["frac"], 4))
         ft = rf.get("ftran")
         if ft:  # north_star's FTRAN entries: us and bytes touched of the column FTRAN per window; the dense-rhs FTRAN as a stream
             def colft(x):
@@ -423,8 +430,8 @@ def main():
         dom = max((k for k in ("fused", "sweep") if k in kern), key=lambda k: kern[k]["total_ms"], default=None)
         # the pricing path that shards over column blocks = tableau-row sweep + d/gamma update + pricing scan
         pricing_us = None
-        if "update" in kern and "sweep" in kern:
-            pricing_us = kern["sweep"]["avg_us"] + kern["update"]["avg_us"]
+        if "update" in kern and ("sweep" in kern or "row_sparse" in kern):
+            pricing_us = kern["sweep" if "sweep" in kern else "row_sparse"]["avg_us"] + kern["update"]["avg_us"]
         roofline = None
         if dom:
             which = ("sweep_band" if st.get("banded_sweep") else "sweep") if dom == "sweep" else dom
@@ -469,6 +476,27 @@ def main():
                         continue
                     windows[name] = window_from_basis(M, prob, path, warm, steps, min(a.samples, 16))
                 out["windows"] = windows
+                late = windows.get("late")
+                if late and "fused" in late.get("kernels", {}):
+                    # The roofline object describes the kernel the SOLVE is bound by: the pass over the nucleus inverse in the
+                    # large-nucleus regime, where > 90 % of the wall time of the full solve is spent (measured live in the late
+                    # window).  In the driver-timed window itself (a nucleus of a few dozen columns) no kernel is bandwidth-bound:
+                    # the tableau row only touches the columns that meet supp(rho); its kernels are listed under `timed_window`.
+                    lk = late["kernels"]["fused"]
+                    traffic, traffic_src = pmc_traffic(a, "stream_late")
+                    timed = {k_: v_ for k_, v_ in (roofline or {}).items() if k_ != "ftran"} or None
+                    ftran_obj = (roofline or {}).get("ftran") or dict(kernel=KERNEL_NAMES["ftran"], column=dict(early=kern.get("ftran")))
+                    roofline = dict(bound="hbm", kernel="k_stream_w (" + KERNEL_NAMES["fused"] + ")", achieved=lk["gbs"], peak=HBM_PEAK_GBS,
+                                    unit="GB/s", frac=lk["frac"], traffic=traffic,
+                                    traffic_measured=("committed:profiles/" + traffic_src) if traffic else None,
+                                    traffic_unit=f"HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/{traffic_src})" if traffic else None,
+                                    avg_launch_us=lk["avg_us"], launches=lk["launches"],
+                                    algorithmic_bytes_per_launch=lk["algorithmic_bytes_per_launch"],
+                                    window=f"late window: {late['steps']} pivots from the committed basis with a nucleus of "
+                                           f"{late['nucleus_size_at_start']} columns (the regime of > 90 % of the solve's wall time)",
+                                    samples=late["sampling"], timed_window=timed,
+                                    ftran=ftran_obj)
+                    out["roofline"] = roofline
                 if roofline:
                     for name in ("mid", "late"):
                         if windows.get(name) and "ftran" in windows[name].get("kernels", {}):

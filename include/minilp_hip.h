@@ -144,6 +144,7 @@ typedef struct mlp_stats {
     double fold_bytes, fold_ms; uint64_t fold_launches; /* sampled folds of the pending rank-1 terms into the nucleus inverse (HIP events) */
     double dense_ftran_bytes, dense_ftran_ms; uint64_t dense_ftran_launches; /* dense-rhs FTRAN of mlp_solution_recompute_basic_values /
                               the polish step: algorithmic bytes (8 k^2 per solve) and kernel-exact time of the pass over the nucleus inverse */
+    double str_ms; uint64_t str_launches; /* sampled sparse tableau rows (small nucleus: only the columns that meet supp(rho)): HIP-event time */
     uint64_t hyper_iters, hyper_bails; /* iterations run by the hypersparse single-workgroup kernel (support-restricted work, sparse models);
                                           iterations it declined (list overflow / too much work for one workgroup) and handed to the multi-kernel path */
     uint64_t ratio_stalls; /* in-kernel waits of the one-launch Harris tests that timed out (grid not co-resident); each one is

@@ -40,6 +40,7 @@ class MlpStats(C.Structure):
                    ("iter_ms", C.c_double), ("iter_samples", C.c_uint64), ("beta_rebuilds", C.c_uint64),
                    ("fold_bytes", C.c_double), ("fold_ms", C.c_double), ("fold_launches", C.c_uint64),
                    ("dense_ftran_bytes", C.c_double), ("dense_ftran_ms", C.c_double), ("dense_ftran_launches", C.c_uint64),
+                   ("str_ms", C.c_double), ("str_launches", C.c_uint64),
                    ("hyper_iters", C.c_uint64), ("hyper_bails", C.c_uint64), ("ratio_stalls", C.c_uint64)])
 
 

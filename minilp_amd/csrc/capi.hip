@@ -303,6 +303,7 @@ void mlp_solution_stats(const mlp_solution* s, mlp_stats* o) {
     o->ftran_bytes = t.ftran_bytes; o->ftran_ms = t.ftran_ms; o->ftran_launches = t.ftran_launches;
     o->iter_ms = t.iter_ms; o->iter_samples = t.iter_samples;
     o->beta_rebuilds = t.beta_rebuilds;
+    o->str_ms = t.str_ms; o->str_launches = t.str_launches;
     o->ratio_stalls = t.ratio_stalls; o->hyper_iters = t.hyper_iters; o->hyper_bails = t.hyper_bails;
     o->dense_ftran_bytes = t.dense_ftran_bytes; o->dense_ftran_ms = t.dense_ftran_ms; o->dense_ftran_launches = t.dense_ftran_launches;
     o->fold_bytes = t.fold_bytes; o->fold_ms = t.fold_ms; o->fold_launches = t.fold_launches;

@@ -130,6 +130,8 @@ struct Stats {
     double solve_wall_s = 0;
     double max_pivot_err = 0;
     uint64_t reinversion_fallbacks = 0;  // blocked (rocSOLVER) inversions that reported a zero pivot and were redone by the Gauss-Jordan kernels
+    double str_ms = 0;  // sampled sparse tableau rows (k_row_touch + k_row_pull, launch-bracketed HIP events)
+    uint64_t str_launches = 0;
     uint64_t hyper_bail_reason[9] = {};  // by reason code of the kernel (hyper.inc)
     uint64_t hyper_iters = 0, hyper_bails = 0;  // iterations taken by the hypersparse kernel; iterations it handed back
     uint64_t ratio_stalls = 0;   // in-kernel waits of the fused ratio test that timed out (each one retried with two launches)
@@ -203,7 +205,7 @@ private:
     long long ratio_spin_limit = 20000000LL; // MLP_RATIO_SPIN_LIMIT: polls before a fused ratio test gives up (0: the first launch stalls; tests)
     bool ranks_share_device = false;
     // sparse tableau row (k_row_touch / k_row_pull) while the nucleus is small
-    int str_kmax = 192;                      // MLP_STR_K: largest nucleus the sparse form is used for (0: never)
+    int str_kmax = 256;                      // MLP_STR_K: largest nucleus the sparse form is used for (0: never)
     bool str_now = false, str_clean = false; // geometry of the batch being run; alpha_r / helper are zero outside touched entries
     DevBuf<int> d_str_list;
     // hypersparse single-workgroup iteration (hyper.inc)

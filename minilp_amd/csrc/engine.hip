@@ -1047,8 +1047,10 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         break;
     case STAGE_ROW:
         if (g.str) {  // small nucleus: the columns that meet supp(rho) only (k_row_touch + k_row_pull)
+            if (with_events) HIPCHECK(hipEventRecord(ev[0], st));  // (sampled iteration: the two launches bracketed together)
             if (phase == 0) launch_row_sparse(dv, g, pse ? 1 : 0, tau_branch ? 0 : 1, 1, st);
             else launch_row_sparse(dv, g, 0, 0, 1, st);
+            if (with_events) HIPCHECK(hipEventRecord(ev[1], st));
             break;
         }
         if (with_events) arm_kernel_timing(1, ev[0], ev[1]);  // sampled iteration: the sweep kernel is timed kernel-exactly
@@ -1403,7 +1405,12 @@ int Engine::run_loop(int phase) {
         int res = process_records(phase, B);
         if (sample && h_ctl->ring_n >= 1 && h_ctl->ring[0].status == ITER_PIVOT) {
             float ms = 0.f;
-            if (!geom().str && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) {
+            if (geom().str) {
+                if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) {
+                    stats.str_ms += ms;
+                    stats.str_launches += 1;
+                }
+            } else if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) {
                 stats.sweep_ms += ms;
                 const double sh = shard_world > 1 ? 1.0 / shard_world : 1.0;  // a rank sweeps its own column block
                 stats.sweep_bytes += sh * (12.0 * (double)nnz_before + 16.0 * num_vars) + 16.0 * m_;
