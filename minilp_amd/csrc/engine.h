@@ -205,7 +205,7 @@ private:
     long long ratio_spin_limit = 20000000LL; // MLP_RATIO_SPIN_LIMIT: polls before a fused ratio test gives up (0: the first launch stalls; tests)
     bool ranks_share_device = false;
     // sparse tableau row (k_row_touch / k_row_pull) while the nucleus is small
-    int str_kmax = 256;                      // MLP_STR_K: largest nucleus the sparse form is used for (0: never)
+    int str_kmax = 230;                      // MLP_STR_K: largest nucleus the sparse form is used for (0: never)
     bool str_now = false, str_clean = false; // geometry of the batch being run; alpha_r / helper are zero outside touched entries
     DevBuf<int> d_str_list;
     // hypersparse single-workgroup iteration (hyper.inc)

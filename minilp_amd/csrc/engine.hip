@@ -455,6 +455,7 @@ DevView* Engine::sync_view() {
     v.str_on = (str_now && !stepping) ? 1 : 0;
     v.pad4 = 0;
     v.str_list = d_str_list.p;
+    v.aq_list = d_str_list.p ? d_str_list.p + (((size_t)num_vars + 63) & ~(size_t)63) : nullptr;
     v.rank = shard_rank; v.world = shard_world; v.mail = d_mail;
     for (int r = 0; r < MAX_WORLD; ++r) v.mail_peer[r] = reinterpret_cast<MailRec*>(peer_box[r]);
     v.mail_fanout = shard_world > 1 ? mail_fanout : 0;
@@ -1346,13 +1347,13 @@ int Engine::run_loop(int phase) {
             }
             if (str_now) {
                 ensure_hyper();  // the epoch stamps
-                d_str_list.ensure((size_t)num_vars + 64, 0, st);
+                d_str_list.ensure((size_t)num_vars + (size_t)m_ + 192, 0, st);  // touched columns | positions of supp(alpha_q)
                 if (!hview.str_list || hview.str_list != d_str_list.p) view_dirty = true;
                 sync_view();
                 if (!str_clean) {
                     HIPCHECK(hipMemsetAsync(d_alpha_r.p, 0, sizeof(double) * (size_t)num_vars, st));
                     HIPCHECK(hipMemsetAsync(d_helper.p, 0, sizeof(double) * (size_t)num_vars, st));
-                    HIPCHECK(hipMemsetAsync(&d_ctl.p->str_n, 0, sizeof(int), st));
+                    HIPCHECK(hipMemsetAsync(&d_ctl.p->aq_n, 0, 4 * sizeof(int), st));  // aq_n, pad, str_n, pad
                     str_clean = true;
                 }
             } else {

@@ -92,6 +92,8 @@ struct Ctl {
     // kernel hands an iteration it will not take (list overflow / too much work for one workgroup) to the multi-kernel path
     int hyper_epoch;
     int hyper_bail;
+    int aq_n;        // sparse primal ratio test: listed positions of supp(alpha_q) this iteration
+    int aq_pad;
     int str_n;       // sparse tableau row (k_row_touch / k_row_pull): non-basic columns touched by the rows of supp(rho) this iteration
     int str_pad;
     unsigned long long hy_prof[24];  // ticks of the 100 MHz wall clock per stage of the hypersparse iteration (diagnostics)
@@ -223,6 +225,7 @@ struct DevView {
     // a pass over all of A.  alpha_r / helper are then kept ZERO outside the touched entries (the update kernel zeroes what it
     // used).
     int* str_list;   // n
+    int* aq_list;    // m: positions of supp(alpha_q) (listed by the FTRAN when str_on and the F products are pushed)
     int str_on, pad4;
 };
 

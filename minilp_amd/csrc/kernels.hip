@@ -591,6 +591,17 @@ __device__ __forceinline__ void lr_dot_listed(unsigned long long mask, int slot,
             if (ab[u] != 0.0) acc += ab[u] * x[u];
     }
 }
+// Sparse primal ratio test (small nucleus, v.str_on, pushed F products): the FTRAN lists the positions of supp(alpha_q) as it
+// touches them — each once, through the epoch stamp of the position — so that the Harris test, ||alpha_q||^2 and the
+// singleton part of v run over that list in ONE block instead of two grid-wide passes over all m positions.
+__device__ __forceinline__ bool aq_listing(const DevView& v) { return v.str_on && !v.pb_on && !v.det_pull && v.world <= 1; }
+__device__ __forceinline__ void aq_list_add(const DevView& v, Ctl* c, int p) {
+    const int ep = c->hyper_epoch + 1;
+    if (atomicExch(&v.hy_stamp_p[p], ep) != ep) {
+        const int o = atomicAdd(&c->aq_n, 1);
+        if (o < v.m) v.aq_list[o] = p;
+    }
+}
 // ------------------------------------------------------------------- wave-level stage heads
 // FTRAN head (one wave): derive the entering column's scalars, land its singleton-row entries in
 // alpha_q and list its entries on nucleus rows.  alpha_q = B^-1 a_q  (solver.rs:671-677).
@@ -638,7 +649,10 @@ __device__ void ftran_prep_wave(const DevView& v, Ctl* c, int lane, int derive_p
         for (int h = 0; h < 2; ++h) {
             if (vx[h]) {
                 sx[h] = rx[h].kslot;
-                if (sx[h] < 0) v.alpha_q[rx[h].pos] = ax[h] / rx[h].diag;
+                if (sx[h] < 0) {
+                    v.alpha_q[rx[h].pos] = ax[h] / rx[h].diag;
+                    if (aq_listing(v)) aq_list_add(v, c, rx[h].pos);
+                }
             }
         }
 #pragma unroll
@@ -781,6 +795,7 @@ __device__ __forceinline__ void close_and_open(const DevView& v, Ctl* c, int pha
         if (close_current && v.str_on) {  // sparse tableau row: a new epoch for the stamps, an empty list
             c->hyper_epoch += 1;
             c->str_n = 0;
+            c->aq_n = 0;
         }
         s_go = 1;
         if (close_current && c->forced) {
@@ -840,12 +855,15 @@ __global__ void __launch_bounds__(64) k_ftran_prep(DevView v, int derive_primal)
 }
 // push of -x * (column of the basic variable at `p`) into the singleton positions
 template <int G>
-__device__ __forceinline__ void push_F(const DevView& v, int p, double x, double* out_pos, int gl) {
+__device__ __forceinline__ void push_F(const DevView& v, int p, double x, double* out_pos, int gl, Ctl* list_ctl = nullptr) {
     int var = v.basic_vars[p];
     int end = v.csc_ptr[var + 1];
     for (int e = v.csc_ptr[var] + gl; e < end; e += G) {
         const RowInfo ri = v.rowinfo[v.csc_row[e]];
-        if (ri.kslot < 0) unsafeAtomicAdd(&out_pos[ri.pos], -v.csc_val[e] * x / ri.diag);
+        if (ri.kslot < 0) {
+            unsafeAtomicAdd(&out_pos[ri.pos], -v.csc_val[e] * x / ri.diag);
+            if (list_ctl) aq_list_add(v, list_ctl, ri.pos);
+        }
     }
 }
 template <int G>
@@ -868,8 +886,9 @@ __global__ void __launch_bounds__(BLK) k_ftran_gather(DevView v) {
     if (gl == 0) {
         v.aK[slot] = acc;
         v.alpha_q[p] = acc;
+        if (acc != 0.0 && aq_listing(v)) aq_list_add(v, c, p);
     }
-    if (acc != 0.0 && !v.pb_on && !v.det_pull) push_F<G>(v, p, acc, v.alpha_q, gl);
+    if (acc != 0.0 && !v.pb_on && !v.det_pull) push_F<G>(v, p, acc, v.alpha_q, gl, aq_listing(v) ? c : nullptr);
 }
 
 // Blocked F push of the large-nucleus regime.  y_S -= D^-1 F x_K through device-scope f64 atomics costs
@@ -1224,6 +1243,8 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_p2(DevView v) {
     ratio_primal_finish(v, c, best);
 }
 
+constexpr int AQ_CAP = 2048;  // positions of supp(alpha_q) the single-block form of the primal ratio test takes on (8 per thread: beyond that
+                              // the two grid-wide passes are faster — measured on config 4: 97 against 77 us per pivot at k = 135 with a cap of 8 192)
 // Both Harris passes in ONE launch (primal): pass 1's grid-wide minimum is published by its last-arriving
 // block, every block waits for it (a 98-block grid is always co-resident) and runs pass 2 on the elements it
 // still holds in registers; the second ticketed reduction ends in ratio_primal_finish as before.  Saves a
@@ -1232,6 +1253,67 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_fused(DevView v, int use_p
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     const int sign = c->it.sign;
+    if (aq_listing(v) && c->aq_n <= AQ_CAP) {
+        // Sparse form: block 0 alone runs both Harris passes (solver.rs:782-853), ||alpha_q||^2 and the singleton part of v
+        // over the listed positions of supp(alpha_q); no grid-wide reduction, no in-kernel wait.  Ties keep the lowest
+        // position (cand_better), whatever the order of the list.
+        if (blockIdx.x != 0) return;
+        const int n_l = c->aq_n;
+        constexpr int PL = AQ_CAP / BLK;
+        double ca[PL], stp[PL];
+        int pos[PL];
+        double mn = INFINITY, sq = 0.0;
+#pragma unroll
+        for (int u = 0; u < PL; ++u) {
+            const int a = threadIdx.x + u * BLK;
+            pos[u] = -1;
+            ca[u] = 0.0;
+            stp[u] = 0.0;
+            if (a >= n_l) continue;
+            const int p = v.aq_list[a];
+            const double coeff = v.alpha_q[p];
+            const int ks = v.kslot_of_pos[p], sr = v.srow_of_pos[p];
+            const double sd = v.sdiag_of_pos[p];
+            const double xb = v.xB[p], lob = v.loB[p], hib = v.hiB[p];
+            if (use_pse) {
+                sq += coeff * coeff;
+                if (ks < 0) v.rv[sr].y = coeff / sd;
+            }
+            const double aa = fabs(coeff);
+            if (aa < EPS) continue;
+            const bool tm = (sign && coeff < 0.0) || (!sign && coeff > 0.0);
+            const double st = tm ? (xb < hib ? hib - xb : 0.0) : (xb > lob ? xb - lob : 0.0);
+            pos[u] = p;
+            ca[u] = aa;
+            stp[u] = st;
+            const double cur = (st + EPS) / aa;
+            if (cur < mn) mn = cur;
+        }
+        __shared__ double s_ms;
+        mn = block_min(mn);
+        sq = block_sum(sq);
+        if (threadIdx.x == 0) {
+            double max_step = fabs(c->it.entering_other - c->it.entering_cur);
+            if (mn < max_step) max_step = mn;
+            c->it.max_step = max_step;
+            c->it.alpha_sq = sq + 1.0;
+            s_ms = max_step;
+        }
+        __syncthreads();
+        const double max_step = s_ms;
+        Cand best = cand_none();
+#pragma unroll
+        for (int u = 0; u < PL; ++u) {
+            if (pos[u] < 0) continue;
+            if (stp[u] / ca[u] <= max_step) {
+                Cand t{ca[u], pos[u]};
+                if (cand_better(t, best)) best = t;
+            }
+        }
+        best = block_best(best);
+        ratio_primal_finish(v, c, best);
+        return;
+    }
     const int epoch0 = c->ratio_epoch;  // written by the previous launch of this kernel: stable here
     constexpr int PT = 4;               // elements per thread (grid_for's default)
     double ca[PT], stp[PT];
@@ -1447,6 +1529,7 @@ __device__ void ftran_head_lds(const DevView& v, Ctl* c, int lane, int derive_pr
                 const double x = a / v.sdiag_of_pos[p];
                 if (atomic_land) unsafeAtomicAdd(&v.alpha_q[p], x);
                 else v.alpha_q[p] = x;
+                if (aq_listing(v)) aq_list_add(v, c, p);
             }
         }
         const bool isk = valid && s >= 0;
@@ -1490,8 +1573,9 @@ __global__ void __launch_bounds__(BLK) k_ftran_fused(DevView v, int derive_prima
     if (gl == 0) {
         v.aK[slot] = acc;
         v.alpha_q[p] = acc;
+        if (acc != 0.0 && aq_listing(v)) aq_list_add(v, c, p);
     }
-    if (acc != 0.0 && !v.pb_on && !v.det_pull) push_F<G>(v, p, acc, v.alpha_q, gl);
+    if (acc != 0.0 && !v.pb_on && !v.det_pull) push_F<G>(v, p, acc, v.alpha_q, gl, aq_listing(v) ? c : nullptr);
 }
 __device__ void btran_head_lds(const DevView& v, Ctl* c, int lane, int derive_dual, bool primary, int* ls, double* la, int* ln) {
     IterState* it = &c->it;

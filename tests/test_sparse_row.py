@@ -18,12 +18,16 @@ CASES = [("sparse", (700, 600, 12, 6)), ("sparse", (2500, 2000, 10, 4)), ("cover
 
 
 @pytest.mark.parametrize("fam,args", CASES, ids=str)
-@pytest.mark.parametrize("banded", [0, 1], ids=["csc sweep", "banded sweep"])
+@pytest.mark.parametrize("banded", [0, 1, 2], ids=["csc sweep", "banded sweep", "pushed F products + sparse ratio test"])
 def test_sparse_tableau_row_takes_the_oracles_pivots(monkeypatch, fam, args, banded):
     monkeypatch.setenv("MLP_STR_K", "4000")
     monkeypatch.setenv("MLP_HYPER", "0")       # (the multi-kernel iteration is the one under test)
-    if banded:
+    if banded == 1:
         monkeypatch.setenv("MLP_BANDED", "1")  # the form config 4 uses beyond the threshold
+    if banded == 2:
+        # the F products pushed with atomics as on config 4 (small models pull them by default): the FTRAN then lists
+        # supp(alpha_q) and the primal Harris test runs over that list in one block (k_ratio_primal_fused, sparse form)
+        monkeypatch.setenv("MLP_DETERMINISTIC", "0")
     lp = GEN[fam](*args)
     so = lpgen.build_problem(O.Problem, lp).solve(trace=True)
     sg = lpgen.build_problem(M.Problem, lp).solve(trace=True)
