@@ -206,6 +206,7 @@ private:
     bool ranks_share_device = false;
     // sparse tableau row (k_row_touch / k_row_pull) while the nucleus is small
     int str_kmax = 230;                      // MLP_STR_K: largest nucleus the sparse form is used for (0: never)
+    bool touch_done = false;                 // the BASIS stage of the iteration being recorded carried the touched-column list
     bool str_now = false, str_clean = false; // geometry of the batch being run; alpha_r / helper are zero outside touched entries
     DevBuf<int> d_str_list;
     // hypersparse single-workgroup iteration (hyper.inc)

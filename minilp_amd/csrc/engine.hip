@@ -994,6 +994,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     // the host-paced stepping API keeps the separate combine so that row_coeffs is readable after STAGE_ROW
     const int inl = (dv.banded && phase == 0 && !stepping && !g.str) ? 1 : 0;
     const bool tau_branch = use_branches && dv.pb_on && phase == 0 && !stepping && shard_world == 1 && !lazy_now(phase);
+    if (stage == STAGE_BASIS) touch_done = false;
     // The pricing decision (q for primal, r for dual) is already in Ctl: it was taken by the
     // previous iteration's update kernel, or by the standalone pricing kernel at batch start.
     switch (stage) {
@@ -1043,13 +1044,14 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
             launch_push_tau(dv, st2);
             HIPCHECK(hipEventRecord(evJoin[0], st2));
         } else {
-            launch_post_fused(dv, g, pse, st, 0, 0, wtau);    // tau by position (F push)  |  v reduce + scatter
+            // tau by position (F push)  |  v reduce + scatter  |  (sparse tableau row, primal: its touched-column list)
+            touch_done = launch_post_fused(dv, g, pse, st, 0, 0, wtau, (g.str && phase == 0) ? 1 : 0) != 0;
         }
         break;
     case STAGE_ROW:
         if (g.str) {  // small nucleus: the columns that meet supp(rho) only (k_row_touch + k_row_pull)
             if (with_events) HIPCHECK(hipEventRecord(ev[0], st));  // (sampled iteration: the two launches bracketed together)
-            if (phase == 0) launch_row_sparse(dv, g, pse ? 1 : 0, tau_branch ? 0 : 1, 1, st);
+            if (phase == 0) launch_row_sparse(dv, g, pse ? 1 : 0, tau_branch ? 0 : 1, touch_done ? 0 : 1, st);
             else launch_row_sparse(dv, g, 0, 0, 1, st);
             if (with_events) HIPCHECK(hipEventRecord(ev[1], st));
             break;

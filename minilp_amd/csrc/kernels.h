@@ -270,7 +270,7 @@ void launch_row_sparse(const DevView& dv, const Geom& g, int mode, int with_stru
 void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st);                 // K7 p1, p2 (+FTRAN head)
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int with_tau = 1);  // tauK/vK partials + eta update of W
-void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic = 0, int skip_push = 0, int with_tau = 1);
+int launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic = 0, int skip_push = 0, int with_tau = 1, int touch = 0);
 void launch_exact_beta(const DevView& dv, hipStream_t st);  // beta_p = ||e_p^T B^-1||^2 for every basic position (lazy dual steepest edge)
 void launch_push_tau(const DevView& dv, hipStream_t st);  // blocked push of -F tau_K alone (runs on a side branch of the graph)  // tau push | v reduce+scatter (classic: partials of k_fused_w's tiling)
 // hypersparse iteration (hyper.inc): up to max_iters dual iterations (no primal steepest edge) in ONE launch of one workgroup

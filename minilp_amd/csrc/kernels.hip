@@ -2921,10 +2921,15 @@ __global__ void __launch_bounds__(BLK) k_post_exchange(DevView v, int with_v, in
 // After the fused pass (horizontally fused): blocks [0, n_push) finish tau = B^-1 rho by position
 // (tau_K from the per-chunk partials in a fixed order, then the push of -F tau_K, solver.rs:1157);
 // the remaining blocks reduce the v partials in a fixed order and scatter v_K by row (solver.rs:1114).
+__device__ __forceinline__ void row_touch_body(const DevView& v, Ctl* c, int block);  // (sparse tableau row, below)
 template <int G, bool WITH_V, int TR, int TC = FW_TC>
-__global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push) {
+__global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push, int touch_from = -1) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
+    if (touch_from >= 0 && (int)blockIdx.x >= touch_from) {  // horizontally fused: the touched-column list of the sparse tableau
+        row_touch_body(v, c, (int)blockIdx.x - touch_from);   // row needs rho only (the BTRAN before this launch), nothing of this pass
+        return;
+    }
     const int k = c->k;
     // row-sharded streaming pass: the partials were exchanged by k_post_exchange; read tau_K (each row from its owner's
     // slot) and the v_K partials (summed in rank order) from the local exchange buffer
@@ -3637,11 +3642,9 @@ void launch_build_colblk(const int* cptr, const int* crow, int N, int rb, int* c
 // helper N^T v (solver.rs:1126-1132) is needed on the columns with alpha_rj != 0 only, i.e. on the same list.
 //   k_row_touch: one wave per row of supp(rho): its CSR entries -> non-basic positions, each listed once (epoch stamp);
 //   k_row_pull : G lanes per listed column pull alpha_rj (and helper_j) from the CSC in storage order (no float atomics).
-__global__ void __launch_bounds__(BLK) k_row_touch(DevView v) {
-    Ctl* c = v.ctl;
-    if (c->halt || c->it.status != ITER_PIVOT) return;
+__device__ __forceinline__ void row_touch_body(const DevView& v, Ctl* c, int block) {
     const int k = c->k;
-    const int w = (int)((blockIdx.x * BLK + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    const int w = (int)((block * BLK + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     if (w > k) return;
     int row;
     if (w < k) {
@@ -3672,6 +3675,11 @@ __global__ void __launch_bounds__(BLK) k_row_touch(DevView v) {
             if (j >= 0) v.str_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = j;
         }
     }
+}
+__global__ void __launch_bounds__(BLK) k_row_touch(DevView v) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    row_touch_body(v, c, (int)blockIdx.x);
 }
 template <int G, int MODE>  // MODE 0: alpha_r, 1: alpha_r + helper, 2: helper
 __global__ void __launch_bounds__(BLK) k_row_pull(DevView v, int n_pull) {
@@ -4031,9 +4039,12 @@ void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st
         else LAUNCH_T(2, (k_fused_w<16, false, false, true, true, false, FW_RL, true>), dim3(nb), b, 0, st, dv);
     }
 }
-void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic, int skip_push, int with_tau) {
+int launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic, int skip_push, int with_tau, int touch) {
+    // touch: also build the touched-column list of the sparse tableau row in this launch (extra blocks); returns 1 when it
+    // did, 0 when the caller still has to launch k_row_touch on its own
     if (!with_tau) skip_push = 1;  // lazy dual steepest edge: no tau, hence no push of -F tau_K
-    if (!with_tau && !with_v) return;
+    if (!with_tau && !with_v) return 0;
+    const int touch_asked = touch;
     if (!classic && dv.lrJ && fw_rows(g) != 8 && FW_RL == 1 && stream_strips()) {  // partials of k_stream_w's strips
 #define POSTX(RB, CH)                                                                                             \
     if (sw_rb() == RB && sw_ch() == CH) hipLaunchKernelGGL((k_post_exchange<RB, CH>), dim3(blocks_for(g.cap)), dim3(BLK), 0, st, dv, with_v, with_tau);
@@ -4056,12 +4067,16 @@ void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t
 #undef POSTS2
         if (dv.pb_on && !skip_push) launch_blocked_push(dv, 1, st);
         else if (dv.det_pull && with_tau) launch_pull_F(dv, g, 1, st);
-        return;
+        return 0;
     }
 #define POSTF(G)                                                                                                  \
     do {                                                                                                          \
         int n_push = with_tau ? blocks_for((long)g.cap * G) : 0;                                                  \
-        if (with_v && fw_rows(g) == 8) hipLaunchKernelGGL((k_post_fused<G, true, 8>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push); \
+        if (with_v && fw_rows(g) == 8 && touch) {                                                                 \
+            const int n_tail = n_push + blocks_for(g.cap, 32);                                                    \
+            hipLaunchKernelGGL((k_post_fused<G, true, 8>), dim3(n_tail + blocks_for((long)(g.cap + 1) * 64)), dim3(BLK), 0, st, dv, n_push, n_tail); \
+            touch = 0;                                                                                            \
+        } else if (with_v && fw_rows(g) == 8) hipLaunchKernelGGL((k_post_fused<G, true, 8>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push); \
         else if (with_v) hipLaunchKernelGGL((k_post_fused<G, true, 16 * FW_RL>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push); \
         else hipLaunchKernelGGL((k_post_fused<G, false, 16>), dim3(n_push), dim3(BLK), 0, st, dv, n_push);        \
     } while (0)
@@ -4069,6 +4084,7 @@ void launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t
 #undef POSTF
     if (dv.pb_on && !skip_push) launch_blocked_push(dv, 1, st);
     else if (dv.det_pull && with_tau) launch_pull_F(dv, g, 1, st);
+    return (touch_asked && !touch) ? 1 : 0;
 }
 void launch_push_tau(const DevView& dv, hipStream_t st) { launch_blocked_push(dv, 1, st); }  // the tau push alone (side branch)
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st) {
