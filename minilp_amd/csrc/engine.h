@@ -338,6 +338,7 @@ private:
     long final_refresh_pivots = 50000;  // MLP_FINAL_REFRESH: re-examine optimality on recomputed reduced costs after this many pivots (0 = never)
     uint64_t iters_since_recalc = 0, iters_since_polish = 0;
     bool basic_values_feasible();
+    bool reduced_costs_feasible();
     int graph_iters = 8;  // MLP_GRAPH_ITERS: iterations per graph once a geometry has run for a while (1 = off)
     // graph slots: [0] one iteration per graph, [1] graph_iters iterations per graph (long runs)
     hipGraphExec_t gexec[2][2][2] = {};

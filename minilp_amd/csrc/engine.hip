@@ -742,6 +742,8 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name) {
                 }
                 if (!wait_flag(&rv[r].ready, 1, 120.0))
                     throw MlpError(-3, "enable_sharding: rank " + std::to_string(r) + " did not publish its mailbox handle within 120 s");
+                if (__atomic_load_n(&rv[r].ready, __ATOMIC_ACQUIRE) == ~(uint64_t)0)
+                    throw MlpError(-3, "enable_sharding: rank " + std::to_string(r) + " failed to set up its mailbox");
                 if (rv[r].pid == mine->pid) throw MlpError(-1, "enable_sharding: two ranks in one process are not supported");
                 void* q = nullptr;
                 hipError_t eo = hipIpcOpenMemHandle(&q, rv[r].handle, hipIpcMemLazyEnablePeerAccess);
@@ -756,6 +758,9 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name) {
             for (int r = 0; r < world; ++r)
                 if (r != rank && !wait_flag(&rv[r].ready, 2, 120.0))
                     throw MlpError(-3, "enable_sharding: rank " + std::to_string(r) + " did not finish mapping the mailboxes within 120 s");
+            for (int r = 0; r < world; ++r)
+                if (r != rank && __atomic_load_n(&rv[r].ready, __ATOMIC_ACQUIRE) == ~(uint64_t)0)
+                    throw MlpError(-3, "enable_sharding: rank " + std::to_string(r) + " failed while mapping the mailboxes");
             d_mail = reinterpret_cast<MailRec*>(own_box);
             mail_fanout = world;
             bool same_dev = true;
@@ -768,7 +773,12 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name) {
                                  : "device-resident mailboxes in each GPU's HBM, written by the peers over xGMI (HIP IPC peer mappings)";
         }
     } catch (...) {
-        release_mailboxes();
+        // tell the peers at once (they would otherwise wait up to 120 s per missing flag): ready = all ones means "failed"
+        if (!host_transport && mail_host) {
+            Rendezvous* rvf = reinterpret_cast<Rendezvous*>(static_cast<uint8_t*>(mail_host) + host_bytes);
+            __atomic_store_n(&rvf[rank].ready, ~(uint64_t)0, __ATOMIC_RELEASE);
+        }
+        release_mailboxes();  // (nobody posts into this rank's box before every rank has reached ready = 2)
         shard_rank = 0; shard_world = 1;
         view_dirty = true;
         throw;
@@ -792,7 +802,9 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name) {
             throw MlpError(-3, "enable_sharding: the mailbox handshake did not complete (rank " + std::to_string(rank) + " heard from " +
                                    std::to_string(hf[1]) + " of " + std::to_string(world) + " ranks): transport '" + transport + "' does not deliver");
     } catch (...) {
-        release_mailboxes();
+        // The peers may still be posting their handshake records into this rank's box through their IPC mappings: it is
+        // NOT freed here (release_mailboxes() runs at the next enable_sharding call or when the Solution goes away);
+        // the view stops pointing at it at once.
         shard_rank = 0; shard_world = 1;
         view_dirty = true;
         throw;
@@ -1547,6 +1559,16 @@ bool Engine::basic_values_feasible() {
     pull_ctl();
     return h_ctl->it.status == ITER_FEASIBLE;
 }
+// no eligible entering column for the current reduced costs?  (the primal pricing scan, solver.rs:696-739)
+bool Engine::reduced_costs_feasible() {
+    sync_view();
+    launch_reset_ring(hview, st);
+    launch_price_primal(hview, geom(), 0, st);
+    pull_ctl();
+    const bool ok = h_ctl->it.status == ITER_OPTIMAL;
+    launch_reset_ring(hview, st);  // (the scan halts the batch when it finds none)
+    return ok;
+}
 void Engine::optimize() {
     for (;;) {
         int res = run_loop(0);
@@ -2128,7 +2150,14 @@ void Engine::load_basis(const uint8_t* blob, size_t len) {
     for (size_t r = 0; r < mm; ++r) { loB[r] = h_lo[bv[r]]; hiB[r] = h_hi[bv[r]]; }
     nnz_nonbasic = 0;
     for (size_t c = 0; c < nn; ++c) {
-        h_nb_fixed[c] = (flags[c] & NB_FIXED) ? 1 : 0;
+        // the blob's non-basic values are checked and its at-min / at-max flags RE-DERIVED from them (solver.rs:184-185:
+        // exact equality with the bounds); only the fixed marker of fix_var is taken from the blob
+        const double x = xN[c], lo = h_lo[nv[c]], hi = h_hi[nv[c]];
+        if (!(x >= lo && x <= hi) || !std::isfinite(x))
+            throw MlpError(-1, "load_basis: non-basic value " + std::to_string(x) + " of variable " + std::to_string(nv[c]) + " lies outside its bounds");
+        const bool fixed = (flags[c] & NB_FIXED) != 0;
+        flags[c] = fixed ? (uint8_t)(NB_AT_MIN | NB_AT_MAX | NB_FIXED) : (uint8_t)((x == lo ? NB_AT_MIN : 0) | (x == hi ? NB_AT_MAX : 0));
+        h_nb_fixed[c] = fixed ? 1 : 0;
         nnz_nonbasic += (size_t)col_nnz(nv[c]);
     }
     d_basic_vars.upload(h_basic_vars, st); d_nb_vars.upload(h_nb_vars, st); d_var_loc.upload(h_var_loc, st);
@@ -2148,6 +2177,10 @@ void Engine::load_basis(const uint8_t* blob, size_t len) {
         std::memcpy(d.data(), p, 8 * nn); p += 8 * nn;
         std::memcpy(gm.data(), p, 8 * nn); p += 8 * nn;
         std::memcpy(bt.data(), p, 8 * mm); p += 8 * mm;
+        for (size_t i = 0; i < nn; ++i)
+            if (!(gm[i] > 0.0) || !std::isfinite(gm[i]) || !std::isfinite(d[i])) throw MlpError(-1, "load_basis: non-finite reduced cost or non-positive primal edge weight in the blob");
+        for (size_t i = 0; i < mm; ++i)
+            if (!(bt[i] > 0.0) || !std::isfinite(bt[i]) || !std::isfinite(xB[i])) throw MlpError(-1, "load_basis: non-finite basic value or non-positive dual edge weight in the blob");
         d_xB.upload(xB, st); d_d.upload(d, st); d_gamma.upload(gm, st); d_beta.upload(bt, st);
         HIPCHECK(hipMemcpyAsync(&d_ctl.p->it.obj, &h.obj, sizeof(double), hipMemcpyHostToDevice, st));
         HIPCHECK(hipStreamSynchronize(st));
@@ -2158,23 +2191,28 @@ void Engine::load_basis(const uint8_t* blob, size_t len) {
     } else {
         std::vector<double> gm(nn, 1.0), bt(mm, 1.0);
         if (mode == 1) {
-            const float* f = reinterpret_cast<const float*>(p);
+            std::vector<float> f(std::max(nn, mm));  // (the caller's buffer need not be aligned for float reads)
+            std::memcpy(f.data(), p, 4 * nn);
             for (size_t i = 0; i < nn; ++i) gm[i] = (double)f[i];
             p += pad8(4 * nn);
-            f = reinterpret_cast<const float*>(p);
+            std::memcpy(f.data(), p, 4 * mm);
             for (size_t i = 0; i < mm; ++i) bt[i] = (double)f[i];
             p += pad8(4 * mm);
+            for (size_t i = 0; i < nn; ++i)
+                if (!(gm[i] > 0.0) || !std::isfinite(gm[i])) throw MlpError(-1, "load_basis: non-positive or non-finite primal edge weight in the blob");
+            for (size_t i = 0; i < mm; ++i)
+                if (!(bt[i] > 0.0) || !std::isfinite(bt[i])) throw MlpError(-1, "load_basis: non-positive or non-finite dual edge weight in the blob");
         }
         d_gamma.upload(gm, st); d_beta.upload(bt, st);
         HIPCHECK(hipStreamSynchronize(st));
         recalc_basic_vals();                       // x_B = B^-1 (b - N x_N), two refinement steps
         primal_feasible = basic_values_feasible();
-        dual_feasible = (h.flags & 2u) != 0;
         enable_pse = (h.flags & 4u) != 0;
-        if (!primal_feasible && !dual_feasible)
-            throw MlpError(-1, "load_basis: the basis is neither primal feasible nor saved as dual feasible (the artificial-"
-                               "objective phase needs a mode-2 checkpoint)");
         recalc_obj_coeffs();                       // d and the objective of the real cost vector
+        dual_feasible = reduced_costs_feasible();  // re-derived from the recomputed d (the saved bit is not trusted)
+        if (!primal_feasible && !dual_feasible)
+            throw MlpError(-1, "load_basis: the basis is neither primal nor dual feasible for this model (the artificial-"
+                               "objective phase needs a mode-2 checkpoint)");
         resume_in_optimize = primal_feasible && !dual_feasible;
     }
     iters_since_recalc = 0;

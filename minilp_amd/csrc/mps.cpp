@@ -42,10 +42,31 @@ double to_f64(const std::string& s, size_t line) {
     if (r.ptr != e || b == e) fail(line, "couldn't parse float from string: `" + s + "`");
     if (r.ec == std::errc::result_out_of_range) {  // from_str saturates: 1e999 -> inf, 1e-999 -> 0
         const bool neg = *b == '-';
-        const size_t epos = s.find_first_of("eE");
-        bool overflow;
-        if (epos != std::string::npos) overflow = s.find('-', epos) == std::string::npos;
-        else overflow = s.find('.') == std::string::npos || s.find('.') > 300;
+        // out of range either way: the decimal exponent of the leading non-zero digit decides (a 400-digit integer
+        // mantissa with "e-5" overflows; "0.000...1e5" may still underflow)
+        const char* q = b + ((*b == '-') ? 1 : 0);
+        long lead = 0;          // decimal exponent of the first non-zero mantissa digit (10^lead), before the exponent part
+        long int_digits = 0, frac_zeros = 0;
+        bool seen_point = false, seen_nonzero = false;
+        for (; q != e && *q != 'e' && *q != 'E'; ++q) {
+            if (*q == '.') { seen_point = true; continue; }
+            if (!seen_nonzero) {
+                if (*q == '0') { if (seen_point) frac_zeros += 1; continue; }
+                seen_nonzero = true;
+                if (seen_point) lead = -(frac_zeros + 1);
+            }
+            if (!seen_point) int_digits += 1;
+        }
+        if (seen_nonzero && lead == 0) lead = int_digits - 1;
+        long ex = 0;
+        if (q != e) {  // exponent part (clamped: only its sign and rough size matter here)
+            ++q;
+            bool eneg = false;
+            if (q != e && (*q == '+' || *q == '-')) { eneg = *q == '-'; ++q; }
+            for (; q != e && *q >= '0' && *q <= '9'; ++q) ex = ex < 100000 ? ex * 10 + (*q - '0') : ex;
+            if (eneg) ex = -ex;
+        }
+        const bool overflow = seen_nonzero && lead + ex > 0;
         v = overflow ? std::numeric_limits<double>::infinity() : 0.0;
         if (neg) v = -v;
     } else if (r.ec != std::errc()) {

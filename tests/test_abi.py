@@ -275,7 +275,9 @@ def test_mps_numbers_parse_like_f64_from_str_whatever_the_locale():
             continue
     try:
         for tok, want in [("1.5", 1.5), ("+1.5", 1.5), ("-2.5e-1", -0.25), (".5", 0.5), ("1.", 1.0), ("1e999", INF), ("-1e999", -INF),
-                          ("1e-999", 0.0), ("inf", INF), ("1E2", 100.0)]:
+                          ("1e-999", 0.0), ("inf", INF), ("1E2", 100.0),
+                          ("1" + "0" * 400 + "e-5", INF), ("-" + "9" * 400 + ".5e-20", -INF),       # a long integer mantissa with a
+                          ("0." + "0" * 400 + "1e5", 0.0), ("0." + "0" * 10 + "1e-400", 0.0)]:       # negative exponent still overflows, and vice versa
             f = M.MpsFile.parse(_mps_with_number(tok), M.MINIMIZE)
             (idx, val, op, rhs), = f.problem.constraints()
             assert val[0] == want, (tok, val[0], switched)

@@ -110,3 +110,42 @@ def test_checkpoint_after_optimality_reloads_as_optimal():
         t2 = t.add_constraint([(0, 1.0), (1, 1.0)], M.LE, 0.5 * (ref[0] + ref[1]) - 1e-3)
         r2 = ref.clone().add_constraint([(0, 1.0), (1, 1.0)], M.LE, 0.5 * (ref[0] + ref[1]) - 1e-3)
         assert obj_close(t2.objective(), r2.objective(), 1e-8)
+
+
+def test_blob_contents_are_validated_not_trusted():
+    """a blob's flags, values and weights are checked or re-derived on load (layout: 56-byte header, int32
+    basic_vars[m], nb_vars[n], uint8 flags[n] padded to 8, f64 x_N[n], then f32 gamma[n], beta[m] in mode 1)."""
+    lp = lpgen.gen_sparse_lp(300, 240, 10, 31)
+    m, n = lp["m"], lp["n"]
+    prob = lpgen.build_problem(M.Problem, lp)
+    ref = prob.solve()
+    s = prob.solve(budget=100)
+    blob = bytearray(s.save_basis(1))
+    pad8 = lambda x: (x + 7) & ~7
+    off_flags = 56 + pad8(4 * m) + pad8(4 * n)
+    off_xn = off_flags + pad8(n)
+    off_gamma = off_xn + 8 * n
+    # (1) garbage at-min / at-max flags: re-derived from x_N against the bounds, the solve reaches the same optimum
+    bad = bytearray(blob)
+    for c in range(n):
+        bad[off_flags + c] = (bad[off_flags + c] & 4) | (3 - (bad[off_flags + c] & 3))
+    t = prob.solve_from_basis(bytes(bad))
+    assert obj_close(t.objective(), ref.objective())
+    # (2) the "dual feasible" bit set on a basis that is not: re-derived from the recomputed reduced costs
+    bad = bytearray(blob)
+    flags_word = struct.unpack_from("<I", bad, 32)[0]
+    struct.pack_into("<I", bad, 32, flags_word | 2)
+    t = prob.solve_from_basis(bytes(bad))
+    assert obj_close(t.objective(), ref.objective())
+    # (3) a non-basic value outside its bounds, a NaN weight, a negative weight: refused
+    for patch in (lambda b: struct.pack_into("<d", b, off_xn, -1.0),
+                  lambda b: struct.pack_into("<f", b, off_gamma, float("nan")),
+                  lambda b: struct.pack_into("<f", b, off_gamma + 4, -2.0)):
+        bad = bytearray(blob)
+        patch(bad)
+        with pytest.raises(M.InternalError):
+            prob.solve_from_basis(bytes(bad))
+    # (4) an unaligned copy of the blob (the f32 weights are read with memcpy)
+    raw = bytearray(b"\0" * 3) + blob
+    t = prob.solve_from_basis(bytes(memoryview(raw)[3:]))
+    assert obj_close(t.objective(), ref.objective())
