@@ -1354,7 +1354,8 @@ int Engine::run_loop(int phase) {
         // helper must be zero outside the touched entries when such a batch starts: any dense sweep (or the hypersparse
         // kernel) in between leaves them dirty.
         {
-            const bool want = str_kmax > 0 && shard_world == 1 && !stepping && k_ + RING + 1 <= str_kmax && max_row_nnz_ <= 4096;
+            // (sharded solves too: a rank lists and pulls the touched columns of its own block of non-basic positions)
+            const bool want = str_kmax > 0 && !stepping && k_ + RING + 1 <= str_kmax && max_row_nnz_ <= 4096;
             if (want != str_now) {
                 str_now = want;
                 view_dirty = true;

@@ -62,6 +62,17 @@ def test_default_transport_is_device_resident():
     assert "traces identical: True" in r.stdout and "device-resident mailboxes" in r.stdout
 
 
+@pytest.mark.parametrize("world,family", [(2, "sparse"), (3, "cover")])
+def test_sharded_pricing_with_the_sparse_tableau_row(world, family):
+    """The sparse tableau row (small nucleus) in a sharded solve: every rank lists and pulls the touched columns of its own
+    block of non-basic positions; forced here for the whole run (MLP_STR_K), primal and dual loop."""
+    env = dict(os.environ, MLP_STR_K="100000", MLP_HYPER="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_test.py"), str(world), "3000", "3500" if family == "cover" else "2600", "12", "400", family],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "traces identical: True" in r.stdout
+
+
 LATE_BASIS = os.path.join(ROOT, "tests", "golden", "cfg4_basis_p240000.bin.gz")
 
 
