@@ -1432,16 +1432,21 @@ int Engine::run_loop(int phase) {
                 stats.sweep_bytes += sh * (12.0 * (double)nnz_before + 16.0 * num_vars) + 16.0 * m_;
                 stats.sweep_launches += 1;
             }
-            if (k_before > 1 && hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) {
+            // (a folding pivot whose fold produced the v partials itself skipped the streaming pass: its empty launch is no sample)
+            const bool pass_skipped = hview.lrJ > 0 && h_ctl->fold && geom().big &&
+                                      fold_fuses_v(hview, enable_pse ? 1 : 0, lazy_now(phase) ? 0 : 1, 0);
+            if (k_before > 1 && !pass_skipped && hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) {
                 // the pass over the nucleus inverse, stamped by the kernel itself: in place it reads and writes W (16 k^2),
                 // in the delayed-update mode it only reads W0 (8 k^2; a rank of the row-sharded pass reads its strips only)
                 stats.fused_ms += ms;
                 const double stream_share = hview.wshard ? 1.0 / shard_world : 1.0;
                 stats.fused_bytes += (hview.lrJ > 0 ? 8.0 * stream_share : 16.0) * (double)k_before * (double)k_before;
                 stats.fused_launches += 1;
+            }
+            {
                 float fms = 0.f;
-                if (hview.lrJ > 0 && h_ctl->fold && geom().big && hipEventElapsedTime(&fms, ev[10], ev[11]) == hipSuccess) {
-                    stats.fold_ms += fms;  // this pivot folded first: read + write of W0
+                if (k_before > 1 && hview.lrJ > 0 && h_ctl->fold && geom().big && hipEventElapsedTime(&fms, ev[10], ev[11]) == hipSuccess) {
+                    stats.fold_ms += fms;  // this pivot folded first: read + write of W0 (and, fused, its part of v)
                     stats.fold_bytes += 16.0 * (double)k_before * (double)k_before;
                     stats.fold_launches += 1;
                 }

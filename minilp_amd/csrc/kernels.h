@@ -280,6 +280,7 @@ void launch_mail_handshake(const DevView& dv, int* out, hipStream_t st);  // tra
 // nucleus inverse, 3 fold) instead of bracketing its launch; (nullptr, nullptr) disarms
 void arm_kernel_timing(int slot, hipEvent_t t0, hipEvent_t t1);
 bool stream_strips_enabled();
+bool fold_fuses_v(const DevView& dv, int with_v, int with_tau, int fold_only);  // a folding pivot's fold also produces the v partials (its streaming pass is skipped)
 int stream_coresident_blocks();  // blocks of the default k_stream_w instance the device holds at once (0: unknown)  // large-nucleus streaming pass in strip form (MLP_STREAM_STRIPS=0 disables)
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_dse, int use_pse, hipStream_t st, int inline_comb = 0,

@@ -2654,11 +2654,12 @@ __device__ __forceinline__ int sw_strip_rows(const DevView& v, int k, int ch, in
     return max(rb, 32);  // (part_v holds cap / 8 rows of partials)
 }
 template <bool WITH_V, int SW_CH, int SW_RB, int SW_RS>
-__global__ void __launch_bounds__(BLK, 4) k_stream_w(DevView v, int with_tau) {  // 4 waves per SIMD: keep the double buffer within 128 VGPRs
+__global__ void __launch_bounds__(BLK, 4) k_stream_w(DevView v, int with_tau, int skip_on_fold = 0) {  // 4 waves per SIMD: keep the double buffer within 128 VGPRs
     static_assert(SW_CH == 2 * BLK || SW_CH == 4 * BLK, "one or two column pairs per thread");
     constexpr int NP = SW_CH / (2 * BLK);
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
+    if (skip_on_fold && c->fold) return;  // the fold of this pivot produced the v partials itself (k_fold_w, fuse_v)
     const int k = c->k, ld = v.ld;
     const int tid = threadIdx.x;
     const int n_tile_blocks = (int)gridDim.x - LR_MAX;
@@ -2783,7 +2784,10 @@ constexpr int FD_CH = 256, FD_RB = 256, FD_RS = 8;
 // results masked or never stored).  With `cond ? load : 0` forms the loop breaks into ~20 basic blocks and the
 // register allocator spills the V values (measured: 1.8 KB of scratch per lane).
 template <int JM>
-__global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : 3)) k_fold_w(DevView v, int mode) {
+__global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : 3)) k_fold_w(DevView v, int mode, int fuse_v) {
+    // fuse_v (a folding pivot of the lazy primal iteration, unsharded): the tile that has just been folded also yields its
+    // part of v_K = W0^T t_K — the streaming pass of that pivot (one more read of the whole inverse) is skipped; the
+    // partials land in part_v by this kernel's strips of FD_RB rows (k_post_fused reads them with that geometry).
     Ctl* c = v.ctl;
     if (mode != 1 && (c->halt || c->it.status != ITER_PIVOT)) return;
     if (!(mode == 1 || c->fold)) return;
@@ -2792,6 +2796,7 @@ __global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : 3)) k_fold_w(DevView v, i
     if (nlow <= 0 || k <= 0) return;
     const int tid = threadIdx.x;
     __shared__ __attribute__((aligned(16))) double s_u[2][FD_RS][JM];
+    __shared__ double s_t[2][FD_RS];
     const int nch = (k + FD_CH - 1) / FD_CH, nstr = (k + FD_RB - 1) / FD_RB;
     const int sa = tid / JM, sj = tid % JM;  // staging: thread -> (row of the step, term)
     const bool stager = sa < FD_RS;
@@ -2813,11 +2818,13 @@ __global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : 3)) k_fold_w(DevView v, i
         }
         double* wcol = Wp + colc;
         double w[FD_RS], wn[FD_RS];
+        double vacc = 0.0;
         __syncthreads();  // the previous tile's readers of s_u are done
         {
             const int row = min(rbeg + (stager ? sa : 0), rend - 1);
             const double x = Up[(size_t)sjc * ld + row];
             if (stager) s_u[0][sa][sj] = (sj < nlow && rbeg + sa < rend) ? x : 0.0;
+            if (fuse_v && stager && sj == 0) s_t[0][sa] = (rbeg + sa < rend) ? v.tK[row] : 0.0;
         }
 #pragma unroll
         for (int a = 0; a < FD_RS; ++a) w[a] = __builtin_nontemporal_load(wcol + (size_t)min(rbeg + a, rend - 1) * ld);
@@ -2829,6 +2836,7 @@ __global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : 3)) k_fold_w(DevView v, i
                 const int row = min(rn + (stager ? sa : 0), rend - 1);
                 const double x = Up[(size_t)sjc * ld + row];
                 if (stager) s_u[buf ^ 1][sa][sj] = (sj < nlow && rn + sa < rend) ? x : 0.0;
+                if (fuse_v && stager && sj == 0) s_t[buf ^ 1][sa] = (rn + sa < rend) ? v.tK[row] : 0.0;
 #pragma unroll
                 for (int a = 0; a < FD_RS; ++a) wn[a] = __builtin_nontemporal_load(wcol + (size_t)min(rn + a, rend - 1) * ld);
             }
@@ -2842,6 +2850,7 @@ __global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : 3)) k_fold_w(DevView v, i
                     acc = __builtin_fma(u.y, vj[j + 1], acc);
                 }
                 w[a] = acc;
+                if (fuse_v) vacc = __builtin_fma(acc, s_t[buf][a], vacc);  // (rows beyond the strip carry t = 0)
             }
             if (active) {
                 if (r0 + FD_RS <= rend) {
@@ -2856,6 +2865,7 @@ __global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : 3)) k_fold_w(DevView v, i
 #pragma unroll
             for (int a = 0; a < FD_RS; ++a) w[a] = wn[a];
         }
+        if (fuse_v && active) v.part_v[(size_t)strip * ld + col] = vacc;
     }
 }
 __global__ void k_reset_nlow(DevView v) {
@@ -2923,7 +2933,7 @@ __global__ void __launch_bounds__(BLK) k_post_exchange(DevView v, int with_v, in
 // the remaining blocks reduce the v partials in a fixed order and scatter v_K by row (solver.rs:1114).
 __device__ __forceinline__ void row_touch_body(const DevView& v, Ctl* c, int block);  // (sparse tableau row, below)
 template <int G, bool WITH_V, int TR, int TC = FW_TC>
-__global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push, int touch_from = -1) {
+__global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push, int touch_from = -1, int fold_fused = 0) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     if (touch_from >= 0 && (int)blockIdx.x >= touch_from) {  // horizontally fused: the touched-column list of the sparse tableau
@@ -2973,7 +2983,9 @@ __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push, int t
     const int i = b * 32 + lane32;
     if (b * 32 >= k) return;
     __shared__ double s_part[8][33];
-    const int tr = sw_strip_rows(v, k, TC, 4, TR);  // (balanced strips exist for the default geometry only: 4 rows per step)
+    // (balanced strips exist for the default geometry only: 4 rows per step; on a folding pivot whose fold produced the
+    // partials itself they come in the fold kernel's strips of FD_RB rows)
+    const int tr = (fold_fused && c->fold) ? FD_RB : sw_strip_rows(v, k, TC, 4, TR);
     const int nstripes = (k + tr - 1) / tr;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (xsh) {
@@ -3948,6 +3960,13 @@ bool stream_strips_enabled() {
     static const bool on = !(std::getenv("MLP_STREAM_STRIPS") && std::atoi(std::getenv("MLP_STREAM_STRIPS")) == 0);
     return on;
 }
+// A folding pivot of the lazy primal iteration (v only, no tau), unsharded: the fold kernel produces the v partials of the
+// freshly folded inverse itself and the streaming pass of that pivot is skipped (one read of the inverse less in every
+// lrJ pivots: 0.49 ms of 1.92 ms at k = 20 500).  MLP_FOLD_FUSE=0 restores fold-then-stream.
+bool fold_fuses_v(const DevView& dv, int with_v, int with_tau, int fold_only) {
+    static const bool off = std::getenv("MLP_FOLD_FUSE") && std::getenv("MLP_FOLD_FUSE")[0] == '0';
+    return !off && with_v && !with_tau && !fold_only && !dv.wshard && dv.lrJ > 0 && stream_strips_enabled();
+}
 static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fold_only, hipStream_t st, int with_tau = 1) {
     const int rows = fw_rows(g);
     int nstripes = (g.cap + rows - 1) / rows, nchunks = (g.cap + FW_TC - 1) / FW_TC;
@@ -3967,13 +3986,14 @@ static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fo
         if (FW_RL == 1 && stream_strips()) {
             // a folding pivot folds first (mode 2: no partials), then EVERY pivot streams W0 once (k_stream_w)
             static const bool old_fold = std::getenv("MLP_OLD_FOLD") != nullptr;  // A/B: the 16 x 1024 fold kernel
+            const int fuse = fold_fuses_v(dv, with_v, with_tau, fold_only) && !old_fold ? 1 : 0;
             if (old_fold) {
                 hipLaunchKernelGGL((k_fused_lr16<false, true>), dim3(nb), b, 0, st, dv, fold_only ? 1 : 2);
             } else {
                 const long ftiles = (long)((g.cap + FD_RB - 1) / FD_RB) * ((g.cap + FD_CH - 1) / FD_CH);
                 const int nf = (int)(ftiles < SW_MAX_BLOCKS ? ftiles : SW_MAX_BLOCKS);
-                if (dv.lrJ <= 16) LAUNCH_T(3, k_fold_w<16>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2);
-                else LAUNCH_T(3, k_fold_w<LR_MAX>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2);
+                if (dv.lrJ <= 16) LAUNCH_T(3, k_fold_w<16>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, fuse);
+                else LAUNCH_T(3, k_fold_w<LR_MAX>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, fuse);
             }
             if (!fold_only) {
                 long tiles = (long)((g.cap + sw_rb() - 1) / sw_rb()) * ((g.cap + sw_ch() - 1) / sw_ch());
@@ -3981,8 +4001,8 @@ static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fo
                 const int nt = (int)(tiles < SW_MAX_BLOCKS ? tiles : SW_MAX_BLOCKS);
 #define SW_LAUNCH(CH, RB, RS)                                                                                     \
     do {                                                                                                          \
-        if (with_v) LAUNCH_T(2, (k_stream_w<true, CH, RB, RS>), dim3(nt + LR_MAX), b, 0, st, dv, with_tau); \
-        else if (with_tau) LAUNCH_T(2, (k_stream_w<false, CH, RB, RS>), dim3(nt + LR_MAX), b, 0, st, dv, 1);  \
+        if (with_v) LAUNCH_T(2, (k_stream_w<true, CH, RB, RS>), dim3(nt + LR_MAX), b, 0, st, dv, with_tau, fuse); \
+        else if (with_tau) LAUNCH_T(2, (k_stream_w<false, CH, RB, RS>), dim3(nt + LR_MAX), b, 0, st, dv, 1, 0);  \
     } while (0)
                 switch (stream_variant()) {
                 case 0: SW_LAUNCH(512, 512, 8); break;
@@ -4054,7 +4074,7 @@ int launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t 
 #undef POSTX
 #define POSTS2(G, RB, CH)                                                                                         \
     if (sw_rb() == RB && sw_ch() == CH) {                                                                         \
-        if (with_v) hipLaunchKernelGGL((k_post_fused<G, true, RB, CH>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push); \
+        if (with_v) hipLaunchKernelGGL((k_post_fused<G, true, RB, CH>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push, -1, fold_fuses_v(dv, with_v, with_tau, 0) ? 1 : 0); \
         else hipLaunchKernelGGL((k_post_fused<G, false, RB, CH>), dim3(n_push), dim3(BLK), 0, st, dv, n_push);    \
     }
 #define POSTS(G)                                                                                                  \
