@@ -1243,6 +1243,82 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_p2(DevView v) {
     ratio_primal_finish(v, c, best);
 }
 
+// Small models (<= 16 384 positions, one GPU): both primal Harris passes, ||alpha_q||^2 and the singleton part of v in ONE BLOCK
+// (two loops over alpha_q; the second re-reads from L2).
+__global__ void __launch_bounds__(BLK) k_ratio_primal_one(DevView v, int use_pse) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    const int sign = c->it.sign;
+    double mn = INFINITY, sq = 0.0;
+    for (int p0 = threadIdx.x; p0 < v.m; p0 += 4 * BLK) {
+        double co[4], xb[4], lob[4], hib[4], sd[4];
+        int ks[4], sr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * BLK;
+            const int pc = p < v.m ? p : 0;
+            co[u] = p < v.m ? v.alpha_q[pc] : 0.0;
+            xb[u] = v.xB[pc];
+            lob[u] = v.loB[pc];
+            hib[u] = v.hiB[pc];
+            ks[u] = v.kslot_of_pos[pc];
+            sr[u] = v.srow_of_pos[pc];
+            sd[u] = v.sdiag_of_pos[pc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (p0 + u * BLK >= v.m) continue;
+            if (use_pse) {
+                sq += co[u] * co[u];
+                if (ks[u] < 0) v.rv[sr[u]].y = co[u] / sd[u];
+            }
+            const double a = fabs(co[u]);
+            if (a < EPS) continue;
+            const bool tm = (sign && co[u] < 0.0) || (!sign && co[u] > 0.0);  // solver.rs:752-771 (as leaving_step)
+            const double st = tm ? (xb[u] < hib[u] ? hib[u] - xb[u] : 0.0) : (xb[u] > lob[u] ? xb[u] - lob[u] : 0.0);
+            const double cur = (st + EPS) / a;
+            if (cur < mn) mn = cur;
+        }
+    }
+    __shared__ double s_ms;
+    mn = block_min(mn);
+    sq = block_sum(sq);
+    if (threadIdx.x == 0) {
+        double max_step = fabs(c->it.entering_other - c->it.entering_cur);
+        if (mn < max_step) max_step = mn;
+        c->it.max_step = max_step;
+        c->it.alpha_sq = sq + 1.0;
+        s_ms = max_step;
+    }
+    __syncthreads();
+    const double max_step = s_ms;
+    Cand best = cand_none();
+    for (int p0 = threadIdx.x; p0 < v.m; p0 += 4 * BLK) {
+        double co[4], xb[4], lob[4], hib[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * BLK;
+            const int pc = p < v.m ? p : 0;
+            co[u] = p < v.m ? v.alpha_q[pc] : 0.0;
+            xb[u] = v.xB[pc];
+            lob[u] = v.loB[pc];
+            hib[u] = v.hiB[pc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // ascending positions per thread: ties keep the lowest position
+            const double a = fabs(co[u]);
+            if (a < EPS) continue;
+            const bool tm = (sign && co[u] < 0.0) || (!sign && co[u] > 0.0);
+            const double st = tm ? (xb[u] < hib[u] ? hib[u] - xb[u] : 0.0) : (xb[u] > lob[u] ? xb[u] - lob[u] : 0.0);
+            if (st / a <= max_step) {
+                Cand t{a, p0 + u * BLK};
+                if (cand_better(t, best)) best = t;
+            }
+        }
+    }
+    best = block_best(best);
+    ratio_primal_finish(v, c, best);
+}
 constexpr int AQ_CAP = 2048;  // positions of supp(alpha_q) the single-block form of the primal ratio test takes on (8 per thread: beyond that
                               // the two grid-wide passes are faster — measured on config 4: 97 against 77 us per pivot at k = 135 with a cap of 8 192)
 // Both Harris passes in ONE launch (primal): pass 1's grid-wide minimum is published by its last-arriving
@@ -2120,6 +2196,66 @@ __device__ void ratio_dual_finish(const DevView& v, Ctl* c, Cand best) {
     }
     __syncthreads();
     if (s_ok && threadIdx.x < 64) ftran_prep_wave(v, c, threadIdx.x, 0);
+}
+// Small models (<= RATIO_ONE_MAX positions, one GPU): both dual Harris passes in ONE BLOCK — two loops over alpha_r (the second
+// re-reads it from L2), no ticketed grid reductions, no in-kernel wait.  Measured on config 3 (n = 10 000): the one-launch
+// grid form costs 12.9 us, of which the scan itself is a fraction.
+constexpr int RATIO_ONE_MAX = 16384;
+__global__ void __launch_bounds__(BLK) k_ratio_dual_one(DevView v) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    IterState* it = &c->it;
+    const int lsign = it->leaving_new_val > v.xB[it->r];
+    double mn = INFINITY;
+    for (int j0 = v.nb_lo + threadIdx.x; j0 < v.nb_hi; j0 += 4 * BLK) {
+        double co[4], dd[4];
+        uint8_t ff[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * BLK;
+            const int jc = j < v.nb_hi ? j : v.nb_lo;
+            co[u] = j < v.nb_hi ? v.alpha_r[jc] : 0.0;
+            ff[u] = v.nbflags[jc];
+            dd[u] = v.d[jc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!dual_eligible(co[u], ff[u], lsign)) continue;
+            const double cur = (fabs(clamp_obj(dd[u], ff[u])) + EPS) / fabs(co[u]);
+            if (cur < mn) mn = cur;
+        }
+    }
+    __shared__ double s_step;
+    mn = block_min(mn);
+    if (threadIdx.x == 0) {
+        it->max_step = mn;
+        s_step = mn;
+    }
+    __syncthreads();
+    const double max_step = s_step;
+    Cand best = cand_none();
+    for (int j0 = v.nb_lo + threadIdx.x; j0 < v.nb_hi; j0 += 4 * BLK) {
+        double co[4], dd[4];
+        uint8_t ff[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * BLK;
+            const int jc = j < v.nb_hi ? j : v.nb_lo;
+            co[u] = j < v.nb_hi ? v.alpha_r[jc] : 0.0;
+            ff[u] = v.nbflags[jc];
+            dd[u] = v.d[jc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // ascending positions per thread: ties keep the lowest position
+            if (!dual_eligible(co[u], ff[u], lsign)) continue;
+            if (fabs(clamp_obj(dd[u], ff[u])) / fabs(co[u]) <= max_step) {
+                Cand t{fabs(co[u]), j0 + u * BLK};
+                if (cand_better(t, best)) best = t;
+            }
+        }
+    }
+    best = block_best(best);
+    ratio_dual_finish(v, c, best);
 }
 // Both dual Harris passes in ONE launch, like k_ratio_primal_fused: pass 1's last-arriving block (after the all-reduce
 // over the ranks of a sharded solve) publishes the step bound, every block waits for it and runs pass 2 on the
@@ -3799,7 +3935,15 @@ static int coresident_half(const void* fn, int slot) {
     }
     return cache[slot][dev];
 }
+static bool ratio_one_enabled() {  // MLP_RATIO_ONE=0: the grid forms at any size (tests of their in-kernel wait on small instances)
+    const char* e = std::getenv("MLP_RATIO_ONE");  // (read per launch: tests switch it inside one process)
+    return !(e && e[0] == '0');
+}
 void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st) {
+    if (dv.world <= 1 && g.m <= 16384 && ratio_one_enabled()) {  // small model: one block, no grid-wide reduction (RATIO_ONE_MAX)
+        hipLaunchKernelGGL(k_ratio_primal_one, dim3(1), dim3(BLK), 0, st, dv, use_pse);
+        return;
+    }
     const int nb = grid_for(g.m);
     // The fused kernel's blocks wait inside the launch for its last-arriving block, which is only safe while the
     // WHOLE grid is co-resident: bound the grid by what this device (or partition: CPX mode, CU mask) can hold at
@@ -3915,6 +4059,10 @@ void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st) {
     hipLaunchKernelGGL(k_init_nb_rng, dim3(blocks_for(g.n)), dim3(BLK), 0, st, dv);
 }
 void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st) {
+    if (dv.world <= 1 && g.n <= RATIO_ONE_MAX && ratio_one_enabled()) {  // small model: one block, no grid-wide reduction
+        hipLaunchKernelGGL(k_ratio_dual_one, dim3(1), dim3(BLK), 0, st, dv);
+        return;
+    }
     const int nb = grid_for(dv.nb_hi - dv.nb_lo);
     const int max_coresident = g.ratio_two ? 0 : coresident_half(reinterpret_cast<const void*>(k_ratio_dual_fused), 1);  // see launch_ratio_primal
     if (nb <= max_coresident && (long)nb * BLK * 4 >= (long)(dv.nb_hi - dv.nb_lo)) {

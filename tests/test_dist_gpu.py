@@ -29,7 +29,7 @@ def test_sharded_pricing_with_the_large_nucleus_machinery(world, extra):
     the nucleus inverse is ROW-SHARDED: every rank streams the strips s with s % world == rank and the tau_K rows /
     v_K partials are exchanged through the peers' device buffers (k_post_exchange); MLP_NO_WSHARD and the host
     mailbox keep the pass replicated."""
-    env = dict(os.environ, MLP_LOWRANK="3", MLP_BIGTILE="1", MLP_LDPAD="16", MLP_BANDED="1", **extra)
+    env = dict(os.environ, MLP_LOWRANK="3", MLP_BIGTILE="1", MLP_LDPAD="16", MLP_BANDED="1", MLP_STR_K="0", **extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_test.py"), str(world), "4000", "3500", "12", "400"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

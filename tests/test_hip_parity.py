@@ -216,8 +216,15 @@ NONDEGENERATE = [("sparse", dict(m=5, n=5, k=3, seed=1)), ("sparse", dict(m=50, 
                  ("dense", dict(m=300, n=33, seed=5))]
 
 
+@pytest.mark.parametrize("small_model_forms", [1, 0], ids=["default", "sweeps and grid-wide ratio tests"])
 @pytest.mark.parametrize("fam,kw", NONDEGENERATE, ids=lambda v: str(v))
-def test_random_lp_matches_oracle_pivot_for_pivot(fam, kw):
+def test_random_lp_matches_oracle_pivot_for_pivot(monkeypatch, fam, kw, small_model_forms):
+    if not small_model_forms:
+        # Round 3 gave small models / small nuclei their own forms (sparse tableau row, single-block ratio tests, the
+        # hypersparse kernel), which these instances would otherwise never leave: the same families with those forms off
+        # keep the sweep over all of A and the grid-wide Harris tests under test at this size too.
+        for k_, v_ in dict(MLP_STR_K="0", MLP_RATIO_ONE="0", MLP_HYPER="0").items():
+            monkeypatch.setenv(k_, v_)
     lp = GEN[fam](**kw)
     so = lpgen.build_problem(O.Problem, lp).solve(trace=True)
     sg = lpgen.build_problem(M.Problem, lp).solve(trace=True)
@@ -613,7 +620,7 @@ def test_warm_start_sequence_at_medium_scale():
     assert wo == wg and obj_close(sg3.objective(), so3.objective()) and obj_close(sg3.objective(), so.objective())
 
 
-@pytest.mark.parametrize("env", [dict(MLP_BANDED="1"), dict(MLP_BANDED="1", MLP_BIGTILE="1", MLP_LOWRANK="3", MLP_LDPAD="16")], ids=["banded", "banded+large-nucleus"])
+@pytest.mark.parametrize("env", [dict(MLP_BANDED="1", MLP_STR_K="0"), dict(MLP_BANDED="1", MLP_BIGTILE="1", MLP_LOWRANK="3", MLP_LDPAD="16", MLP_STR_K="0")], ids=["banded", "banded+large-nucleus"])
 def test_rows_appended_on_the_device_match_the_oracle_step_by_step(monkeypatch, env):
     """Solution::add_constraint (solver.rs:549-634) keeps the matrix on the device: CSR row appended in place, CSC
     re-laid out by one copy kernel, band-major copy and row-block offsets rebuilt by device kernels (forced on here;
@@ -712,6 +719,8 @@ def test_a_stalled_one_launch_ratio_test_is_retried_with_two_launches(monkeypatc
     arrive before the last one see no published bound); the engine then latches the two-launch form, re-runs the
     iteration, and the solve takes the oracle's pivots as if nothing had happened."""
     monkeypatch.setenv("MLP_RATIO_SPIN_LIMIT", "0")
+    monkeypatch.setenv("MLP_RATIO_ONE", "0")   # (models this small otherwise run the test in a single block: no wait to stall)
+    monkeypatch.setenv("MLP_HYPER", "0")       # (and sparse dual loops run in the persistent workgroup)
     lp = GEN[fam](*args)
     sg = lpgen.build_problem(M.Problem, lp).solve(budget=300, trace=True)
     so = lpgen.build_problem(O.Problem, lp).solve(budget=300, trace=True)

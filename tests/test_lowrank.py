@@ -21,12 +21,13 @@ pytestmark = pytest.mark.gpu
 def lowrank(request):
     j, big = request.param
     os.environ["MLP_LOWRANK"] = str(j)
+    os.environ["MLP_STR_K"] = "0"   # (the sweeps of the large-nucleus regime are what runs there, not the sparse tableau row)
     if big:
         os.environ["MLP_BIGTILE"] = "1"
         os.environ["MLP_LDPAD"] = "16"
         os.environ["MLP_BANDED"] = "1"   # banded tableau-row sweep (otherwise from 32 768 rows on)
     yield j
-    for k in ("MLP_LOWRANK", "MLP_BIGTILE", "MLP_LDPAD", "MLP_BANDED"):
+    for k in ("MLP_LOWRANK", "MLP_BIGTILE", "MLP_LDPAD", "MLP_BANDED", "MLP_STR_K"):
         os.environ.pop(k, None)
 
 

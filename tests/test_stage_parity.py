@@ -114,7 +114,7 @@ def test_every_stage_matches_the_oracle(fam, args, iters):
 def test_every_stage_matches_with_the_large_nucleus_machinery(monkeypatch):
     """Same comparison with the delayed-update mode (J = 3), the 16-row tiles, the padded pitch, the blocked F push
     and the banded sweep forced on: the stages are then served by the other kernel variants."""
-    for k, v in dict(MLP_LOWRANK="3", MLP_BIGTILE="1", MLP_LDPAD="16", MLP_BANDED="1").items():
+    for k, v in dict(MLP_LOWRANK="3", MLP_BIGTILE="1", MLP_LDPAD="16", MLP_BANDED="1", MLP_STR_K="0").items():
         monkeypatch.setenv(k, v)
     lp = GEN["sparse"](300, 260, 10, 41)
     n, worst, _ = _step_and_compare(lp, 120)

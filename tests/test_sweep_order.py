@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(params=["1", "0"], ids=["packed", "indirect"])
 def order_env(request):
-    env = {"MLP_BANDED": "1", "MLP_ORDER_FROM": "0", "MLP_ORDER_EVERY": "7", "MLP_SWEEP_PACKED": request.param}
+    # (MLP_STR_K=0: the sparse tableau row would otherwise serve these small nuclei and the sweep under test never run)
+    env = {"MLP_BANDED": "1", "MLP_ORDER_FROM": "0", "MLP_ORDER_EVERY": "7", "MLP_SWEEP_PACKED": request.param, "MLP_STR_K": "0"}
     os.environ.update(env)
     yield request.param
     for k in env:
