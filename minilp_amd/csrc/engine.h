@@ -287,11 +287,11 @@ private:
     bool colblk_dirty = true;
     bool pb_disable = false;     // MLP_NO_BLOCKED_PUSH
     void ensure_colblk();
-    DevBuf<double> d_sdiag_of_pos, d_W, d_U, d_V;
+    DevBuf<double> d_sdiag_of_pos, d_W, d_U, d_V, d_Ut;
     int ld_pad = 16;    // MLP_LDPAD: extra doubles per row of a large W (row pitch = cap + pad): breaks the power-of-two stride
     int pad_for(int cap) const { return (cap >= 8192 || force_big_tiles) ? ld_pad : 0; }
     int ld() const { return cap_ + pad_for(cap_); }
-    int lr_force = -1;  // MLP_LOWRANK: force the delayed-update period (0 = off); default: 16 from cap 8192, 32 from 32768
+    int lr_force = -1;  // MLP_LOWRANK: force the delayed-update period (0 = off); default: 32 from cap 8192
     DevBuf<double> d_work;  // alpha_q | tau | rv (2m) | hS  — one memset per batch
     DevBuf<double> d_alpha_r, d_helper;
     DevBuf<int2> d_nb_rng;

@@ -434,9 +434,12 @@ DevView* Engine::sync_view() {
     v.pk_ptr = pk ? d_pk_ptr.p : nullptr; v.pk_row = pk ? d_pk_row.p : nullptr; v.pk_val = pk ? d_pk_val.p : nullptr;
     v.pk_valid = pk ? d_pk_valid.p : nullptr;
     v.pos_of_kslot = d_pos_of_kslot.p; v.row_of_kslot = d_row_of_kslot.p; v.W = d_W.p;
-    v.U = d_U.p; v.V = d_V.p;
+    v.U = d_U.p; v.V = d_V.p; v.Ut = d_Ut.p;
     // delayed-update period: 32 from capacity 8192 on (the fold's k^2 cost outgrows the O(k J) overheads)
-    v.lrJ = lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 32 : 0);  // (16 up to cap 16 384 in round 1: 304 vs 296 us per pivot at k = 10 000)
+    // (16 up to cap 16 384 in round 1: 304 vs 296 us per pivot at k = 10 000).  A period of 64 was measured in round 3 at
+    // k = 20 500: the fused fold REPLACES that pivot's streaming pass, so its net cost is (1 338 - 479) / 32 = 27 us per pivot
+    // and a period of 64 could save 13 of them at best; the 64-term kernel (occupancy 2) took 3.2 ms: 716 vs 695 us per pivot
+    v.lrJ = lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 32 : 0);
     v.alpha_q = d_work.p;
     v.tau = d_work.p + (size_t)m_;
     v.rv = reinterpret_cast<double2*>(d_work.p + 2 * (size_t)m_);
@@ -572,6 +575,12 @@ void Engine::ensure_nucleus_cap(int need) {
     d_part_tau.ensure((size_t)nchunks * nld, 0, st);
     d_U.ensure((size_t)LR_MAX * nld, 0, st);
     d_V.ensure((size_t)LR_MAX * nld, 0, st);
+    {   // slot-major copy of U for the fold (pending terms were folded above: it starts empty; stale entries beyond nlow are
+        // multiplied by zero, so they must be finite: zero them once per allocation)
+        const size_t before = d_Ut.cap;
+        d_Ut.ensure((size_t)LR_MAX * nld, 0, st);
+        if (d_Ut.cap != before) HIPCHECK(hipMemsetAsync(d_Ut.p, 0, sizeof(double) * d_Ut.cap, st));
+    }
     cap_ = ncap;
     view_dirty = true;
 }

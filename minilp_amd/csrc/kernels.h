@@ -171,6 +171,8 @@ struct DevView {
     int* row_of_kslot;     // cap: col slot -> row
     double* W;             // cap x ld, row-major: W[rowslot(p)][colslot(i)] = (B^-1)[p, i]  (W0 in delayed-update mode)
     double* U;             // LR_MAX x ld: pending rank-1 terms, row-slot side   (delayed-update mode)
+    double* Ut;            // ld x LR_MAX: the same terms slot-major (Ut[slot][j] = U[j][slot]), kept in step by lowrank_append: the fold
+                           // reads the LR_MAX values of a row slot as ONE contiguous, wave-uniform (scalar) load
     double* V;             // LR_MAX x ld: pending rank-1 terms, col-slot side
     int lrJ;               // 0: every pivot updates W in place; J > 0: fold every J pivots
     // Balanced strips of the streaming pass: with sw_nbal > 0 (the number of k_stream_w blocks the device holds at once)

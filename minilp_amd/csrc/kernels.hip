@@ -1785,30 +1785,42 @@ __device__ __forceinline__ void lowrank_append(const DevView& v, Ctl* c, const S
         if (s < lim) {
             int sr_src = (u.kase == 2 && s == u.sr) ? last : s;   // row slot whose term value lands in slot s
             int sc_src = (u.kase == 2 && s == u.cq) ? last : s;   // col slot whose term value lands in slot s
-            Un[s] = -(v.aK[sr_src] - (sr_src == u.sr ? 1.0 : 0.0)) * inv_alpha;
+            const double un = -(v.aK[sr_src] - (sr_src == u.sr ? 1.0 : 0.0)) * inv_alpha;
+            Un[s] = un;
+            v.Ut[(size_t)s * LR_MAX + jn] = un;
             Vn[s] = v.rK[sc_src];
         }
         if (u.kase == 2 && s < jn) {  // pending terms follow the move of the last slot
             double* Uj = v.U + (size_t)s * ld;
             double* Vj = v.V + (size_t)s * ld;
-            if (u.sr != last) Uj[u.sr] = Uj[last];
+            if (u.sr != last) {
+                const double x = Uj[last];
+                Uj[u.sr] = x;
+                v.Ut[(size_t)u.sr * LR_MAX + s] = x;
+            }
             if (u.cq != last) Vj[u.cq] = Vj[last];
         }
     } else if (u.kase == 1) {
         if (s < kold) {
-            Un[s] = -v.aK[s] * inv_alpha;
+            const double un = -v.aK[s] * inv_alpha;
+            Un[s] = un;
+            v.Ut[(size_t)s * LR_MAX + jn] = un;
             Vn[s] = v.rK[s];
         } else if (s == kold) {
             Un[kold] = 0.0;
+            v.Ut[(size_t)kold * LR_MAX + jn] = 0.0;
             Vn[kold] = 0.0;
         }
         if (s < jn) {  // the new slot does not exist in the pending terms
             v.U[(size_t)s * ld + kold] = 0.0;
+            v.Ut[(size_t)kold * LR_MAX + s] = 0.0;
             v.V[(size_t)s * ld + kold] = 0.0;
         }
     } else if (u.kase == 3) {
         if (s < kold) {
-            Un[s] = -v.aK[s] * inv_alpha;
+            const double un = -v.aK[s] * inv_alpha;
+            Un[s] = un;
+            v.Ut[(size_t)s * LR_MAX + jn] = un;
             Vn[s] = (s == u.cq) ? 0.0 : v.rK[s];
         }
         if (s < jn) v.V[(size_t)s * ld + u.cq] = 0.0;
@@ -3004,6 +3016,106 @@ __global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : 3)) k_fold_w(DevView v, i
         if (fuse_v && active) v.part_v[(size_t)strip * ld + col] = vacc;
     }
 }
+// The same fold with the U side read through the SCALAR unit (round 3).  k_fold_w stages the FD_RS x JM values U[j][row]
+// of a step in LDS and every thread reads them back as broadcasts: 16 ds_read_b128 per element row — at 420 M elements per
+// fold that is ~105 M LDS wave-instructions, which bound the kernel (1.43 ms = 4.7 TB/s at k = 20 500 where a read + write
+// stream of the matrix takes ~1.2 ms).  The values of one row are the same for every lane of the wave, so they belong in
+// scalar registers: lowrank_append keeps a slot-major copy Ut[slot][j], a row's JM values are one contiguous 256-byte
+// block, loaded with s_load (constant address space: nothing in this kernel writes Ut or t_K) and used as the scalar operand
+// of the FMAs.  No LDS, no barriers.  Measured at k = 20 500 (rocprofv3): 1 338 us against 1 426 us, 695 vs 707 us per pivot
+// of the late window (MLP_FOLD_SCALAR=0 keeps the LDS form for the A/B).  What bounds it now is the scalar-load latency per
+// row (one batch, one wait: s_load returns out of order, there is no partial wait), hidden only by the 3 waves per SIMD.
+typedef const __attribute__((address_space(4))) double const_f64;
+typedef double sreg8 __attribute__((ext_vector_type(8)));  // 16 consecutive SGPRs
+template <int JM>
+__global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : JM <= 32 ? 3 : 2)) k_fold_w2(DevView v, int mode, int fuse_v) {
+    Ctl* c = v.ctl;
+    if (mode != 1 && (c->halt || c->it.status != ITER_PIVOT)) return;
+    if (!(mode == 1 || c->fold)) return;
+    const int k = c->k, ld = v.ld;
+    const int nlow = min(c->nlow, JM);
+    if (nlow <= 0 || k <= 0) return;
+    const int tid = threadIdx.x;
+    const int nch = (k + FD_CH - 1) / FD_CH, nstr = (k + FD_RB - 1) / FD_RB;
+    double* __restrict__ Wp = v.W;
+    const double* __restrict__ Vp = v.V;
+    const_f64* Utc = (const_f64*)(uintptr_t)v.Ut;
+    const_f64* tKc = (const_f64*)(uintptr_t)v.tK;
+    for (int tile = blockIdx.x; tile < nstr * nch; tile += gridDim.x) {
+        const int strip = tile / nch, chunk = tile % nch;
+        const int rbeg = strip * FD_RB, rend = min(k, rbeg + FD_RB);
+        const int col = chunk * FD_CH + tid;
+        const bool active = col < k;
+        const int colc = active ? col : k - 1;
+        double vj[JM];
+#pragma unroll
+        for (int j = 0; j < JM; ++j) {
+            const double x = Vp[(size_t)min(j, nlow - 1) * ld + colc];
+            vj[j] = (active && j < nlow) ? x : 0.0;
+        }
+        double* wcol = Wp + colc;
+        double w[FD_RS], wn[FD_RS];
+        double vacc = 0.0;
+#pragma unroll
+        for (int a = 0; a < FD_RS; ++a) w[a] = __builtin_nontemporal_load(wcol + (size_t)min(rbeg + a, rend - 1) * ld);
+        for (int r0 = rbeg; r0 < rend; r0 += FD_RS) {
+            if (r0 + FD_RS < rend) {  // uniform branch: the last step has no successor
+#pragma unroll
+                for (int a = 0; a < FD_RS; ++a) wn[a] = __builtin_nontemporal_load(wcol + (size_t)min(r0 + FD_RS + a, rend - 1) * ld);
+            }
+#pragma unroll
+            for (int a = 0; a < FD_RS; ++a) {
+                const int row = min(r0 + a, rend - 1);  // (uniform: rows beyond the strip repeat its last row, their results are dropped)
+                // Scalar loads return out of order — the only wait there is is "all of them" — so a row's values are fetched
+                // as ONE batch, spelled out: left to the scheduler the 64-byte groups of several rows are interleaved, each
+                // with its own full wait (measured 716 vs 697 us per pivot).
+                double acc = w[a], tk;
+                const_f64* ur = Utc + (size_t)row * LR_MAX;
+                const_f64* tp = tKc + row;
+                if constexpr (JM == 16) {
+                    sreg8 u0, u1;
+                    asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\ts_load_dwordx2 %2, %4, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&s"(u0), "=&s"(u1), "=&s"(tk) : "s"(ur), "s"(tp) : "memory");
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc = __builtin_fma(u0[j], vj[j], acc);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc = __builtin_fma(u1[j], vj[8 + j], acc);
+                } else {
+#pragma unroll
+                    for (int h = 0; h < JM / 32; ++h) {
+                        sreg8 u0, u1, u2, u3;
+                        asm volatile("s_load_dwordx16 %0, %5, 0x0\n\ts_load_dwordx16 %1, %5, 0x40\n\ts_load_dwordx16 %2, %5, 0x80\n\t"
+                                     "s_load_dwordx16 %3, %5, 0xc0\n\ts_load_dwordx2 %4, %6, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&s"(u0), "=&s"(u1), "=&s"(u2), "=&s"(u3), "=&s"(tk) : "s"(ur + 32 * h), "s"(tp) : "memory");
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc = __builtin_fma(u0[j], vj[32 * h + j], acc);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc = __builtin_fma(u1[j], vj[32 * h + 8 + j], acc);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc = __builtin_fma(u2[j], vj[32 * h + 16 + j], acc);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc = __builtin_fma(u3[j], vj[32 * h + 24 + j], acc);
+                    }
+                }
+                w[a] = acc;
+                vacc = __builtin_fma(acc, (fuse_v && r0 + a < rend) ? tk : 0.0, vacc);
+            }
+            if (active) {
+                if (r0 + FD_RS <= rend) {
+#pragma unroll
+                    for (int a = 0; a < FD_RS; ++a) __builtin_nontemporal_store(w[a], wcol + (size_t)(r0 + a) * ld);
+                } else {
+#pragma unroll
+                    for (int a = 0; a < FD_RS; ++a)
+                        if (r0 + a < rend) __builtin_nontemporal_store(w[a], wcol + (size_t)(r0 + a) * ld);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < FD_RS; ++a) w[a] = wn[a];
+        }
+        if (fuse_v && active) v.part_v[(size_t)strip * ld + col] = vacc;
+    }
+}
 __global__ void k_reset_nlow(DevView v) {
     v.ctl->nlow = 0;
     v.ctl->fold = 0;
@@ -4140,8 +4252,14 @@ static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fo
             } else {
                 const long ftiles = (long)((g.cap + FD_RB - 1) / FD_RB) * ((g.cap + FD_CH - 1) / FD_CH);
                 const int nf = (int)(ftiles < SW_MAX_BLOCKS ? ftiles : SW_MAX_BLOCKS);
-                if (dv.lrJ <= 16) LAUNCH_T(3, k_fold_w<16>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, fuse);
-                else LAUNCH_T(3, k_fold_w<LR_MAX>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, fuse);
+                static const bool scalar_u = !(std::getenv("MLP_FOLD_SCALAR") && std::getenv("MLP_FOLD_SCALAR")[0] == '0');  // A/B: LDS-staged U
+                if (scalar_u) {
+                    if (dv.lrJ <= 16) LAUNCH_T(3, k_fold_w2<16>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, fuse);
+                    else LAUNCH_T(3, k_fold_w2<LR_MAX>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, fuse);
+                } else {
+                    if (dv.lrJ <= 16) LAUNCH_T(3, k_fold_w<16>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, fuse);
+                    else LAUNCH_T(3, k_fold_w<LR_MAX>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, fuse);
+                }
             }
             if (!fold_only) {
                 long tiles = (long)((g.cap + sw_rb() - 1) / sw_rb()) * ((g.cap + sw_ch() - 1) / sw_ch());
