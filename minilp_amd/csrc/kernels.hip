@@ -3116,6 +3116,10 @@ __global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : JM <= 32 ? 3 : 2)) k_fold
         if (fuse_v && active) v.part_v[(size_t)strip * ld + col] = vacc;
     }
 }
+// (Measured and rejected in round 3: the same update on the matrix cores — v_mfma_f64_16x16x4_f64, operands one f64 per lane
+// from plain vector loads, 235 VGPRs, 2 waves per SIMD: correct, 707 us per pivot of the late window against 698 for this
+// form.  The f64 matrix rate of gfx950 equals its vector rate, and the 16 x 16 tile layout turns every load of W into four
+// 128-byte row segments.)
 __global__ void k_reset_nlow(DevView v) {
     v.ctl->nlow = 0;
     v.ctl->fold = 0;

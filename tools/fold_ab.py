@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of the fold kernel on the late window of config 4 (k = 20 493): MLP_FOLD_SCALAR=1 (U through the scalar unit, the
-default) against =0 (U staged in LDS).  Prints us/pivot and the sampled fold kernel time of each."""
+"""A/B of the fold kernel on the late window of config 4 (k = 20 493): the two forms of the fold kernel — U through the
+scalar unit (default), U staged in LDS (MLP_FOLD_SCALAR=0).  Prints us/pivot and the sampled fold kernel time of each."""
 import os
 import subprocess
 import sys
@@ -25,7 +25,7 @@ s.continue_solve(64)
 t0 = time.perf_counter(); s.continue_solve(512); dt = time.perf_counter() - t0
 print("graph:   %%.1f us/pivot, objective %%.12g" %% (dt * 1e6 / 512, s.objective()))
 ''' % ROOT
-for val in ("1", "0", "1", "0"):
-    env = dict(os.environ, MLP_FOLD_SCALAR=val)
+for val in ("scalar", "lds", "scalar", "lds"):
+    env = dict(os.environ, MLP_FOLD_SCALAR="0" if val == "lds" else "1")
     out = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True)
-    print("MLP_FOLD_SCALAR=" + val, out.stdout.strip().replace("\n", " | "), out.stderr.strip()[-300:], flush=True)
+    print("fold = " + val + ":", out.stdout.strip().replace("\n", " | "), out.stderr.strip()[-300:], flush=True)
