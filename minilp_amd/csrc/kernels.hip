@@ -4256,7 +4256,8 @@ static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fo
             } else {
                 const long ftiles = (long)((g.cap + FD_RB - 1) / FD_RB) * ((g.cap + FD_CH - 1) / FD_CH);
                 const int nf = (int)(ftiles < SW_MAX_BLOCKS ? ftiles : SW_MAX_BLOCKS);
-                static const bool scalar_u = !(std::getenv("MLP_FOLD_SCALAR") && std::getenv("MLP_FOLD_SCALAR")[0] == '0');  // A/B: LDS-staged U
+                const char* fs = std::getenv("MLP_FOLD_SCALAR");  // A/B: "0" = the form with U staged in LDS (read per launch: tests toggle it)
+                const bool scalar_u = !(fs && fs[0] == '0');
                 if (scalar_u) {
                     if (dv.lrJ <= 16) LAUNCH_T(3, k_fold_w2<16>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, fuse);
                     else LAUNCH_T(3, k_fold_w2<LR_MAX>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, fuse);

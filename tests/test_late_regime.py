@@ -71,6 +71,22 @@ def test_default_machinery_from_saved_basis_keeps_the_invariants(cfg4, path, k0,
           f"max |W - W_fresh| {drift:.2e} (max |W| {scale:.2e}), cases {st['kase']}")
 
 
+def test_both_forms_of_the_fold_kernel_give_the_same_inverse(cfg4, monkeypatch):
+    """The fold W0 += sum_j U_j V_j^T reads U through the scalar unit by default (k_fold_w2); MLP_FOLD_SCALAR=0 keeps the
+    form that stages U in LDS (k_fold_w).  Both add the terms of an element in the same order with explicit FMAs: 96
+    pivots from the mid basis (three folds, the fused v partials of each driving the next pricing decisions) must give
+    the same trace and bit-identical values."""
+    lp, prob = cfg4
+    runs = []
+    for form in ("1", "0"):
+        monkeypatch.setenv("MLP_FOLD_SCALAR", form)
+        s = _load(prob, MID, trace=True)
+        s.continue_solve(96)
+        runs.append((s.trace(), s.objective(), s.values().tobytes()))
+    assert runs[0][0] == runs[1][0]
+    assert runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
+
+
 def _backward_error(resid, *abs_terms):
     den = sum(abs_terms)
     den = np.where(den > 0, den, 1.0)
