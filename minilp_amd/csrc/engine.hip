@@ -961,6 +961,7 @@ void Engine::try_new(const ProblemData& pd) {
     h_ctl->it.status = ITER_NONE;
     h_ctl->up.kase = -1;
     h_ctl->ratio_spin_limit = ratio_spin_limit;
+    h_ctl->kprof_on = (std::getenv("MLP_KPROF") && std::getenv("MLP_KPROF")[0] == '1') ? 1 : 0;  // kernel timeline marks (diagnostics)
     HIPCHECK(hipMemcpyAsync(d_ctl.p, h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, st));
     ensure_nucleus_cap(256);
     push_maps();
@@ -1097,9 +1098,22 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         throw MlpError(-1, "unknown stage");
     }
 }
+static bool use_graph_env() {
+    const char* ng = std::getenv("MLP_NO_GRAPH");
+    return !(ng && ng[0] == '1');
+}
 void Engine::record_iteration(int phase, bool with_events) {
     if (with_events) HIPCHECK(hipEventRecord(ev[8], st));
-    for (int i = 0; i < 6; ++i) launch_stage(phase, kStageOrder[phase][i], with_events);
+    // MLP_DEBUG_SYNC=1 with MLP_NO_GRAPH=1 (eager launches): synchronise after every stage and name it — a device fault is then
+    // reported at the stage it belongs to
+    static const bool debug_sync = std::getenv("MLP_DEBUG_SYNC") != nullptr && !use_graph_env();
+    for (int i = 0; i < 6; ++i) {
+        launch_stage(phase, kStageOrder[phase][i], with_events);
+        if (debug_sync) {
+            const hipError_t e = hipStreamSynchronize(st);
+            std::fprintf(stderr, "[mlp] phase %d stage %d: %s\n", phase, kStageOrder[phase][i], hipGetErrorString(e));
+        }
+    }
     if (with_events) HIPCHECK(hipEventRecord(ev[9], st));
 }
 size_t Engine::nnz_nucleus_cols() {
@@ -1377,7 +1391,7 @@ int Engine::run_loop(int phase) {
                 if (!str_clean) {
                     HIPCHECK(hipMemsetAsync(d_alpha_r.p, 0, sizeof(double) * (size_t)num_vars, st));
                     HIPCHECK(hipMemsetAsync(d_helper.p, 0, sizeof(double) * (size_t)num_vars, st));
-                    HIPCHECK(hipMemsetAsync(&d_ctl.p->aq_n, 0, 4 * sizeof(int), st));  // aq_n, pad, str_n, pad
+                    HIPCHECK(hipMemsetAsync(&d_ctl.p->aq_n, 0, 2 * sizeof(int), st));  // aq_n, str_n
                     str_clean = true;
                 }
             } else {
@@ -2358,6 +2372,12 @@ uint64_t Engine::state(const char* what, double* out, uint64_t cap) {
         tmp.push_back((double)h_ctl->hy_prof[14] * 0.01);  // prologues
         tmp.push_back(0.0);
         for (int i = 16; i < 24; ++i) tmp.push_back((double)h_ctl->hy_prof[i] * 0.01);  // sub-stage marks (experiments)
+    }
+    else if (w == "kernel_timeline") {  // MLP_KPROF=1: wall-clock marks of the last iteration, microseconds relative to the earliest mark
+        pull_ctl();
+        unsigned long long t0 = ~0ull;
+        for (int i = 0; i < 24; ++i) if (h_ctl->hy_prof[i] && h_ctl->hy_prof[i] < t0) t0 = h_ctl->hy_prof[i];
+        for (int i = 0; i < 24; ++i) tmp.push_back(h_ctl->hy_prof[i] ? (double)(h_ctl->hy_prof[i] - t0) * 0.01 : -1.0);
     }
     else if (w == "hyper_bail_reasons") {
         for (int i = 0; i < 9; ++i) tmp.push_back((double)stats.hyper_bail_reason[i]);

@@ -93,8 +93,9 @@ struct Ctl {
     int hyper_epoch;
     int hyper_bail;
     int aq_n;        // sparse primal ratio test: listed positions of supp(alpha_q) this iteration
-    int aq_pad;
     int str_n;       // sparse tableau row (k_row_touch / k_row_pull): non-basic columns touched by the rows of supp(rho) this iteration
+                     // (aq_n and str_n are adjacent: the host clears the pair with one 8-byte memset)
+    int kprof_on;    // MLP_KPROF=1: kernels stamp the wall clock into hy_prof (KMARK; state("kernel_timeline"))
     int str_pad;
     unsigned long long hy_prof[24];  // ticks of the 100 MHz wall clock per stage of the hypersparse iteration (diagnostics)
     PivotRec ring[RING];

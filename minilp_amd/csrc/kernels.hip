@@ -60,6 +60,17 @@ __device__ __forceinline__ double wave_sum(double x) {
     for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
     return x;
 }
+// MLP_KPROF=1 (diagnostics): thread 0 of the marking block stamps the 100 MHz wall clock into Ctl.hy_prof[i]; after a batch the
+// slots hold the timeline of its LAST iteration (kernel entries and the marks inside the two chain-bound kernels), read
+// through state("kernel_timeline").  Off: one scalar load and a not-taken branch per mark.
+#define KMARK(c, i)                                                                   \
+    do {                                                                              \
+        if ((c)->kprof_on && threadIdx.x == 0) (c)->hy_prof[i] = wall_clock64();        \
+    } while (0)
+#define KMARK0(c, i)                                                                  \
+    do {                                                                              \
+        if (blockIdx.x == 0 && blockIdx.y == 0) KMARK(c, i);                          \
+    } while (0)
 __device__ __forceinline__ Cand block_best(Cand c) {  // result valid in thread 0
     __shared__ double s_key[BLK / 64];
     __shared__ int s_idx[BLK / 64];
@@ -206,6 +217,7 @@ __device__ __forceinline__ bool grid_best_p(Cand& c, double& pay, const DevView&
         st_agent(&v.red_key2[blockIdx.x], pay);
     }
     if (!last_block_arrives(v.ticket, (unsigned)nblocks)) return false;
+    KMARK(v.ctl, 16);
     Cand x = cand_none();
     double xp = 0.0;
     for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
@@ -215,6 +227,7 @@ __device__ __forceinline__ bool grid_best_p(Cand& c, double& pay, const DevView&
             xp = ld_agent(&v.red_key2[i]);
         }
     }
+    KMARK(v.ctl, 17);
     block_best_p(x, xp);
     c = x;
     pay = xp;
@@ -851,6 +864,7 @@ __global__ void __launch_bounds__(BLK) k_price_dual(DevView v, int use_dse) {
 __global__ void __launch_bounds__(64) k_ftran_prep(DevView v, int derive_primal) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
+    KMARK0(c, 0);
     ftran_prep_wave(v, c, threadIdx.x, derive_primal);
 }
 // push of -x * (column of the basic variable at `p`) into the singleton positions
@@ -870,6 +884,7 @@ template <int G>
 __global__ void __launch_bounds__(BLK) k_ftran_gather(DevView v) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
+    KMARK0(c, 18);
     int slot = (blockIdx.x * BLK + threadIdx.x) / G;
     int gl = threadIdx.x & (G - 1);
     if (slot >= c->k) return;
@@ -900,6 +915,7 @@ constexpr int PB_TILE = 512;  // slot descriptors staged in LDS per round
 __global__ void __launch_bounds__(BLK) k_push_stage1(DevView v, int which) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
+    KMARK0(c, 19);
     __shared__ double acc[PB_ROWS];
     __shared__ double s_x[PB_TILE];
     __shared__ int s_beg[PB_TILE], s_len[PB_TILE];
@@ -1022,8 +1038,9 @@ __global__ void __launch_bounds__(PBB_THREADS) k_push_band(DevView v, int which,
     for (int t = tid; t < nrows; t += PBB_THREADS) dst[t] = acc[t];
 }
 __global__ void __launch_bounds__(BLK) k_push_combine(DevView v, int which, int nchunks) {
-    const Ctl* c = v.ctl;
+    Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
+    KMARK0(c, 20);
     const int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= v.m) return;
     const RowInfo ri = v.rowinfo[i];
@@ -1211,6 +1228,7 @@ __device__ void ratio_primal_finish(const DevView& v, Ctl* c, Cand best) {
             }
         }
     }
+    KMARK(c, 5);
     __syncthreads();
     if (s_r >= 0) {
         // the BTRAN head (wave 0) and the partition plan (first lane of wave 1) are independent chains of dependent
@@ -1319,7 +1337,7 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_one(DevView v, int use_pse
     best = block_best(best);
     ratio_primal_finish(v, c, best);
 }
-constexpr int AQ_CAP = 2048;  // positions of supp(alpha_q) the single-block form of the primal ratio test takes on (8 per thread: beyond that
+constexpr int AQ_CAP = 1024;  // positions of supp(alpha_q) the single-block form of the primal ratio test takes on (8 per thread: beyond that
                               // the two grid-wide passes are faster — measured on config 4: 97 against 77 us per pivot at k = 135 with a cap of 8 192)
 // Both Harris passes in ONE launch (primal): pass 1's grid-wide minimum is published by its last-arriving
 // block, every block waits for it (a 98-block grid is always co-resident) and runs pass 2 on the elements it
@@ -1329,6 +1347,7 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_fused(DevView v, int use_p
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     const int sign = c->it.sign;
+    KMARK0(c, 1);
     if (aq_listing(v) && c->aq_n <= AQ_CAP) {
         // Sparse form: block 0 alone runs both Harris passes (solver.rs:782-853), ||alpha_q||^2 and the singleton part of v
         // over the listed positions of supp(alpha_q); no grid-wide reduction, no in-kernel wait.  Ties keep the lowest
@@ -1339,33 +1358,52 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_fused(DevView v, int use_p
         double ca[PL], stp[PL];
         int pos[PL];
         double mn = INFINITY, sq = 0.0;
+        // every input of the thread's (up to PL) listed positions is loaded before anything is stored: with the loads behind the
+        // per-element `continue` and the rv.y stores between them (possible aliases for the compiler) the PL elements became PL
+        // serial round trips of two dependent levels each — measured with MLP_KPROF: 20.5 us from kernel entry to "loads done"
+        // at k = 107, of a 76 us iteration
+        double co[PL], xbv[PL], lov[PL], hiv[PL], sdv[PL];
+        int ksv[PL], srv[PL];
 #pragma unroll
         for (int u = 0; u < PL; ++u) {
             const int a = threadIdx.x + u * BLK;
-            pos[u] = -1;
+            pos[u] = a < n_l ? v.aq_list[a] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < PL; ++u) {
+            const int p = pos[u] < 0 ? 0 : pos[u];
+            co[u] = v.alpha_q[p];
+            ksv[u] = v.kslot_of_pos[p];
+            srv[u] = v.srow_of_pos[p];
+            sdv[u] = v.sdiag_of_pos[p];
+            xbv[u] = v.xB[p];
+            lov[u] = v.loB[p];
+            hiv[u] = v.hiB[p];
+        }
+#pragma unroll
+        for (int u = 0; u < PL; ++u) {
             ca[u] = 0.0;
             stp[u] = 0.0;
-            if (a >= n_l) continue;
-            const int p = v.aq_list[a];
-            const double coeff = v.alpha_q[p];
-            const int ks = v.kslot_of_pos[p], sr = v.srow_of_pos[p];
-            const double sd = v.sdiag_of_pos[p];
-            const double xb = v.xB[p], lob = v.loB[p], hib = v.hiB[p];
+            if (pos[u] < 0) continue;
+            const double coeff = co[u];
             if (use_pse) {
                 sq += coeff * coeff;
-                if (ks < 0) v.rv[sr].y = coeff / sd;
+                if (ksv[u] < 0) v.rv[srv[u]].y = coeff / sdv[u];
             }
             const double aa = fabs(coeff);
-            if (aa < EPS) continue;
+            if (aa < EPS) {
+                pos[u] = -1;
+                continue;
+            }
             const bool tm = (sign && coeff < 0.0) || (!sign && coeff > 0.0);
-            const double st = tm ? (xb < hib ? hib - xb : 0.0) : (xb > lob ? xb - lob : 0.0);
-            pos[u] = p;
+            const double st = tm ? (xbv[u] < hiv[u] ? hiv[u] - xbv[u] : 0.0) : (xbv[u] > lov[u] ? xbv[u] - lov[u] : 0.0);
             ca[u] = aa;
             stp[u] = st;
             const double cur = (st + EPS) / aa;
             if (cur < mn) mn = cur;
         }
         __shared__ double s_ms;
+        KMARK(c, 2);
         mn = block_min(mn);
         sq = block_sum(sq);
         if (threadIdx.x == 0) {
@@ -1376,6 +1414,7 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_fused(DevView v, int use_p
             s_ms = max_step;
         }
         __syncthreads();
+        KMARK(c, 3);
         const double max_step = s_ms;
         Cand best = cand_none();
 #pragma unroll
@@ -1387,7 +1426,9 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_fused(DevView v, int use_p
             }
         }
         best = block_best(best);
+        KMARK(c, 4);
         ratio_primal_finish(v, c, best);
+        KMARK(c, 6);
         return;
     }
     const int epoch0 = c->ratio_epoch;  // written by the previous launch of this kernel: stable here
@@ -1452,9 +1493,11 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_fused(DevView v, int use_p
     }
     __syncthreads();
     if (s_gave_up) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // ANY block that gives up declares the stall, the first one writes the record (atomic on halt): block 0 may be the one
+        // block that did not give up — the last arriver of pass 1 — and then nobody would (the iteration went on with a stale
+        // leaving row; found when a diagnostic mark delayed block 0: GPU memory fault in the update kernel)
+        if (threadIdx.x == 0 && atomicExch(&c->halt, 1) == 0) {
             c->it.status = ITER_STALL;  // not a property of the model: the grid was not co-resident (see launch_ratio_primal)
-            c->halt = 1;
             push_rec(c, 0);
         }
         return;
@@ -1507,6 +1550,7 @@ template <int G>
 __global__ void __launch_bounds__(BLK) k_btran(DevView v, int n_gather) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
+    KMARK0(c, 7);
     const int k = c->k;
     if ((int)blockIdx.x < n_gather) {
         const int n = c->it.blist_n;
@@ -1632,6 +1676,7 @@ template <int G>
 __global__ void __launch_bounds__(BLK) k_ftran_fused(DevView v, int derive_primal) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
+    KMARK0(c, 0);
     __shared__ int s_ls[HEAD_CAP];
     __shared__ double s_la[HEAD_CAP];
     __shared__ int s_n;
@@ -1973,6 +2018,7 @@ template <int MODE, bool VORD>
 __global__ void __launch_bounds__(BAND_THREADS) k_sweep_band(DevView v, int chunks) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
+    KMARK0(c, 22);
     extern __shared__ double2 s_rv[];
     const int n_band_blocks = v.nbands * chunks;
     if ((int)blockIdx.x >= n_band_blocks) {  // horizontally fused: the partition change (primal iteration)
@@ -2331,9 +2377,8 @@ __global__ void __launch_bounds__(BLK) k_ratio_dual_fused(DevView v) {
     }
     __syncthreads();
     if (s_state) {
-        if (s_state == 1 && blockIdx.x == 0 && threadIdx.x == 0) {
+        if (s_state == 1 && threadIdx.x == 0 && atomicExch(&c->halt, 1) == 0) {  // (any block: see k_ratio_primal_fused)
             it->status = ITER_STALL;
-            c->halt = 1;
             push_rec(c, 1);
         }
         return;
@@ -2407,6 +2452,7 @@ template <int TR, bool WITH_TAU, bool WITH_V, bool DO_UPDATE, bool NT = false, b
 __global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
+    KMARK0(c, 8);
     if (LR && c->fold) return;
     const int k = c->k, ld = v.ld;
     const int n_tile_blocks = TILED ? (int)gridDim.x - (LR ? LR_MAX : 0) : 0;
@@ -2808,6 +2854,7 @@ __global__ void __launch_bounds__(BLK, 4) k_stream_w(DevView v, int with_tau, in
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     if (skip_on_fold && c->fold) return;  // the fold of this pivot produced the v partials itself (k_fold_w, fuse_v)
+    KMARK0(c, 21);
     const int k = c->k, ld = v.ld;
     const int tid = threadIdx.x;
     const int n_tile_blocks = (int)gridDim.x - LR_MAX;
@@ -3188,6 +3235,7 @@ template <int G, bool WITH_V, int TR, int TC = FW_TC>
 __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push, int touch_from = -1, int fold_fused = 0) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
+    KMARK0(c, 9);
     if (touch_from >= 0 && (int)blockIdx.x >= touch_from) {  // horizontally fused: the touched-column list of the sparse tableau
         row_touch_body(v, c, (int)blockIdx.x - touch_from);   // row needs rho only (the BTRAN before this launch), nothing of this pass
         return;
@@ -3296,6 +3344,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
     const IterState* it = &c->it;
     const int status = it->status;
     if (status != ITER_PIVOT && status != ITER_FLIP) return;
+    KMARK0(c, 12);
     if ((int)blockIdx.x >= n_upd) {  // horizontally fused (dual iteration without PSE): the partition change, which touches
         if (status == ITER_PIVOT)    // W and the slot maps only — nothing the update blocks read or write
             struct_update_body(v, c, ((int)blockIdx.x - n_upd) * BLK + threadIdx.x);
@@ -3429,8 +3478,11 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
     }
     // every block arrives here only after its own updates; the last arriver closes this iteration
     // (record) and opens the next one with the pricing decision
+    KMARK0(c, 13);
     if (!grid_best_p(cand, cand_d, v, n_upd)) return;
+    KMARK(c, 14);
     close_and_open(v, c, phase, cand, cand_d, true);
+    KMARK(c, 15);
 }
 
 // ------------------------------------------------------------------- helpers outside the pivot graph
@@ -3943,12 +3995,14 @@ __device__ __forceinline__ void row_touch_body(const DevView& v, Ctl* c, int blo
 __global__ void __launch_bounds__(BLK) k_row_touch(DevView v) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
+    KMARK0(c, 10);
     row_touch_body(v, c, (int)blockIdx.x);
 }
 template <int G, int MODE>  // MODE 0: alpha_r, 1: alpha_r + helper, 2: helper
 __global__ void __launch_bounds__(BLK) k_row_pull(DevView v, int n_pull) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
+    KMARK0(c, 11);
     if ((int)blockIdx.x >= n_pull) {
         struct_update_body(v, c, ((int)blockIdx.x - n_pull) * BLK + threadIdx.x);
         return;
