@@ -89,7 +89,8 @@ int mlp_solution_continue(mlp_solution* s, int64_t budget);
  * pivot like the uninterrupted one.  mlp_problem_solve_from_basis builds the same problem (Solver::try_new),
  * installs the basis, re-inverts the nucleus on the device (BasisSolver::reset, solver.rs:1286-1303), recomputes
  * x_B and the reduced costs from the basis (modes 0/1; solver.rs:1177-1231) and continues like mlp_problem_solve_ex.
- * A blob of another model (row / variable counts differ, sets do not partition the variables) => MLP_EINVAL. */
+ * A blob of another model (row / variable counts differ, sets do not partition the variables) => MLP_EINVAL.
+ * A sharded solution (mlp_solution_enable_sharding) saves mode 0 only: the partition is what every rank holds in full. */
 uint64_t mlp_solution_save_basis(const mlp_solution* s, int mode, void* buf, uint64_t cap);
 int mlp_problem_solve_from_basis(const mlp_problem* p, const void* blob, uint64_t len, mlp_solution** out, int64_t budget,
                                  uint32_t flags);

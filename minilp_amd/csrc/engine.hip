@@ -2094,7 +2094,9 @@ size_t basis_blob_size(int mode, size_t m, size_t n) {
 }  // namespace
 std::vector<uint8_t> Engine::save_basis(int mode) {
     if (mode < 0 || mode > 2) throw MlpError(-1, "save_basis: mode must be 0, 1 or 2");
-    if (shard_world > 1) throw MlpError(-1, "save_basis: not available on a sharded solution");
+    // a sharded solve keeps reduced costs and weights per column block: what every rank holds in full is the partition
+    // itself (basic / non-basic sets, bound flags, x_N) — mode 0
+    if (shard_world > 1 && mode != 0) throw MlpError(-1, "save_basis: a sharded solution saves mode 0 only (sets, flags, x_N)");
     HIPCHECK(hipStreamSynchronize(st));
     if (mode >= 1) ensure_beta();
     pull_ctl();

@@ -86,3 +86,22 @@ def test_sharding_at_config4_size_from_the_late_basis(world, pivots):
                         "basis=" + LATE_BASIS], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "traces identical: True" in r.stdout and "device-resident mailboxes" in r.stdout
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_solve_to_optimality_is_optimal_for_a_fresh_unsharded_engine(world):
+    """A whole solve under sharding (6 723 pivots, every exchange of the protocol each pivot), then the final partition —
+    mlp_solution_save_basis mode 0, the one mode a sharded solution offers — is loaded into a fresh UNSHARDED engine: it
+    must be optimal as it stands (no further pivot) and pass the duality certificate (tools/shard_full_solve.py; the same
+    tool run on config 4 itself is what exposed the long-run defect recorded in DESIGN.md §6 / profiles/r03g_sharded_long_run.log)."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_full_solve.py"), str(world), "3000", "3000", "12"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert len({(g["pivots"], g["objective"]) for g in rec["all_ranks"]}) == 1          # every rank took the same pivots
+    ru = rec["reloaded_unsharded"]
+    assert ru["optimal_as_loaded"] and ru["further_pivots"] == 0
+    assert abs(ru["objective"] - rec["all_ranks"][0]["objective"]) <= 1e-9 * abs(ru["objective"])
+    ce = ru["certificate"]
+    assert ce["relative_gap"] < 1e-9 and ce["max_primal_violation"] < 1e-9 and ce["max_dual_violation"] < 1e-7
