@@ -409,12 +409,23 @@ DevView* Engine::sync_view() {
     v.nb_vars = d_nb_vars.p; v.d = d_d.p; v.xN = d_xN.p; v.gamma = d_gamma.p; v.nbflags = d_nbflags.p;
     v.kslot_of_pos = d_kslot_of_pos.p; v.srow_of_pos = d_srow_of_pos.p; v.sdiag_of_pos = d_sdiag_of_pos.p;
     v.kslot_of_row = d_kslot_of_row.p; v.pos_of_srow = d_pos_of_srow.p; v.rowinfo = d_rowinfo.p;
-    v.pb_on = ((cap_ > 4096 || force_big_tiles) && !pb_disable) ? 1 : 0;
+    // A sharded solve needs its ranks to be BIT-IDENTICAL replicas of the basic side (alpha_q, x_B, W, rho): the reduced costs
+    // and weights live per column block, every rank updates its block with ITS rho and v but with the step rank 0 decided from
+    // the entering column's owner — consistent only while all ranks hold the same numbers.  The F products through float
+    // atomics (blocked push: LDS atomics; small nucleus: global atomics) are reproducible to rounding only; at config-4 size
+    // that rounding-level difference between the ranks grows (each block's implicit dual vector is corrected by the OTHER
+    // block's entering columns: an expansive coupled recurrence) until the reduced costs are off by 1e-1 relative and the
+    // solve makes 5x less progress per pivot (found in round 3: DESIGN.md §6, profiles/r03g_sharded_long_run.log).  So a
+    // sharded solve takes the deterministic pull (k_pull_F: fixed summation order), as small models do anyway.
+    // MLP_SHARD_ATOMICS=1 restores the atomic forms (experiments).
+    static const bool shard_atomics = std::getenv("MLP_SHARD_ATOMICS") != nullptr;
+    const bool shard_det = shard_world > 1 && !shard_atomics;
+    v.pb_on = ((cap_ > 4096 || force_big_tiles) && !pb_disable && !shard_det) ? 1 : 0;
     if (v.pb_on) ensure_colblk();
     v.colblk = v.pb_on ? d_colblk.p : nullptr;
     v.push_part = v.pb_on ? d_push_part.p : nullptr;
     v.pb_rb = (m_ + PB_ROWS - 1) / PB_ROWS;
-    v.det_pull = (!v.pb_on && (det_mode == 1 || (det_mode < 0 && h_rcol.size() <= ((size_t)1 << 21)))) ? 1 : 0;
+    v.det_pull = (!v.pb_on && (det_mode == 1 || shard_det || (det_mode < 0 && h_rcol.size() <= ((size_t)1 << 21)))) ? 1 : 0;
     v.banded = use_banded() ? 1 : 0;
     if (v.banded) ensure_banded();
     v.bptr = v.banded ? d_bptr.p : nullptr;
@@ -961,7 +972,7 @@ void Engine::try_new(const ProblemData& pd) {
     h_ctl->it.status = ITER_NONE;
     h_ctl->up.kase = -1;
     h_ctl->ratio_spin_limit = ratio_spin_limit;
-    h_ctl->kprof_on = (std::getenv("MLP_KPROF") && std::getenv("MLP_KPROF")[0] == '1') ? 1 : 0;  // kernel timeline marks (diagnostics)
+    h_ctl->kprof_on = std::getenv("MLP_KPROF") ? std::atoi(std::getenv("MLP_KPROF")) : 0;  // 1: kernel timeline marks; 2..5: per-rank quantity in the records (diagnostics)
     HIPCHECK(hipMemcpyAsync(d_ctl.p, h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, st));
     ensure_nucleus_cap(256);
     push_maps();

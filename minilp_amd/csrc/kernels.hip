@@ -65,7 +65,7 @@ __device__ __forceinline__ double wave_sum(double x) {
 // through state("kernel_timeline").  Off: one scalar load and a not-taken branch per mark.
 #define KMARK(c, i)                                                                   \
     do {                                                                              \
-        if ((c)->kprof_on && threadIdx.x == 0) (c)->hy_prof[i] = wall_clock64();        \
+        if ((c)->kprof_on == 1 && threadIdx.x == 0) (c)->hy_prof[i] = wall_clock64();        \
     } while (0)
 #define KMARK0(c, i)                                                                  \
     do {                                                                              \
@@ -314,6 +314,16 @@ __device__ __forceinline__ void push_rec(Ctl* c, int phase) {  // single thread
         r.klist_n = c->it.klist_n;
         r.blist_n = c->it.blist_n;
         r.pivot_coeff = c->it.pivot_coeff;
+        // MLP_KPROF=2..5 (diagnostics): the record carries a per-rank quantity of the iteration in place of the pivot element, so
+        // that the traces of the ranks of a sharded solve can be compared: ||alpha_q||^2 + 1, ||rho||^2, 1 / alpha_q[r], sum of U[j].t_K
+        if (c->kprof_on == 2) r.pivot_coeff = c->it.alpha_sq;
+        else if (c->kprof_on == 3) r.pivot_coeff = c->it.rho_sq;
+        else if (c->kprof_on == 4) r.pivot_coeff = c->it.inv_alpha;
+        else if (c->kprof_on == 5) {
+            double sh = 0.0;
+            for (int j = 0; j < c->nlow && j < LR_MAX; ++j) sh += c->lr_h[j];
+            r.pivot_coeff = sh;
+        }
         r.obj = c->it.obj;
     }
     c->ring_n = n + 1;

@@ -93,7 +93,8 @@ def test_sharded_solve_to_optimality_is_optimal_for_a_fresh_unsharded_engine(wor
     """A whole solve under sharding (6 723 pivots, every exchange of the protocol each pivot), then the final partition —
     mlp_solution_save_basis mode 0, the one mode a sharded solution offers — is loaded into a fresh UNSHARDED engine: it
     must be optimal as it stands (no further pivot) and pass the duality certificate (tools/shard_full_solve.py; the same
-    tool run on config 4 itself is what exposed the long-run defect recorded in DESIGN.md §6 / profiles/r03g_sharded_long_run.log)."""
+    tool run on config 4 itself is what exposed the replica-divergence defect of DESIGN.md §6: sharded solves now take
+    the deterministic F products so that the ranks stay bit-identical; profiles/r03g_sharded_long_run.log)."""
     import json
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_full_solve.py"), str(world), "3000", "3000", "12"],
                        capture_output=True, text=True, timeout=900)

@@ -1,4 +1,5 @@
-"""Debug: objective progress of a sharded (2 ranks) and the unsharded solve over many pivots from the late basis of config 4."""
+"""Debug: objective progress of a sharded (2 ranks) and the unsharded solve over many pivots from the late basis of config 4.
+  python shard_progress.py CHUNK COUNT [nounsharded]"""
 import gzip, os, sys, time
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -7,10 +8,10 @@ sys.path.insert(0, ROOT)
 
 def line(tag, s, t0):
     st = s.stats()
-    print("%s %7d pivots  objective %.6f  nucleus %d  reinversions %d  final refreshes %d  max_pivot_err %.1e  flips %d  %.0f s" % (
-        tag, st["iterations"], s.objective(), st["nucleus_size"], st["reinversions"], st["final_refreshes"], st["max_pivot_err"], st.get("bound_flips", -1), time.time() - t0), flush=True)
+    print("%s %7d pivots  objective %.6f  nucleus %d  reinversions %d  max_pivot_err %.1e  %.0f s" % (
+        tag, st["iterations"], s.objective(), st["nucleus_size"], st["reinversions"], st["max_pivot_err"], time.time() - t0), flush=True)
 
-def worker(rank, world, port, chunk, count, out):
+def worker(rank, world, port, chunk, count, unsh, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import minilp_amd as M
@@ -30,16 +31,18 @@ def worker(rank, world, port, chunk, count, out):
     if rank == 0:
         md.remove_mailbox(box)
         del s
-        ref = p.solve_from_basis(blob, budget=0)
-        t0 = time.time()
-        for i in range(count):
-            ref.continue_solve(chunk)
-            line("unsharded", ref, t0)
+        if unsh:
+            ref = p.solve_from_basis(blob, budget=0)
+            t0 = time.time()
+            for i in range(count):
+                ref.continue_solve(chunk)
+                line("unsharded", ref, t0)
         out.put(True)
     dist.barrier(); dist.destroy_process_group()
 
 if __name__ == "__main__":
     chunk, count = int(sys.argv[1]), int(sys.argv[2])
+    unsh = not (len(sys.argv) > 3 and sys.argv[3] == "nounsharded")
     ctx = mp.get_context("spawn"); out = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, 2, 29581, chunk, count, out)) for r in range(2)]
+    procs = [ctx.Process(target=worker, args=(r, 2, 29581, chunk, count, unsh, out)) for r in range(2)]
     [p.start() for p in procs]; [p.join(3000) for p in procs]
