@@ -263,6 +263,7 @@ private:
     DevBuf<unsigned short> d_pk_row;
     DevBuf<double> d_pk_val;
     DevBuf<unsigned char> d_pk_valid;
+    DevBuf<unsigned char> d_fmark;   // det_pull: row marks of the FTRAN pull (zero outside an FTRAN)
     bool use_pack = true;           // MLP_SWEEP_PACKED=0: the sweep always takes the indirect path through the full copy
     bool pack_built = false;
     size_t band_total_ = 0;         // entries of the band-major copy (incl. pad entries)

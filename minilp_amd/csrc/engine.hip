@@ -426,6 +426,14 @@ DevView* Engine::sync_view() {
     v.push_part = v.pb_on ? d_push_part.p : nullptr;
     v.pb_rb = (m_ + PB_ROWS - 1) / PB_ROWS;
     v.det_pull = (!v.pb_on && (det_mode == 1 || shard_det || (det_mode < 0 && h_rcol.size() <= ((size_t)1 << 21)))) ? 1 : 0;
+    if (v.det_pull) {  // (a pooled block is not zero: cleared whenever the allocation changes; the pull clears what it consumes)
+        const unsigned char* before = d_fmark.p;
+        d_fmark.ensure((size_t)m_ + 64, 0, st);
+        if (d_fmark.p != before) HIPCHECK(hipMemsetAsync(d_fmark.p, 0, d_fmark.cap, st));
+        v.fmark = d_fmark.p;
+    } else {
+        v.fmark = nullptr;
+    }
     v.banded = use_banded() ? 1 : 0;
     if (v.banded) ensure_banded();
     v.bptr = v.banded ? d_bptr.p : nullptr;

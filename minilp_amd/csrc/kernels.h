@@ -166,6 +166,7 @@ struct DevView {
     double* bval;           // same length as brow (+ 8 spare entries)
     double2* band_part;     // nbands x n partial (alpha_r, helper)
     int nbands, banded;
+    unsigned char* fmark;  // det_pull: singleton positions the current FTRAN's nucleus columns reach (zero outside an FTRAN); nullptr: pull every row
     int det_pull;  // small models: the F products are pulled per singleton row (fixed summation order) instead of
                    // pushed with float atomics, so that a solve is reproducible bit for bit from run to run
     int* pos_of_kslot;     // cap: row slot -> position

@@ -890,6 +890,19 @@ __device__ __forceinline__ void push_F(const DevView& v, int p, double x, double
         }
     }
 }
+// Deterministic FTRAN of a large model with a small nucleus (sharded solves of config 4: DESIGN.md §6): the pull per singleton
+// row walks every entry of the row, 10^7 entries per pivot whatever the nucleus size.  The gather MARKS the singleton positions
+// that a nucleus column with alpha_K != 0 reaches (plain idempotent stores); k_pull_F then skips the unmarked rows — their sum
+// would be an exact zero — and clears the marks it consumes.  Same sums in the same order: results are bit-identical.
+template <int G>
+__device__ __forceinline__ void mark_F(const DevView& v, int p, int gl) {
+    const int var = v.basic_vars[p];
+    const int end = v.csc_ptr[var + 1];
+    for (int e = v.csc_ptr[var] + gl; e < end; e += G) {
+        const RowInfo ri = v.rowinfo[v.csc_row[e]];
+        if (ri.kslot < 0) v.fmark[ri.pos] = 1;
+    }
+}
 template <int G>
 __global__ void __launch_bounds__(BLK) k_ftran_gather(DevView v) {
     Ctl* c = v.ctl;
@@ -914,6 +927,7 @@ __global__ void __launch_bounds__(BLK) k_ftran_gather(DevView v) {
         if (acc != 0.0 && aq_listing(v)) aq_list_add(v, c, p);
     }
     if (acc != 0.0 && !v.pb_on && !v.det_pull) push_F<G>(v, p, acc, v.alpha_q, gl, aq_listing(v) ? c : nullptr);
+    else if (acc != 0.0 && v.det_pull && v.fmark) mark_F<G>(v, p, gl);
 }
 
 // Blocked F push of the large-nucleus regime.  y_S -= D^-1 F x_K through device-scope f64 atomics costs
@@ -1081,6 +1095,11 @@ __global__ void __launch_bounds__(BLK) k_pull_F(DevView v, int which) {
     const int p = (blockIdx.x * BLK + threadIdx.x) / G;
     const int gl = threadIdx.x & (G - 1);
     if (p >= v.m || v.kslot_of_pos[p] >= 0) return;
+    if (!which && v.fmark) {  // (the G lanes of a position read the mark before lane 0 clears it: same wave, in order)
+        const unsigned char mk = v.fmark[p];
+        if (!mk) return;
+        if (gl == 0) v.fmark[p] = 0;
+    }
     const int i = v.srow_of_pos[p];
     const double* xK = which ? v.tauK : v.aK;
     double acc = 0.0;
@@ -1707,6 +1726,7 @@ __global__ void __launch_bounds__(BLK) k_ftran_fused(DevView v, int derive_prima
         if (acc != 0.0 && aq_listing(v)) aq_list_add(v, c, p);
     }
     if (acc != 0.0 && !v.pb_on && !v.det_pull) push_F<G>(v, p, acc, v.alpha_q, gl, aq_listing(v) ? c : nullptr);
+    else if (acc != 0.0 && v.det_pull && v.fmark) mark_F<G>(v, p, gl);
 }
 __device__ void btran_head_lds(const DevView& v, Ctl* c, int lane, int derive_dual, bool primary, int* ls, double* la, int* ln) {
     IterState* it = &c->it;
