@@ -33,6 +33,14 @@ enum { MLP_EQ = 0, MLP_LE = 1, MLP_GE = 2 };      /* lib.rs:160-169 ComparisonOp
 enum { MLP_OK = 0, MLP_INFEASIBLE = 1, MLP_UNBOUNDED = 2,
        MLP_EINVAL = -1, MLP_ESINGULAR = -2, MLP_EHIP = -3, MLP_ENOGPU = -4, MLP_ENOMEM = -5 };
 
+/* ABI version of this header: bumped whenever a struct below changes.  From version 4 on mlp_stats only GROWS AT ITS END
+ * (fields are appended, never inserted or removed), so a host built against an older version-4+ header reads a valid
+ * prefix; mlp_stats_size() is sizeof(mlp_stats) as the LIBRARY was built — a host checks it (and mlp_abi_version())
+ * against its own header before trusting the layout. */
+#define MLP_ABI_VERSION 4u
+uint32_t mlp_abi_version(void);
+uint64_t mlp_stats_size(void);
+
 const char* mlp_last_error(void);
 /* Number of visible HIP devices (0 => every solve returns MLP_ENOGPU; there is no CPU fallback). */
 int mlp_device_count(void);
@@ -102,7 +110,8 @@ int mlp_solution_budget_exhausted(const mlp_solution* s);
  * solver.rs:1286-1303); returns max |W_incremental - W_fresh| through *max_diff when non-NULL. */
 int mlp_solution_reinvert(mlp_solution* s, double* max_diff);
 
-/* x_B = B^-1 (b - N x_N) recomputed from the basis, with two steps of iterative refinement (the reference's
+/* The objective value and the reduced costs are recomputed for the new point as well (solver.rs:1199-1231).
+ * x_B = B^-1 (b - N x_N) recomputed from the basis, with two steps of iterative refinement (the reference's
  * recalc_basic_var_vals, solver.rs:1177-1197, which it leaves unused; here it is the polish step of long runs and is
  * exported for hosts that want it after many warm-start pivots).  A dense-rhs FTRAN: with a large nucleus it is one
  * streaming read of the nucleus inverse (8 k^2 bytes) per step; in profile mode mlp_stats.dense_ftran_* time it. */
@@ -150,6 +159,9 @@ typedef struct mlp_stats {
                                           iterations it declined (list overflow / too much work for one workgroup) and handed to the multi-kernel path */
     uint64_t ratio_stalls; /* in-kernel waits of the one-launch Harris tests that timed out (grid not co-resident); each one is
                               retried with the two-launch form, which then stays selected */
+    /* ---- appended in ABI version 4 ---- */
+    uint64_t reinversion_fallbacks; /* re-inversions of the nucleus that a first attempt reported singular and the Gauss-Jordan
+                                       kernels then re-examined (0 in a healthy run) */
 } mlp_stats;
 void mlp_solution_stats(const mlp_solution* s, mlp_stats* out);
 void mlp_solution_reset_stats(mlp_solution* s);

@@ -41,7 +41,11 @@ class MlpStats(C.Structure):
                    ("fold_bytes", C.c_double), ("fold_ms", C.c_double), ("fold_launches", C.c_uint64),
                    ("dense_ftran_bytes", C.c_double), ("dense_ftran_ms", C.c_double), ("dense_ftran_launches", C.c_uint64),
                    ("str_ms", C.c_double), ("str_launches", C.c_uint64),
-                   ("hyper_iters", C.c_uint64), ("hyper_bails", C.c_uint64), ("ratio_stalls", C.c_uint64)])
+                   ("hyper_iters", C.c_uint64), ("hyper_bails", C.c_uint64), ("ratio_stalls", C.c_uint64),
+                   ("reinversion_fallbacks", C.c_uint64)])  # appended in ABI version 4 (the struct only grows at its end from here on)
+
+
+ABI_VERSION = 4  # include/minilp_hip.h: MLP_ABI_VERSION
 
 
 class MlpIterInfo(C.Structure):  # include/minilp_hip.h: mlp_iter_info
@@ -77,6 +81,11 @@ def lib():
         f.restype = res
         f.argtypes = list(args)
 
+    sig("mlp_abi_version", u32)
+    sig("mlp_stats_size", u64)
+    if L.mlp_abi_version() != ABI_VERSION or L.mlp_stats_size() != C.sizeof(MlpStats):
+        raise ImportError(f"{_SO} was built from another version of include/minilp_hip.h (ABI {L.mlp_abi_version()}, mlp_stats "
+                          f"{L.mlp_stats_size()} bytes; this binding: ABI {ABI_VERSION}, {C.sizeof(MlpStats)} bytes): rebuild it")
     sig("mlp_last_error", C.c_char_p)
     sig("mlp_device_count", i32)
     sig("mlp_set_device", i32, i32)

@@ -166,6 +166,7 @@ int mlp_solution_set_sampling(mlp_solution* s, int every_iteration) {
 }
 int mlp_solution_continue(mlp_solution* s, int64_t budget) {
     return guarded([&] {
+        if (!s) throw MlpError(MLP_EINVAL, "NULL solution");
         s->eng->pivot_budget = budget;
         s->eng->budget_exhausted = false;
         s->eng->initial_solve();
@@ -198,20 +199,32 @@ int mlp_engine_stage(mlp_solution* s, int stage, mlp_iter_info* out) {
     });
     return rc != 0 ? (rc > 0 ? MLP_EINVAL : rc) : status;
 }
-int mlp_solution_budget_exhausted(const mlp_solution* s) { return s->eng->budget_exhausted ? 1 : 0; }
+int mlp_solution_budget_exhausted(const mlp_solution* s) { return (s && s->eng->budget_exhausted) ? 1 : 0; }
 int mlp_solution_reinvert(mlp_solution* s, double* max_diff) {
     return guarded([&] {
+        if (!s) throw MlpError(MLP_EINVAL, "NULL solution");
         double d = s->eng->reinvert(true);
         if (max_diff) *max_diff = d;
     });
 }
 
 int mlp_solution_recompute_basic_values(mlp_solution* s) {
-    return guarded([&] { s->eng->recalc_basic_vals(); });
+    return guarded([&] {
+        if (!s) throw MlpError(MLP_EINVAL, "NULL solution");
+        // x_B, then the objective of the recomputed point (and the reduced costs with it: solver.rs:1199-1231), so that
+        // mlp_solution_objective and the values agree afterwards
+        s->eng->recalc_basic_vals();
+        s->eng->refresh_objective();
+    });
 }
+uint32_t mlp_abi_version(void) { return MLP_ABI_VERSION; }
+uint64_t mlp_stats_size(void) { return (uint64_t)sizeof(mlp_stats); }
 
 int mlp_solution_enable_sharding(mlp_solution* s, int rank, int world, const char* shm_name) {
-    return guarded([&] { s->eng->enable_sharding(rank, world, shm_name); });
+    return guarded([&] {
+        if (!s || !shm_name) throw MlpError(MLP_EINVAL, "NULL solution / rendezvous name");
+        s->eng->enable_sharding(rank, world, shm_name);
+    });
 }
 
 const char* mlp_solution_transport(const mlp_solution* s) { return s ? s->eng->transport.c_str() : "none"; }
@@ -287,6 +300,11 @@ int mlp_solution_add_gomory_cut(mlp_solution** s, uint32_t var) {
 }
 
 void mlp_solution_stats(const mlp_solution* s, mlp_stats* o) {
+    if (!o) return;
+    if (!s) {
+        std::memset(o, 0, sizeof(*o));
+        return;
+    }
     Engine* e = s->eng;
     const Stats& t = e->stats;
     std::memset(o, 0, sizeof(*o));
@@ -308,6 +326,7 @@ void mlp_solution_stats(const mlp_solution* s, mlp_stats* o) {
     o->dense_ftran_bytes = t.dense_ftran_bytes; o->dense_ftran_ms = t.dense_ftran_ms; o->dense_ftran_launches = t.dense_ftran_launches;
     o->fold_bytes = t.fold_bytes; o->fold_ms = t.fold_ms; o->fold_launches = t.fold_launches;
     for (int i = 0; i < 5; ++i) o->kase[i] = t.kase[i];
+    o->reinversion_fallbacks = t.reinversion_fallbacks;
 }
 void mlp_solution_reset_stats(mlp_solution* s) {
     guarded([&] { s->eng->resolve_events(); });

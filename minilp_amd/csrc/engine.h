@@ -54,6 +54,7 @@ struct DevPool {
     static constexpr size_t kMaxBlock = (size_t)64 << 20;   // larger blocks are not cached
     static constexpr size_t kMaxCached = (size_t)4 << 30;   // total bytes kept in the cache
     static void* get(size_t bytes, size_t* got_bytes, int* device);   // on the current device
+    static void* get_raw(size_t bytes, size_t* got_bytes, int* device);
     static void put(void* p, size_t bytes, int device);                // back to the free list of ITS device
     static void trim();  // hipFree everything cached
 };
@@ -132,7 +133,7 @@ struct Stats {
     uint64_t reinversion_fallbacks = 0;  // blocked (rocSOLVER) inversions that reported a zero pivot and were redone by the Gauss-Jordan kernels
     double str_ms = 0;  // sampled sparse tableau rows (k_row_touch + k_row_pull, launch-bracketed HIP events)
     uint64_t str_launches = 0;
-    uint64_t hyper_bail_reason[9] = {};  // by reason code of the kernel (hyper.inc)
+    uint64_t hyper_bail_reason[10] = {};  // by reason code of the kernel (hyper.inc)
     uint64_t hyper_iters = 0, hyper_bails = 0;  // iterations taken by the hypersparse kernel; iterations it handed back
     uint64_t ratio_stalls = 0;   // in-kernel waits of the fused ratio test that timed out (each one retried with two launches)
     uint64_t beta_rebuilds = 0;  // lazy dual steepest edge: exact rebuilds of beta from the basis inverse
@@ -200,6 +201,9 @@ private:
     std::vector<int> h_cptr, h_crow;       // initial build only (try_new); dropped after the first device-side append
     std::vector<double> h_cval;
     int max_col_nnz_ = 0, max_row_nnz_ = 0;   // longest column / row of A (in-kernel stage heads need them to fit an LDS list)
+    double amax_ = 0.0;                       // max |A_ij| (incl. the slack identity): scale bound of the deterministic blocked push
+    bool force_det_push_ = false;             // set around recalc_basic_vals: the blocked push in its deterministic form
+    bool pb_det_default = false;              // unsharded solves: deterministic blocked push by default (set from the measured A/B)
     bool no_head_fusion = false;             // MLP_NO_HEAD_FUSION: keep the stage heads as launches of their own
     bool ratio_two = false;                  // MLP_RATIO_TWO_KERNELS, or latched by an ITER_STALL: two launches for the two Harris passes
     long long ratio_spin_limit = 20000000LL; // MLP_RATIO_SPIN_LIMIT: polls before a fused ratio test gives up (0: the first launch stalls; tests)
@@ -380,6 +384,7 @@ private:
     int step_phase = 0, step_pos = -1;
     bool stepping = false;
     void recalc_basic_vals();  // x_B recomputed from the basis (polish of long runs)
+    void refresh_objective() { recalc_obj_coeffs(); }  // objective + reduced costs of the current point, from the basis (solver.rs:1199-1231)
     int step_open(StepInfo* out);
     int step_stage(int stage, StepInfo* out);
     int step_finish(int phase, int status);

@@ -217,7 +217,22 @@ size_t round_block(size_t bytes) {
     return b;
 }
 }  // namespace
+// MLP_POOL_POISON=1 (debugging): every block handed out — recycled or fresh — is filled with 0xFF bytes first (NaN as a double,
+// -1 as an int), so that a kernel reading memory nobody initialised shows up deterministically instead of depending on what
+// the previous owner of the block left behind.
+static bool pool_poison() {
+    static const bool on = std::getenv("MLP_POOL_POISON") != nullptr && std::atoi(std::getenv("MLP_POOL_POISON")) != 0;
+    return on;
+}
 void* DevPool::get(size_t bytes, size_t* got_bytes, int* device) {
+    void* p = get_raw(bytes, got_bytes, device);
+    if (pool_poison()) {
+        (void)hipMemset(p, 0xFF, *got_bytes);
+        (void)hipDeviceSynchronize();
+    }
+    return p;
+}
+void* DevPool::get_raw(size_t bytes, size_t* got_bytes, int* device) {
     if (bytes == 0) bytes = 1;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -364,8 +379,15 @@ void Engine::refresh_nb_order(bool force) {
         const size_t np = (size_t)nb * ((size_t)num_vars + 1);
         try {
             d_pk_ptr.ensure(np, 0, st);
-            d_pk_row.ensure(band_total_ + 16, 0, st);
-            d_pk_val.ensure(band_total_ + 16, 0, st);
+            {   // (the sweep reads whole groups of 8 entries: what lies beyond the packed total must be valid row indices and
+                // finite values — zero a fresh allocation once; later refills leave entries of older copies there, which are)
+                const unsigned short* r0 = d_pk_row.p;
+                const double* v0 = d_pk_val.p;
+                d_pk_row.ensure(band_total_ + 16, 0, st);
+                d_pk_val.ensure(band_total_ + 16, 0, st);
+                if (d_pk_row.p != r0) HIPCHECK(hipMemsetAsync(d_pk_row.p, 0, sizeof(unsigned short) * d_pk_row.cap, st));
+                if (d_pk_val.p != v0) HIPCHECK(hipMemsetAsync(d_pk_val.p, 0, sizeof(double) * d_pk_val.cap, st));
+            }
             d_pk_valid.ensure((size_t)num_vars, 0, st);
             d_scan_tmp.ensure(np / 4096 + 8, 0, st);
         } catch (MlpError&) {  // no room for the second copy: the sweep keeps the indirect path
@@ -420,12 +442,27 @@ DevView* Engine::sync_view() {
     // MLP_SHARD_ATOMICS=1 restores the atomic forms (experiments).
     static const bool shard_atomics = std::getenv("MLP_SHARD_ATOMICS") != nullptr;
     const bool shard_det = shard_world > 1 && !shard_atomics;
-    v.pb_on = ((cap_ > 4096 || force_big_tiles) && !pb_disable && !shard_det) ? 1 : 0;
+    // Round 4: the blocked push has a DETERMINISTIC form (k_push_stage1_det: fixed-point limbs, integer LDS atomics — exact,
+    // hence independent of the order in which they land), so a sharded solve no longer needs the pull for a nucleus beyond a
+    // few hundred columns: it takes the blocked push from capacity 512 on (below that the marked pull touches few rows and
+    // is cheaper than the push's fixed cost).  MLP_PB_DET=1 / 0 forces the deterministic form on / off for unsharded solves.
+    static const int pb_det_env = std::getenv("MLP_PB_DET") ? std::atoi(std::getenv("MLP_PB_DET")) : -1;
+    int hbits = 1;
+    while (hbits < 31 && (1 << hbits) <= max_row_nnz_) hbits += 1;  // terms one accumulator can receive: < 2^hbits
+    const bool det_fits = hbits <= 20;
+    const bool pb_det = det_fits && (shard_det || force_det_push_ || pb_det_env == 1 || (pb_det_env < 0 && pb_det_default));
+    // (small models take the pull sharded or not — MLP_DETERMINISTIC auto — so that their sharded and unsharded runs stay bit-identical)
+    const bool pb_size = cap_ > 4096 || force_big_tiles ||
+                         (shard_det && pb_det && cap_ >= 512 && det_mode != 1 && h_rcol.size() > ((size_t)1 << 21));
+    v.pb_on = (pb_size && !pb_disable && (!shard_det || pb_det)) ? 1 : 0;
+    v.pb_det = (v.pb_on && pb_det) ? 1 : 0;
+    v.pb_hbits = hbits;
+    v.pb_amax = amax_;
     if (v.pb_on) ensure_colblk();
     v.colblk = v.pb_on ? d_colblk.p : nullptr;
     v.push_part = v.pb_on ? d_push_part.p : nullptr;
     v.pb_rb = (m_ + PB_ROWS - 1) / PB_ROWS;
-    v.det_pull = (!v.pb_on && (det_mode == 1 || shard_det || (det_mode < 0 && h_rcol.size() <= ((size_t)1 << 21)))) ? 1 : 0;
+    v.det_pull = (!v.pb_on && (det_mode == 1 || shard_det || force_det_push_ || (det_mode < 0 && h_rcol.size() <= ((size_t)1 << 21)))) ? 1 : 0;
     if (v.det_pull) {  // (a pooled block is not zero: cleared whenever the allocation changes; the pull clears what it consumes)
         const unsigned char* before = d_fmark.p;
         d_fmark.ensure((size_t)m_ + 64, 0, st);
@@ -520,6 +557,8 @@ void Engine::build_csc() {  // counting transpose of the CSR: ascending row inde
     max_col_nnz_ = 0;
     max_row_nnz_ = 0;
     for (int r = 0; r < m_; ++r) max_row_nnz_ = std::max(max_row_nnz_, h_rptr[r + 1] - h_rptr[r]);
+    amax_ = 0.0;
+    for (double a : h_rval) amax_ = std::max(amax_, std::fabs(a));  // scale bound of the deterministic blocked push
     h_colnnz.resize(N_);
     h_single_row.assign(N_, -1);
     h_single_val.assign(N_, 0.0);
@@ -1373,7 +1412,7 @@ int Engine::run_loop(int phase) {
                 // one workgroup): nothing of it was applied; the multi-kernel path takes over for a while — the longer, the
                 // more often this happens in a row (a model that is not hypersparse settles on the multi-kernel path)
                 stats.hyper_bails += 1;
-                if (h_ctl->hyper_bail > 0 && h_ctl->hyper_bail < 9) stats.hyper_bail_reason[h_ctl->hyper_bail] += 1;
+                if (h_ctl->hyper_bail > 0 && h_ctl->hyper_bail < 10) stats.hyper_bail_reason[h_ctl->hyper_bail] += 1;
                 // Dense iterations come in clusters (measured on config 3: handing over one pivot at a time costs 173 bail-outs
                 // and 185 ms against 28 and 172 ms with a back-off): after a run of >= 16 hypersparse iterations the multi-kernel
                 // path takes that one pivot only; after a short run it keeps going for 4, 8, ... 512 pivots before the next attempt
@@ -1410,7 +1449,7 @@ int Engine::run_loop(int phase) {
                 if (!str_clean) {
                     HIPCHECK(hipMemsetAsync(d_alpha_r.p, 0, sizeof(double) * (size_t)num_vars, st));
                     HIPCHECK(hipMemsetAsync(d_helper.p, 0, sizeof(double) * (size_t)num_vars, st));
-                    HIPCHECK(hipMemsetAsync(&d_ctl.p->aq_n, 0, 2 * sizeof(int), st));  // aq_n, str_n
+                    launch_str_reset(hview, st);  // new stamp epoch, aq_n = str_n = 0
                     str_clean = true;
                 }
             } else {
@@ -1522,6 +1561,7 @@ int Engine::run_loop(int phase) {
             // vectors and re-takes the same pricing decision from the unchanged d / gamma / x_B / beta.
             ratio_two = true;
             stats.ratio_stalls += 1;
+            str_clean = false;  // the stalled iteration stamped / listed columns without closing: the next batch re-zeroes and clears the counters
             if (pivot_budget >= 0) pivot_budget += 1;  // the stalled record consumed one unit
             HIPCHECK(hipMemsetAsync(d_ticket.p, 0, sizeof(unsigned) * std::min<size_t>(d_ticket.cap, 64), st));
             continue;
@@ -1546,7 +1586,9 @@ void Engine::ensure_beta() {
 bool Engine::hyper_capable(int phase) const {
     if (hyper_mode == 0 || phase != 1 || enable_pse || shard_world != 1 || stepping) return false;
     if ((lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 32 : 0)) != 0 || use_banded()) return false;
-    if (cap_ > 4096) return false;  // (the kernel's dense passes over the nucleus slots hold 4 elements per thread)
+    if (cap_ > 4096) return false;  // (the kernel's dense passes over the nucleus slots hold HY_KU = 8 elements per thread: 4 096 slots)
+    // the launch reserves capacity for k_ + RING + 1 slots first (ensure_nucleus_cap): that must not double a 4 096-slot W
+    if (std::min(k_ + RING + 1, std::max(m_, 1)) > 4096) return false;
     if (max_col_nnz_ > HEAD_LIST_CAP || max_row_nnz_ > HEAD_LIST_CAP) return false;
     if (hyper_mode == 1) return true;
     // few non-zeros per row OR per column (the TSP relaxations of config 5: 129 per degree row, 2 + cuts per column)
@@ -1682,6 +1724,15 @@ void Engine::recalc_obj_coeffs() {
 // x_B = B^-1 (b - N x_N) from scratch (solver.rs:1177-1197 is the reference's unused counterpart).
 void Engine::recalc_basic_vals() {
     flush_lowrank();  // the dense solve reads W0 as the whole inverse
+    // The recomputed x_B must not depend on the order float atomics land in: the ranks of a sharded solve each load the basis
+    // in their own process BEFORE sharding is enabled and must start as bit-identical replicas (tools/shard_bitwise.py found
+    // 102 basic values differing by 2e-14 between two ranks after the load).  The blocked push takes its deterministic form here.
+    struct DetScope {
+        Engine* e;
+        bool was;
+        explicit DetScope(Engine* e_) : e(e_), was(e_->force_det_push_) { e->force_det_push_ = true; e->view_dirty = true; }
+        ~DetScope() { e->force_det_push_ = was; e->view_dirty = true; }
+    } det_scope(this);
     sync_view();
     DevBuf<double> rhs, r;
     rhs.upload(h_rhs, st);
@@ -1843,6 +1894,8 @@ void Engine::append_row_on_device(const Constraint& c, int slack, int row) {
         max_col_nnz_ = std::max(max_col_nnz_, h_colnnz[var]);
     }
     max_row_nnz_ = std::max(max_row_nnz_, (int)kn + 1);
+    for (size_t p = 0; p < kn; ++p) amax_ = std::max(amax_, std::fabs(c.val[p]));
+    amax_ = std::max(amax_, 1.0);  // (the slack entry)
     h_colnnz.push_back(1);
     h_single_row.push_back(row);
     h_single_val.push_back(1.0);
@@ -2284,7 +2337,7 @@ Engine* Engine::clone() {
     e->h_obj = h_obj; e->h_lo = h_lo; e->h_hi = h_hi; e->h_rhs = h_rhs;
     e->h_rptr = h_rptr; e->h_rcol = h_rcol; e->h_rval = h_rval;
     e->h_colnnz = h_colnnz; e->h_single_row = h_single_row; e->h_single_val = h_single_val;
-    e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->no_head_fusion = no_head_fusion;
+    e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->amax_ = amax_; e->no_head_fusion = no_head_fusion;
     e->sw_balanced = sw_balanced; e->str_kmax = str_kmax; e->hyper_mode = hyper_mode; e->hyper_heavy = hyper_heavy; e->ratio_two = ratio_two; e->ratio_spin_limit = ratio_spin_limit; e->ranks_share_device = false; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->use_pack = use_pack; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
     e->h_basic_vars = h_basic_vars; e->h_nb_vars = h_nb_vars; e->h_var_loc = h_var_loc;
     e->h_kslot_of_pos = h_kslot_of_pos; e->h_srow_of_pos = h_srow_of_pos; e->h_kslot_of_row = h_kslot_of_row;
@@ -2401,7 +2454,18 @@ uint64_t Engine::state(const char* what, double* out, uint64_t cap) {
         for (int i = 0; i < 24; ++i) tmp.push_back(h_ctl->hy_prof[i] ? (double)(h_ctl->hy_prof[i] - t0) * 0.01 : -1.0);
     }
     else if (w == "hyper_bail_reasons") {
-        for (int i = 0; i < 9; ++i) tmp.push_back((double)stats.hyper_bail_reason[i]);
+        for (int i = 0; i < 10; ++i) tmp.push_back((double)stats.hyper_bail_reason[i]);
+    } else if (w == "w_checksum") {  // (tests of the sharded path) checksum of the nucleus inverse after folding the pending terms: [low 32 bits, high 32 bits, k]
+        flush_lowrank();
+        sync_view();
+        DevBuf<unsigned long long> cs;
+        cs.ensure(1, 0, st);
+        HIPCHECK(hipMemsetAsync(cs.p, 0, sizeof(unsigned long long), st));
+        if (k_ > 0) launch_checksum_w(hview, cs.p, st);
+        unsigned long long h = 0;
+        HIPCHECK(hipMemcpyAsync(&h, cs.p, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        tmp = {(double)(h & 0xffffffffull), (double)(h >> 32), (double)k_};
     } else if (w == "reinvert_scale") tmp = {last_reinvert_scale};  // max |entry| of the fresh nucleus inverse of the last reinvert()
     else if (w == "host_basic_vars") tmp.assign(h_basic_vars.begin(), h_basic_vars.end());
     else if (w == "host_nb_vars") tmp.assign(h_nb_vars.begin(), h_nb_vars.end());

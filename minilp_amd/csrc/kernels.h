@@ -158,6 +158,13 @@ struct DevView {
     int* colblk;
     double* push_part;
     int pb_rb, pb_on;
+    // Deterministic form of the blocked push (pb_det; sharded solves, where the ranks must stay bit-identical replicas, and —
+    // measured no slower — the default everywhere): the LDS accumulators are fixed-point integers (a 64-bit high limb and a
+    // 32-bit low limb per row, scaled per slot chunk by the largest |x_K| of the chunk times pb_amax = max |A|), so that the
+    // LDS atomics are exact, associative integer additions: the result does not depend on their order.  pb_hbits = bits of
+    // headroom for the number of terms one accumulator can receive (ceil(log2(longest row + 1))).
+    int pb_det, pb_hbits;
+    double pb_amax;
     // banded tableau-row sweep (large m): a second copy of A in band-major order (bands of BAND_ROWS rows;
     // per band a CSC with 16-bit local row indices), so that a workgroup can hold its band of (rho, v) in LDS
     int* bptr;              // nbands x (N + 1)
@@ -231,6 +238,29 @@ struct DevView {
     int* str_list;   // n
     int* aq_list;    // m: positions of supp(alpha_q) (listed by the FTRAN when str_on and the F products are pushed)
     int str_on, pad4;
+    // ---- compact factor of the basis (csrc/factor.inc) -------------------------------------
+    // fac_on: B^-1 is NOT held as singleton split + dense nucleus inverse but as a frozen PEELED TRIANGULAR FACTOR of the
+    // basis B0 of the last refactorisation — an iterated column-singleton peel orders (pivot row, position) pairs into levels
+    // such that B0 is upper triangular in that order; nothing is stored beyond A itself and the order (lu.rs:118-304 without
+    // fill: the peel IS the factorisation when the bump is empty) — plus the eta transformations since then in additive form,
+    // B^-1 = B0^-1 + sum_{j < nlow} U_j V_j^T (solver.rs:1274-1284 kept as full-space rank-1 terms, dense, at most fac_J).
+    // Solves are level-scheduled pulls (k_fac_solve; lu.rs:79-106, 432-463): FTRAN walks CSR rows in descending level
+    // order, BTRAN walks CSC columns in ascending level order; the maps below are SNAPSHOTS taken at the refactorisation
+    // (basic_vars / var_loc move on with every pivot).
+    int fac_on, fac_J;
+    int* fac_meta;           // [0] number of levels, [1] number of peeled positions (device copy; read by the solve kernel)
+    int* fac_pos_of_var;     // N: position of a variable in B0, -1 when it was non-basic
+    int* fac_var_of_pos;     // m: variable at a position in B0
+    int* fac_prow;           // m: pivot row of a position
+    double* fac_pval;        // m: pivot element A[prow[p], var_of_pos[p]]
+    int* fac_items;          // m: positions in level order
+    int* fac_lptr;           // levels + 1 offsets into fac_items
+    double* fac_U;           // fac_J x m, by position: U_j = -(alpha_q - e_r) / alpha_q[r] of the j-th pivot since the refactorisation
+    double* fac_V;           // fac_J x m, by row: V_j = rho_r of that pivot
+    double* fac_rhs;         // m, by row: right-hand side of a column FTRAN (zero outside a solve: the solve clears what the head scattered)
+    double* fac_x0;          // m: result of the B0 solve before the rank-1 terms are added (by position for FTRAN, by row for BTRAN)
+    double* fac_coef;        // 2 * fac_J + 1: coefficients V_j . rhs / U_j . c of the running solve
+    unsigned* fac_bar;       // [0] grid barrier counter, [1] exit ticket, [2] reduction ticket
 };
 
 // fused pass tiling
@@ -299,6 +329,19 @@ void launch_shift_nonbasic(const DevView& dv, const Geom& g, int col, double val
 void launch_sq_norms_add_row(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_copy_rho_sq_to_beta(const DevView& dv, int row, hipStream_t st);
 void launch_build_nucleus(const DevView& dv, const Geom& g, double* Kd, int k, hipStream_t st);
+// compact factor (factor.inc)
+void launch_fac_solve(const DevView& dv, const Geom& g, int dir, int src, int dst, const double* src_ptr, hipStream_t st);  // dir 0 FTRAN / 1 BTRAN
+void launch_fac_head(const DevView& dv, int phase, int which, hipStream_t st);   // stage head outside a ratio-test finaliser (primal FTRAN / dual BTRAN)
+void launch_fac_post_ftran(const DevView& dv, const Geom& g, int use_pse, hipStream_t st);  // dual: ||alpha_q||^2 (+ 1), plan
+void launch_fac_append(const DevView& dv, hipStream_t st);                      // U_nlow, V_nlow from alpha_q / rho of this pivot; nlow += 1
+void launch_fac_gather_cb(const DevView& dv, hipStream_t st);                   // alpha_q[p] = c[basic_vars[p]]
+void launch_fac_copy_to_xb(const DevView& dv, int refine, hipStream_t st);      // x_B (+)= tau (recalc_basic_vals), clears tau
+// refactorisation (host-paced peel): init, then claim/commit per level, then the level lists
+void launch_fac_peel_init(const DevView& dv, int* cnt, int* level, int* row_lev, int* claim, int* counters, hipStream_t st);
+void launch_fac_peel_level(const DevView& dv, int lev, int* cnt, int* level, int* row_lev, int* claim, int* cand_row, int* counters, hipStream_t st);
+void launch_fac_peel_fill(const DevView& dv, const int* level, int* cursor, hipStream_t st);
+void launch_str_reset(const DevView& dv, hipStream_t st);  // sparse tableau row: new stamp epoch, empty lists
+void launch_checksum_w(const DevView& dv, unsigned long long* out, hipStream_t st);  // order-independent checksum of W[0:k, 0:k] and the slot maps (tests)
 void launch_fold_lowrank(const DevView& dv, const Geom& g, hipStream_t st);  // W0 += U^T V, nlow := 0 (host-requested flush)
 void launch_gauss_jordan(double* Kd, double* Winv, int k, int ld, int* d_flag, double* d_scratch, hipStream_t st);
 

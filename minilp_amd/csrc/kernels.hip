@@ -1011,6 +1011,124 @@ __global__ void __launch_bounds__(BLK) k_push_stage1(DevView v, int which) {
     double* dst = v.push_part + (size_t)cc * v.m + row0;
     for (int t = tid; t < nrows; t += BLK) dst[t] = acc[t];
 }
+// Deterministic form of the same kernel (DevView.pb_det).  The only order-dependent arithmetic of k_push_stage1 is the sum
+// an LDS accumulator receives through float atomics.  Here every product a * x is split into two fixed-point limbs relative
+// to a bound of the chunk — 2^e > max |x_K| of the chunk's slots times max |A| —
+//     hi = rint(term * 2^(P - e))                           (|hi| <= 2^P, P = min(52, 62 - pb_hbits): exact as a double)
+//     lo = rint((term - hi * 2^(e - P)) * 2^(P - e + LS))   (the remainder is exact; |lo| <= 2^(LS - 1), LS = min(54, 62 - pb_hbits))
+// and the limbs are added with INTEGER LDS atomics (ds_add_u64, two's complement): exact and associative, so the accumulated
+// pair does not depend on the order in which the atomics land, and the value written to push_part —
+// H * 2^(e - P) + L * 2^(e - P - LS), one rounding — is a pure function of the inputs.  Resolution 2^(e - P - LS): 106 bits
+// below the largest possible term, so a row whose terms are all 10^-16 of the chunk's largest (the rounding noise of
+// "structural zeros" of alpha_K) still keeps 53 significant bits — the componentwise backward error of the solve is that
+// of the float sum (tests/test_late_regime.py checks it against the matrix itself).  Ranks of a sharded solve thereby stay
+// bit-identical replicas without the pull over every singleton row (k_pull_F: nnz(A) work per call), and unsharded runs of
+// the large-nucleus regime become reproducible bit for bit.
+constexpr int PBD_TILE = 256;  // slot descriptors per round
+constexpr int PBD_CHUNKS_DEFAULT = 16;  // slot chunks of the deterministic form (MLP_PB_CHUNKS overrides)
+constexpr size_t PBD_LDS = sizeof(unsigned long long) * 2 * PB_ROWS + sizeof(double) * PBD_TILE + sizeof(int) * 2 * PBD_TILE;
+__global__ void __launch_bounds__(BLK) k_push_stage1_det(DevView v, int which) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    KMARK0(c, 19);
+    extern __shared__ unsigned long long s_pbd[];  // 68 KB: two workgroups per CU
+    unsigned long long* accH = s_pbd;                      // PB_ROWS
+    unsigned long long* accL = s_pbd + PB_ROWS;            // PB_ROWS
+    double* s_x = reinterpret_cast<double*>(s_pbd + 2 * PB_ROWS);  // PBD_TILE
+    int* s_beg = reinterpret_cast<int*>(s_x + PBD_TILE);   // PBD_TILE
+    int* s_len = s_beg + PBD_TILE;                         // PBD_TILE
+    __shared__ double s_bound;
+    int b = blockIdx.x, cc = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {  // XCD-aware tile map (see k_push_stage1)
+        const int L = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y, idx = L >> 3;
+        cc = (L & 7) + 8 * (idx / (int)gridDim.x);
+        b = idx % (int)gridDim.x;
+    }
+    const int tid = threadIdx.x;
+    const int row0 = b * PB_ROWS;
+    const int nrows = min(PB_ROWS, v.m - row0);
+    for (int t = tid; t < nrows; t += BLK) {
+        accH[t] = 0ull;
+        accL[t] = 0ull;
+    }
+    const int k = c->k;
+    const int per = (k + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int s_lo = cc * per, s_hi = min(k, s_lo + per);
+    const double* xK = which ? v.tauK : v.aK;
+    {   // bound of the chunk: max |x_K| over its slots (max is order-independent: every row block of the chunk finds the same)
+        double mx = 0.0;
+        for (int s = s_lo + tid; s < s_hi; s += BLK) mx = fmax(mx, fabs(xK[s]));
+        mx = block_max(mx);
+        if (tid == 0) s_bound = mx * v.pb_amax;
+    }
+    __syncthreads();
+    const double bound = s_bound;
+    double* dst = v.push_part + (size_t)cc * v.m + row0;
+    if (!(bound > 0.0) || !(bound < INFINITY)) {  // nothing to push (or a non-finite x: the float form would propagate it; report zero)
+        for (int t = tid; t < nrows; t += BLK) dst[t] = 0.0;
+        return;
+    }
+    int e;
+    (void)frexp(bound, &e);  // bound < 2^e
+    if (e < -900) e = -900;  // (keeps every scale below a finite power of two)
+    const int P = min(52, 62 - v.pb_hbits), LS = min(54, 62 - v.pb_hbits);
+    const double S1 = ldexp(1.0, P - e), iS1 = ldexp(1.0, e - P), SL = ldexp(1.0, P - e + LS), iSL = ldexp(1.0, e - P - LS);
+    const int lane = tid & 7, grp = tid >> 3;  // 8 lanes per slot, 32 slots side by side
+    const int stride = v.pb_rb + 1;
+    for (int tile0 = s_lo; tile0 < s_hi; tile0 += PBD_TILE) {
+        const int nt = min(PBD_TILE, s_hi - tile0);
+        __syncthreads();
+        for (int t = tid; t < nt; t += BLK) {  // phase A: one thread per slot fetches (x, segment of the column inside this row block)
+            const int slot = tile0 + t;
+            const double x = xK[slot];
+            const int var = v.basic_vars[v.pos_of_kslot[slot]];
+            const int beg = v.colblk[(size_t)var * stride + b], end = v.colblk[(size_t)var * stride + b + 1];
+            s_x[t] = x;
+            s_beg[t] = beg;
+            s_len[t] = (x != 0.0) ? end - beg : 0;
+        }
+        __syncthreads();
+        for (int base = grp * 4; base < nt; base += (BLK / 8) * 4) {  // phase B: four slots per 8-lane group in flight
+            int r[4];
+            double a[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = base + j;
+                const int len = t < nt ? s_len[t] : 0;
+                r[j] = -1;
+                a[j] = 0.0;
+                if (lane < len) {
+                    const int en = s_beg[t] + lane;
+                    r[j] = v.csc_row[en] - row0;
+                    a[j] = v.csc_val[en] * s_x[t];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (r[j] >= 0) {
+                    const long long hi = __double2ll_rn(a[j] * S1);
+                    const long long lo = __double2ll_rn((a[j] - (double)hi * iS1) * SL);
+                    atomicAdd(&accH[r[j]], (unsigned long long)hi);
+                    atomicAdd(&accL[r[j]], (unsigned long long)lo);
+                }
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {  // segments longer than 8 entries (rare)
+                const int t = base + j;
+                const int len = t < nt ? s_len[t] : 0;
+                for (int o = 8 + lane; o < len; o += 8) {
+                    const int en = s_beg[t] + o;
+                    const double term = v.csc_val[en] * s_x[t];
+                    const long long hi = __double2ll_rn(term * S1);
+                    const long long lo = __double2ll_rn((term - (double)hi * iS1) * SL);
+                    atomicAdd(&accH[v.csc_row[en] - row0], (unsigned long long)hi);
+                    atomicAdd(&accL[v.csc_row[en] - row0], (unsigned long long)lo);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < nrows; t += BLK) dst[t] = (double)(long long)accH[t] * iS1 + (double)(long long)accL[t] * iSL;
+}
 // The same product through the band-major copy of A (when the banded sweep keeps one): block (band b, chunk c) walks the
 // nucleus slots of its chunk and reads each column's segment inside the band — one 8-byte load for the (begin, end) pair,
 // a contiguous run of ~8 entries — instead of 25 row blocks each re-reading every column's offsets and ~4 entries out of
@@ -1128,7 +1246,7 @@ static void launch_blocked_push(const DevView& dv, int which, hipStream_t st) {
     // but by the serial descriptor / entry chains of its slot tiles.  The row-block form stays the default;
     // MLP_PUSH_BAND=1 selects the band form for experiments.
     static const bool band_push = std::getenv("MLP_PUSH_BAND") != nullptr;
-    if (dv.banded && band_push) {
+    if (dv.banded && band_push && !dv.pb_det) {
         static bool attr_set = false;
         const size_t lds = sizeof(double) * (BAND_ROWS + PBB_TILE) + sizeof(int) * 2 * PBB_TILE;
         if (!attr_set) {
@@ -1146,7 +1264,15 @@ static void launch_blocked_push(const DevView& dv, int which, hipStream_t st) {
     static const int want = std::getenv("MLP_PB_CHUNKS") ? std::atoi(std::getenv("MLP_PB_CHUNKS")) : 0;
     int chunks = want > 0 ? want : PB_CHUNKS_DEFAULT;
     if (chunks > PB_CHUNKS) chunks = PB_CHUNKS;
-    hipLaunchKernelGGL(k_push_stage1, dim3(dv.pb_rb, chunks), dim3(BLK), 0, st, dv, which);
+    if (dv.pb_det) {  // fixed-point limbs: order-independent
+        static bool det_attr = false;
+        if (!det_attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_push_stage1_det), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PBD_LDS);
+            det_attr = true;
+        }
+        if (want <= 0) chunks = PBD_CHUNKS_DEFAULT;  // (two workgroups per CU by LDS: row blocks x chunks should fit one round)
+        hipLaunchKernelGGL(k_push_stage1_det, dim3(dv.pb_rb, chunks), dim3(BLK), PBD_LDS, st, dv, which);
+    } else hipLaunchKernelGGL(k_push_stage1, dim3(dv.pb_rb, chunks), dim3(BLK), 0, st, dv, which);
     hipLaunchKernelGGL(k_push_combine, dim3((dv.m + BLK - 1) / BLK), dim3(BLK), 0, st, dv, which, chunks);
 }
 
@@ -2059,6 +2185,11 @@ __global__ void __launch_bounds__(BAND_THREADS) k_sweep_band(DevView v, int chun
     const int row0 = b * BAND_ROWS;
     const int nrows = min(BAND_ROWS, v.m - row0);
     for (int t = tid; t < nrows; t += BAND_THREADS) s_rv[t] = v.rv[row0 + t];
+    // The entry loop reads whole groups of 8 entries and MASKS the ones beyond a segment's end by a zero value: their row
+    // indices (a neighbour's, or spare entries) still index this LDS array, and 0 * (stale LDS holding a NaN pattern) is NaN.
+    // The last band is short: give the rows beyond it a defined value.  (Found in round 4: the integer accumulators the
+    // deterministic blocked push leaves behind in LDS read as NaNs; three entries of a tableau row came out non-finite.)
+    for (int t = nrows + tid; t < BAND_ROWS; t += BAND_THREADS) s_rv[t] = make_double2(0.0, 0.0);
     __syncthreads();
     const int base = VORD ? 0 : v.nb_lo;
     const int span = VORD ? v.m + v.n : v.nb_hi - v.nb_lo;  // variables, or this rank's non-basic positions
@@ -3197,9 +3328,37 @@ __global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : JM <= 32 ? 3 : 2)) k_fold
 // from plain vector loads, 235 VGPRs, 2 waves per SIMD: correct, 707 us per pivot of the late window against 698 for this
 // form.  The f64 matrix rate of gfx950 equals its vector rate, and the 16 x 16 tile layout turns every load of W into four
 // 128-byte row segments.)
+// Sparse tableau row / sparse ratio test: a batch that starts on state it cannot trust (a dense sweep ran in between, or an
+// iteration stamped and listed columns without closing — ITER_STALL retry, halted batch) advances the stamp epoch and clears
+// both list counters, so that no stale stamp can hide a column from the next iteration's lists.
+__global__ void k_str_reset(DevView v) {
+    v.ctl->hyper_epoch += 1;
+    v.ctl->aq_n = 0;
+    v.ctl->str_n = 0;
+}
+void launch_str_reset(const DevView& dv, hipStream_t st) { hipLaunchKernelGGL(k_str_reset, dim3(1), dim3(1), 0, st, dv); }
 __global__ void k_reset_nlow(DevView v) {
     v.ctl->nlow = 0;
     v.ctl->fold = 0;
+}
+// Order-independent checksum of the k x k nucleus inverse and of its slot maps (tests of the sharded path: every rank of a
+// solve must hold the same bits): the sum over (i, j) of bits(W[i][j]) * (2 (i k + j) + 1) mod 2^64, plus the two maps.
+__global__ void __launch_bounds__(BLK) k_checksum_w(DevView v, unsigned long long* out) {
+    const int k = v.ctl->k;
+    unsigned long long acc = 0ull;
+    const long total = (long)k * k;
+    for (long e = (long)blockIdx.x * BLK + threadIdx.x; e < total; e += (long)gridDim.x * BLK) {
+        const int i = (int)(e / k), j = (int)(e % k);
+        acc += (unsigned long long)__double_as_longlong(v.W[(size_t)i * v.ld + j]) * (2ull * (unsigned long long)e + 1ull);
+    }
+    for (int s = blockIdx.x * BLK + threadIdx.x; s < k; s += gridDim.x * BLK)
+        acc += (unsigned long long)(unsigned)v.pos_of_kslot[s] * 0x9E3779B97F4A7C15ull + (unsigned long long)(unsigned)v.row_of_kslot[s] * 0xC2B2AE3D27D4EB4Full * (unsigned long long)(s + 1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+void launch_checksum_w(const DevView& dv, unsigned long long* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_checksum_w, dim3(2048), dim3(BLK), 0, st, dv, out);
 }
 
 // Row-sharded streaming pass, step 2 of 3 (k_stream_w -> k_post_exchange -> k_post_fused): reduce this rank's partials

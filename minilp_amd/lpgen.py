@@ -196,3 +196,48 @@ def to_mps(lp, ranges=None):
                 out.append(f" UP BND X{j} {hi!r}")
     out.append("ENDATA")
     return "\n".join(out) + "\n"
+
+
+def gen_transport_lp(S, D, deg, seed=7, tight=1.0):
+    """Generalised transportation (network-with-gains) family — the LARGE-AND-SPARSE-NUCLEUS evidence family of SURVEY §8 f3.
+    S supply nodes, D demand nodes, every demand node is linked to `deg` distinct supply nodes: n = D * deg arcs, every column has
+    exactly two entries (its supply row and its demand row).  Min c'x,  sum_j g_ij x_ij <= s_i,  sum_i h_ij x_ij >= d_j,  x >= 0
+    with continuous random gains, costs, supplies and demands (non-degenerate: pivot sequences are comparable).  x = 0 is dual
+    feasible (c > 0) and primal infeasible (the demand rows), so the solve is the dual simplex.  Every basis of such a model is
+    a forest of trees / one-cycle components: permutable to triangular form up to a small bump, i.e. its LU has no fill, while
+    the explicit inverse of the structural part is dense along every root path — the case a compact factor exists for."""
+    n = D * deg
+    draws = 2 * deg + 8
+    cand = (splitmix64(_stream(seed, 41), D * draws) % np.uint64(S)).astype(np.int64).reshape(D, draws)
+    sup = np.empty((D, deg), dtype=np.int64)
+    first = np.sort(cand[:, :deg], axis=1)
+    ok = (first[:, 1:] != first[:, :-1]).all(axis=1) if deg > 1 else np.ones(D, dtype=bool)
+    sup[ok] = first[ok]
+    for r in np.nonzero(~ok)[0]:
+        _, idx = np.unique(cand[r], return_index=True)
+        keep = np.sort(idx)[:deg]
+        assert len(keep) == deg, "not enough distinct candidates"
+        sup[r] = np.sort(cand[r][keep])
+    arc_sup = sup.reshape(-1)                       # arc a = j * deg + t  ->  supply node
+    used = np.unique(arc_sup)                       # supply nodes without an arc would be empty rows (dropped by the solver): renumber
+    arc_sup = np.searchsorted(used, arc_sup)
+    S = len(used)
+    arc_dem = np.repeat(np.arange(D, dtype=np.int64), deg)
+    g = 0.5 + uniform01(_stream(seed, 42), n)       # gain on the supply row
+    h = 0.5 + uniform01(_stream(seed, 43), n)       # gain on the demand row
+    c = 1.0 + uniform01(_stream(seed, 44), n)
+    d = 1.0 + uniform01(_stream(seed, 45), D)
+    load = np.bincount(arc_sup, weights=np.ones(n), minlength=S)
+    # supplies: `tight` = 1 leaves about three times the supply the demands need (few supply rows bind at the optimum: shallow
+    # basis trees); smaller values make more supply rows bind (deeper trees, more pivots); below ~0.35 instances turn infeasible
+    s = (1.0 + uniform01(_stream(seed, 46), S)) * (0.6 + load) * (2.0 * D / max(1.0, float(n))) * 1.5 * tight
+    # CSR: S supply rows (arcs sorted by arc index), then D demand rows
+    order = np.argsort(arc_sup, kind="stable")
+    sup_ptr = np.concatenate(([0], np.cumsum(np.bincount(arc_sup, minlength=S)))).astype(np.int64)
+    indptr = np.concatenate((sup_ptr, sup_ptr[-1] + deg * np.arange(1, D + 1, dtype=np.int64)))
+    indices = np.concatenate((order, np.arange(n, dtype=np.int64)))
+    data = np.concatenate((g[order], h))
+    ops = np.concatenate((np.full(S, LE, dtype=np.int32), np.full(D, GE, dtype=np.int32)))
+    rhs = np.concatenate((s, d))
+    return dict(name=f"transport_{S}x{D}_deg{deg}_s{seed}_t{tight}", direction=MINIMIZE, m=S + D, n=n, obj=c, lo=np.zeros(n),
+                hi=np.full(n, np.inf), indptr=indptr, indices=indices, data=data, ops=ops, rhs=rhs)

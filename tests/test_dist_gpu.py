@@ -106,3 +106,30 @@ def test_sharded_solve_to_optimality_is_optimal_for_a_fresh_unsharded_engine(wor
     assert abs(ru["objective"] - rec["all_ranks"][0]["objective"]) <= 1e-9 * abs(ru["objective"])
     ce = ru["certificate"]
     assert ce["relative_gap"] < 1e-9 and ce["max_primal_violation"] < 1e-9 and ce["max_dual_violation"] < 1e-7
+
+
+@pytest.mark.parametrize("mode", ["default", "replicated"])
+def test_sharded_ranks_stay_bit_identical_replicas_over_8000_pivots_from_the_late_basis(mode):
+    """The gate that can SEE replica divergence (the 256-pivot identical-pivot gate above could not; the round-3
+    defect showed after ~6 000 pivots).  Two ranks continue config 4 from the committed late basis (nucleus 20 493) for 8 000
+    pivots with the DEFAULT sharded machinery — deterministic blocked F push (fixed-point limbs), row-sharded streaming pass —
+    and stop every 1 000 pivots; tools/shard_bitwise.py compares SHA-1 digests of what every rank holds:
+      * at EVERY checkpoint the ranks hold the same bits of x_B, of the basic / non-basic sets and of the nucleus inverse and its
+        slot maps (order-independent checksum), and at the last one of the dual steepest-edge weights rebuilt from the inverse;
+      * the objective keeps the unsharded run's pace to 1e-9 relative at every checkpoint;
+      * mode "replicated" (MLP_NO_WSHARD=1: the streaming pass is not split, so the sharded arithmetic equals the unsharded
+        run's operation for operation): the UNION of the ranks' d and gamma blocks, x_B and the inverse equal the unsharded
+        run's bit for bit at every checkpoint."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_bitwise.py"), "2", "8000", "1000", mode],
+                       capture_output=True, text=True, timeout=1500)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, r.stdout[-2000:] + r.stderr[-2000:]
+    rec = json.loads(lines[-1])
+    assert len(rec["checkpoints"]) == 8 and rec["checkpoints"][-1]["pivots"] >= 8000
+    for cp in rec["checkpoints"]:
+        assert cp["replicas_identical"], (cp["pivots"], cp["replicas_differ_in"])
+        assert cp["objective_rel_diff"] <= 1e-9, cp
+        if mode == "replicated":
+            assert cp["bitwise_equal_to_unsharded"], (cp["pivots"], cp["vs_unsharded"])
+    assert r.returncode == 0 and rec["ok"]

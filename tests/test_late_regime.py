@@ -131,6 +131,9 @@ def test_stepped_stages_satisfy_the_defining_equations_against_the_matrix(cfg4, 
         if r < 0:
             continue  # bound flip: no BTRAN / basis update in this iteration
         alpha, rho, tau, v, alpha_r = got["alpha"], got["rho"], got["tau"], got["v"], got["alpha_r"]
+        for nm_, vec_ in got.items():
+            bad_ = np.nonzero(~np.isfinite(vec_))[0]
+            assert len(bad_) == 0, (nm_, "non-finite entries", len(bad_), bad_[:8].tolist(), "pivot", done, "q", q, "r", r)
         e_r = np.zeros(m)
         e_r[r] = 1.0
         errs = dict(
