@@ -162,6 +162,12 @@ typedef struct mlp_stats {
     /* ---- appended in ABI version 4 ---- */
     uint64_t reinversion_fallbacks; /* re-inversions of the nucleus that a first attempt reported singular and the Gauss-Jordan
                                        kernels then re-examined (0 in a healthy run) */
+    /* compact factor of the basis (a peeled triangular factor + additive eta terms instead of the explicit
+     * nucleus inverse; selected by the measured shape of the basis, MLP_FACTOR=1 / 0 forces it on / off) */
+    uint64_t factor_active;     /* 1 while B^-1 is held as the compact factor */
+    uint64_t factor_refactors;  /* refactorisations (peels of the current basis) so far */
+    uint64_t factor_levels;     /* levels of the last peel = dependent steps of one triangular solve */
+    uint64_t factor_switches;   /* switches between the two representations */
 } mlp_stats;
 void mlp_solution_stats(const mlp_solution* s, mlp_stats* out);
 void mlp_solution_reset_stats(mlp_solution* s);

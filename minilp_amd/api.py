@@ -42,7 +42,9 @@ class MlpStats(C.Structure):
                    ("dense_ftran_bytes", C.c_double), ("dense_ftran_ms", C.c_double), ("dense_ftran_launches", C.c_uint64),
                    ("str_ms", C.c_double), ("str_launches", C.c_uint64),
                    ("hyper_iters", C.c_uint64), ("hyper_bails", C.c_uint64), ("ratio_stalls", C.c_uint64),
-                   ("reinversion_fallbacks", C.c_uint64)])  # appended in ABI version 4 (the struct only grows at its end from here on)
+                   ("reinversion_fallbacks", C.c_uint64),
+                   ("factor_active", C.c_uint64), ("factor_refactors", C.c_uint64), ("factor_levels", C.c_uint64),
+                   ("factor_switches", C.c_uint64)])  # appended in ABI version 4 (the struct only grows at its end from here on)
 
 
 ABI_VERSION = 4  # include/minilp_hip.h: MLP_ABI_VERSION

@@ -327,6 +327,8 @@ void mlp_solution_stats(const mlp_solution* s, mlp_stats* o) {
     o->fold_bytes = t.fold_bytes; o->fold_ms = t.fold_ms; o->fold_launches = t.fold_launches;
     for (int i = 0; i < 5; ++i) o->kase[i] = t.kase[i];
     o->reinversion_fallbacks = t.reinversion_fallbacks;
+    o->factor_active = e->factor_active() ? 1 : 0; o->factor_refactors = t.fac_refactors; o->factor_levels = t.fac_levels;
+    o->factor_switches = t.fac_switches;
 }
 void mlp_solution_reset_stats(mlp_solution* s) {
     guarded([&] { s->eng->resolve_events(); });

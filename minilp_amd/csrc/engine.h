@@ -137,6 +137,7 @@ struct Stats {
     uint64_t hyper_iters = 0, hyper_bails = 0;  // iterations taken by the hypersparse kernel; iterations it handed back
     uint64_t ratio_stalls = 0;   // in-kernel waits of the fused ratio test that timed out (each one retried with two launches)
     uint64_t beta_rebuilds = 0;  // lazy dual steepest edge: exact rebuilds of beta from the basis inverse
+    uint64_t fac_refactors = 0, fac_levels = 0, fac_switches = 0;  // compact factor: refactorisations (peels), levels of the last one, mode switches
     // dense-rhs FTRAN x_B = B^-1 (b - N x_N) (recalc_basic_vals): the streaming read of the nucleus inverse, kernel-exact
     double dense_ftran_bytes = 0, dense_ftran_ms = 0;
     uint64_t dense_ftran_launches = 0;
@@ -222,13 +223,33 @@ private:
     DevBuf<double> d_hy_score;               // m dual pricing scores (derived by the kernel at every launch)
     size_t hy_stamp_len = 0;
     bool hyper_capable(int phase) const;
+    // ---- compact factor of the basis (csrc/factor.inc): B^-1 = (peeled triangular factor of the
+    // basis at the last refactorisation)^-1 + at most fac_J_ additive rank-1 terms, instead of the explicit nucleus inverse
+    int fac_mode = -1;                       // MLP_FACTOR: 1 from the start (falls back to the explicit inverse when the peel leaves a bump),
+                                             // 0 never, -1 auto: tried when the nucleus would need more than fac_auto_cap_ slots
+    bool fac_on_ = false;
+    int fac_J_ = 32;                         // MLP_FACTOR_J: pivots between refactorisations (rank-1 terms kept)
+    int fac_nlev_ = 0;
+    int fac_auto_cap_ = 8192;                // MLP_FACTOR_FROM
+    uint64_t fac_tried_at_ = 0;              // lifetime pivot count of the last attempt that found a bump
+    bool fac_tried_ = false;
+    DevBuf<int> d_fac_pos_of_var, d_fac_var_of_pos, d_fac_prow, d_fac_items, d_fac_lptr, d_fac_meta, d_fac_tmp, d_fac_counters;
+    DevBuf<double> d_fac_pval, d_fac_U, d_fac_V, d_fac_rhs, d_fac_x0, d_fac_coef;
+    DevBuf<unsigned> d_fac_bar;
+    void fac_alloc();
+    void fac_fill_view(DevView& v) const;
+    bool fac_refactor();                     // the peel + level lists from the current basis; false when it leaves a bump
+    bool fac_enter();                        // switch to the compact factor (false: the basis does not peel; nothing changed)
+    void fac_make_room(int need);
+    void fac_leave();                        // back to the explicit nucleus inverse (re-inversion from A)
+    void launch_stage_fac(int phase, int stage, bool with_events);
     void ensure_hyper();         // sharded solve with another rank on this GPU (or unknown): same
     // Lazy dual steepest edge: the primal loop never reads beta, so its iterations skip tau = B^-1 rho (solver.rs:1157)
     // and the beta recurrence; beta is rebuilt exactly from the basis inverse (k_exact_beta) when something next needs it
     bool lazy_dse = true;                    // MLP_LAZY_DSE=0: maintain beta in every pivot like the reference
     bool beta_stale = false;
     bool batch_lazy = false;                 // the iterations being recorded skip the beta recurrence
-    bool lazy_now(int phase) const { return lazy_dse && enable_dse && phase == 0 && !stepping && max_row_nnz_ <= HEAD_LIST_CAP; }
+    bool lazy_now(int phase) const { return lazy_dse && enable_dse && phase == 0 && !stepping && !fac_on_ && max_row_nnz_ <= HEAD_LIST_CAP; }
     void ensure_beta();
     std::vector<int> h_colnnz, h_single_row;
     std::vector<double> h_single_val;
@@ -284,6 +305,7 @@ private:
     bool use_banded() const;
   public:
     bool banded_active() const { return use_banded(); }
+    bool factor_active() const { return fac_on_; }
     void restart_sampling() { batches_run = 0; }
   private:
     void ensure_banded();

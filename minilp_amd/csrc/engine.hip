@@ -112,6 +112,9 @@ Engine::Engine() {
     if (const char* hh = std::getenv("MLP_HYPER_HEAVY")) hyper_heavy = std::atol(hh);        // work bound per iteration (tests force bail-outs)
     if (const char* rs = std::getenv("MLP_RATIO_SPIN_LIMIT")) ratio_spin_limit = std::atoll(rs);
     if (const char* sb = std::getenv("MLP_STREAM_BALANCED")) sw_balanced = std::atoi(sb);
+    if (const char* fm = std::getenv("MLP_FACTOR")) fac_mode = std::atoi(fm) > 0 ? 1 : 0;
+    if (const char* fj = std::getenv("MLP_FACTOR_J")) fac_J_ = std::max(1, std::min(64, std::atoi(fj)));
+    if (const char* ff = std::getenv("MLP_FACTOR_FROM")) fac_auto_cap_ = std::max(256, std::atoi(ff));
     const char* nhf = std::getenv("MLP_NO_HEAD_FUSION");
     no_head_fusion = nhf && std::atoi(nhf) != 0;
     const char* nws = std::getenv("MLP_NO_WSHARD");
@@ -321,11 +324,12 @@ Geom Engine::geom() const {
     g.sweep_variant = sweep_variant;
     g.big = (cap_ > 4096 || force_big_tiles) ? 1 : 0;
     const int lr = lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 32 : 0);  // as in sync_view
-    g.head_fused = (!no_head_fusion && lr == 0 && max_col_nnz_ <= HEAD_LIST_CAP && max_row_nnz_ <= HEAD_LIST_CAP) ? 1 : 0;
+    g.head_fused = (!no_head_fusion && !fac_on_ && lr == 0 && max_col_nnz_ <= HEAD_LIST_CAP && max_row_nnz_ <= HEAD_LIST_CAP) ? 1 : 0;
+    g.fac = fac_on_ ? 1 : 0;
     // in-kernel wait between the two Harris passes: never while the ranks of a sharded solve share a device (their grids
     // compete for the same CUs), never again after a wait has timed out once
     g.ratio_two = (ratio_two || (shard_world > 1 && ranks_share_device)) ? 1 : 0;
-    g.str = (str_now && !stepping) ? 1 : 0;
+    g.str = (str_now && !stepping && !fac_on_) ? 1 : 0;
     return g;
 }
 
@@ -495,7 +499,7 @@ DevView* Engine::sync_view() {
     // (16 up to cap 16 384 in round 1: 304 vs 296 us per pivot at k = 10 000).  A period of 64 was measured in round 3 at
     // k = 20 500: the fused fold REPLACES that pivot's streaming pass, so its net cost is (1 338 - 479) / 32 = 27 us per pivot
     // and a period of 64 could save 13 of them at best; the 64-term kernel (occupancy 2) took 3.2 ms: 716 vs 695 us per pivot
-    v.lrJ = lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 32 : 0);
+    v.lrJ = fac_on_ ? 0 : (lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 32 : 0));  // (compact factor: Ctl.nlow counts ITS rank-1 terms)
     v.alpha_q = d_work.p;
     v.tau = d_work.p + (size_t)m_;
     v.rv = reinterpret_cast<double2*>(d_work.p + 2 * (size_t)m_);
@@ -511,7 +515,8 @@ DevView* Engine::sync_view() {
     v.hy_var_slot = d_hy_stamp.p ? d_hy_stamp.p + num_vars + m_ : nullptr;
     v.hy_brng = d_hy_stamp.p ? reinterpret_cast<int2*>(d_hy_stamp.p + ((2 * ((size_t)num_vars + m_) + 1) & ~(size_t)1)) : nullptr;
     v.hy_score = d_hy_score.p;
-    v.str_on = (str_now && !stepping) ? 1 : 0;
+    v.str_on = (str_now && !stepping && !fac_on_) ? 1 : 0;
+    fac_fill_view(v);
     v.pad4 = 0;
     v.str_list = d_str_list.p;
     v.aq_list = d_str_list.p ? d_str_list.p + (((size_t)num_vars + 63) & ~(size_t)63) : nullptr;
@@ -595,8 +600,20 @@ void Engine::alloc_row_buffers(int m_new) {
 }
 
 void Engine::ensure_nucleus_cap(int need) {
+    if (fac_on_) return;       // compact factor: there is no nucleus inverse to grow
     if (need > m_) need = m_;  // the nucleus can never exceed the number of rows
     if (need <= cap_) return;
+    // Selection of the second representation by the MEASURED shape of the basis: before the explicit inverse
+    // grows past fac_auto_cap_ slots (8 k^2 bytes, O(k^2) traffic per pivot), peel the current basis; if the peel consumes
+    // every column (no bump: the LU of this basis has no fill) the solve continues on the compact factor.  A basis that does
+    // not peel (config 4: a random sparse nucleus fills to dense) keeps the explicit inverse; the attempt is repeated only
+    // after the nucleus has doubled again.
+    if (fac_mode < 0 && need > fac_auto_cap_ && shard_world == 1 && !stepping && d_ctl.p && k_ > 0 &&
+        (!fac_tried_ || cap_ >= 2 * (int)fac_tried_at_)) {
+        fac_tried_ = true;
+        fac_tried_at_ = (uint64_t)std::max(cap_, 1);
+        if (fac_enter()) return;
+    }
     flush_lowrank();  // pending rank-1 terms are folded before the buffers move
     HIPCHECK(hipStreamSynchronize(st));
     long ncap_l = std::max(256L, (long)cap_ * 2);
@@ -740,6 +757,7 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name) {
     if (world < 1 || world > MAX_WORLD || rank < 0 || rank >= world)
         throw MlpError(-1, "enable_sharding: bad rank/world (at most " + std::to_string(MAX_WORLD) + " ranks)");
     HIPCHECK(hipStreamSynchronize(st));
+    if (fac_on_ && world > 1) fac_leave();  // (the compact factor is a one-GPU representation)
     release_mailboxes();
     if (world == 1) {
         shard_rank = 0; shard_world = 1;
@@ -1027,6 +1045,7 @@ void Engine::try_new(const ProblemData& pd) {
     launch_init_nb_rng(hview, geom(), st);
     HIPCHECK(hipStreamSynchronize(st));
     values_dirty = true;
+    if (fac_mode == 1 && m_ > 0) (void)fac_enter();  // MLP_FACTOR=1: the compact factor from the slack basis on (one level)
 }
 
 // ------------------------------------------------------------------ values / objective
@@ -1074,6 +1093,10 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     // the host-paced stepping API keeps the separate combine so that row_coeffs is readable after STAGE_ROW
     const int inl = (dv.banded && phase == 0 && !stepping && !g.str) ? 1 : 0;
     const bool tau_branch = use_branches && dv.pb_on && phase == 0 && !stepping && shard_world == 1 && !lazy_now(phase);
+    if (dv.fac_on) {  // compact factor of the basis (factor.inc): the same stages over level-scheduled solves
+        launch_stage_fac(phase, stage, with_events);
+        return;
+    }
     if (stage == STAGE_BASIS) touch_done = false;
     // The pricing decision (q for primal, r for dual) is already in Ctl: it was taken by the
     // previous iteration's update kernel, or by the standalone pricing kernel at batch start.
@@ -1259,6 +1282,7 @@ int Engine::step_stage(int stage, StepInfo* out) {
     if (step_pos == 0) {
         sync_view();
         ensure_nucleus_cap(k_ + 2);
+        fac_make_room(1);
         sync_view();
         launch_reset_ring(hview, st);  // one record per stepped iteration
     }
@@ -1277,7 +1301,7 @@ int Engine::step_stage(int stage, StepInfo* out) {
         step_pos = 0;
         status = res;
         if (res != ITER_PIVOT) status = step_finish(phase, res);
-        else if (!(h_ctl->max_pivot_err <= refresh_tol) && k_ > 0) rebuild_inverse();
+        else if (!(h_ctl->max_pivot_err <= refresh_tol) && (k_ > 0 || fac_on_)) rebuild_inverse();
         h_ctl->it.status = status;
     } else if (status != ITER_PIVOT && status != ITER_FLIP) {
         // UNBOUNDED / INFEASIBLE / SINGULAR decided inside the iteration
@@ -1365,6 +1389,7 @@ int Engine::process_records(int phase, int launched) {
 
 int Engine::run_loop(int phase) {
     if (phase == 1) ensure_beta();  // the dual pricing reads beta
+    if (fac_on_) pull_ctl();        // (the count of pending rank-1 terms)
     str_clean = false;  // (whatever ran since the last loop may have written alpha_r / helper densely)
     batch_lazy = lazy_now(phase);
     for (;;) {
@@ -1397,6 +1422,7 @@ int Engine::run_loop(int phase) {
             int B = RING;
             if (pivot_budget > 0 && (int64_t)B > pivot_budget) B = (int)pivot_budget;
             ensure_nucleus_cap(k_ + B + 1);
+            if (fac_on_) continue;  // (the capacity request switched to the compact factor: plan the batch again)
             ensure_hyper();
             sync_view();
             launch_reset_ring(hview, st);
@@ -1427,7 +1453,7 @@ int Engine::run_loop(int phase) {
                 hyper_bail_streak = 0;
             }
             if (h_ctl->max_pivot_err > stats.max_pivot_err) stats.max_pivot_err = h_ctl->max_pivot_err;
-            if (res == ITER_PIVOT && !(h_ctl->max_pivot_err <= refresh_tol) && k_ > 0) rebuild_inverse();
+            if (res == ITER_PIVOT && !(h_ctl->max_pivot_err <= refresh_tol) && (k_ > 0 || fac_on_)) rebuild_inverse();
             if (res != ITER_PIVOT) return res;
             continue;
         }
@@ -1436,7 +1462,7 @@ int Engine::run_loop(int phase) {
         // kernel) in between leaves them dirty.
         {
             // (sharded solves too: a rank lists and pulls the touched columns of its own block of non-basic positions)
-            const bool want = str_kmax > 0 && !stepping && k_ + RING + 1 <= str_kmax && max_row_nnz_ <= 4096;
+            const bool want = str_kmax > 0 && !stepping && !fac_on_ && k_ + RING + 1 <= str_kmax && max_row_nnz_ <= 4096;
             if (want != str_now) {
                 str_now = want;
                 view_dirty = true;
@@ -1464,7 +1490,7 @@ int Engine::run_loop(int phase) {
         // long runs move on to graphs of several iterations and batches of a full record ring: one
         // launch and one host round trip cover more pivots (6 990 -> 7 300 pivots/s on config 4); short
         // warm-start re-solves never pay for capturing the longer graph
-        const bool multi = graph_now && long_run;
+        const bool multi = graph_now && long_run && !fac_on_;
         int B = graph_now ? (multi ? RING : batch) : 1;
         if (pivot_budget > 0 && (int64_t)B > pivot_budget) B = (int)pivot_budget;
         if (hyper_gap > 0 && B > hyper_gap) B = hyper_gap;
@@ -1478,7 +1504,24 @@ int Engine::run_loop(int phase) {
             }
         }
         const bool graph_batch = graph_now;
-        ensure_nucleus_cap(k_ + B + 1);
+        {
+            const bool fac_before = fac_on_;
+            ensure_nucleus_cap(k_ + B + 1);  // (may switch to the compact factor: then the batch is planned again)
+            if (fac_on_ != fac_before) continue;
+        }
+        if (fac_on_) {
+            // compact factor: every basis change of the batch appends a rank-1 term; refactor (re-peel the current basis)
+            // when fewer than a batch of them fit — the reference's rule is eta nnz >= LU nnz (solver.rs:1096-1103)
+            int room = fac_J_ - h_ctl->nlow;
+            if (room < std::min(fac_J_, std::max(1, std::min(B, 8)))) {
+                if (!fac_refactor()) {  // the basis no longer peels: back to the explicit inverse
+                    fac_leave();
+                    continue;
+                }
+                room = fac_J_;
+            }
+            if (B > room) B = room;
+        }
         sync_view();
         const DevView& dv = hview;
         launch_reset_ring(dv, st);
@@ -1552,7 +1595,7 @@ int Engine::run_loop(int phase) {
         }
         // drift monitor: the pivot element from FTRAN and from the tableau row must agree
         if (h_ctl->max_pivot_err > stats.max_pivot_err) stats.max_pivot_err = h_ctl->max_pivot_err;
-        if (res == ITER_PIVOT && !(h_ctl->max_pivot_err <= refresh_tol) && k_ > 0) rebuild_inverse();
+        if (res == ITER_PIVOT && !(h_ctl->max_pivot_err <= refresh_tol) && (k_ > 0 || fac_on_)) rebuild_inverse();
         if (res == ITER_STALL && !ratio_two && shard_world == 1 && !(phase == 1 && h_ctl->forced)) {
             // The in-kernel wait between the two Harris passes timed out: the grid was not co-resident (another process
             // holds the CUs, or the occupancy estimate was wrong for this partition).  Nothing of the iteration has been
@@ -1584,7 +1627,7 @@ void Engine::ensure_beta() {
 // row / column short enough for the in-kernel stage heads.  auto: models with few non-zeros per row (the regime where the
 // multi-kernel iteration loses to reach-restricted CPU work); MLP_HYPER=1 / 0 force it on (where it applies) / off.
 bool Engine::hyper_capable(int phase) const {
-    if (hyper_mode == 0 || phase != 1 || enable_pse || shard_world != 1 || stepping) return false;
+    if (hyper_mode == 0 || phase != 1 || enable_pse || shard_world != 1 || stepping || fac_on_) return false;
     if ((lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 32 : 0)) != 0 || use_banded()) return false;
     if (cap_ > 4096) return false;  // (the kernel's dense passes over the nucleus slots hold HY_KU = 8 elements per thread: 4 096 slots)
     // the launch reserves capacity for k_ + RING + 1 slots first (ensure_nucleus_cap): that must not double a 4 096-slot W
@@ -1606,6 +1649,172 @@ void Engine::ensure_hyper() {
     view_dirty = true;
 }
 
+// ------------------------------------------------------------------ compact factor of the basis (factor.inc)
+constexpr int FAC_MAX_LEVELS = 4096;
+void Engine::fac_alloc() {
+    const size_t mm = (size_t)std::max(m_, 1), NN = (size_t)std::max(N_, 1), J = (size_t)fac_J_;
+    d_fac_pos_of_var.ensure(NN, 0, st); d_fac_var_of_pos.ensure(mm, 0, st); d_fac_prow.ensure(mm, 0, st);
+    d_fac_items.ensure(mm, 0, st); d_fac_lptr.ensure(FAC_MAX_LEVELS + 2, 0, st); d_fac_meta.ensure(4, 0, st);
+    d_fac_tmp.ensure(5 * mm, 0, st); d_fac_counters.ensure(4, 0, st);
+    d_fac_pval.ensure(mm, 0, st); d_fac_x0.ensure(mm, 0, st); d_fac_coef.ensure(2 * J + 2, 0, st);
+    d_fac_U.ensure(J * mm, 0, st); d_fac_V.ensure(J * mm, 0, st);
+    {   // the right-hand side vector is zero outside a solve, the barrier words outside a kernel
+        const double* before = d_fac_rhs.p;
+        d_fac_rhs.ensure(mm, 0, st);
+        if (d_fac_rhs.p != before) HIPCHECK(hipMemsetAsync(d_fac_rhs.p, 0, sizeof(double) * d_fac_rhs.cap, st));
+        const unsigned* b0 = d_fac_bar.p;
+        d_fac_bar.ensure(4, 0, st);
+        if (d_fac_bar.p != b0) HIPCHECK(hipMemsetAsync(d_fac_bar.p, 0, sizeof(unsigned) * d_fac_bar.cap, st));
+    }
+}
+void Engine::fac_fill_view(DevView& v) const {
+    v.fac_on = fac_on_ ? 1 : 0;
+    v.fac_J = fac_J_;
+    v.fac_meta = d_fac_meta.p; v.fac_pos_of_var = d_fac_pos_of_var.p; v.fac_var_of_pos = d_fac_var_of_pos.p;
+    v.fac_prow = d_fac_prow.p; v.fac_pval = d_fac_pval.p; v.fac_items = d_fac_items.p; v.fac_lptr = d_fac_lptr.p;
+    v.fac_U = d_fac_U.p; v.fac_V = d_fac_V.p; v.fac_rhs = d_fac_rhs.p; v.fac_x0 = d_fac_x0.p; v.fac_coef = d_fac_coef.p;
+    v.fac_bar = d_fac_bar.p;
+}
+// The refactorisation (BasisSolver::reset, solver.rs:1286-1303 -> lu_factorize, lu.rs:118-304): an iterated column-singleton
+// peel of the CURRENT basis on the device, one level per pair of launches, paced by the host (it reads one counter per level:
+// ~20 us per level, amortised over fac_J_ pivots).  Returns false — and leaves the factor as it was — when the peel stops
+// before every column is consumed (the basis has a bump: its LU would fill).
+bool Engine::fac_refactor() {
+    HIPCHECK(hipStreamSynchronize(st));
+    if (m_ <= 0) return false;
+    fac_alloc();
+    sync_view();
+    DevView t = hview;  // (also used to probe while the explicit inverse is still the representation in use)
+    fac_fill_view(t);
+    const size_t mm = (size_t)m_;
+    int* cnt = d_fac_tmp.p;
+    int* level = cnt + mm;
+    int* row_lev = level + mm;
+    int* claim = row_lev + mm;
+    int* cand_row = claim + mm;
+    HIPCHECK(hipMemsetAsync(d_fac_counters.p, 0, 4 * sizeof(int), st));
+    launch_fac_peel_init(t, cnt, level, row_lev, claim, st);
+    std::vector<int> lptr(1, 0);
+    int total = 0;
+    for (int lev = 1; lev <= FAC_MAX_LEVELS; ++lev) {
+        launch_fac_peel_level(t, lev, cnt, level, row_lev, claim, cand_row, d_fac_counters.p, st);
+        int hc[4] = {0, 0, 0, 0};
+        HIPCHECK(hipMemcpyAsync(hc, d_fac_counters.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        if (hc[2]) throw MlpError(-2, "singular basis matrix: a basic column lost its last unclaimed row in the peel (solver.rs:1301)");
+        if (hc[0] == total) break;
+        total = hc[0];
+        lptr.push_back(total);
+        if (total == m_) break;
+    }
+    if (total != m_) return false;  // a bump is left: not the shape this representation is for
+    const int nlev = (int)lptr.size() - 1;
+    HIPCHECK(hipMemcpyAsync(d_fac_lptr.p, lptr.data(), sizeof(int) * lptr.size(), hipMemcpyHostToDevice, st));
+    const int meta[4] = {nlev, total, 0, 0};
+    HIPCHECK(hipMemcpyAsync(d_fac_meta.p, meta, sizeof(meta), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)std::max(nlev, 1), st));  // (cnt is free again: the per-level fill cursors)
+    launch_fac_peel_fill(t, level, cnt, st);
+    HIPCHECK(hipMemsetAsync(&d_ctl.p->nlow, 0, 2 * sizeof(int), st));  // a fresh factor has no pending terms
+    HIPCHECK(hipStreamSynchronize(st));  // (lptr / meta were staged from local memory)
+    h_ctl->nlow = 0;
+    fac_nlev_ = nlev;
+    stats.fac_refactors += 1;
+    stats.fac_levels = (uint64_t)nlev;
+    stats.reinversions += 1;
+    return true;
+}
+// room for `need` more rank-1 terms before an iteration that runs outside run_loop (stepping API, fix_var's forced pivot)
+void Engine::fac_make_room(int need) {
+    if (!fac_on_) return;
+    pull_ctl();
+    if (fac_J_ - h_ctl->nlow >= need) return;
+    if (!fac_refactor()) fac_leave();
+}
+bool Engine::fac_enter() {
+    if (fac_on_) return true;
+    if (shard_world > 1 || m_ <= 0 || !d_ctl.p) return false;
+    ensure_beta();      // (the exact rebuild of the dual edge weights reads the explicit inverse: do it while there is one)
+    flush_lowrank();
+    if (!fac_refactor()) return false;
+    // the explicit inverse and its work arrays go back to the allocator: this representation exists to not hold them
+    HIPCHECK(hipStreamSynchronize(st));
+    d_W.release(); d_U.release(); d_V.release(); d_Ut.release(); d_part_v.release(); d_part_tau.release();
+    cap_ = 0;
+    k_ = 0;
+    ensure_nucleus_cap(256);  // (small placeholders: the launch geometry of the shared kernels is sized by the capacity)
+    HIPCHECK(hipMemcpyAsync(&d_ctl.p->k, &k_, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    fac_on_ = true;
+    str_now = false;
+    view_dirty = true;
+    stats.fac_switches += 1;
+    sync_view();
+    return true;
+}
+void Engine::fac_leave() {
+    if (!fac_on_) return;
+    HIPCHECK(hipStreamSynchronize(st));
+    fac_on_ = false;
+    view_dirty = true;
+    stats.fac_switches += 1;
+    const int keep_mode = fac_mode;
+    const bool keep_tried = fac_tried_;
+    fac_mode = 0;  // (the re-inversion below must not switch straight back)
+    try {
+        rebuild_inverse();  // classify singleton / nucleus columns, invert the nucleus from A (may end in MLP_ENOMEM on the models this mode exists for)
+    } catch (...) {
+        fac_mode = keep_mode;
+        throw;
+    }
+    fac_mode = keep_mode;
+    fac_tried_ = keep_tried;
+    HIPCHECK(hipMemsetAsync(&d_ctl.p->nlow, 0, 2 * sizeof(int), st));
+    HIPCHECK(hipStreamSynchronize(st));
+}
+// One stage of an iteration on the compact factor: the heads, ratio tests, tableau row and update are the kernels of the default
+// path (their partition-specific parts are switched off by DevView.fac_on); the solves are k_fac_solve, and the pivot's eta
+// transformation is appended as a rank-1 term just before the update kernel zeroes alpha_q and rho behind itself.
+void Engine::launch_stage_fac(int phase, int stage, bool with_events) {
+    const DevView& dv = hview;
+    const Geom g = geom();
+    const int pse = enable_pse ? 1 : 0, dse = enable_dse ? 1 : 0;
+    const int inl = (dv.banded && phase == 0 && !stepping) ? 1 : 0;
+    switch (stage) {
+    case STAGE_FTRAN:
+        if (with_events) HIPCHECK(hipEventRecord(ev[6], st));
+        if (phase == 0) launch_ftran_prep(dv, 1, st);            // entering column's scalars; the column becomes the right-hand side
+        launch_fac_solve(dv, g, 0, 0, 0, nullptr, 0, st);        // alpha_q = B^-1 a_q
+        if (with_events) HIPCHECK(hipEventRecord(ev[7], st));
+        if (phase == 1) launch_post_ftran(dv, g, pse, st);       // ||alpha_q||^2 + 1, plan (1 / alpha_q[r])
+        break;
+    case STAGE_RATIO:
+        if (phase == 0) launch_ratio_primal(dv, g, pse, st);
+        else launch_ratio_dual(dv, g, st);                       // (its finaliser scatters the entering column for the FTRAN)
+        break;
+    case STAGE_BTRAN:
+        if (phase == 1) launch_btran_prep(dv, 1, 0, st);         // leaving row's scalars
+        launch_fac_solve(dv, g, 1, 0, 0, nullptr, 0, st);        // rho = B^-T e_r, ||rho||^2
+        break;
+    case STAGE_BASIS:
+        if (pse) launch_fac_solve(dv, g, 1, 1, 1, nullptr, 0, st);   // v = B^-T alpha_q      (solver.rs:1114)
+        if (dse) launch_fac_solve(dv, g, 0, 1, 1, nullptr, 0, st);   // tau = B^-1 rho        (solver.rs:1157)
+        break;
+    case STAGE_ROW:
+        if (phase == 0) launch_sweep(dv, g, pse ? 1 : 0, 0, st, inl);
+        else launch_sweep(dv, g, 0, 0, st);
+        break;
+    case STAGE_APPLY:
+        if (phase == 1 && pse) launch_sweep(dv, g, 2, 0, st);
+        if (with_events) HIPCHECK(hipEventRecord(ev[4], st));
+        launch_fac_append(dv, st);
+        launch_update_pivot(dv, g, phase, dse, pse, st, inl, 0);
+        if (with_events) HIPCHECK(hipEventRecord(ev[5], st));
+        break;
+    default:
+        throw MlpError(-1, "unknown stage");
+    }
+}
+
 // ------------------------------------------------------------------ loops (solver.rs:470-547)
 void Engine::initial_solve() {
     double t0 = now_s();
@@ -1623,7 +1832,7 @@ void Engine::initial_solve() {
     for (int round = 0; round < 3 && !budget_exhausted && final_refresh_pivots > 0 &&
                         iters_since_polish >= (uint64_t)final_refresh_pivots; ++round) {
         iters_since_polish = 0;
-        if (k_ > 0) rebuild_inverse();  // fresh K^-1 from A first: the polish is only as accurate as the inverse it uses
+        if (k_ > 0 || fac_on_) rebuild_inverse();  // fresh K^-1 from A first: the polish is only as accurate as the inverse it uses
         recalc_basic_vals();
         recalc_obj_coeffs();  // objective (and reduced costs) of the recomputed point
         stats.final_refreshes += 1;
@@ -1698,7 +1907,8 @@ void Engine::calc_col_coeffs(int col) {  // solver.rs:671-677
     launch_clear_work(hview, st);
     launch_set_iter(dv, ITER_PIVOT, col, -1, 0.0, 0, st);
     launch_ftran_prep(dv, 0, st);
-    launch_ftran_gather(dv, geom(), st);
+    if (dv.fac_on) launch_fac_solve(dv, geom(), 0, 0, 0, nullptr, 0, st);
+    else launch_ftran_gather(dv, geom(), st);
 }
 void Engine::calc_row_coeffs(int row, bool with_sweep) {  // solver.rs:680-693
     sync_view();
@@ -1706,7 +1916,8 @@ void Engine::calc_row_coeffs(int row, bool with_sweep) {  // solver.rs:680-693
     launch_clear_work(hview, st);
     launch_set_iter(dv, ITER_PIVOT, -1, row, 0.0, 0, st);
     launch_btran_prep(dv, 0, 0, st);
-    launch_btran(dv, geom(), 0, st);
+    if (dv.fac_on) launch_fac_solve(dv, geom(), 1, 0, 0, nullptr, 0, st);
+    else launch_btran(dv, geom(), 0, st);
     if (with_sweep) launch_sweep(dv, geom(), 0, 0, st);
 }
 
@@ -1770,6 +1981,7 @@ void Engine::fix_var(int var, double val) {  // solver.rs:378-415
         // basic: one forced dual pivot towards `val` (solver.rs:384-391)
         int row = h_var_loc[var];
         ensure_nucleus_cap(k_ + 2);
+        fac_make_room(1);
         if (str_now) {  // (the forced iteration runs outside run_loop: dense tableau row, whatever the last batch used)
             str_now = false;
             view_dirty = true;
@@ -1912,6 +2124,7 @@ void Engine::append_row_on_device(const Constraint& c, int slack, int row) {
 void Engine::add_constraint(Constraint c) {
     double t0 = now_s();
     if (!primal_feasible || !dual_feasible) throw MlpError(-1, "add_constraint: model not solved (solver.rs:555-556)");
+    if (fac_on_) fac_leave();  // (a new row changes every per-row array of the factor: warm starts run on the explicit inverse)
     ensure_beta();
     if (c.idx.empty()) {
         bool taut = c.op == 0 ? (0.0 == c.rhs) : c.op == 1 ? (0.0 <= c.rhs) : (0.0 >= c.rhs);
@@ -1992,6 +2205,14 @@ void Engine::add_constraint(Constraint c) {
 // nucleus), build K = B[R_K, P_K] densely from the CSC and invert it on the device.
 void Engine::rebuild_inverse() {
     HIPCHECK(hipStreamSynchronize(st));
+    if (fac_on_) {  // compact factor: the counterpart of BasisSolver::reset is a new peel of the current basis
+        if (fac_refactor()) return;
+        fac_on_ = false;  // the basis no longer peels: fall through to the explicit inverse
+        view_dirty = true;
+        stats.fac_switches += 1;
+    } else if (fac_mode == 1 && shard_world == 1 && !stepping) {
+        if (fac_enter()) return;
+    }
     HIPCHECK(hipMemsetAsync(&d_ctl.p->nlow, 0, 2 * sizeof(int), st));  // a fresh inverse has no pending terms
     std::vector<int> claimed(m_, -1);
     std::vector<int> nuc_pos;
@@ -2091,6 +2312,11 @@ void Engine::rebuild_inverse() {
 }
 
 double Engine::reinvert(bool replace) {
+    if (fac_on_) {  // compact factor: a fresh peel of the current basis (there is no incremental inverse to compare with)
+        (void)replace;
+        rebuild_inverse();
+        return 0.0;
+    }
     flush_lowrank();
     pull_maps();
     if (k_ == 0) return 0.0;
@@ -2390,6 +2616,9 @@ Engine* Engine::clone() {
     HIPCHECK(hipStreamSynchronize(s2));
     std::memcpy(e->h_ctl, h_ctl, sizeof(Ctl));
     e->values_dirty = true;
+    e->fac_mode = fac_mode; e->fac_J_ = fac_J_; e->fac_auto_cap_ = fac_auto_cap_;
+    if (fac_on_ && !e->fac_enter())  // (a fresh peel of the same basis: the same operator, no pending terms)
+        throw MlpError(-3, "clone: the basis of a solution on the compact factor must peel");
     return owner.release();
 }
 

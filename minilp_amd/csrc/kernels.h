@@ -281,6 +281,7 @@ struct Geom {
     int big;            // fused W pass: 64-row x 1024-column blocks, non-temporal (cap > 4096, or forced by MLP_BIGTILE)
     int head_fused;     // stage heads run inside the consuming kernel (delayed-update mode off, every column / row fits the LDS list)
     int str;            // sparse tableau row instead of the sweep over all of A (nucleus of at most MLP_STR_K columns, one GPU)
+    int fac;            // compact factor of the basis instead of the explicit nucleus inverse (factor.inc)
     int ratio_two;      // the two Harris passes as two launches (no in-kernel wait): MLP_RATIO_TWO_KERNELS, ranks sharing a device, after an ITER_STALL
 };
 
@@ -330,14 +331,13 @@ void launch_sq_norms_add_row(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_copy_rho_sq_to_beta(const DevView& dv, int row, hipStream_t st);
 void launch_build_nucleus(const DevView& dv, const Geom& g, double* Kd, int k, hipStream_t st);
 // compact factor (factor.inc)
-void launch_fac_solve(const DevView& dv, const Geom& g, int dir, int src, int dst, const double* src_ptr, hipStream_t st);  // dir 0 FTRAN / 1 BTRAN
-void launch_fac_head(const DevView& dv, int phase, int which, hipStream_t st);   // stage head outside a ratio-test finaliser (primal FTRAN / dual BTRAN)
-void launch_fac_post_ftran(const DevView& dv, const Geom& g, int use_pse, hipStream_t st);  // dual: ||alpha_q||^2 (+ 1), plan
-void launch_fac_append(const DevView& dv, hipStream_t st);                      // U_nlow, V_nlow from alpha_q / rho of this pivot; nlow += 1
-void launch_fac_gather_cb(const DevView& dv, hipStream_t st);                   // alpha_q[p] = c[basic_vars[p]]
-void launch_fac_copy_to_xb(const DevView& dv, int refine, hipStream_t st);      // x_B (+)= tau (recalc_basic_vals), clears tau
-// refactorisation (host-paced peel): init, then claim/commit per level, then the level lists
-void launch_fac_peel_init(const DevView& dv, int* cnt, int* level, int* row_lev, int* claim, int* counters, hipStream_t st);
+// one level-scheduled solve: dir 0 FTRAN (src 0 entering column | 1 rho | 2 src_ptr by row; dst 0 alpha_q | 1 tau),
+// dir 1 BTRAN (src 0 e_r | 1 alpha_q | 2 src_ptr by position; dst 0 rho + ||rho||^2 | 1 v); always: whatever the iteration status
+void launch_fac_solve(const DevView& dv, const Geom& g, int dir, int src, int dst, const double* src_ptr, int always, hipStream_t st);
+void launch_fac_append(const DevView& dv, hipStream_t st);     // U_nlow, V_nlow from alpha_q / rho of this pivot; nlow += 1
+void launch_fac_gather_cb(const DevView& dv, hipStream_t st);  // alpha_q[p] = c[basic_vars[p]]
+// refactorisation (host-paced peel): init, then claim + commit per level, then the level lists
+void launch_fac_peel_init(const DevView& dv, int* cnt, int* level, int* row_lev, int* claim, hipStream_t st);
 void launch_fac_peel_level(const DevView& dv, int lev, int* cnt, int* level, int* row_lev, int* claim, int* cand_row, int* counters, hipStream_t st);
 void launch_fac_peel_fill(const DevView& dv, const int* level, int* cursor, hipStream_t st);
 void launch_str_reset(const DevView& dv, hipStream_t st);  // sparse tableau row: new stamp epoch, empty lists

@@ -541,6 +541,12 @@ __device__ void plan_update(const DevView& v, Ctl* c, int phase) {
     StructUpdate& u = c->up;
     u.kase = -1;
     if (c->it.status != ITER_PIVOT) return;
+    if (v.fac_on) {  // compact factor (factor.inc): no partition to maintain; the pivot becomes a rank-1 term (k_fac_append)
+        c->it.inv_alpha = 1.0 / v.alpha_q[c->it.r];
+        c->fold = 0;
+        u.r = c->it.r;
+        return;
+    }
     const int r = c->it.r, ev = c->it.entering_var;
     const int sr = v.kslot_of_pos[r];
     const bool old_nuc = sr >= 0;
@@ -644,6 +650,11 @@ __device__ void ftran_prep_wave(const DevView& v, Ctl* c, int lane, int derive_p
         }
     }
     int base = v.csc_ptr[var], end = v.csc_ptr[var + 1];
+    if (v.fac_on) {  // compact factor: the entering column becomes the right-hand side (by row) of the level-scheduled solve
+        for (int e = base + lane; e < end; e += 64) v.fac_rhs[v.csc_row[e]] = v.csc_val[e];
+        if (lane == 0) it->klist_n = 0;
+        return;
+    }
     int cnt = 0;
     // delayed-update mode: c_j = V[j] . (listed entries of a_q), lane j serves pending term j (LR_MAX <= 64).  The
     // listed entries travel by shuffle in list order (the same summation order as a walk over the stored list), so
@@ -706,6 +717,13 @@ __device__ void btran_prep_wave(const DevView& v, Ctl* c, int lane, int r, int d
         it->leaving_var = v.basic_vars[r];
         it->q = -1;
         it->entering_var = -1;
+    }
+    if (v.fac_on) {  // compact factor: rho = B^-T e_r comes from the level-scheduled solve (k_fac_solve), nothing to list
+        if (lane == 0) {
+            it->blist_n = 0;
+            if (plan_after) plan_update(v, c, phase);
+        }
+        return;
     }
     int sr = v.kslot_of_pos[r];
     const int nlow = v.lrJ ? c->nlow : 0;
@@ -1680,7 +1698,7 @@ __global__ void __launch_bounds__(BLK) k_post_ftran(DevView v, int use_pse) {
         for (int p = blockIdx.x * BLK + threadIdx.x; p < v.m; p += gridDim.x * BLK) {
             double coeff = v.alpha_q[p];
             sq += coeff * coeff;
-            if (v.kslot_of_pos[p] < 0) v.rv[v.srow_of_pos[p]].y = coeff / v.sdiag_of_pos[p];
+            if (!v.fac_on && v.kslot_of_pos[p] < 0) v.rv[v.srow_of_pos[p]].y = coeff / v.sdiag_of_pos[p];
         }
     }
     if (!grid_sum(sq, v)) return;
@@ -4218,6 +4236,7 @@ __global__ void __launch_bounds__(BLK) k_row_pull(DevView v, int n_pull) {
 }
 
 #include "hyper.inc"  // the hypersparse single-workgroup iteration (uses the stage helpers above)
+#include "factor.inc"  // the compact factor of the basis: peel, level-scheduled solves, additive eta terms
 
 // ===================================================================================== launchers
 #define LANES_SWITCH(L, STMT4, STMT16, STMT32) \
@@ -4641,6 +4660,11 @@ void launch_set_iter(const DevView& dv, int status, int q, int r, double lnv, in
 }
 void launch_reset_ring(const DevView& dv, hipStream_t st) { hipLaunchKernelGGL(k_reset_ring, dim3(1), dim3(1), 0, st, dv); }
 void launch_btran_dense(const DevView& dv, const Geom& g, hipStream_t st) {
+    if (dv.fac_on) {  // compact factor: c_B by position -> alpha_q, y = B^-T c_B -> rv.y
+        launch_fac_gather_cb(dv, st);
+        launch_fac_solve(dv, g, 1, 1, 1, nullptr, 1, st);
+        return;
+    }
     if (g.cap <= 0) return;
     // c_B by position -> alpha_q, y_S -> rv.y; then tK, vK = W^T tK, scatter into rv.y
     hipLaunchKernelGGL(k_gather_basic_obj, dim3(blocks_for(g.m)), dim3(BLK), 0, st, dv);
@@ -4692,6 +4716,12 @@ void launch_recalc_basic_vals(const DevView& dv, const Geom& g, const double* rh
     else if (g.lanes <= 16) hipLaunchKernelGGL(k_residual_rhs<16>, dim3(blocks_for((long)g.m * 16)), dim3(BLK), 0, st, dv, rhs, r_tmp, refine);
     else hipLaunchKernelGGL(k_residual_rhs<64>, dim3(blocks_for((long)g.m * 64)), dim3(BLK), 0, st, dv, rhs, r_tmp, refine);
     launch_clear_work(dv, st);
+    if (dv.fac_on) {  // compact factor: tau = B^-1 r by one level-scheduled solve
+        launch_fac_solve(dv, g, 0, 2, 1, r_tmp, 1, st);
+        hipLaunchKernelGGL(k_copy_tau_to_xb, dim3(blocks_for(g.m)), dim3(BLK), 0, st, dv, refine);
+        launch_clear_work(dv, st);
+        return;
+    }
     const int t = g.m > g.cap ? g.m : g.cap;
     hipLaunchKernelGGL(k_seed_dense_ftran, dim3(blocks_for(t)), dim3(BLK), 0, st, dv, (const double*)r_tmp);
     // Large-nucleus regime: the dense-rhs FTRAN x_K = W0 r_K is ONE streaming read of the nucleus inverse through the

@@ -286,3 +286,62 @@ def test_mps_numbers_parse_like_f64_from_str_whatever_the_locale():
             assert "parse float" in str(e.value), bad
     finally:
         locale.setlocale(locale.LC_NUMERIC, old)
+
+
+def _c_prototypes(header_text):
+    """{name: number of parameters} of every function prototype of the C header."""
+    text = re.sub(r"/\*.*?\*/", " ", header_text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(mlp_[a-z_0-9]+)\s*\(([^()]*)\)\s*;", text):
+        args = " ".join(m.group(2).split())
+        protos[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    return protos
+
+
+def _rust_extern_fns(path):
+    """{name: number of parameters} of every fn declared inside `extern "C" { ... }` blocks of a Rust source file."""
+    src = "\n".join(ln.split("//")[0] for ln in open(path).read().splitlines())
+    fns = {}
+    for blk in re.finditer(r'extern\s+"C"\s*\{(.*?)\n\}', src, flags=re.S):
+        for m in re.finditer(r"\bfn\s+([a-z_0-9]+)\s*\(([^()]*)\)", blk.group(1)):
+            args = " ".join(m.group(2).split()).rstrip(",")
+            fns[m.group(1)] = 0 if not args else args.count(",") + 1
+    return fns
+
+
+def test_rust_sys_crate_declares_only_what_the_library_exports_with_the_headers_arity():
+    """The Rust crates cannot be compiled here (no cargo / rustc in the image); this makes the FFI layer checkable anyway: every
+    `extern "C"` declaration of integration/rust/minilp-hip-sys must be a symbol libminilp_hip.so exports, with the number of
+    parameters include/minilp_hip.h gives it."""
+    sys_rs = os.path.join(ROOT, "integration", "rust", "minilp-hip-sys", "src", "lib.rs")
+    fns = _rust_extern_fns(sys_rs)
+    assert len(fns) >= 40, sorted(fns)
+    protos = _c_prototypes(open(os.path.join(ROOT, "include", "minilp_hip.h")).read())
+    lib = ctypes.CDLL(M.lib_path())
+    for name, nargs in sorted(fns.items()):
+        assert hasattr(lib, name), f"{name} is declared in minilp-hip-sys but not exported by the library"
+        assert name in protos, f"{name} is declared in minilp-hip-sys but not in the C header"
+        assert protos[name] == nargs, f"{name}: {nargs} parameters in minilp-hip-sys, {protos[name]} in the C header"
+    # and the drop-in crate calls nothing the sys crate does not declare
+    used = set(re.findall(r"\bsys::(mlp_[a-z_0-9]+)\s*\(", open(os.path.join(ROOT, "integration", "rust", "minilp", "src", "lib.rs")).read()))
+    used |= set(re.findall(r"\bsys::(mlp_[a-z_0-9]+)\s*\(", open(os.path.join(ROOT, "integration", "rust", "minilp", "src", "mps.rs")).read()))
+    assert used and used <= set(fns), sorted(used - set(fns))
+
+
+def test_rust_api_surface_document_matches_the_crate_source():
+    """integration/rust/API_SURFACE.md (generated by tools/rust_api_surface.py in the build container, where the reference
+    sources are) lists every public item of the reference's lib.rs / mps.rs next to the crate's: none missing, none different —
+    and the crate's side of the list is re-derived here from the crate source, so the document cannot go stale."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rust_api_surface", os.path.join(ROOT, "tools", "rust_api_surface.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    doc = open(os.path.join(ROOT, "integration", "rust", "API_SURFACE.md")).read()
+    assert "### MISSING" not in doc and "### different" not in doc
+    counts = re.findall(r"public items in the reference: \*\*(\d+)\*\*; present in the crate with an identical signature: \*\*(\d+)\*\*", doc)
+    assert len(counts) == 2 and all(a == b and int(a) > 0 for a, b in counts), counts
+    for fname in ("lib.rs", "mps.rs"):
+        ours = mod.pub_items(os.path.join(ROOT, "integration", "rust", "minilp", "src", fname))
+        section = doc.split("## `%s`" % fname)[1].split("\n## `")[0]
+        listed = re.findall(r"^\* `(.*)`$", section.split("### identical")[1].split("###")[0], flags=re.M)
+        assert listed and all(sig in set(ours.values()) for sig in listed), [s for s in listed if s not in set(ours.values())]

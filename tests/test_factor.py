@@ -1,0 +1,199 @@
+"""GPU: the COMPACT FACTOR of the basis (minilp_amd/csrc/factor.inc) — the second
+representation of B^-1 next to the explicit nucleus inverse: an iterated column-singleton peel of the basis (a triangular
+factor without fill: lu.rs:118-304 / ordering.rs:4-21 carried to the fixed point), level-scheduled pulls for FTRAN / BTRAN
+(lu.rs:79-106, 432-463) and the eta transformations since the last refactorisation as additive rank-1 terms
+(solver.rs:1274-1284).  Gates: the oracle's pivot sequence on the non-degenerate families (the operator is the same
+whichever representation applies it), objective / values at the optimum, the defining equations of every solve against the
+matrix itself, and the switches between the two representations."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import minilp_amd as M
+from minilp_amd import api as A
+from minilp_amd import lpgen
+from oracle import minilp_oracle as O
+from tests.common import X_ATOL, check_feasible, obj_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(lp, **kw):
+    so = lpgen.build_problem(O.Problem, lp).solve(trace=True)
+    sg = lpgen.build_problem(M.Problem, lp).solve(trace=True, **kw)
+    return so, sg
+
+
+@pytest.mark.parametrize("args,tight", [((300, 300, 3, 7), 1.0), ((800, 1000, 4, 11), 0.5), ((2500, 2500, 4, 3), 0.4), ((4000, 5000, 5, 9), 0.4)], ids=str)
+def test_transport_family_on_the_compact_factor_takes_the_oracles_pivots(monkeypatch, args, tight):
+    """Network-with-gains instances (every column has two entries: every basis is a forest, its peel leaves no bump): the whole
+    solve — the dual simplex — runs on the compact factor from the slack basis on (MLP_FACTOR=1), refactoring every 32 pivots."""
+    monkeypatch.setenv("MLP_FACTOR", "1")
+    lp = lpgen.gen_transport_lp(*args, tight=tight)
+    so, sg = _pair(lp)
+    st = sg.stats()
+    print(args, "pivots", st["iterations"], "refactorisations", st["factor_refactors"], "levels", st["factor_levels"], "switches", st["factor_switches"])
+    assert st["factor_active"] == 1 and st["factor_switches"] == 1 and st["factor_refactors"] >= st["iterations"] // 32
+    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+    assert obj_close(sg.objective(), so.objective())
+    assert np.abs(sg.values() - so.values()).max() <= X_ATOL
+    check_feasible(lp, sg.values())
+    assert sg.stats()["max_pivot_err"] < 1e-9      # the pivot element from FTRAN and from the tableau row agree
+    bo, bg = so.state("dual_edge_sq_norms"), sg.state("dual_edge_sq_norms")
+    assert np.abs(bo - bg).max() <= 1e-8 * max(1.0, np.abs(bo).max())
+
+
+@pytest.mark.parametrize("J", [1, 5, 64])
+def test_refactor_period_does_not_change_the_pivot_sequence(monkeypatch, J):
+    """MLP_FACTOR_J: one term (refactor after every pivot), five, sixty-four pending rank-1 terms."""
+    monkeypatch.setenv("MLP_FACTOR", "1")
+    monkeypatch.setenv("MLP_FACTOR_J", str(J))
+    lp = lpgen.gen_transport_lp(600, 700, 4, 5, tight=0.45)
+    so, sg = _pair(lp)
+    assert sg.stats()["factor_active"] == 1
+    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+    assert obj_close(sg.objective(), so.objective())
+
+
+def test_a_basis_that_stops_peeling_goes_back_to_the_explicit_inverse(monkeypatch):
+    """Config-4 family (random sparse rows): the slack basis peels (one level) and so do the first bases, then the nucleus
+    closes cycles — a bump — and the solve continues on the explicit inverse; the oracle's pivots throughout (primal loop
+    with both steepest-edge recurrences: v = B^-T alpha_q and tau = B^-1 rho through the factor while it lasts)."""
+    monkeypatch.setenv("MLP_FACTOR", "1")
+    lp = lpgen.gen_sparse_lp(400, 300, 12, 7)
+    so, sg = _pair(lp)
+    st = sg.stats()
+    print("pivots", st["iterations"], "refactorisations", st["factor_refactors"], "switches", st["factor_switches"])
+    assert st["factor_switches"] >= 2 and st["factor_active"] == 0 and st["factor_refactors"] >= 1
+    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+    assert obj_close(sg.objective(), so.objective())
+    assert np.abs(sg.values() - so.values()).max() <= X_ATOL
+
+
+def test_two_phase_instance_on_the_compact_factor(monkeypatch):
+    """Transport rows with the objective reversed on a bounded box: neither primal nor dual feasible at the start — dual loop on
+    the artificial objective, recalc_obj_coeffs through the factor (dense-rhs BTRAN), then the primal loop with steepest edge."""
+    monkeypatch.setenv("MLP_FACTOR", "1")
+    lp = lpgen.gen_transport_lp(500, 600, 4, 13, tight=0.5)
+    lp = dict(lp)
+    lp["direction"] = lpgen.MAXIMIZE
+    lp["hi"] = np.full(lp["n"], 3.0)
+    so, sg = _pair(lp)
+    st = sg.stats()
+    print("pivots", st["iterations"], "primal", st["primal_iters"], "dual", st["dual_iters"], "refactorisations", st["factor_refactors"], "active", st["factor_active"])
+    assert st["primal_iters"] > 0 and st["dual_iters"] > 0
+    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+    assert obj_close(sg.objective(), so.objective())
+    assert np.abs(sg.values() - so.values()).max() <= X_ATOL
+
+
+def test_auto_selection_switches_when_the_nucleus_outgrows_the_threshold(monkeypatch):
+    """Default policy with the threshold lowered (MLP_FACTOR_FROM: 8 192 slots by default): the solve starts on the explicit
+    inverse, and when the nucleus needs more capacity the current basis is peeled — it leaves no bump, so the solve continues
+    on the compact factor, same pivots as the oracle."""
+    monkeypatch.setenv("MLP_FACTOR_FROM", "256")
+    monkeypatch.setenv("MLP_HYPER", "0")
+    lp = lpgen.gen_transport_lp(1500, 1500, 4, 21, tight=0.45)
+    so, sg = _pair(lp)
+    st = sg.stats()
+    print("pivots", st["iterations"], "refactorisations", st["factor_refactors"], "levels", st["factor_levels"], "nucleus capacity", st["nucleus_capacity"])
+    assert st["factor_active"] == 1 and st["factor_switches"] == 1 and st["iterations"] > 1000
+    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+    assert obj_close(sg.objective(), so.objective())
+    assert np.abs(sg.values() - so.values()).max() <= X_ATOL
+
+
+def test_auto_selection_keeps_the_explicit_inverse_for_a_nucleus_that_does_not_peel(monkeypatch):
+    monkeypatch.setenv("MLP_FACTOR_FROM", "256")
+    lp = lpgen.gen_sparse_lp(3000, 2600, 12, 4)
+    so, sg = _pair(lp)
+    st = sg.stats()
+    assert st["factor_active"] == 0 and st["factor_switches"] == 0 and st["nucleus_size"] > 256
+    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+
+
+def _backward_error(resid, *abs_terms):
+    den = sum(abs_terms)
+    den = np.where(den > 0, den, 1.0)
+    return float((np.abs(resid) / den).max())
+
+
+def test_stepped_stages_on_the_compact_factor_satisfy_the_defining_equations(monkeypatch):
+    """Engine-level stepping with the compact factor and several pending rank-1 terms: after every stage the vector it produced
+    is checked against the constraint matrix itself by scipy — B alpha_q = a_q, B^T rho = e_r, B tau = rho, alpha_r = N^T rho —
+    nothing of the engine on the reference side (the same check tests/test_late_regime.py makes on the explicit inverse)."""
+    monkeypatch.setenv("MLP_FACTOR", "1")
+    monkeypatch.setenv("MLP_FACTOR_J", "8")
+    lp = lpgen.gen_transport_lp(900, 900, 4, 17, tight=0.45)
+    m, n = lp["m"], lp["n"]
+    Acsc = sp.csr_matrix((lp["data"], lp["indices"], lp["indptr"]), shape=(m, n)).tocsc()
+    Aext = sp.hstack([Acsc, sp.identity(m, format="csc")], format="csc")
+    Aabs = abs(Aext)
+    s = lpgen.build_problem(M.Problem, lp).solve(budget=300)    # 300 pivots in: pending terms, several levels
+    assert s.stats()["factor_active"] == 1
+    st, info = s.engine_open()
+    assert st == A.ITER_PIVOT and info["phase"] == 1
+    worst = {}
+    for done in range(20):
+        bv = s.state("basic_vars").astype(np.int64)
+        nb = s.state("nb_vars").astype(np.int64)
+        B, Babs = Aext[:, bv], Aabs[:, bv]
+        r = int(info["row"])
+        got = {}
+        while True:
+            stage = info["next_stage"]
+            st, info = s.engine_stage(stage)
+            if stage == A.STAGE_BTRAN:
+                got["rho"] = s.state("inv_basis_row_coeffs")
+            elif stage == A.STAGE_ROW:
+                got["alpha_r"] = s.state("row_coeffs")
+            elif stage == A.STAGE_RATIO:
+                q = int(info["col"])
+            elif stage == A.STAGE_FTRAN:
+                got["alpha"] = s.state("col_coeffs")
+            elif stage == A.STAGE_BASIS:
+                got["tau"] = s.state("tau")
+            if stage == A.STAGE_APPLY or st not in (A.ITER_PIVOT, A.ITER_FLIP):
+                break
+        assert stage == A.STAGE_APPLY and st in (A.ITER_PIVOT, A.ITER_FLIP, A.ITER_FEASIBLE), (stage, st)
+        aq = np.asarray(Aext[:, int(nb[q])].todense()).ravel()
+        e_r = np.zeros(m)
+        e_r[r] = 1.0
+        alpha, rho, tau, alpha_r = got["alpha"], got["rho"], got["tau"], got["alpha_r"]
+        errs = dict(ftran=_backward_error(B @ alpha - aq, Babs @ np.abs(alpha), np.abs(aq)),
+                    btran=_backward_error(B.T @ rho - e_r, Babs.T @ np.abs(rho), e_r),
+                    tau=_backward_error(B @ tau - rho, Babs @ np.abs(tau), np.abs(rho)))
+        N, Nabs = Aext[:, nb], Aabs[:, nb]
+        errs["row"] = float((np.abs(alpha_r - N.T @ rho) / np.maximum(Nabs.T @ np.abs(rho), 1e-300)).max())
+        for kname, e in errs.items():
+            worst[kname] = max(worst.get(kname, 0.0), e)
+            assert e < 1e-9, (kname, e, done)
+        if st == A.ITER_FEASIBLE:
+            break
+    print("stepped pivots on the compact factor; worst componentwise backward errors:", {k: f"{e:.1e}" for k, e in worst.items()})
+
+
+def test_clone_fix_and_unfix_on_the_compact_factor(monkeypatch):
+    """Solution::clone re-peels the same basis; fix_var / unfix_var (solver.rs:378-438) run their forced dual pivot and the
+    re-solves on the factor; add_constraint (a new row) goes back to the explicit inverse."""
+    monkeypatch.setenv("MLP_FACTOR", "1")
+    lp = lpgen.gen_transport_lp(400, 500, 4, 23, tight=0.5)
+    so = lpgen.build_problem(O.Problem, lp).solve()
+    sg = lpgen.build_problem(M.Problem, lp).solve()
+    assert sg.stats()["factor_active"] == 1 and obj_close(sg.objective(), so.objective())
+    x = sg.values()
+    j = int(np.argmax(x))
+    cg, co = sg.clone(), so.clone()
+    cg = cg.fix_var(j, 0.5 * x[j])
+    co = co.fix_var(j, 0.5 * x[j])
+    assert cg.stats()["factor_active"] == 1
+    assert obj_close(cg.objective(), co.objective())
+    cg, _ = cg.unfix_var(j)
+    co, _ = co.unfix_var(j)
+    assert obj_close(cg.objective(), co.objective()) and obj_close(cg.objective(), so.objective())
+    assert obj_close(sg.objective(), so.objective())                      # the original is untouched by its clone's pivots
+    k = int(np.argsort(x)[-2])
+    sg2 = sg.add_constraint([(j, 1.0), (k, 1.0)], lpgen.LE, 0.7 * (x[j] + x[k]))
+    so2 = so.add_constraint([(j, 1.0), (k, 1.0)], lpgen.LE, 0.7 * (x[j] + x[k]))
+    assert sg2.stats()["factor_active"] == 0
+    assert obj_close(sg2.objective(), so2.objective())
