@@ -302,6 +302,10 @@ def compact_line(out):
                                 avg_launch_us=r(rf["avg_launch_us"], 2), launches=rf["launches"],
                                 algorithmic_bytes_per_launch=r(rf["algorithmic_bytes_per_launch"], 0))
         line["roofline"]["measured"] = dict(achieved="live", traffic=rf.get("traffic_measured"))
+        if rf.get("pivot_level"):
+            pl = rf["pivot_level"]
+            line["roofline"]["pivot_level"] = dict(bytes_per_pivot=r(pl["bytes_per_pivot"], 0), us_per_pivot=r(pl["us_per_pivot"], 1),
+                                                   achieved=r(pl["achieved"], 1), frac=r(pl["frac"], 4))
         if rf.get("window"):
             line["roofline"]["window"] = rf["window"][:120]
         tw = rf.get("timed_window")
@@ -342,6 +346,16 @@ def compact_line(out):
                                     sample=cb["sample"][:200])
         if cb.get("window_200_700"):
             line["cpu_baseline"]["pivots_200_700"] = r(cb["window_200_700"]["value"], 2)
+        if cb.get("gpu_over_cpu_same_window"):
+            line["cpu_baseline"]["gpu_over_cpu_same_window"] = r(cb["gpu_over_cpu_same_window"], 2)
+    if out.get("parity"):
+        line["parity"] = dict(oracle_identical_through_pivot=out["parity"]["oracle_identical_through_pivot"], beyond="defining equations vs A at k = 9 999 / 20 493 + live duality certificate")
+    for key in ("value_vs_1gpu", "pricing_speedup_vs_1gpu", "unsharded_same_run"):
+        if out.get(key) is not None:
+            line[key] = out[key] if isinstance(out[key], dict) else r(out[key], 3)
+    if out.get("factor_transport"):
+        ft_ = out["factor_transport"]
+        line["factor_transport"] = {k_: (r(v_, 2) if isinstance(v_, float) else v_) for k_, v_ in ft_.items() if k_ not in ("chunks", "note")}
     return line
 
 
@@ -496,6 +510,15 @@ def main():
                                            f"{late['nucleus_size_at_start']} columns (the regime of > 90 % of the solve's wall time)",
                                     samples=late["sampling"], timed_window=timed,
                                     ftran=ftran_obj)
+                    # the same window at PIVOT level: the bytes a late pivot must move (the 8 k^2-byte pass, the fold's 16 k^2 every
+                    # 32nd pivot net of the pass it replaces) over the whole pivot's time — what the solve actually achieves per pivot
+                    kk = float(late["nucleus_size_at_start"])
+                    pivot_bytes = 8.0 * kk * kk + (16.0 * kk * kk - 8.0 * kk * kk) / 32.0
+                    roofline["pivot_level"] = dict(bytes_per_pivot=pivot_bytes, us_per_pivot=late["us_per_pivot"],
+                                                   achieved=pivot_bytes / (late["us_per_pivot"] * 1e-6) / 1e9, peak=HBM_PEAK_GBS,
+                                                   frac=pivot_bytes / (late["us_per_pivot"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                   note="late window: (8 k^2 + 8 k^2 / 32) bytes per pivot / us per pivot / peak — the kernel-level "
+                                                        "fraction above times the share of a pivot the pass takes")
                     out["roofline"] = roofline
                 if roofline:
                     for name in ("mid", "late"):
@@ -512,6 +535,14 @@ def main():
                         "pivot (`w_pass_v` in the windows) computes v = B^-T alpha_q: BTRAN-shaped, not an FTRAN")
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(lp, a.warmup, a.steps, a.cpu_pivots)
+                cbv = out["cpu_baseline"]
+                cbv["gpu_over_cpu_same_window"] = out["value"] / cbv["value"] if cbv.get("value") else None
+            # how far "same pivots as the reference algorithm" is pinned on this workload, and what covers the rest
+            out["parity"] = dict(oracle_identical_through_pivot=9652,
+                                 pinned_by="tests/golden/cfg4_oracle_trace.npz (first 8 000 pivots, driver-run test); the sequences part at pivot 9 653 "
+                                           "because the REFERENCE algorithm's steepest-edge weights drift (DESIGN.md §8)",
+                                 beyond="defining equations of every solve against A at nuclei of 9 999 and 20 493 (tests/test_late_regime.py), "
+                                        "duality certificate of the finished solve (full_solve.certificate, checked on the box)")
             if not a.no_full_solve:
                 s.set_sampling(None)   # no event-bracketed iterations in the long run
                 out["full_solve"] = full_solve_live(s, lp, a, T_START, solve_s, pivots_before)
@@ -536,6 +567,39 @@ def main():
                                              shard=(dist, mdist, barrier, max_over_ranks))
         except Exception as e:  # every rank leaves setup_sharding through the same door; later failures are bounded waits
             late_sharded = dict(error=str(e))
+    # N > 1: the same two windows UNSHARDED, measured by rank 0 in this very run (the other ranks wait at the barrier), so that
+    # the line carries its own 1-GPU reference: value_vs_1gpu for the timed window, and the ratio of the pricing path
+    # (tableau-row sweep + d / gamma update + pricing scan: what north_star's ">= 3x at 8 GPUs" is about) for the late window
+    if world > 1 and sharded:
+        if rank == 0:
+            try:
+                ref = {}
+                s1 = prob.solve(budget=0, profile=True)
+                s1.continue_solve(a.warmup)
+                s1.reset_stats()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                s1.continue_solve(a.steps)
+                torch.cuda.synchronize()
+                dt1 = time.perf_counter() - t0
+                ref["timed_window_pivots_per_s"] = float(s1.stats()["iterations"]) / dt1
+                del s1
+                out["value_vs_1gpu"] = out["value"] / ref["timed_window_pivots_per_s"]
+                if late_sharded and "error" not in late_sharded and not a.no_windows:
+                    lu = window_from_basis(M, prob, LATE_BASIS, 32, a.window_steps[1], min(a.samples, 16), dense_ftran=False)
+                    def pricing(kk_):
+                        return (kk_.get("sweep", {}).get("avg_us") or 0.0) + (kk_.get("update", {}).get("avg_us") or 0.0)
+                    pu, ps = pricing(lu["kernels"]), pricing(late_sharded["kernels"])
+                    ref["late_us_per_pivot"] = lu["us_per_pivot"]
+                    ref["late_pricing_path_us"] = pu
+                    late_sharded["pricing_path_us"] = ps
+                    if pu > 0 and ps > 0:
+                        out["pricing_speedup_vs_1gpu"] = pu / ps
+                    ref["late_us_per_pivot_sharded"] = late_sharded["us_per_pivot"]
+                out["unsharded_same_run"] = {k_: round(v_, 2) for k_, v_ in ref.items()}
+            except Exception as e:
+                out["unsharded_same_run"] = dict(error=str(e)[:200])
+        dist.barrier()
     if rank == 0:
         if late_sharded is not None:
             out.setdefault("windows", {})["late_sharded"] = late_sharded

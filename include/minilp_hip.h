@@ -130,6 +130,19 @@ int mlp_solution_recompute_basic_values(mlp_solution* s);
  * returns when every rank has mapped every mailbox (bounded waits: a missing rank is an error, MLP_EHIP).
  * Primal and dual loops; the Solution mutators are refused.  mlp_solution_transport names the transport in use. */
 int mlp_solution_enable_sharding(mlp_solution* s, int rank, int world, const char* shm_name);
+/* The same with the transport named by the caller: NULL / "" = the default above (or MLP_TRANSPORT), "peer", "host",
+ * "rccl" — north_star's literal transport: the mailbox records of every exchange (16-byte pricing candidates, the ratio decision,
+ *          the dual loop's minimum / candidate) are delivered by ncclAllGather over xGMI: the pivot kernels post into and poll their
+ *          own device box, and while a batch of pivots is in flight the host pumps stage -> ncclAllGather -> deliver rounds on a
+ *          second stream until every rank's batch has drained.  rccl_id = the 128-byte ncclUniqueId made by rank 0
+ *          (mlp_rccl_unique_id) and distributed by the launcher; librccl.so is loaded at run time.  Slower per exchange than
+ *          the peer stores (a collective per round), so it is the fallback for nodes where the peer mappings do not deliver;
+ * "pump" — the rccl transport's protocol with peer copies between IPC-mapped staging buffers in place of the collective (RCCL
+ *          refuses two ranks on one device; this is how the protocol is tested on a one-GPU box).
+ * The pump transports accept world = 1. */
+int mlp_solution_enable_sharding_ex(mlp_solution* s, int rank, int world, const char* shm_name, const char* transport,
+                                    const void* rccl_id);
+int mlp_rccl_unique_id(void* out128);
 const char* mlp_solution_transport(const mlp_solution* s);
 
 typedef struct mlp_stats {
@@ -168,6 +181,8 @@ typedef struct mlp_stats {
     uint64_t factor_refactors;  /* refactorisations (peels of the current basis) so far */
     uint64_t factor_levels;     /* levels of the last peel = dependent steps of one triangular solve */
     uint64_t factor_switches;   /* switches between the two representations */
+    uint64_t factor_bump;       /* columns the last peel left over (cycles of the basis graph; their inverse is kept explicitly) */
+    uint64_t factor_bump_max;   /* largest bump of any refactorisation so far */
 } mlp_stats;
 void mlp_solution_stats(const mlp_solution* s, mlp_stats* out);
 void mlp_solution_reset_stats(mlp_solution* s);

@@ -88,7 +88,12 @@ extern "C" {
     pub fn mlp_problem_solve_from_basis(p: *const mlp_problem, blob: *const std::os::raw::c_void, len: u64,
                                         out: *mut *mut mlp_solution, pivot_budget: i64, flags: u32) -> c_int;
     pub fn mlp_solution_enable_sharding(s: *mut mlp_solution, rank: c_int, world: c_int, shm_name: *const c_char) -> c_int;
+    pub fn mlp_solution_enable_sharding_ex(s: *mut mlp_solution, rank: c_int, world: c_int, shm_name: *const c_char,
+                                           transport: *const c_char, rccl_id: *const std::os::raw::c_void) -> c_int;
+    pub fn mlp_rccl_unique_id(out128: *mut std::os::raw::c_void) -> c_int;
     pub fn mlp_solution_transport(s: *const mlp_solution) -> *const c_char;
+    pub fn mlp_abi_version() -> u32;
+    pub fn mlp_stats_size() -> u64;
 
     pub fn mlp_engine_open(s: *mut mlp_solution, out: *mut mlp_iter_info) -> c_int;
     pub fn mlp_engine_stage(s: *mut mlp_solution, stage: c_int, out: *mut mlp_iter_info) -> c_int;

@@ -44,7 +44,7 @@ class MlpStats(C.Structure):
                    ("hyper_iters", C.c_uint64), ("hyper_bails", C.c_uint64), ("ratio_stalls", C.c_uint64),
                    ("reinversion_fallbacks", C.c_uint64),
                    ("factor_active", C.c_uint64), ("factor_refactors", C.c_uint64), ("factor_levels", C.c_uint64),
-                   ("factor_switches", C.c_uint64)])  # appended in ABI version 4 (the struct only grows at its end from here on)
+                   ("factor_switches", C.c_uint64), ("factor_bump", C.c_uint64), ("factor_bump_max", C.c_uint64)])  # appended in ABI version 4 (the struct only grows at its end from here on)
 
 
 ABI_VERSION = 4  # include/minilp_hip.h: MLP_ABI_VERSION
@@ -112,6 +112,8 @@ def lib():
     sig("mlp_solution_reinvert", i32, vp, pdbl)
     sig("mlp_solution_recompute_basic_values", i32, vp)
     sig("mlp_solution_enable_sharding", i32, vp, i32, i32, C.c_char_p)
+    sig("mlp_solution_enable_sharding_ex", i32, vp, i32, i32, C.c_char_p, C.c_char_p, vp)
+    sig("mlp_rccl_unique_id", i32, vp)
     sig("mlp_solution_transport", C.c_char_p, vp)
     sig("mlp_solution_clone", vp, vp)
     sig("mlp_solution_free", None, vp)
@@ -145,6 +147,13 @@ def lib():
 
 def device_count():
     return lib().mlp_device_count()
+
+
+def rccl_unique_id():
+    """128-byte ncclUniqueId (rank 0 makes it, the launcher distributes it) for Solution.enable_sharding_ex(..., "rccl", id)."""
+    buf = (C.c_char * 128)()
+    _raise(lib().mlp_rccl_unique_id(C.cast(buf, C.c_void_p)))
+    return bytes(buf)
 
 
 def set_device(device):
@@ -386,6 +395,12 @@ class Solution:
     def enable_sharding(self, rank, world, shm_name):
         """Column-block sharding of the pricing path (include/minilp_hip.h); see minilp_amd.dist."""
         _raise(lib().mlp_solution_enable_sharding(self._h, int(rank), int(world), shm_name.encode()))
+
+    def enable_sharding_ex(self, rank, world, shm_name, transport, rccl_id=None):
+        """enable_sharding with the transport named: "peer", "host", "rccl" (rccl_id: rank 0's 128-byte id) or "pump"."""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(rccl_id)) if rccl_id else None
+        _raise(lib().mlp_solution_enable_sharding_ex(self._h, int(rank), int(world), shm_name.encode(), transport.encode(),
+                                                      C.cast(buf, C.c_void_p) if buf is not None else None))
 
     def transport(self):
         return lib().mlp_solution_transport(self._h).decode()

@@ -227,6 +227,18 @@ int mlp_solution_enable_sharding(mlp_solution* s, int rank, int world, const cha
     });
 }
 
+int mlp_solution_enable_sharding_ex(mlp_solution* s, int rank, int world, const char* shm_name, const char* transport, const void* rccl_id) {
+    return guarded([&] {
+        if (!s || !shm_name) throw MlpError(MLP_EINVAL, "NULL solution / rendezvous name");
+        s->eng->enable_sharding(rank, world, shm_name, transport, rccl_id);
+    });
+}
+int mlp_rccl_unique_id(void* out128) {
+    return guarded([&] {
+        if (!out128) throw MlpError(MLP_EINVAL, "NULL buffer");
+        Engine::rccl_unique_id(out128);
+    });
+}
 const char* mlp_solution_transport(const mlp_solution* s) { return s ? s->eng->transport.c_str() : "none"; }
 
 mlp_solution* mlp_solution_clone(const mlp_solution* s) {
@@ -328,7 +340,7 @@ void mlp_solution_stats(const mlp_solution* s, mlp_stats* o) {
     for (int i = 0; i < 5; ++i) o->kase[i] = t.kase[i];
     o->reinversion_fallbacks = t.reinversion_fallbacks;
     o->factor_active = e->factor_active() ? 1 : 0; o->factor_refactors = t.fac_refactors; o->factor_levels = t.fac_levels;
-    o->factor_switches = t.fac_switches;
+    o->factor_switches = t.fac_switches; o->factor_bump = t.fac_bump; o->factor_bump_max = t.fac_bump_max;
 }
 void mlp_solution_reset_stats(mlp_solution* s) {
     guarded([&] { s->eng->resolve_events(); });

@@ -137,7 +137,7 @@ struct Stats {
     uint64_t hyper_iters = 0, hyper_bails = 0;  // iterations taken by the hypersparse kernel; iterations it handed back
     uint64_t ratio_stalls = 0;   // in-kernel waits of the fused ratio test that timed out (each one retried with two launches)
     uint64_t beta_rebuilds = 0;  // lazy dual steepest edge: exact rebuilds of beta from the basis inverse
-    uint64_t fac_refactors = 0, fac_levels = 0, fac_switches = 0;  // compact factor: refactorisations (peels), levels of the last one, mode switches
+    uint64_t fac_refactors = 0, fac_levels = 0, fac_switches = 0, fac_bump = 0, fac_bump_max = 0;  // compact factor: refactorisations (peels), levels of the last one, mode switches
     // dense-rhs FTRAN x_B = B^-1 (b - N x_N) (recalc_basic_vals): the streaming read of the nucleus inverse, kernel-exact
     double dense_ftran_bytes = 0, dense_ftran_ms = 0;
     uint64_t dense_ftran_launches = 0;
@@ -170,7 +170,11 @@ public:
     // beta, objective as f64 (a loaded solve continues pivot for pivot).
     std::vector<uint8_t> save_basis(int mode);
     void load_basis(const uint8_t* blob, size_t len);  // call after try_new on the same problem
-    void enable_sharding(int rank, int world, const char* shm_name);  // column-block pricing across ranks
+    // column-block pricing across ranks.  transport: nullptr / "" = MLP_TRANSPORT or the default (device mailboxes written by the peers,
+    // MLP_MAILBOX=host for the host mailbox); "rccl" = records delivered by ncclAllGather (rccl_id: the 128-byte ncclUniqueId of
+    // rank 0); "pump" = the same pump protocol with peer copies in place of the collective (ranks sharing one GPU: tests)
+    void enable_sharding(int rank, int world, const char* shm_name, const char* transport_name = nullptr, const void* rccl_id = nullptr);
+    static void rccl_unique_id(void* out128);
     bool sharded() const { return shard_world > 1; }
 
     int num_vars = 0;
@@ -234,8 +238,13 @@ private:
     uint64_t fac_tried_at_ = 0;              // lifetime pivot count of the last attempt that found a bump
     bool fac_tried_ = false;
     DevBuf<int> d_fac_pos_of_var, d_fac_var_of_pos, d_fac_prow, d_fac_items, d_fac_lptr, d_fac_meta, d_fac_tmp, d_fac_counters;
-    DevBuf<double> d_fac_pval, d_fac_U, d_fac_V, d_fac_rhs, d_fac_x0, d_fac_coef;
+    DevBuf<double> d_fac_pval, d_fac_U, d_fac_V, d_fac_rhs, d_fac_x0, d_fac_coef, d_fac_part;
     DevBuf<unsigned> d_fac_bar;
+    DevBuf<int> d_fac_bpos, d_fac_brow, d_fac_bslot_of_row, d_fac_irow, d_fac_fptr, d_fac_fidx, d_fac_bptr, d_fac_bidx;
+    DevBuf<double> d_fac_ipiv, d_fac_fval, d_fac_bval;
+    DevBuf<double> d_fac_Wb;   // allocated with the first bump
+    int fac_bump_ = 0;
+    int fac_bump_max_ = 256;                 // MLP_FACTOR_BUMP: largest bump the compact factor carries (beyond it: explicit inverse)
     void fac_alloc();
     void fac_fill_view(DevView& v) const;
     bool fac_refactor();                     // the peel + level lists from the current basis; false when it leaves a bump
@@ -339,6 +348,20 @@ private:
     size_t xb_cap_ = 0;                    // doubles per vector slot of the exchange buffer (>= the largest possible nucleus)
     bool no_wshard = false;                // MLP_NO_WSHARD: keep the streaming pass replicated on every rank
     void release_mailboxes();
+    // pump transport (MLP_TRANSPORT=rccl | pump): the kernels post into / poll this rank's own device box; while a batch is in flight
+    // the host moves the records between the ranks on a second stream: stage -> all-gather -> deliver (kernels.hip: k_mail_stage)
+    int pump_backend_ = 0;                 // 0 off, 1 RCCL all-gather, 2 peer copies through HIP IPC + a shared-memory barrier
+    hipStream_t st_pump = nullptr;
+    void* pump_stage_ = nullptr;           // world x MAIL_PUMP_RECS records
+    void* pump_stage_peer_[MAX_WORLD] = {};
+    unsigned long long* pump_host_ = nullptr;  // pinned: [0, world) gathered batch words, [world] this rank's word
+    unsigned long long pump_seq_ = 0, pump_gen_ = 0;
+    uint64_t pump_rounds_ = 0;
+    void* rccl_comm_ = nullptr;
+    void enable_pump(int rank, int world, void* shm, size_t host_bytes, int backend, const void* rccl_id);
+    void pump_until_idle();                // call after enqueueing kernels that contain exchanges, before synchronising the stream
+    void pump_round(bool done_local, bool* all_done);
+    void shm_barrier();
   public:
     std::string transport = "none";        // human-readable name of the exchange transport
   private:

@@ -20,6 +20,7 @@
 #include <memory>
 #include <mutex>
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -115,6 +116,7 @@ Engine::Engine() {
     if (const char* fm = std::getenv("MLP_FACTOR")) fac_mode = std::atoi(fm) > 0 ? 1 : 0;
     if (const char* fj = std::getenv("MLP_FACTOR_J")) fac_J_ = std::max(1, std::min(64, std::atoi(fj)));
     if (const char* ff = std::getenv("MLP_FACTOR_FROM")) fac_auto_cap_ = std::max(256, std::atoi(ff));
+    if (const char* fb = std::getenv("MLP_FACTOR_BUMP")) fac_bump_max_ = std::max(0, std::min(FAC_BMAX, std::atoi(fb)));
     const char* nhf = std::getenv("MLP_NO_HEAD_FUSION");
     no_head_fusion = nhf && std::atoi(nhf) != 0;
     const char* nws = std::getenv("MLP_NO_WSHARD");
@@ -737,7 +739,173 @@ bool wait_flag(volatile uint64_t* f, uint64_t want, double seconds) {
     }
     return true;
 }
+// RCCL is loaded at run time (dlopen) and only when the rccl transport is asked for: the library has no link-time dependency
+// on it, and a process that already holds a copy (torch ships one) shares that copy.
+struct NcclId { char internal[128]; };
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(NcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi& rccl_api() {
+    static RcclApi api;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (api.lib) return api;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) != nullptr) break;  // a copy the process already holds
+    for (size_t i = 0; !h && i < sizeof(names) / sizeof(names[0]); ++i) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!h) throw MlpError(-3, std::string("rccl transport: cannot load librccl.so: ") + (dlerror() ? dlerror() : "not found"));
+    api.GetUniqueId = reinterpret_cast<int (*)(NcclId*)>(dlsym(h, "ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<int (*)(void**, int, NcclId, int)>(dlsym(h, "ncclCommInitRank"));
+    api.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(h, "ncclAllGather"));
+    api.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy"));
+    api.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(h, "ncclGetErrorString"));
+    if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy)
+        throw MlpError(-3, "rccl transport: librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy");
+    api.lib = h;
+    return api;
+}
+void rccl_check(int rc, const char* what) {
+    if (rc == 0) return;
+    RcclApi& a = rccl_api();
+    throw MlpError(-3, std::string("rccl transport: ") + what + " failed: " + (a.GetErrorString ? a.GetErrorString(rc) : std::to_string(rc).c_str()));
+}
+void rccl_destroy(void* comm) {
+    if (comm) (void)rccl_api().CommDestroy(comm);
+}
 }  // namespace
+void Engine::rccl_unique_id(void* out128) {
+    NcclId id;
+    std::memset(&id, 0, sizeof(id));
+    rccl_check(rccl_api().GetUniqueId(&id), "ncclGetUniqueId");
+    std::memcpy(out128, &id, sizeof(id));
+}
+// ---- pump transport: see kernels.hip (k_mail_stage / k_mail_deliver) for the protocol on the device side
+void Engine::enable_pump(int rank, int world, void* shm, size_t host_bytes, int backend, const void* rccl_id) {
+    const size_t blk = (size_t)MAIL_PUMP_RECS * sizeof(MailRec);
+    hipError_t e = hipExtMallocWithFlags(&own_box, host_bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        own_box = nullptr;
+        e = hipExtMallocWithFlags(&own_box, host_bytes, hipDeviceMallocFinegrained);
+    }
+    if (e != hipSuccess) throw MlpError(-3, std::string("enable_sharding: cannot allocate the device mailbox: ") + hipGetErrorString(e));
+    HIPCHECK(hipMemset(own_box, 0, host_bytes));
+    HIPCHECK(hipMalloc(&pump_stage_, blk * (size_t)world));
+    HIPCHECK(hipMemset(pump_stage_, 0, blk * (size_t)world));
+    HIPCHECK(hipHostMalloc(reinterpret_cast<void**>(&pump_host_), sizeof(unsigned long long) * (size_t)(world + 1), hipHostMallocDefault));
+    std::memset(pump_host_, 0, sizeof(unsigned long long) * (size_t)(world + 1));
+    HIPCHECK(hipStreamCreateWithFlags(&st_pump, hipStreamNonBlocking));
+    HIPCHECK(hipDeviceSynchronize());
+    pump_backend_ = backend;  // (from here on release_mailboxes() tears the pump down)
+    pump_seq_ = 0;
+    pump_gen_ = 0;
+    for (int r = 0; r < MAX_WORLD; ++r) {
+        peer_box[r] = nullptr;
+        pump_stage_peer_[r] = nullptr;
+    }
+    d_mail = reinterpret_cast<MailRec*>(own_box);
+    mail_fanout = 1;
+    xb_cap_ = 0;  // (no row-sharded streaming pass: its vectors travel through peer stores only)
+    if (backend == 1) {
+        if (!rccl_id) throw MlpError(-1, "enable_sharding: the rccl transport needs rank 0's ncclUniqueId (mlp_rccl_unique_id)");
+        NcclId id;
+        std::memcpy(&id, rccl_id, sizeof(id));
+        rccl_check(rccl_api().CommInitRank(&rccl_comm_, world, id, rank), "ncclCommInitRank");
+        ranks_share_device = false;  // (RCCL refuses two ranks on one device)
+        transport = "RCCL: the ranks' mailbox records delivered by ncclAllGather over xGMI, pumped on a second stream while a batch of pivots is in flight";
+    } else {
+        // peer copies in place of the collective (ranks sharing one GPU, which RCCL refuses: how the pump protocol is tested)
+        Rendezvous* rv = reinterpret_cast<Rendezvous*>(static_cast<uint8_t*>(shm) + host_bytes);
+        Rendezvous* mine = rv + rank;
+        HIPCHECK(hipIpcGetMemHandle(&mine->handle, pump_stage_));
+        mine->pid = (int32_t)getpid();
+        __atomic_store_n(&mine->ready, (uint64_t)1, __ATOMIC_RELEASE);
+        for (int r = 0; r < world; ++r) {
+            if (r == rank) {
+                pump_stage_peer_[r] = pump_stage_;
+                continue;
+            }
+            if (!wait_flag(&rv[r].ready, 1, 120.0))
+                throw MlpError(-3, "enable_sharding: rank " + std::to_string(r) + " did not publish its staging buffer within 120 s");
+            if (__atomic_load_n(&rv[r].ready, __ATOMIC_ACQUIRE) == ~(uint64_t)0)
+                throw MlpError(-3, "enable_sharding: rank " + std::to_string(r) + " failed to set up its staging buffer");
+            void* q = nullptr;
+            hipError_t eo = hipIpcOpenMemHandle(&q, rv[r].handle, hipIpcMemLazyEnablePeerAccess);
+            if (eo != hipSuccess)
+                throw MlpError(-3, "enable_sharding: hipIpcOpenMemHandle of rank " + std::to_string(r) + "'s staging buffer failed: " + hipGetErrorString(eo));
+            pump_stage_peer_[r] = q;
+        }
+        __atomic_store_n(&mine->ready, (uint64_t)2, __ATOMIC_RELEASE);
+        for (int r = 0; r < world; ++r)
+            if (r != rank && !wait_flag(&rv[r].ready, 2, 120.0))
+                throw MlpError(-3, "enable_sharding: rank " + std::to_string(r) + " did not finish mapping the staging buffers within 120 s");
+        ranks_share_device = true;
+        transport = "pump: the ranks' mailbox records delivered by peer copies between staging buffers (HIP IPC) behind a shared-memory "
+                    "barrier — the RCCL transport's protocol with the collective replaced, for ranks that share one GPU";
+    }
+}
+void Engine::shm_barrier() {  // all ranks of the solve, through the counter at the head of the rendezvous object
+    if (shard_world <= 1 || !mail_host) return;
+    volatile uint64_t* cnt = reinterpret_cast<volatile uint64_t*>(mail_host);
+    const uint64_t target = (++pump_gen_) * (uint64_t)shard_world;
+    __atomic_add_fetch(cnt, (uint64_t)1, __ATOMIC_SEQ_CST);
+    const double t0 = now_s();
+    long spins = 0;
+    while (__atomic_load_n(cnt, __ATOMIC_ACQUIRE) < target) {
+        if ((++spins & 0xfff) == 0 && now_s() - t0 > 120.0) throw MlpError(-3, "pump transport: a peer rank did not reach the barrier within 120 s");
+        __builtin_ia32_pause();
+    }
+}
+void Engine::pump_round(bool done_local, bool* all_done) {
+    const int world = shard_world, rank = shard_rank;
+    const size_t blk = (size_t)MAIL_PUMP_RECS * sizeof(MailRec);
+    uint8_t* stage = static_cast<uint8_t*>(pump_stage_);
+    pump_host_[world] = done_local ? pump_seq_ : pump_seq_ - 1;  // this rank's "my batch is done" word travels with its records
+    HIPCHECK(hipMemcpyAsync(stage + (size_t)rank * blk + (size_t)(MAIL_PUMP_RECS - 1) * sizeof(MailRec), &pump_host_[world], sizeof(unsigned long long),
+                            hipMemcpyHostToDevice, st_pump));
+    launch_mail_stage(hview, stage, st_pump);
+    if (pump_backend_ == 1) {
+        rccl_check(rccl_api().AllGather(stage + (size_t)rank * blk, stage, blk, /* ncclInt8 */ 0, rccl_comm_, st_pump), "ncclAllGather");
+    } else {
+        HIPCHECK(hipStreamSynchronize(st_pump));
+        shm_barrier();  // every rank's block is staged
+        for (int r = 0; r < world; ++r)
+            if (r != rank)
+                HIPCHECK(hipMemcpyAsync(stage + (size_t)r * blk, static_cast<uint8_t*>(pump_stage_peer_[r]) + (size_t)r * blk, blk, hipMemcpyDeviceToDevice, st_pump));
+        HIPCHECK(hipStreamSynchronize(st_pump));
+        shm_barrier();  // nobody stages the next round while a peer still copies this one
+    }
+    launch_mail_deliver(hview, stage, st_pump);
+    HIPCHECK(hipMemcpy2DAsync(pump_host_, sizeof(unsigned long long), stage + (size_t)(MAIL_PUMP_RECS - 1) * sizeof(MailRec), blk, sizeof(unsigned long long),
+                              (size_t)world, hipMemcpyDeviceToHost, st_pump));
+    HIPCHECK(hipStreamSynchronize(st_pump));
+    bool all = true;
+    for (int r = 0; r < world; ++r) all = all && pump_host_[r] >= pump_seq_;
+    *all_done = all;
+    pump_rounds_ += 1;
+}
+// The exchanges of the kernels just enqueued on `st` complete only if the pump runs: keep delivering until EVERY rank's stream has
+// drained (each round is a collective, and the decision to stop is taken from the gathered words: all ranks stop together).
+void Engine::pump_until_idle() {
+    if (!pump_backend_) return;
+    pump_seq_ += 1;
+    const double t0 = now_s();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q != hipSuccess && q != hipErrorNotReady) HIPCHECK(q);
+        bool all = false;
+        pump_round(q == hipSuccess, &all);
+        if (all) break;
+        if (now_s() - t0 > 600.0) throw MlpError(-3, "pump transport: the batch did not drain on every rank within 600 s");
+    }
+}
 void Engine::release_mailboxes() {
     for (int r = 0; r < MAX_WORLD; ++r) {
         if (peer_box[r] && r != shard_rank) (void)hipIpcCloseMemHandle(peer_box[r]);
@@ -745,6 +913,22 @@ void Engine::release_mailboxes() {
     }
     if (own_box) (void)hipFree(own_box);
     own_box = nullptr;
+    if (pump_backend_) {
+        if (st_pump) (void)hipStreamSynchronize(st_pump);
+        for (int r = 0; r < MAX_WORLD; ++r) {
+            if (pump_stage_peer_[r] && pump_stage_peer_[r] != pump_stage_) (void)hipIpcCloseMemHandle(pump_stage_peer_[r]);
+            pump_stage_peer_[r] = nullptr;
+        }
+        if (rccl_comm_) rccl_destroy(rccl_comm_);
+        rccl_comm_ = nullptr;
+        if (pump_stage_) (void)hipFree(pump_stage_);
+        pump_stage_ = nullptr;
+        if (pump_host_) (void)hipHostFree(pump_host_);
+        pump_host_ = nullptr;
+        if (st_pump) (void)hipStreamDestroy(st_pump);
+        st_pump = nullptr;
+        pump_backend_ = 0;
+    }
     if (mail_host) {
         if (mail_registered) (void)hipHostUnregister(mail_host);
         (void)munmap(mail_host, mail_bytes);
@@ -753,19 +937,24 @@ void Engine::release_mailboxes() {
     mail_registered = false;
     d_mail = nullptr;
 }
-void Engine::enable_sharding(int rank, int world, const char* shm_name) {
+void Engine::enable_sharding(int rank, int world, const char* shm_name, const char* transport_name, const void* rccl_id) {
     if (world < 1 || world > MAX_WORLD || rank < 0 || rank >= world)
         throw MlpError(-1, "enable_sharding: bad rank/world (at most " + std::to_string(MAX_WORLD) + " ranks)");
     HIPCHECK(hipStreamSynchronize(st));
     if (fac_on_ && world > 1) fac_leave();  // (the compact factor is a one-GPU representation)
     release_mailboxes();
-    if (world == 1) {
+    std::string tname = transport_name ? transport_name : "";
+    if (tname.empty() && std::getenv("MLP_TRANSPORT")) tname = std::getenv("MLP_TRANSPORT");
+    const int pump = tname == "rccl" ? 1 : (tname == "pump" ? 2 : 0);
+    if (!tname.empty() && !pump && tname != "peer" && tname != "host")
+        throw MlpError(-1, "enable_sharding: unknown transport '" + tname + "' (peer, host, rccl, pump)");
+    if (world == 1 && !pump) {  // (the pump transports accept a world of one: the collective path is then exercised end to end with a single rank)
         shard_rank = 0; shard_world = 1;
         view_dirty = true;
         return;
     }
     const char* mb = std::getenv("MLP_MAILBOX");
-    const bool host_transport = mb && std::string(mb) == "host";
+    const bool host_transport = !pump && (tname == "host" || (tname.empty() && mb && std::string(mb) == "host"));
     const size_t host_bytes = kHostBoxBytesPerRank * (size_t)world;
     const size_t bytes = host_bytes + sizeof(Rendezvous) * (size_t)world;
     int fd = shm_open(shm_name, O_RDWR, 0600);
@@ -781,7 +970,9 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name) {
     mail_host = p; mail_bytes = bytes;
     shard_rank = rank;  // release_mailboxes() skips this rank's own entry of peer_box
     try {
-        if (host_transport) {
+        if (pump) {
+            enable_pump(rank, world, p, host_bytes, pump, rccl_id);
+        } else if (host_transport) {
             HIPCHECK(hipHostRegister(p, bytes, hipHostRegisterMapped));
             mail_registered = true;
             void* dp = nullptr;
@@ -880,6 +1071,7 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name) {
         flag.ensure(2, 0, st);
         HIPCHECK(hipMemsetAsync(flag.p, 0, 2 * sizeof(int), st));
         launch_mail_handshake(hview, flag.p, st);
+        if (pump_backend_) pump_until_idle();  // (the handshake records travel through the pump like every other record)
         int hf[2] = {0, 0};
         HIPCHECK(hipMemcpyAsync(hf, flag.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
@@ -1541,6 +1733,7 @@ int Engine::run_loop(int phase) {
         const size_t nnz_before = nnz_nonbasic;
         const int k_before = k_;
         const size_t nnz_nuc_before = sample ? nnz_nucleus_cols() : 0;
+        pump_until_idle();  // (pump transports: deliver the exchanges of the batch while it runs)
         pull_ctl();
         int res = process_records(phase, B);
         if (sample && h_ctl->ring_n >= 1 && h_ctl->ring[0].status == ITER_PIVOT) {
@@ -1656,8 +1849,21 @@ void Engine::fac_alloc() {
     d_fac_pos_of_var.ensure(NN, 0, st); d_fac_var_of_pos.ensure(mm, 0, st); d_fac_prow.ensure(mm, 0, st);
     d_fac_items.ensure(mm, 0, st); d_fac_lptr.ensure(FAC_MAX_LEVELS + 2, 0, st); d_fac_meta.ensure(4, 0, st);
     d_fac_tmp.ensure(5 * mm, 0, st); d_fac_counters.ensure(4, 0, st);
-    d_fac_pval.ensure(mm, 0, st); d_fac_x0.ensure(mm, 0, st); d_fac_coef.ensure(2 * J + 2, 0, st);
+    d_fac_pval.ensure(mm, 0, st); d_fac_x0.ensure(mm, 0, st); d_fac_coef.ensure(2 * J + 2, 0, st); d_fac_part.ensure(J * 1024, 0, st);
     d_fac_U.ensure(J * mm, 0, st); d_fac_V.ensure(J * mm, 0, st);
+    d_fac_bpos.ensure(FAC_BMAX, 0, st); d_fac_brow.ensure(FAC_BMAX, 0, st);
+    {   // resolved edge lists: at most the entries of A (incl. the slack identity) on either side
+        const size_t nz = h_rcol.size() + 8;
+        d_fac_irow.ensure(mm, 0, st); d_fac_ipiv.ensure(mm, 0, st);
+        d_fac_fptr.ensure(mm + 2, 0, st); d_fac_bptr.ensure(mm + 2, 0, st);
+        d_fac_fidx.ensure(nz, 0, st); d_fac_fval.ensure(nz, 0, st); d_fac_bidx.ensure(nz, 0, st); d_fac_bval.ensure(nz, 0, st);
+        d_scan_tmp.ensure((mm + 2) / 4096 + 8, 0, st);
+    }
+    {   // (no bump yet: every row is a pivot row of the peel)
+        const int* before = d_fac_bslot_of_row.p;
+        d_fac_bslot_of_row.ensure(mm, 0, st);
+        if (d_fac_bslot_of_row.p != before) HIPCHECK(hipMemsetAsync(d_fac_bslot_of_row.p, 0xFF, sizeof(int) * d_fac_bslot_of_row.cap, st));
+    }
     {   // the right-hand side vector is zero outside a solve, the barrier words outside a kernel
         const double* before = d_fac_rhs.p;
         d_fac_rhs.ensure(mm, 0, st);
@@ -1672,8 +1878,11 @@ void Engine::fac_fill_view(DevView& v) const {
     v.fac_J = fac_J_;
     v.fac_meta = d_fac_meta.p; v.fac_pos_of_var = d_fac_pos_of_var.p; v.fac_var_of_pos = d_fac_var_of_pos.p;
     v.fac_prow = d_fac_prow.p; v.fac_pval = d_fac_pval.p; v.fac_items = d_fac_items.p; v.fac_lptr = d_fac_lptr.p;
-    v.fac_U = d_fac_U.p; v.fac_V = d_fac_V.p; v.fac_rhs = d_fac_rhs.p; v.fac_x0 = d_fac_x0.p; v.fac_coef = d_fac_coef.p;
+    v.fac_U = d_fac_U.p; v.fac_V = d_fac_V.p; v.fac_rhs = d_fac_rhs.p; v.fac_x0 = d_fac_x0.p; v.fac_coef = d_fac_coef.p; v.fac_part = d_fac_part.p;
     v.fac_bar = d_fac_bar.p;
+    v.fac_irow = d_fac_irow.p; v.fac_ipiv = d_fac_ipiv.p; v.fac_fptr = d_fac_fptr.p; v.fac_fidx = d_fac_fidx.p; v.fac_fval = d_fac_fval.p;
+    v.fac_bptr = d_fac_bptr.p; v.fac_bidx = d_fac_bidx.p; v.fac_bval = d_fac_bval.p;
+    v.fac_bpos = d_fac_bpos.p; v.fac_brow = d_fac_brow.p; v.fac_bslot_of_row = d_fac_bslot_of_row.p; v.fac_Wb = d_fac_Wb.p;
 }
 // The refactorisation (BasisSolver::reset, solver.rs:1286-1303 -> lu_factorize, lu.rs:118-304): an iterated column-singleton
 // peel of the CURRENT basis on the device, one level per pair of launches, paced by the host (it reads one counter per level:
@@ -1707,13 +1916,62 @@ bool Engine::fac_refactor() {
         lptr.push_back(total);
         if (total == m_) break;
     }
-    if (total != m_) return false;  // a bump is left: not the shape this representation is for
+    // What the peel leaves is the BUMP (columns on cycles of the basis graph).  A small bump is carried along with its explicit
+    // inverse (Gauss-Jordan here, b^2 doubles); a large one means this basis is not the shape the representation is for.
+    const int b = m_ - total;
+    if (b > fac_bump_max_) return false;
+    if (b > 0 || fac_bump_ > 0) {
+        std::vector<int> hlev(mm), hrow(mm), bslot(mm, -1), bpos, brow;
+        HIPCHECK(hipMemcpyAsync(hlev.data(), level, sizeof(int) * mm, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipMemcpyAsync(hrow.data(), row_lev, sizeof(int) * mm, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        for (int p = 0; p < m_; ++p)
+            if (hlev[p] == 0) bpos.push_back(p);        // ascending positions / rows: a deterministic slot order
+        for (int i = 0; i < m_; ++i)
+            if (hrow[i] == 0) {
+                bslot[i] = (int)brow.size();
+                brow.push_back(i);
+            }
+        if ((int)bpos.size() != b || (int)brow.size() != b) throw MlpError(-2, "singular basis matrix: the bump of the peel is not square (solver.rs:1301)");
+        HIPCHECK(hipMemcpyAsync(d_fac_bslot_of_row.p, bslot.data(), sizeof(int) * mm, hipMemcpyHostToDevice, st));
+        if (b > 0) {
+            d_fac_Wb.ensure((size_t)FAC_BMAX * FAC_BMAX, 0, st);
+            t.fac_Wb = d_fac_Wb.p;
+            if (hview.fac_Wb != d_fac_Wb.p) view_dirty = true;
+            HIPCHECK(hipMemcpyAsync(d_fac_bpos.p, bpos.data(), sizeof(int) * (size_t)b, hipMemcpyHostToDevice, st));
+            HIPCHECK(hipMemcpyAsync(d_fac_brow.p, brow.data(), sizeof(int) * (size_t)b, hipMemcpyHostToDevice, st));
+            DevBuf<double> Kd, scratch;
+            DevBuf<int> flag;
+            Kd.ensure((size_t)b * FAC_BMAX, 0, st);
+            scratch.ensure((size_t)b + 8, 0, st);
+            flag.ensure(2, 0, st);
+            HIPCHECK(hipMemsetAsync(flag.p, 0, 2 * sizeof(int), st));
+            launch_fac_bump_build(t, Kd.p, b, st);
+            launch_gauss_jordan(Kd.p, d_fac_Wb.p, b, FAC_BMAX, flag.p, scratch.p, st);
+            int hflag = 0;
+            HIPCHECK(hipMemcpyAsync(&hflag, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipStreamSynchronize(st));
+            if (hflag) throw MlpError(-2, "singular basis matrix: the bump of the peel is singular (solver.rs:1301)");
+        }
+        HIPCHECK(hipStreamSynchronize(st));  // (staged from local vectors)
+    }
+    fac_bump_ = b;
+    stats.fac_bump = (uint64_t)b;
+    if ((uint64_t)b > stats.fac_bump_max) stats.fac_bump_max = (uint64_t)b;
     const int nlev = (int)lptr.size() - 1;
     HIPCHECK(hipMemcpyAsync(d_fac_lptr.p, lptr.data(), sizeof(int) * lptr.size(), hipMemcpyHostToDevice, st));
-    const int meta[4] = {nlev, total, 0, 0};
+    // the tail: the levels from `tail` on all hold at most FAC_TAIL positions (one workgroup walks them: factor.inc)
+    int tail = nlev;
+    while (tail > 0 && lptr[tail] - lptr[tail - 1] <= 512) tail -= 1;
+    const int meta[4] = {nlev, total, b, tail};
     HIPCHECK(hipMemcpyAsync(d_fac_meta.p, meta, sizeof(meta), hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)std::max(nlev, 1), st));  // (cnt is free again: the per-level fill cursors)
     launch_fac_peel_fill(t, level, cnt, st);
+    // resolved edge lists of the two solves in level order: counts -> exclusive scans -> fill
+    launch_fac_edges(t, 0, d_fac_fptr.p, d_fac_bptr.p, st);
+    launch_exclusive_scan(d_fac_fptr.p, d_fac_fptr.p, (long)total + 1, d_scan_tmp.p, st);
+    launch_exclusive_scan(d_fac_bptr.p, d_fac_bptr.p, (long)total + 1, d_scan_tmp.p, st);
+    launch_fac_edges(t, 1, d_fac_fptr.p, d_fac_bptr.p, st);
     HIPCHECK(hipMemsetAsync(&d_ctl.p->nlow, 0, 2 * sizeof(int), st));  // a fresh factor has no pending terms
     HIPCHECK(hipStreamSynchronize(st));  // (lptr / meta were staged from local memory)
     h_ctl->nlow = 0;
@@ -1855,6 +2113,7 @@ bool Engine::basic_values_feasible() {
     sync_view();
     launch_reset_ring(hview, st);
     launch_price_dual(hview, geom(), enable_dse ? 1 : 0, st);
+    pump_until_idle();
     pull_ctl();
     return h_ctl->it.status == ITER_FEASIBLE;
 }
@@ -1863,6 +2122,7 @@ bool Engine::reduced_costs_feasible() {
     sync_view();
     launch_reset_ring(hview, st);
     launch_price_primal(hview, geom(), 0, st);
+    pump_until_idle();
     pull_ctl();
     const bool ok = h_ctl->it.status == ITER_OPTIMAL;
     launch_reset_ring(hview, st);  // (the scan halts the batch when it finds none)
@@ -2616,7 +2876,7 @@ Engine* Engine::clone() {
     HIPCHECK(hipStreamSynchronize(s2));
     std::memcpy(e->h_ctl, h_ctl, sizeof(Ctl));
     e->values_dirty = true;
-    e->fac_mode = fac_mode; e->fac_J_ = fac_J_; e->fac_auto_cap_ = fac_auto_cap_;
+    e->fac_mode = fac_mode; e->fac_J_ = fac_J_; e->fac_auto_cap_ = fac_auto_cap_; e->fac_bump_max_ = fac_bump_max_;
     if (fac_on_ && !e->fac_enter())  // (a fresh peel of the same basis: the same operator, no pending terms)
         throw MlpError(-3, "clone: the basis of a solution on the compact factor must peel");
     return owner.release();

@@ -248,20 +248,34 @@ struct DevView {
     // order, BTRAN walks CSC columns in ascending level order; the maps below are SNAPSHOTS taken at the refactorisation
     // (basic_vars / var_loc move on with every pivot).
     int fac_on, fac_J;
-    int* fac_meta;           // [0] number of levels, [1] number of peeled positions (device copy; read by the solve kernel)
+    int* fac_meta;           // [0] number of levels, [1] peeled positions, [2] bump columns, [3] first level of the single-workgroup tail
     int* fac_pos_of_var;     // N: position of a variable in B0, -1 when it was non-basic
     int* fac_var_of_pos;     // m: variable at a position in B0
     int* fac_prow;           // m: pivot row of a position
     double* fac_pval;        // m: pivot element A[prow[p], var_of_pos[p]]
     int* fac_items;          // m: positions in level order
     int* fac_lptr;           // levels + 1 offsets into fac_items
+    // per place in fac_items (level order), rebuilt with the peel: pivot row and pivot element, and the RESOLVED edge lists of the
+    // two solves — FTRAN: the other basic columns of the pivot row as (position, value), BTRAN: the other rows of the column
+    int* fac_irow; double* fac_ipiv;
+    int* fac_fptr; int* fac_fidx; double* fac_fval;   // m + 1 | entries of the basis
+    int* fac_bptr; int* fac_bidx; double* fac_bval;
     double* fac_U;           // fac_J x m, by position: U_j = -(alpha_q - e_r) / alpha_q[r] of the j-th pivot since the refactorisation
     double* fac_V;           // fac_J x m, by row: V_j = rho_r of that pivot
     double* fac_rhs;         // m, by row: right-hand side of a column FTRAN (zero outside a solve: the solve clears what the head scattered)
     double* fac_x0;          // m: result of the B0 solve before the rank-1 terms are added (by position for FTRAN, by row for BTRAN)
     double* fac_coef;        // 2 * fac_J + 1: coefficients V_j . rhs / U_j . c of the running solve
+    double* fac_part;        // fac_J x 1024: per-workgroup partial sums of those dot products (dense right-hand sides)
     unsigned* fac_bar;       // [0] grid barrier counter, [1] exit ticket, [2] reduction ticket
+    // the BUMP: what the peel leaves (columns on cycles of the basis graph: a generalised network has one-cycle components).
+    // In peel order B0 = [[U, F], [0, K]] with K the bump (fac_meta[2] columns, at most FAC_BMAX): its inverse is kept explicitly
+    // (fac_Wb, Gauss-Jordan at the refactorisation); FTRAN solves the bump first, BTRAN last.
+    int* fac_bpos;           // FAC_BMAX: position of a bump slot
+    int* fac_brow;           // FAC_BMAX: row of a bump slot
+    int* fac_bslot_of_row;   // m: bump slot of a row, -1 for a pivot row of the peel
+    double* fac_Wb;          // FAC_BMAX x FAC_BMAX, row-major: Wb[s][u] = (K^-1)[position slot s, row slot u]
 };
+constexpr int FAC_BMAX = 1024;
 
 // fused pass tiling
 constexpr int FW_TR = 8;     // minimum rows per block (sizes the partial buffers; kernels use 8 or 16)
@@ -311,6 +325,10 @@ void launch_push_tau(const DevView& dv, hipStream_t st);  // blocked push of -F 
 // hypersparse iteration (hyper.inc): up to max_iters dual iterations (no primal steepest edge) in ONE launch of one workgroup
 void launch_hyper_dual(const DevView& dv, int use_dse, int max_iters, long heavy, hipStream_t st);  // heavy <= 0: default work bound
 void launch_mail_handshake(const DevView& dv, int* out, hipStream_t st);  // transport self-test at enable_sharding
+// pump transport: stage this rank's records / deliver the peers' records (between them: an all-gather of the staging blocks)
+constexpr int MAIL_PUMP_RECS = MAIL_KINDS * 2 + 1;  // 64-byte records per rank in the staging buffer (the last one: the host's batch word)
+void launch_mail_stage(const DevView& dv, void* stage, hipStream_t st);
+void launch_mail_deliver(const DevView& dv, const void* stage, hipStream_t st);
 // sampled iterations: stamp (t0, t1) at the start / end of the next kernel of a slot (1 tableau-row sweep, 2 pass over the
 // nucleus inverse, 3 fold) instead of bracketing its launch; (nullptr, nullptr) disarms
 void arm_kernel_timing(int slot, hipEvent_t t0, hipEvent_t t1);
@@ -340,6 +358,8 @@ void launch_fac_gather_cb(const DevView& dv, hipStream_t st);  // alpha_q[p] = c
 void launch_fac_peel_init(const DevView& dv, int* cnt, int* level, int* row_lev, int* claim, hipStream_t st);
 void launch_fac_peel_level(const DevView& dv, int lev, int* cnt, int* level, int* row_lev, int* claim, int* cand_row, int* counters, hipStream_t st);
 void launch_fac_peel_fill(const DevView& dv, const int* level, int* cursor, hipStream_t st);
+void launch_fac_edges(const DevView& dv, int pass, int* fcnt, int* bcnt, hipStream_t st);  // resolved edge lists in level order: pass 0 counts, pass 1 fills
+void launch_fac_bump_build(const DevView& dv, double* Kd, int b, hipStream_t st);  // K = B0[bump rows, bump columns], dense, row-major with pitch FAC_BMAX
 void launch_str_reset(const DevView& dv, hipStream_t st);  // sparse tableau row: new stamp epoch, empty lists
 void launch_checksum_w(const DevView& dv, unsigned long long* out, hipStream_t st);  // order-independent checksum of W[0:k, 0:k] and the slot maps (tests)
 void launch_fold_lowrank(const DevView& dv, const Geom& g, hipStream_t st);  // W0 += U^T V, nlow := 0 (host-requested flush)

@@ -531,6 +531,49 @@ __global__ void __launch_bounds__(64) k_mail_handshake(DevView v, int* out) {
         out[0] = ok ? 1 : 0;
     }
 }
+// ---- pump transport (MLP_TRANSPORT=rccl | pump): delivery of the mailbox records by a collective instead of peer stores -------
+// The pivot kernels post into and poll their OWN device box (mail_fanout = 1, exactly as with the host mailbox); a pump on a second
+// stream moves the records between the ranks while a batch of iterations is in flight:
+//   k_mail_stage   : this rank's records of every (kind, parity) are copied, seqlock-consistently, into its block of a staging buffer;
+//   all-gather     : ncclAllGather of the blocks (RCCL over xGMI), or — ranks sharing one GPU, which RCCL refuses — peer copies;
+//   k_mail_deliver : the other ranks' records go from the staging buffer into this rank's box, payload first, then the epoch
+//                    with release, which is what the polling kernels acquire on.
+// A record is only overwritten (epoch e + 2 into the slot of e) after every rank has consumed e, so a staged record is never torn
+// with respect to an epoch a consumer still waits for.  The last record of every staging block carries the host's "my batch is
+// done" word of the pump protocol (Engine::pump_until_idle).
+constexpr int PUMP_RECS = MAIL_KINDS * 2 + 1;  // records per rank in the staging buffer
+__global__ void __launch_bounds__(64) k_mail_stage(DevView v, MailRec* stage) {
+    const int t = threadIdx.x;
+    if (t >= MAIL_KINDS * 2) return;
+    const MailRec* src = v.mail + (size_t)t * v.world + v.rank;  // [kind * 2 + parity][rank]
+    MailRec* dst = stage + (size_t)v.rank * PUMP_RECS + t;
+    const unsigned long long e1 = __hip_atomic_load(&src->epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+    double f[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) f[i] = __hip_atomic_load(&src->f[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long e2 = __hip_atomic_load(&src->epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (e1 != e2) return;  // being rewritten: the previous staged copy stands, the next round takes the new one
+    dst->epoch = e1;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) dst->f[i] = f[i];
+}
+__global__ void __launch_bounds__(256) k_mail_deliver(DevView v, const MailRec* stage) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int t = idx % (MAIL_KINDS * 2), r = idx / (MAIL_KINDS * 2);
+    if (r >= v.world || r == v.rank) return;
+    const MailRec* src = stage + (size_t)r * PUMP_RECS + t;
+    MailRec* dst = v.mail + (size_t)t * v.world + r;
+    const unsigned long long e = src->epoch;
+    if (e == 0ull || e == __hip_atomic_load(&dst->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;
+    mail_store(dst, e, src->f);
+}
+void launch_mail_stage(const DevView& dv, void* stage, hipStream_t st) {
+    hipLaunchKernelGGL(k_mail_stage, dim3(1), dim3(64), 0, st, dv, reinterpret_cast<MailRec*>(stage));
+}
+void launch_mail_deliver(const DevView& dv, const void* stage, hipStream_t st) {
+    const int n = dv.world * MAIL_KINDS * 2;
+    hipLaunchKernelGGL(k_mail_deliver, dim3((n + 255) / 256), dim3(256), 0, st, dv, reinterpret_cast<const MailRec*>(stage));
+}
 void launch_mail_handshake(const DevView& dv, int* out, hipStream_t st) {
     hipLaunchKernelGGL(k_mail_handshake, dim3(1), dim3(64), 0, st, dv, out);
 }

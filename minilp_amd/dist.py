@@ -46,14 +46,27 @@ def remove_mailbox(name):
         pass
 
 
-def _try_enable(solution, dist, rank, world):
+def _try_enable(solution, dist, rank, world, transport=None):
     """One collective attempt: rank 0 creates the rendezvous object, every rank enables sharding; returns
-    (box name, list of per-rank error strings)."""
-    box = [create_mailbox(world) if rank == 0 else None]
+    (box name, list of per-rank error strings).  transport None: the engine's default (device mailboxes written by the peers,
+    or what MLP_TRANSPORT / MLP_MAILBOX say); "rccl": rank 0 also makes the ncclUniqueId that travels with the box name."""
+    uid = None
+    if transport == "rccl" and rank == 0:
+        import minilp_amd as _M
+        try:
+            uid = _M.api.rccl_unique_id()
+        except Exception as e:
+            uid = f"error: {e}"
+    box = [create_mailbox(world) if rank == 0 else None, uid]
     dist.broadcast_object_list(box, src=0)
     err = None
     try:
-        solution.enable_sharding(rank, world, box[0])
+        if transport is None:
+            solution.enable_sharding(rank, world, box[0])
+        elif transport == "rccl" and not isinstance(box[1], (bytes, bytearray)):
+            raise RuntimeError(f"rank 0 could not make an ncclUniqueId ({box[1]})")
+        else:
+            solution.enable_sharding_ex(rank, world, box[0], transport, box[1] if transport == "rccl" else None)
     except Exception as e:  # every rank must leave through the same door
         err = f"rank {rank}: {e}"
     errs = [None] * world
@@ -67,20 +80,27 @@ def setup_sharding(solution, dist=None):
     should remove it at the end).
 
     Transport: device mailboxes written by the peers over xGMI (HIP IPC).  If ANY rank cannot set that up (IPC or peer
-    access unavailable on the node), all ranks together fall back ONCE to the host-memory mailbox — still the same
+    access unavailable on the node, or the handshake does not deliver), all ranks together fall back to the RCCL transport
+    (records delivered by ncclAllGather, pumped by the host while a batch is in flight) and, failing that too, to the host-memory mailbox — still the same
     sharded solve of one LP, only the 64-byte exchanges take the PCIe route; `Solution.transport()` says which one is
     in use.  If that fails too the call raises on every rank (never a silent change of what is being run)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return None
     rank, world = dist.get_rank(), dist.get_world_size()
-    name, bad = _try_enable(solution, dist, rank, world)
-    if bad and os.environ.get("MLP_MAILBOX") != "host":
+    forced = os.environ.get("MLP_TRANSPORT")  # "peer" / "host" / "rccl" / "pump": no fallback chain, that transport or an error
+    name, bad = _try_enable(solution, dist, rank, world, forced if forced in ("rccl", "pump") else None)
+    if bad and not forced and os.environ.get("MLP_MAILBOX") != "host":
+        # fallback chain: peer stores -> RCCL all-gather pump (ranks on distinct devices) -> host-memory mailbox
         if rank == 0:
             remove_mailbox(name)
-            print("[minilp_amd.dist] peer transport unavailable (" + "; ".join(bad) + "): falling back to the host-memory mailbox",
-                  flush=True)
-        os.environ["MLP_MAILBOX"] = "host"   # read by the engine at enable_sharding
-        name, bad = _try_enable(solution, dist, rank, world)
+            print("[minilp_amd.dist] peer transport unavailable (" + "; ".join(bad) + "): trying the RCCL all-gather transport", flush=True)
+        name, bad = _try_enable(solution, dist, rank, world, "rccl")
+        if bad:
+            if rank == 0:
+                remove_mailbox(name)
+                print("[minilp_amd.dist] RCCL transport unavailable (" + "; ".join(bad) + "): falling back to the host-memory mailbox", flush=True)
+            os.environ["MLP_MAILBOX"] = "host"   # read by the engine at enable_sharding
+            name, bad = _try_enable(solution, dist, rank, world)
     if bad:
         if rank == 0:
             remove_mailbox(name)

@@ -133,3 +133,38 @@ def test_sharded_ranks_stay_bit_identical_replicas_over_8000_pivots_from_the_lat
         if mode == "replicated":
             assert cp["bitwise_equal_to_unsharded"], (cp["pivots"], cp["vs_unsharded"])
     assert r.returncode == 0 and rec["ok"]
+
+
+@pytest.mark.parametrize("family,rows,cols", [("sparse", "3000", "3000"), ("cover", "3000", "3500")], ids=["primal loop", "dual loop"])
+def test_pump_transport_delivers_every_exchange_between_two_ranks(family, rows, cols):
+    """MLP_TRANSPORT=pump: the protocol of the RCCL transport — the kernels post into and poll their OWN device box, the host
+    pumps stage -> all-gather -> deliver rounds on a second stream until every rank's batch has drained — with peer copies
+    between IPC-mapped staging buffers in place of ncclAllGather (RCCL refuses two ranks on one device, which is what this box
+    has).  Every exchange kind travels through it: pricing all-gather and ratio decision (primal), leaving row, pass-1 minimum
+    and pass-2 candidate (dual); the sharded run must take the unsharded run's pivots."""
+    env = dict(os.environ, MLP_TRANSPORT="pump")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_test.py"), "2", rows, cols, "12", "300", family],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "traces identical: True" in r.stdout and "transport: pump" in r.stdout
+
+
+def test_rccl_transport_with_a_world_of_one():
+    """MLP_TRANSPORT=rccl end to end with the one rank a one-GPU box allows: librccl.so is loaded at run time, ncclGetUniqueId /
+    ncclCommInitRank / ncclAllGather run for real (every batch of pivots is accompanied by pump rounds whose collective is the
+    RCCL all-gather), the handshake passes through it, and the solve takes the pivots of a solve without any transport."""
+    import minilp_amd as M
+    from minilp_amd import api, dist as md, lpgen
+    lp = lpgen.gen_sparse_lp(1500, 1400, 12, 9)
+    prob = lpgen.build_problem(M.Problem, lp)
+    ref = prob.solve(trace=True)
+    s = prob.solve(budget=0, trace=True)
+    box = md.create_mailbox(1)
+    try:
+        s.enable_sharding_ex(0, 1, box, "rccl", api.rccl_unique_id())
+        assert s.transport().startswith("RCCL")
+        s.continue_solve(-1)
+    finally:
+        md.remove_mailbox(box)
+    assert [t[:5] for t in s.trace()] == [t[:5] for t in ref.trace()]
+    assert abs(s.objective() - ref.objective()) <= 1e-9 * abs(ref.objective())

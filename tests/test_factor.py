@@ -50,9 +50,15 @@ def test_refactor_period_does_not_change_the_pivot_sequence(monkeypatch, J):
     monkeypatch.setenv("MLP_FACTOR_J", str(J))
     lp = lpgen.gen_transport_lp(600, 700, 4, 5, tight=0.45)
     so, sg = _pair(lp)
-    assert sg.stats()["factor_active"] == 1
+    st = sg.stats()
+    print("J", J, "pivots", st["iterations"], "refactorisations", st["factor_refactors"], "largest bump", st["factor_bump_max"])
+    assert st["factor_active"] == 1
     assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
     assert obj_close(sg.objective(), so.objective())
+    if J == 1:
+        # refactoring after every pivot samples EVERY basis of the solve: some of them carry one-cycle components (a network with
+        # gains has them), which the peel leaves as a bump — solved through its explicit inverse
+        assert st["factor_refactors"] >= st["basis_changes"] and st["factor_bump_max"] > 0
 
 
 def test_a_basis_that_stops_peeling_goes_back_to_the_explicit_inverse(monkeypatch):
@@ -60,28 +66,44 @@ def test_a_basis_that_stops_peeling_goes_back_to_the_explicit_inverse(monkeypatc
     closes cycles — a bump — and the solve continues on the explicit inverse; the oracle's pivots throughout (primal loop
     with both steepest-edge recurrences: v = B^-T alpha_q and tau = B^-1 rho through the factor while it lasts)."""
     monkeypatch.setenv("MLP_FACTOR", "1")
+    monkeypatch.setenv("MLP_FACTOR_BUMP", "8")   # (default 256 columns: beyond it the bump's O(b^2) solve in one workgroup stops paying)
     lp = lpgen.gen_sparse_lp(400, 300, 12, 7)
     so, sg = _pair(lp)
     st = sg.stats()
-    print("pivots", st["iterations"], "refactorisations", st["factor_refactors"], "switches", st["factor_switches"])
+    print("pivots", st["iterations"], "refactorisations", st["factor_refactors"], "switches", st["factor_switches"], "largest bump carried", st["factor_bump_max"])
     assert st["factor_switches"] >= 2 and st["factor_active"] == 0 and st["factor_refactors"] >= 1
     assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
     assert obj_close(sg.objective(), so.objective())
     assert np.abs(sg.values() - so.values()).max() <= X_ATOL
 
 
-def test_two_phase_instance_on_the_compact_factor(monkeypatch):
-    """Transport rows with the objective reversed on a bounded box: neither primal nor dual feasible at the start — dual loop on
-    the artificial objective, recalc_obj_coeffs through the factor (dense-rhs BTRAN), then the primal loop with steepest edge."""
+def test_a_growing_bump_is_carried_through_its_explicit_inverse(monkeypatch):
+    """The same instance with the default bump limit: the nucleus of a random sparse model is all cycles, so the bump grows to the
+    size of the nucleus and every solve goes through B0 = [[U, F], [0, K]] with the dense K^-1 — FTRAN solves the bump first,
+    BTRAN last.  The oracle's pivots, primal loop with both steepest-edge solves."""
     monkeypatch.setenv("MLP_FACTOR", "1")
-    lp = lpgen.gen_transport_lp(500, 600, 4, 13, tight=0.5)
-    lp = dict(lp)
-    lp["direction"] = lpgen.MAXIMIZE
-    lp["hi"] = np.full(lp["n"], 3.0)
+    monkeypatch.setenv("MLP_FACTOR_J", "7")
+    lp = lpgen.gen_sparse_lp(400, 300, 12, 7)
     so, sg = _pair(lp)
     st = sg.stats()
-    print("pivots", st["iterations"], "primal", st["primal_iters"], "dual", st["dual_iters"], "refactorisations", st["factor_refactors"], "active", st["factor_active"])
-    assert st["primal_iters"] > 0 and st["dual_iters"] > 0
+    print("pivots", st["iterations"], "refactorisations", st["factor_refactors"], "largest bump", st["factor_bump_max"], "levels", st["factor_levels"])
+    assert st["factor_active"] == 1 and st["factor_bump_max"] >= 20
+    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+    assert obj_close(sg.objective(), so.objective())
+    assert np.abs(sg.values() - so.values()).max() <= X_ATOL
+
+
+def test_two_phase_instance_on_the_compact_factor(monkeypatch):
+    """Neither primal nor dual feasible at the start (lpgen.gen_twophase_lp): the dual loop on the artificial objective,
+    recalc_obj_coeffs through the factor (dense-rhs BTRAN y = B^-T c_B), then the primal loop with steepest edge — v = B^-T alpha_q
+    and tau = B^-1 rho are two more level-scheduled solves per pivot; the rows are random, so the basis carries a bump."""
+    monkeypatch.setenv("MLP_FACTOR", "1")
+    lp = lpgen.gen_twophase_lp(300, 260, 8, 6)
+    so, sg = _pair(lp)
+    st = sg.stats()
+    print("pivots", st["iterations"], "primal", st["primal_iters"], "dual", st["dual_iters"], "refactorisations", st["factor_refactors"], "active", st["factor_active"],
+          "largest bump", st["factor_bump_max"])
+    assert st["primal_iters"] > 0 and st["dual_iters"] > 0 and st["factor_active"] == 1
     assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
     assert obj_close(sg.objective(), so.objective())
     assert np.abs(sg.values() - so.values()).max() <= X_ATOL
