@@ -247,8 +247,8 @@ private:
     int fac_bump_max_ = 256;                 // MLP_FACTOR_BUMP: largest bump the compact factor carries (beyond it: explicit inverse)
     void fac_alloc();
     void fac_fill_view(DevView& v) const;
-    bool fac_refactor();                     // the peel + level lists from the current basis; false when it leaves a bump
-    bool fac_enter();                        // switch to the compact factor (false: the basis does not peel; nothing changed)
+    bool fac_refactor(int bump_limit = -1);  // the peel + level lists from the current basis; false when it leaves a bump beyond the limit (-1: MLP_FACTOR_BUMP)
+    bool fac_enter(int bump_limit = -1);     // switch to the compact factor (false: the basis does not peel; nothing changed)
     void fac_make_room(int need);
     void fac_leave();                        // back to the explicit nucleus inverse (re-inversion from A)
     void launch_stage_fac(int phase, int stage, bool with_events);

@@ -614,7 +614,7 @@ void Engine::ensure_nucleus_cap(int need) {
         (!fac_tried_ || cap_ >= 2 * (int)fac_tried_at_)) {
         fac_tried_ = true;
         fac_tried_at_ = (uint64_t)std::max(cap_, 1);
-        if (fac_enter()) return;
+        if (fac_enter(32)) return;  // (automatic selection: only a basis that peels almost completely — a bump that grows would flip back)
     }
     flush_lowrank();  // pending rank-1 terms are folded before the buffers move
     HIPCHECK(hipStreamSynchronize(st));
@@ -897,12 +897,21 @@ void Engine::pump_until_idle() {
     if (!pump_backend_) return;
     pump_seq_ += 1;
     const double t0 = now_s();
+    double next_report = 1.0;
     for (;;) {
         const hipError_t q = hipStreamQuery(st);
         if (q != hipSuccess && q != hipErrorNotReady) HIPCHECK(q);
         bool all = false;
         pump_round(q == hipSuccess, &all);
         if (all) break;
+        static const bool dbg = std::getenv("MLP_PUMP_DEBUG") != nullptr;
+        if (dbg && now_s() - t0 > next_report) {
+            next_report += 1.0;
+            std::fprintf(stderr, "[mlp pump] rank %d seq %llu: %.1f s, %llu rounds so far, local stream %s, words", shard_rank, pump_seq_, now_s() - t0,
+                         (unsigned long long)pump_rounds_, q == hipSuccess ? "idle" : "busy");
+            for (int r = 0; r < shard_world; ++r) std::fprintf(stderr, " %llu", pump_host_[r]);
+            std::fprintf(stderr, "\n");
+        }
         if (now_s() - t0 > 600.0) throw MlpError(-3, "pump transport: the batch did not drain on every rank within 600 s");
     }
 }
@@ -1677,7 +1686,9 @@ int Engine::run_loop(int phase) {
         const bool have_graph = gexec[phase][enable_pse ? 1 : 0][0] != nullptr;
         // (the one or two iterations handed over by the hypersparse kernel run eagerly: no graph is captured for them)
         const bool brief = hyper_gap > 0 && hyper_gap <= 4;
-        const bool graph_now = use_graph && !sample && !brief && (have_graph || eager_iters_in_geom >= 4);
+        // (pump transports launch eagerly: measured on the test box, a replayed graph keeps the pump's second stream from making
+        // progress until the graph has drained — its kernels then wait for records that cannot arrive)
+        const bool graph_now = use_graph && !pump_backend_ && !sample && !brief && (have_graph || eager_iters_in_geom >= 4);
         if (!have_graph && !brief) eager_iters_in_geom += 1;
         // long runs move on to graphs of several iterations and batches of a full record ring: one
         // launch and one host round trip cover more pivots (6 990 -> 7 300 pivots/s on config 4); short
@@ -1888,9 +1899,10 @@ void Engine::fac_fill_view(DevView& v) const {
 // peel of the CURRENT basis on the device, one level per pair of launches, paced by the host (it reads one counter per level:
 // ~20 us per level, amortised over fac_J_ pivots).  Returns false — and leaves the factor as it was — when the peel stops
 // before every column is consumed (the basis has a bump: its LU would fill).
-bool Engine::fac_refactor() {
+bool Engine::fac_refactor(int bump_limit) {
     HIPCHECK(hipStreamSynchronize(st));
     if (m_ <= 0) return false;
+    if (bump_limit < 0) bump_limit = fac_bump_max_;
     fac_alloc();
     sync_view();
     DevView t = hview;  // (also used to probe while the explicit inverse is still the representation in use)
@@ -1919,7 +1931,7 @@ bool Engine::fac_refactor() {
     // What the peel leaves is the BUMP (columns on cycles of the basis graph).  A small bump is carried along with its explicit
     // inverse (Gauss-Jordan here, b^2 doubles); a large one means this basis is not the shape the representation is for.
     const int b = m_ - total;
-    if (b > fac_bump_max_) return false;
+    if (b > bump_limit) return false;
     if (b > 0 || fac_bump_ > 0) {
         std::vector<int> hlev(mm), hrow(mm), bslot(mm, -1), bpos, brow;
         HIPCHECK(hipMemcpyAsync(hlev.data(), level, sizeof(int) * mm, hipMemcpyDeviceToHost, st));
@@ -1988,12 +2000,12 @@ void Engine::fac_make_room(int need) {
     if (fac_J_ - h_ctl->nlow >= need) return;
     if (!fac_refactor()) fac_leave();
 }
-bool Engine::fac_enter() {
+bool Engine::fac_enter(int bump_limit) {
     if (fac_on_) return true;
     if (shard_world > 1 || m_ <= 0 || !d_ctl.p) return false;
     ensure_beta();      // (the exact rebuild of the dual edge weights reads the explicit inverse: do it while there is one)
     flush_lowrank();
-    if (!fac_refactor()) return false;
+    if (!fac_refactor(bump_limit)) return false;
     // the explicit inverse and its work arrays go back to the allocator: this representation exists to not hold them
     HIPCHECK(hipStreamSynchronize(st));
     d_W.release(); d_U.release(); d_V.release(); d_Ut.release(); d_part_v.release(); d_part_tau.release();
@@ -2471,7 +2483,7 @@ void Engine::rebuild_inverse() {
         view_dirty = true;
         stats.fac_switches += 1;
     } else if (fac_mode == 1 && shard_world == 1 && !stepping) {
-        if (fac_enter()) return;
+        if (fac_enter(32)) return;  // (automatic selection: only a basis that peels almost completely — a bump that grows would flip back)
     }
     HIPCHECK(hipMemsetAsync(&d_ctl.p->nlow, 0, 2 * sizeof(int), st));  // a fresh inverse has no pending terms
     std::vector<int> claimed(m_, -1);
