@@ -3493,7 +3493,10 @@ __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push, int t
     const int k = c->k;
     // row-sharded streaming pass: the partials were exchanged by k_post_exchange; read tau_K (each row from its owner's
     // slot) and the v_K partials (summed in rank order) from the local exchange buffer
-    const bool xsh = v.wshard != 0;
+    // (only the strip tiling goes through the exchange: the classic 8- / 16-row tiling of the dense solves outside the pivot loop —
+    // recalc_basic_vals of the polish step, recalc_obj_coeffs — stays replicated.  Round 4: a sharded solve that reached the polish
+    // with a large nucleus read the stale exchange buffer here and reported an objective of zero.)
+    const bool xsh = v.wshard != 0 && TR > 16;
     const double* xb = nullptr;
     if (xsh) {  // k_post_exchange (previous launch) returned only after every rank's flag had arrived (or set halt)
         const unsigned long long ep = c->xepoch[4];

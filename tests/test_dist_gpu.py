@@ -168,3 +168,22 @@ def test_rccl_transport_with_a_world_of_one():
         md.remove_mailbox(box)
     assert [t[:5] for t in s.trace()] == [t[:5] for t in ref.trace()]
     assert abs(s.objective() - ref.objective()) <= 1e-9 * abs(ref.objective())
+
+
+def test_sharded_solve_with_the_large_nucleus_machinery_survives_the_polish_step():
+    """A whole sharded solve with the delayed-update mode, the row-sharded streaming pass and the blocked push forced on AND the
+    polish of long runs forced early (MLP_FINAL_REFRESH: re-inversion, x_B = B^-1 (b - N x_N) by the dense-rhs solve, reduced costs
+    recomputed).  The dense solves outside the pivot loop run replicated in the classic tiling; in round 4 they were found to read
+    the exchange buffer of the row-sharded pass instead (the 2-rank solve of config 4 ended with an objective of zero on the
+    ranks while its final basis was optimal).  Every rank must report the objective a fresh unsharded engine finds for the final basis."""
+    import json
+    env = dict(os.environ, MLP_FINAL_REFRESH="1000", MLP_LOWRANK="3", MLP_BIGTILE="1", MLP_LDPAD="16", MLP_BANDED="1", MLP_STR_K="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_full_solve.py"), "2", "3000", "3000", "12"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    ru = rec["reloaded_unsharded"]
+    assert ru["optimal_as_loaded"] and ru["further_pivots"] == 0
+    for g in rec["all_ranks"]:
+        assert abs(g["objective"] - ru["objective"]) <= 1e-9 * abs(ru["objective"]), (g, ru["objective"])
+    assert ru["certificate"]["relative_gap"] < 1e-9
