@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--wall-guard", type=float, default=1300.0,
                     help="full solve: stop (complete = false) once the whole bench run has lasted this many seconds")
     ap.add_argument("--chunk", type=int, default=50000, help="full solve: pivots per continue call")
+    ap.add_argument("--no-factor-transport", action="store_true", help="skip the 200 000-row transport solve on the compact factor (row f3)")
     ap.add_argument("--independent", action="store_true",
                     help="N > 1: one independent LP per rank (weak scaling) instead of column-block sharded pricing of ONE LP")
     return ap.parse_args()
@@ -273,6 +274,52 @@ def full_solve_live(s, lp, a, t_start, spent_s, pivots_done):
                                   max_primal_violation=float(max((A @ x - b).max(), (-x).max(), 0.0)),
                                   max_dual_violation=float(max((c - A.T @ y).max(), (-y).max(), 0.0)),
                                   checked="on the box with scipy mat-vecs (weak duality), no solver")
+    return out
+
+
+def factor_transport(a):
+    """SURVEY §8 row f3, measured live: the 200 000-row network-with-gains instance (lpgen.gen_transport_lp(100000, 100000, 4, tight=0.4):
+    m = 198 079, n = 400 000) solved to optimality on the COMPACT FACTOR of the basis (auto-selected when the explicit nucleus
+    inverse would pass 8 192 slots), with the oracle timed on the same box over the first 20 000 pivots (its whole solve, 92 s on
+    this box class, is the committed figure of profiles/r04_transport_200k_evidence.json)."""
+    import minilp_amd as M
+    from minilp_amd import lpgen
+    from oracle import minilp_oracle as O
+    lp = lpgen.gen_transport_lp(100000, 100000, 4, tight=0.4)
+    out = dict(measured="live", family="network with gains (lpgen.gen_transport_lp 100000 x 100000, 4 arcs per demand node, tight 0.4)",
+               rows=int(lp["m"]), cols=int(lp["n"]), nnz=int(len(lp["data"])))
+    prob = lpgen.build_problem(M.Problem, lp)
+    t0 = time.perf_counter()
+    s = prob.solve(budget=0)
+    s.continue_solve(20000)
+    t_first = time.perf_counter() - t0
+    s.continue_solve(-1)
+    wall = time.perf_counter() - t0
+    st = s.stats()
+    out.update(gpu_wall_s=wall, pivots=int(st["iterations"]), gpu_us_per_pivot=wall * 1e6 / max(1, int(st["iterations"])),
+               gpu_first_20000_us_per_pivot=t_first * 1e6 / 20000, objective=s.objective(), factor_active=int(st["factor_active"]),
+               levels_at_end=int(st["factor_levels"]), refactorisations=int(st["factor_refactors"]), largest_bump=int(st["factor_bump_max"]),
+               max_pivot_err=float(st["max_pivot_err"]))
+    del s
+    if not a.no_cpu_baseline:
+        so = lpgen.build_problem(O.Problem, lp).solve(budget=0)
+        t0 = time.perf_counter()
+        so.continue_solve(20000)
+        dt = time.perf_counter() - t0
+        out["oracle_first_20000_us_per_pivot"] = dt * 1e6 / 20000
+        out["gpu_over_oracle_first_20000"] = out["oracle_first_20000_us_per_pivot"] / out["gpu_first_20000_us_per_pivot"]
+        del so
+    try:
+        ev = json.load(open(os.path.join(ROOT, "profiles", "r04_transport_200k_evidence.json")))
+        orc, den = ev["runs"].get("oracle", {}), ev["runs"].get("dense", {})
+        out["committed"] = dict(source="profiles/r04_transport_200k_evidence.json", oracle_full_solve_s=orc.get("wall_s"), oracle_pivots=orc.get("pivots"),
+                                oracle_objective=orc.get("objective"),
+                                explicit_inverse_us_per_pivot_at_60000=(den.get("chunks") or [{}])[-1].get("us_per_pivot"))
+        if orc.get("wall_s"):
+            out["gpu_over_oracle_full_solve"] = orc["wall_s"] / wall
+            out["objective_matches_oracle"] = bool(abs(orc["objective"] - out["objective"]) <= 1e-9 * abs(orc["objective"]))
+    except (OSError, KeyError, ValueError):
+        pass
     return out
 
 
@@ -548,6 +595,11 @@ def main():
                 out["full_solve"] = full_solve_live(s, lp, a, T_START, solve_s, pivots_before)
             del s
             s = None
+            if not a.no_factor_transport:
+                try:
+                    out["factor_transport"] = factor_transport(a)
+                except Exception as e:   # reported, never voids the line
+                    out["factor_transport"] = dict(error=str(e)[:200])
     # N > 1, sharded: the late window as well (all ranks take part): this is where the row-sharded streaming pass of
     # the nucleus inverse pays; a failure here is reported inside the line, it does not void the timed figure above
     late_sharded = None

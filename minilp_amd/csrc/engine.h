@@ -243,6 +243,7 @@ private:
     DevBuf<int> d_fac_bpos, d_fac_brow, d_fac_bslot_of_row, d_fac_irow, d_fac_fptr, d_fac_fidx, d_fac_bptr, d_fac_bidx;
     DevBuf<double> d_fac_ipiv, d_fac_fval, d_fac_bval;
     DevBuf<double> d_fac_Wb;   // allocated with the first bump
+    bool fac_pair_ = true;                   // MLP_FACTOR_PAIR=0: every solve walks the levels on its own (A/B)
     int fac_bump_ = 0;
     int fac_bump_max_ = 256;                 // MLP_FACTOR_BUMP: largest bump the compact factor carries (beyond it: explicit inverse)
     void fac_alloc();

@@ -116,6 +116,7 @@ Engine::Engine() {
     if (const char* fm = std::getenv("MLP_FACTOR")) fac_mode = std::atoi(fm) > 0 ? 1 : 0;
     if (const char* fj = std::getenv("MLP_FACTOR_J")) fac_J_ = std::max(1, std::min(64, std::atoi(fj)));
     if (const char* ff = std::getenv("MLP_FACTOR_FROM")) fac_auto_cap_ = std::max(256, std::atoi(ff));
+    if (const char* fp = std::getenv("MLP_FACTOR_PAIR")) fac_pair_ = fp[0] != '0';
     if (const char* fb = std::getenv("MLP_FACTOR_BUMP")) fac_bump_max_ = std::max(0, std::min(FAC_BMAX, std::atoi(fb)));
     const char* nhf = std::getenv("MLP_NO_HEAD_FUSION");
     no_head_fusion = nhf && std::atoi(nhf) != 0;
@@ -1860,7 +1861,7 @@ void Engine::fac_alloc() {
     d_fac_pos_of_var.ensure(NN, 0, st); d_fac_var_of_pos.ensure(mm, 0, st); d_fac_prow.ensure(mm, 0, st);
     d_fac_items.ensure(mm, 0, st); d_fac_lptr.ensure(FAC_MAX_LEVELS + 2, 0, st); d_fac_meta.ensure(4, 0, st);
     d_fac_tmp.ensure(5 * mm, 0, st); d_fac_counters.ensure(4, 0, st);
-    d_fac_pval.ensure(mm, 0, st); d_fac_x0.ensure(mm, 0, st); d_fac_coef.ensure(2 * J + 2, 0, st); d_fac_part.ensure(J * 1024, 0, st);
+    d_fac_pval.ensure(mm, 0, st); d_fac_x0.ensure(2 * mm, 0, st); d_fac_coef.ensure(2 * 64 + 2, 0, st); d_fac_part.ensure((size_t)2 * 64 * 1024, 0, st);
     d_fac_U.ensure(J * mm, 0, st); d_fac_V.ensure(J * mm, 0, st);
     d_fac_bpos.ensure(FAC_BMAX, 0, st); d_fac_brow.ensure(FAC_BMAX, 0, st);
     {   // resolved edge lists: at most the entries of A (incl. the slack identity) on either side
@@ -2053,7 +2054,9 @@ void Engine::launch_stage_fac(int phase, int stage, bool with_events) {
     case STAGE_FTRAN:
         if (with_events) HIPCHECK(hipEventRecord(ev[6], st));
         if (phase == 0) launch_ftran_prep(dv, 1, st);            // entering column's scalars; the column becomes the right-hand side
-        launch_fac_solve(dv, g, 0, 0, 0, nullptr, 0, st);        // alpha_q = B^-1 a_q
+        // alpha_q = B^-1 a_q; in a dual iteration rho is known already, so tau = B^-1 rho (solver.rs:1157) shares the walk over the levels
+        if (phase == 1 && dse && fac_pair_) launch_fac_solve2(dv, g, 0, 0, 0, 1, 1, st);
+        else launch_fac_solve(dv, g, 0, 0, 0, nullptr, 0, st);
         if (with_events) HIPCHECK(hipEventRecord(ev[7], st));
         if (phase == 1) launch_post_ftran(dv, g, pse, st);       // ||alpha_q||^2 + 1, plan (1 / alpha_q[r])
         break;
@@ -2063,11 +2066,13 @@ void Engine::launch_stage_fac(int phase, int stage, bool with_events) {
         break;
     case STAGE_BTRAN:
         if (phase == 1) launch_btran_prep(dv, 1, 0, st);         // leaving row's scalars
-        launch_fac_solve(dv, g, 1, 0, 0, nullptr, 0, st);        // rho = B^-T e_r, ||rho||^2
+        // rho = B^-T e_r, ||rho||^2; in a primal iteration alpha_q is known already, so v = B^-T alpha_q (solver.rs:1114) shares the walk
+        if (phase == 0 && pse && fac_pair_) launch_fac_solve2(dv, g, 1, 0, 0, 1, 1, st);
+        else launch_fac_solve(dv, g, 1, 0, 0, nullptr, 0, st);
         break;
     case STAGE_BASIS:
-        if (pse) launch_fac_solve(dv, g, 1, 1, 1, nullptr, 0, st);   // v = B^-T alpha_q      (solver.rs:1114)
-        if (dse) launch_fac_solve(dv, g, 0, 1, 1, nullptr, 0, st);   // tau = B^-1 rho        (solver.rs:1157)
+        if (pse && !(phase == 0 && fac_pair_)) launch_fac_solve(dv, g, 1, 1, 1, nullptr, 0, st);   // v = B^-T alpha_q      (solver.rs:1114)
+        if (dse && !(phase == 1 && fac_pair_)) launch_fac_solve(dv, g, 0, 1, 1, nullptr, 0, st);   // tau = B^-1 rho        (solver.rs:1157)
         break;
     case STAGE_ROW:
         if (phase == 0) launch_sweep(dv, g, pse ? 1 : 0, 0, st, inl);
@@ -2888,7 +2893,7 @@ Engine* Engine::clone() {
     HIPCHECK(hipStreamSynchronize(s2));
     std::memcpy(e->h_ctl, h_ctl, sizeof(Ctl));
     e->values_dirty = true;
-    e->fac_mode = fac_mode; e->fac_J_ = fac_J_; e->fac_auto_cap_ = fac_auto_cap_; e->fac_bump_max_ = fac_bump_max_;
+    e->fac_mode = fac_mode; e->fac_J_ = fac_J_; e->fac_auto_cap_ = fac_auto_cap_; e->fac_bump_max_ = fac_bump_max_; e->fac_pair_ = fac_pair_;
     if (fac_on_ && !e->fac_enter())  // (a fresh peel of the same basis: the same operator, no pending terms)
         throw MlpError(-3, "clone: the basis of a solution on the compact factor must peel");
     return owner.release();
