@@ -71,7 +71,7 @@ def pmc_traffic(a, which):
     MI355X_MICROARCH.md prescribes and as tools/pmc_calib.sh confirms).  PMC counters cannot be
     collected from inside the timed run, so the figure is the committed per-launch average; null when
     the workload differs from the profiled one."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             doc = json.load(open(os.path.join(ROOT, "profiles", name)))
         except OSError:
@@ -80,7 +80,8 @@ def pmc_traffic(a, which):
         if (w.get("rows"), w.get("cols"), w.get("nnz_per_row"), w.get("seed")) != (a.rows, a.cols, a.nnz_per_row, a.seed):
             return None, None
         k = doc.get("kernels", {}).get(which)
-        return (k["hbm_bytes_per_launch"], name) if k else (None, None)
+        # (launches that exit at once — the streaming pass of a folding pivot is skipped — are left out of the average when the file says so)
+        return (k.get("hbm_bytes_per_working_launch", k["hbm_bytes_per_launch"]), name) if k else (None, None)
     return None, None
 
 

@@ -29,7 +29,7 @@ def collect(w):
                 if r.get("Counter_Name") == c:
                     acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
         for k, v in acc.items():
-            big = [x for x in v if x > 0.5 * max(v)]   # the launches that do the work (the fold kernel is launched every pivot and exits at once on 31 of 32)
+            big = [x for x in v if x >= 0.5 * max(v)] or v   # the launches that do the work (the fold kernel is launched every pivot and exits at once on 31 of 32)
             res[k][c] = (sum(v) / len(v), len(v), max(v), sum(big) / len(big), len(big))
     return res
 for w in ("early", "late"):
@@ -38,7 +38,8 @@ for w in ("early", "late"):
             continue
         name = None
         if "k_sweep_band" in k: name = "sweep" if w == "early" else "sweep_late"
-        elif "k_stream_w" in k: name = "stream_late"
+        elif "k_stream_w<true" in k: name = "stream_late"
+        elif "k_stream_w<false" in k: name = "stream_dense_ftran_late"   # the dense-rhs FTRAN x_B = B^-1 (b - N x_N) at load time (tau side of the strip kernel)
         elif "k_fold_w2" in k: name = "fold_late"      # (the default fold kernel: U through the scalar unit)
         elif "k_fold_w<" in k: name = "fold_lds_late"
         elif "k_fused_w" in k and w == "early": name = "fused"
@@ -48,7 +49,8 @@ for w in ("early", "late"):
         if name is None or (name in doc["kernels"]):
             continue
         f, wr = d["FETCH_SIZE"], d["WRITE_SIZE"]
-        rec = dict(kernel=k, launches=f[1], fetch_size_kb=f[0], write_size_kb=wr[0], hbm_bytes_per_launch=(2.0 * f[0] + wr[0]) * 1024.0)
+        rec = dict(kernel=k, launches=f[1], fetch_size_kb=f[0], write_size_kb=wr[0], hbm_bytes_per_launch=(2.0 * f[0] + wr[0]) * 1024.0,
+                   working_launches=f[4], hbm_bytes_per_working_launch=(2.0 * f[3] + wr[3]) * 1024.0)  # launches that exit at once (a skipped pass, a non-folding pivot) left out
         if name.startswith("fold"):  # most launches exit at once (a fold every 32nd pivot): report the launches that fold, averaged
             rec["folding_launches"] = f[4]
             rec["hbm_bytes_per_folding_launch"] = (2.0 * f[3] + wr[3]) * 1024.0
