@@ -117,6 +117,7 @@ Engine::Engine() {
     if (const char* fj = std::getenv("MLP_FACTOR_J")) fac_J_ = std::max(1, std::min(64, std::atoi(fj)));
     if (const char* ff = std::getenv("MLP_FACTOR_FROM")) fac_auto_cap_ = std::max(256, std::atoi(ff));
     if (const char* fp = std::getenv("MLP_FACTOR_PAIR")) fac_pair_ = fp[0] != '0';
+    if (const char* fs = std::getenv("MLP_FACTOR_SKIP")) fac_skip_ = fs[0] != '0';
     if (const char* fb = std::getenv("MLP_FACTOR_BUMP")) fac_bump_max_ = std::max(0, std::min(FAC_BMAX, std::atoi(fb)));
     const char* nhf = std::getenv("MLP_NO_HEAD_FUSION");
     no_head_fusion = nhf && std::atoi(nhf) != 0;
@@ -1861,7 +1862,12 @@ void Engine::fac_alloc() {
     d_fac_pos_of_var.ensure(NN, 0, st); d_fac_var_of_pos.ensure(mm, 0, st); d_fac_prow.ensure(mm, 0, st);
     d_fac_items.ensure(mm, 0, st); d_fac_lptr.ensure(FAC_MAX_LEVELS + 2, 0, st); d_fac_meta.ensure(4, 0, st);
     d_fac_tmp.ensure(5 * mm, 0, st); d_fac_counters.ensure(4, 0, st);
-    d_fac_pval.ensure(mm, 0, st); d_fac_x0.ensure(2 * mm, 0, st); d_fac_coef.ensure(2 * 64 + 2, 0, st); d_fac_part.ensure((size_t)2 * 64 * 1024, 0, st);
+    {   // the work vectors of the solves are zero outside a solve (the levels a solve skips read as zero)
+        const double* before = d_fac_x0.p;
+        d_fac_x0.ensure(2 * mm, 0, st);
+        if (d_fac_x0.p != before) HIPCHECK(hipMemsetAsync(d_fac_x0.p, 0, sizeof(double) * d_fac_x0.cap, st));
+    }
+    d_fac_pval.ensure(mm, 0, st); d_fac_coef.ensure(2 * 64 + 2, 0, st); d_fac_part.ensure((size_t)2 * 64 * 1024, 0, st);
     d_fac_U.ensure(J * mm, 0, st); d_fac_V.ensure(J * mm, 0, st);
     d_fac_bpos.ensure(FAC_BMAX, 0, st); d_fac_brow.ensure(FAC_BMAX, 0, st);
     {   // resolved edge lists: at most the entries of A (incl. the slack identity) on either side
@@ -1870,6 +1876,7 @@ void Engine::fac_alloc() {
         d_fac_fptr.ensure(mm + 2, 0, st); d_fac_bptr.ensure(mm + 2, 0, st);
         d_fac_fidx.ensure(nz, 0, st); d_fac_fval.ensure(nz, 0, st); d_fac_bidx.ensure(nz, 0, st); d_fac_bval.ensure(nz, 0, st);
         d_scan_tmp.ensure((mm + 2) / 4096 + 8, 0, st);
+        d_fac_lev3.ensure(3 * mm, 0, st);
     }
     {   // (no bump yet: every row is a pivot row of the peel)
         const int* before = d_fac_bslot_of_row.p;
@@ -1892,6 +1899,9 @@ void Engine::fac_fill_view(DevView& v) const {
     v.fac_prow = d_fac_prow.p; v.fac_pval = d_fac_pval.p; v.fac_items = d_fac_items.p; v.fac_lptr = d_fac_lptr.p;
     v.fac_U = d_fac_U.p; v.fac_V = d_fac_V.p; v.fac_rhs = d_fac_rhs.p; v.fac_x0 = d_fac_x0.p; v.fac_coef = d_fac_coef.p; v.fac_part = d_fac_part.p;
     v.fac_bar = d_fac_bar.p;
+    v.fac_lev_of_pos = d_fac_lev3.p; v.fac_lev_of_row = d_fac_lev3.p ? d_fac_lev3.p + (size_t)std::max(m_, 1) : nullptr;
+    v.fac_reach_of_pos = d_fac_lev3.p ? d_fac_lev3.p + 2 * (size_t)std::max(m_, 1) : nullptr;
+    v.fac_skip = fac_skip_ ? 1 : 0; v.fac_pad1 = 0;
     v.fac_irow = d_fac_irow.p; v.fac_ipiv = d_fac_ipiv.p; v.fac_fptr = d_fac_fptr.p; v.fac_fidx = d_fac_fidx.p; v.fac_fval = d_fac_fval.p;
     v.fac_bptr = d_fac_bptr.p; v.fac_bidx = d_fac_bidx.p; v.fac_bval = d_fac_bval.p;
     v.fac_bpos = d_fac_bpos.p; v.fac_brow = d_fac_brow.p; v.fac_bslot_of_row = d_fac_bslot_of_row.p; v.fac_Wb = d_fac_Wb.p;
@@ -1981,10 +1991,18 @@ bool Engine::fac_refactor(int bump_limit) {
     HIPCHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)std::max(nlev, 1), st));  // (cnt is free again: the per-level fill cursors)
     launch_fac_peel_fill(t, level, cnt, st);
     // resolved edge lists of the two solves in level order: counts -> exclusive scans -> fill
-    launch_fac_edges(t, 0, d_fac_fptr.p, d_fac_bptr.p, st);
+    HIPCHECK(hipMemsetAsync(d_fac_lev3.p, 0xFF, sizeof(int) * 3 * mm, st));  // (-1: bump positions / rows keep it)
+    launch_fac_edges(t, 0, d_fac_fptr.p, d_fac_bptr.p, level, st);
     launch_exclusive_scan(d_fac_fptr.p, d_fac_fptr.p, (long)total + 1, d_scan_tmp.p, st);
     launch_exclusive_scan(d_fac_bptr.p, d_fac_bptr.p, (long)total + 1, d_scan_tmp.p, st);
-    launch_fac_edges(t, 1, d_fac_fptr.p, d_fac_bptr.p, st);
+    launch_fac_edges(t, 1, d_fac_fptr.p, d_fac_bptr.p, level, st);
+    if (fac_skip_ && b == 0)  // the level ranges of the solves (factor.inc): reach of every position, levels in descending order
+        for (int lev = nlev - 1; lev >= 0; --lev) launch_fac_reach(t, lev, lptr[lev + 1] - lptr[lev], st);
+    {   // level statistics produced before this refactorisation describe the old levels: conservative values until the next producer
+        const int stat[4] = {INT_MAX, INT_MAX, 0, INT_MAX};  // fac_aq_hi, fac_rho_hi, fac_aq_lo, fac_aq_reach
+        HIPCHECK(hipMemcpyAsync(&d_ctl.p->fac_aq_hi, stat, sizeof(stat), hipMemcpyHostToDevice, st));
+        HIPCHECK(hipStreamSynchronize(st));
+    }
     HIPCHECK(hipMemsetAsync(&d_ctl.p->nlow, 0, 2 * sizeof(int), st));  // a fresh factor has no pending terms
     HIPCHECK(hipStreamSynchronize(st));  // (lptr / meta were staged from local memory)
     h_ctl->nlow = 0;
@@ -2893,7 +2911,7 @@ Engine* Engine::clone() {
     HIPCHECK(hipStreamSynchronize(s2));
     std::memcpy(e->h_ctl, h_ctl, sizeof(Ctl));
     e->values_dirty = true;
-    e->fac_mode = fac_mode; e->fac_J_ = fac_J_; e->fac_auto_cap_ = fac_auto_cap_; e->fac_bump_max_ = fac_bump_max_; e->fac_pair_ = fac_pair_;
+    e->fac_mode = fac_mode; e->fac_J_ = fac_J_; e->fac_auto_cap_ = fac_auto_cap_; e->fac_bump_max_ = fac_bump_max_; e->fac_pair_ = fac_pair_; e->fac_skip_ = fac_skip_;
     if (fac_on_ && !e->fac_enter())  // (a fresh peel of the same basis: the same operator, no pending terms)
         throw MlpError(-3, "clone: the basis of a solution on the compact factor must peel");
     return owner.release();

@@ -95,6 +95,12 @@ struct Ctl {
     int aq_n;        // sparse primal ratio test: listed positions of supp(alpha_q) this iteration
     int str_n;       // sparse tableau row (k_row_touch / k_row_pull): non-basic columns touched by the rows of supp(rho) this iteration
                      // (aq_n and str_n are adjacent: the host clears the pair with one 8-byte memset)
+    // compact factor (factor.inc): level ranges a solve has to walk, produced by the solve / head that precedes it (a right-hand side
+    // that is zero on every level beyond L leaves those levels at zero: they are skipped)
+    int fac_aq_hi;     // FTRAN of the entering column: highest level among the pivot positions of its rows
+    int fac_rho_hi;    // FTRAN of rho (tau = B^-1 rho): highest level among the rows of supp(rho)        (atomicMax by the BTRAN's epilogue)
+    int fac_aq_lo;     // BTRAN of alpha_q (v = B^-T alpha_q): lowest level among supp(alpha_q)           (atomicMin by the FTRAN's epilogue)
+    int fac_aq_reach;  // ... and the highest level its dependents reach                                   (atomicMax)
     int kprof_on;    // MLP_KPROF=1: kernels stamp the wall clock into hy_prof (KMARK; state("kernel_timeline"))
     int str_pad;
     unsigned long long hy_prof[24];  // ticks of the 100 MHz wall clock per stage of the hypersparse iteration (diagnostics)
@@ -257,6 +263,10 @@ struct DevView {
     int* fac_lptr;           // levels + 1 offsets into fac_items
     // per place in fac_items (level order), rebuilt with the peel: pivot row and pivot element, and the RESOLVED edge lists of the
     // two solves — FTRAN: the other basic columns of the pivot row as (position, value), BTRAN: the other rows of the column
+    int* fac_lev_of_pos;     // m: level of a position (-1: bump)
+    int* fac_lev_of_row;     // m: level of the position that pivots on a row (-1: bump row)
+    int* fac_reach_of_pos;   // m: highest level any BTRAN dependent of the position reaches
+    int fac_skip, fac_pad1;  // MLP_FACTOR_SKIP: walk only the levels a right-hand side can reach
     int* fac_irow; double* fac_ipiv;
     int* fac_fptr; int* fac_fidx; double* fac_fval;   // m + 1 | entries of the basis
     int* fac_bptr; int* fac_bidx; double* fac_bval;
@@ -359,7 +369,8 @@ void launch_fac_gather_cb(const DevView& dv, hipStream_t st);  // alpha_q[p] = c
 void launch_fac_peel_init(const DevView& dv, int* cnt, int* level, int* row_lev, int* claim, hipStream_t st);
 void launch_fac_peel_level(const DevView& dv, int lev, int* cnt, int* level, int* row_lev, int* claim, int* cand_row, int* counters, hipStream_t st);
 void launch_fac_peel_fill(const DevView& dv, const int* level, int* cursor, hipStream_t st);
-void launch_fac_edges(const DevView& dv, int pass, int* fcnt, int* bcnt, hipStream_t st);  // resolved edge lists in level order: pass 0 counts, pass 1 fills
+void launch_fac_edges(const DevView& dv, int pass, int* fcnt, int* bcnt, const int* level, hipStream_t st);  // resolved edge lists in level order: pass 0 counts, pass 1 fills
+void launch_fac_reach(const DevView& dv, int lev, int count, hipStream_t st);  // reach_of_pos of one level (levels in descending order)
 void launch_fac_bump_build(const DevView& dv, double* Kd, int b, hipStream_t st);  // K = B0[bump rows, bump columns], dense, row-major with pitch FAC_BMAX
 void launch_str_reset(const DevView& dv, hipStream_t st);  // sparse tableau row: new stamp epoch, empty lists
 void launch_checksum_w(const DevView& dv, unsigned long long* out, hipStream_t st);  // order-independent checksum of W[0:k, 0:k] and the slot maps (tests)

@@ -694,8 +694,19 @@ __device__ void ftran_prep_wave(const DevView& v, Ctl* c, int lane, int derive_p
     }
     int base = v.csc_ptr[var], end = v.csc_ptr[var + 1];
     if (v.fac_on) {  // compact factor: the entering column becomes the right-hand side (by row) of the level-scheduled solve
-        for (int e = base + lane; e < end; e += 64) v.fac_rhs[v.csc_row[e]] = v.csc_val[e];
-        if (lane == 0) it->klist_n = 0;
+        int hi = -1;
+        for (int e = base + lane; e < end; e += 64) {
+            const int row = v.csc_row[e];
+            v.fac_rhs[row] = v.csc_val[e];
+            const int lv = v.fac_lev_of_row[row];
+            hi = max(hi, lv < 0 ? INT_MAX : lv);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) hi = max(hi, __shfl_down(hi, o, 64));
+        if (lane == 0) {
+            it->klist_n = 0;
+            c->fac_aq_hi = hi;  // the FTRAN walks the levels from this one down
+        }
         return;
     }
     int cnt = 0;
@@ -4708,7 +4719,7 @@ void launch_reset_ring(const DevView& dv, hipStream_t st) { hipLaunchKernelGGL(k
 void launch_btran_dense(const DevView& dv, const Geom& g, hipStream_t st) {
     if (dv.fac_on) {  // compact factor: c_B by position -> alpha_q, y = B^-T c_B -> rv.y
         launch_fac_gather_cb(dv, st);
-        launch_fac_solve(dv, g, 1, 1, 1, nullptr, 1, st);
+        launch_fac_solve(dv, g, 1, 2, 1, dv.alpha_q, 1, st);  // (src 2: an arbitrary dense vector — every level is walked)
         return;
     }
     if (g.cap <= 0) return;
