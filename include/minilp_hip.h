@@ -103,7 +103,8 @@ uint64_t mlp_solution_save_basis(const mlp_solution* s, int mode, void* buf, uin
 int mlp_problem_solve_from_basis(const mlp_problem* p, const void* blob, uint64_t len, mlp_solution** out, int64_t budget,
                                  uint32_t flags);
 /* flags bit1 (HIP-event timing): 1 = sample EVERY iteration as an eager, event-bracketed one (measurement passes),
- * 0 = the default cadence (every 8th / 4th batch), < 0 = switch the sampling off for the rest of the solve */
+ * 0 = the default cadence (every 8th / 4th batch), < 0 = switch the sampling off (until the next call with a value >= 0, which
+ * also switches HIP-event timing on for a solution created without flag bit1) */
 int mlp_solution_set_sampling(mlp_solution* s, int every_iteration);
 int mlp_solution_budget_exhausted(const mlp_solution* s);
 /* Recompute the dense nucleus inverse from A (the counterpart of BasisSolver::reset,

@@ -160,6 +160,7 @@ int mlp_solution_set_sampling(mlp_solution* s, int every_iteration) {
             s->eng->profile = false;
             s->eng->sample_every = 0;
         } else {
+            s->eng->profile = true;  // (also switches the sampling back on after a `< 0` call)
             s->eng->sample_every = every_iteration ? 1 : 0;
         }
     });

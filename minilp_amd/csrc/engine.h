@@ -242,6 +242,7 @@ private:
     DevBuf<unsigned> d_fac_bar;
     DevBuf<int> d_fac_bpos, d_fac_brow, d_fac_bslot_of_row, d_fac_irow, d_fac_fptr, d_fac_fidx, d_fac_bptr, d_fac_bidx;
     DevBuf<double> d_fac_ipiv, d_fac_fval, d_fac_bval;
+    DevBuf<int> d_fac_lcount;
     DevBuf<int> d_fac_lev3;   // 3 m: level of a position | level of a row's pivot position | reach of a position
     bool fac_skip_ = true;    // MLP_FACTOR_SKIP=0: every solve walks every level (A/B)
     DevBuf<double> d_fac_Wb;   // allocated with the first bump

@@ -1928,7 +1928,33 @@ bool Engine::fac_refactor(int bump_limit) {
     launch_fac_peel_init(t, cnt, level, row_lev, claim, st);
     std::vector<int> lptr(1, 0);
     int total = 0;
-    for (int lev = 1; lev <= FAC_MAX_LEVELS; ++lev) {
+    static const bool peel_paced = std::getenv("MLP_FACTOR_PEEL_PACED") != nullptr;  // the round-4 first cut: the host paces the levels
+    bool device_peel_done = false;
+    if (!peel_paced) {
+        // one launch for the whole peel (grid barriers between the phases), one read-back of the level counts
+        d_fac_lcount.ensure(FAC_MAX_LEVELS + 2, 0, st);
+        launch_fac_peel_all(t, cnt, level, row_lev, claim, cand_row, d_fac_counters.p, d_fac_lcount.p, FAC_MAX_LEVELS, st);
+        std::vector<int> lc(FAC_MAX_LEVELS + 2, 0);
+        int hc[4] = {0, 0, 0, 0};
+        HIPCHECK(hipMemcpyAsync(hc, d_fac_counters.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipMemcpyAsync(lc.data(), d_fac_lcount.p, sizeof(int) * 64, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        if (hc[2]) throw MlpError(-2, "singular basis matrix: a basic column lost its last unclaimed row in the peel (solver.rs:1301)");
+        if (!hc[1]) {
+            const int nl = lc[0];
+            if (nl >= 63) {  // (rare: more levels than the first read-back covered)
+                HIPCHECK(hipMemcpyAsync(lc.data(), d_fac_lcount.p, sizeof(int) * (size_t)(nl + 1), hipMemcpyDeviceToHost, st));
+                HIPCHECK(hipStreamSynchronize(st));
+            }
+            for (int l = 1; l <= nl; ++l) lptr.push_back(lc[l]);
+            total = nl > 0 ? lc[nl] : 0;
+            device_peel_done = true;
+        } else {  // a grid barrier gave up: redo the peel level by level
+            HIPCHECK(hipMemsetAsync(d_fac_counters.p, 0, 4 * sizeof(int), st));
+            launch_fac_peel_init(t, cnt, level, row_lev, claim, st);
+        }
+    }
+    for (int lev = 1; !device_peel_done && lev <= FAC_MAX_LEVELS; ++lev) {
         launch_fac_peel_level(t, lev, cnt, level, row_lev, claim, cand_row, d_fac_counters.p, st);
         int hc[4] = {0, 0, 0, 0};
         HIPCHECK(hipMemcpyAsync(hc, d_fac_counters.p, sizeof(hc), hipMemcpyDeviceToHost, st));

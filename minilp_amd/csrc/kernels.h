@@ -368,6 +368,8 @@ void launch_fac_gather_cb(const DevView& dv, hipStream_t st);  // alpha_q[p] = c
 // refactorisation (host-paced peel): init, then claim + commit per level, then the level lists
 void launch_fac_peel_init(const DevView& dv, int* cnt, int* level, int* row_lev, int* claim, hipStream_t st);
 void launch_fac_peel_level(const DevView& dv, int lev, int* cnt, int* level, int* row_lev, int* claim, int* cand_row, int* counters, hipStream_t st);
+void launch_fac_peel_all(const DevView& dv, int* cnt, int* level, int* row_lev, int* claim, int* cand_row, int* counters, int* lcount, int max_levels,
+                         hipStream_t st);  // the whole peel in one launch: lcount[0] = levels, lcount[l] = positions peeled up to level l
 void launch_fac_peel_fill(const DevView& dv, const int* level, int* cursor, hipStream_t st);
 void launch_fac_edges(const DevView& dv, int pass, int* fcnt, int* bcnt, const int* level, hipStream_t st);  // resolved edge lists in level order: pass 0 counts, pass 1 fills
 void launch_fac_reach(const DevView& dv, int lev, int count, hipStream_t st);  // reach_of_pos of one level (levels in descending order)
