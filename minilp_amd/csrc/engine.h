@@ -243,12 +243,14 @@ private:
     DevBuf<int> d_fac_bpos, d_fac_brow, d_fac_bslot_of_row, d_fac_irow, d_fac_fptr, d_fac_fidx, d_fac_bptr, d_fac_bidx;
     DevBuf<double> d_fac_ipiv, d_fac_fval, d_fac_bval;
     DevBuf<int> d_fac_lcount;
+    DevBuf<double> d_fac_Kd, d_fac_Wtmp, d_fac_gjval;  // bump inversion: K, the work copy of the inverse, partial maxima | scratch
+    DevBuf<int> d_fac_gjrow;
     DevBuf<int> d_fac_lev3;   // 3 m: level of a position | level of a row's pivot position | reach of a position
     bool fac_skip_ = true;    // MLP_FACTOR_SKIP=0: every solve walks every level (A/B)
     DevBuf<double> d_fac_Wb;   // allocated with the first bump
     bool fac_pair_ = true;                   // MLP_FACTOR_PAIR=0: every solve walks the levels on its own (A/B)
     int fac_bump_ = 0;
-    int fac_bump_max_ = 256;                 // MLP_FACTOR_BUMP: largest bump the compact factor carries (beyond it: explicit inverse)
+    int fac_bump_max_ = FAC_BMAX;            // MLP_FACTOR_BUMP: largest bump the compact factor carries (beyond it: explicit inverse)
     void fac_alloc();
     void fac_fill_view(DevView& v) const;
     bool fac_refactor(int bump_limit = -1);  // the peel + level lists from the current basis; false when it leaves a bump beyond the limit (-1: MLP_FACTOR_BUMP)
@@ -387,7 +389,7 @@ private:
     bool values_dirty = true;
 
     // --- iteration graphs: [phase][pse]
-    bool use_graph = true, use_branches = false;
+    bool use_graph = true, use_branches = false, use_vbranch = true;
     int batch = 32;  // (round 4: 16 -> 32: one host round trip per 32 replayed iterations; the driver's 20-pivot window is then ONE batch)
     long final_refresh_pivots = 50000;  // MLP_FINAL_REFRESH: re-examine optimality on recomputed reduced costs after this many pivots (0 = never)
     uint64_t iters_since_recalc = 0, iters_since_polish = 0;

@@ -80,6 +80,8 @@ Engine::Engine() {
     // pivot at k = 20 500 and 367.7 vs 358.6 us at k = 10 000 — the two kernels do not overlap usefully with the sweep and
     // the fork / join costs a little; off unless MLP_BRANCH=1
     use_branches = br && br[0] == '1';
+    const char* vb = std::getenv("MLP_VBRANCH");
+    use_vbranch = !(vb && vb[0] == '0');
     const char* rt = std::getenv("MLP_REFRESH_TOL");
     if (rt) refresh_tol = std::atof(rt);
     const char* lr = std::getenv("MLP_LOWRANK");
@@ -1300,6 +1302,11 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         launch_stage_fac(phase, stage, with_events);
         return;
     }
+    // v branch (round 4): in the lazy primal iteration of the delayed-update mode the pass over the nucleus inverse computes
+    // v = B^-T alpha_q only — it needs alpha_q, not the leaving row — so it leaves the chain FTRAN -> ratio test -> BTRAN -> pass
+    // and runs on the side stream beside the ratio test and the BTRAN (t_K, the fold of a folding pivot, the streaming pass);
+    // the BTRAN waits for the fold (W0 must be whole), the tails of the pass wait for the stream.  MLP_VBRANCH=0: the serial order.
+    const bool vbr = use_vbranch && phase == 0 && pse && lazy && !stepping && shard_world == 1 && !g.head_fused && vbranch_supported(dv, g);
     if (stage == STAGE_BASIS) touch_done = false;
     // The pricing decision (q for primal, r for dual) is already in Ctl: it was taken by the
     // previous iteration's update kernel, or by the standalone pricing kernel at batch start.
@@ -1310,12 +1317,29 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
             launch_ftran_fused(dv, g, 1, st);              // K2 head inside the gather kernel (one launch)
         } else {
             if (phase == 0) launch_ftran_prep(dv, 1, st);  // K2 head: entering column scalars, singleton rows, list
-            launch_ftran_gather(dv, g, st);                // K2: alpha_q = B^-1 a_q (dual: the head ran in RATIO)
+            launch_ftran_gather(dv, g, st, vbr ? 1 : 0);   // K2: alpha_q = B^-1 a_q (dual: the head ran in RATIO); v branch: + y_S by row
         }
         if (with_events) HIPCHECK(hipEventRecord(ev[7], st));
         if (phase == 1) {
             launch_post_ftran(dv, g, pse, st);         // alpha_sq, y_S, partition plan
             if (pse) launch_btran_rhs(dv, g, st);      // tK
+        }
+        if (vbr) {
+            HIPCHECK(hipEventRecord(evFork[1], st));
+            HIPCHECK(hipStreamWaitEvent(st2, evFork[1], 0));
+            launch_pse_tk(dv, g, st2);                  // tK = alpha_K - F^T y_S (y_S on the fly)
+            if (with_events) {  // sampled iteration: the pass and the fold are timed kernel-exactly (beside the ratio test, as they run)
+                arm_kernel_timing(2, ev[2], ev[3]);
+                arm_kernel_timing(3, ev[10], ev[11]);
+            }
+            launch_fused_w_side(dv, g, 1, st2);         // the fold of a folding pivot (also the v partials of that pivot)
+            HIPCHECK(hipEventRecord(evFork[2], st2));  // W0 is whole again
+            launch_fused_w_side(dv, g, 2, st2);         // vK partials: one read of W0
+            if (with_events) {
+                arm_kernel_timing(2, nullptr, nullptr);
+                arm_kernel_timing(3, nullptr, nullptr);
+            }
+            HIPCHECK(hipEventRecord(evJoin[1], st2));
         }
         break;
     case STAGE_RATIO:
@@ -1327,18 +1351,27 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
             launch_btran_fused(dv, g, 0, 1, st);                  // K3 head inside the BTRAN kernel (one launch)
         } else {
             if (phase == 1) launch_btran_prep(dv, 1, 0, st);      // K3 head (device-driven by it.r)
-            launch_btran(dv, g, phase == 0 ? pse : 0, st);        // K3: rho, rK, ||rho||^2  |  tK = alpha_K - F^T y_S
+            if (vbr) {
+                HIPCHECK(hipStreamWaitEvent(st, evFork[2], 0));   // a folding pivot: rho is a row of the folded W0
+                launch_btran(dv, g, 0, st, 1);                    // K3: rho, rK, ||rho||^2 (tK was built on the side stream)
+            } else {
+                launch_btran(dv, g, phase == 0 ? pse : 0, st);    // K3: rho, rK, ||rho||^2  |  tK = alpha_K - F^T y_S
+            }
         }
         break;
     case STAGE_BASIS:
-        if (with_events) {  // sampled iteration: the pass over the nucleus inverse and the fold are timed kernel-exactly
-            arm_kernel_timing(2, ev[2], ev[3]);
-            arm_kernel_timing(3, ev[10], ev[11]);
-        }
-        launch_fused_w(dv, g, pse, st, wtau);                 // tauK / vK partials + eta update of W
-        if (with_events) {
-            arm_kernel_timing(2, nullptr, nullptr);
-            arm_kernel_timing(3, nullptr, nullptr);
+        if (vbr) {
+            HIPCHECK(hipStreamWaitEvent(st, evJoin[1], 0));   // the v partials have landed
+        } else {
+            if (with_events) {  // sampled iteration: the pass over the nucleus inverse and the fold are timed kernel-exactly
+                arm_kernel_timing(2, ev[2], ev[3]);
+                arm_kernel_timing(3, ev[10], ev[11]);
+            }
+            launch_fused_w(dv, g, pse, st, wtau);                 // tauK / vK partials + eta update of W
+            if (with_events) {
+                arm_kernel_timing(2, nullptr, nullptr);
+                arm_kernel_timing(3, nullptr, nullptr);
+            }
         }
         if (tau_branch) {
             // large-nucleus regime: the blocked push of -F tau_K (two kernels, ~40 us of serial chains) is needed by the
@@ -1860,8 +1893,8 @@ constexpr int FAC_MAX_LEVELS = 4096;
 void Engine::fac_alloc() {
     const size_t mm = (size_t)std::max(m_, 1), NN = (size_t)std::max(N_, 1), J = (size_t)fac_J_;
     d_fac_pos_of_var.ensure(NN, 0, st); d_fac_var_of_pos.ensure(mm, 0, st); d_fac_prow.ensure(mm, 0, st);
-    d_fac_items.ensure(mm, 0, st); d_fac_lptr.ensure(FAC_MAX_LEVELS + 2, 0, st); d_fac_meta.ensure(4, 0, st);
-    d_fac_tmp.ensure(5 * mm, 0, st); d_fac_counters.ensure(4, 0, st);
+    d_fac_items.ensure(mm, 0, st); d_fac_lptr.ensure(FAC_MAX_LEVELS + 2, 0, st); d_fac_meta.ensure(8, 0, st);
+    d_fac_tmp.ensure(8 * mm, 0, st); d_fac_counters.ensure(4, 0, st);
     {   // the work vectors of the solves are zero outside a solve (the levels a solve skips read as zero)
         const double* before = d_fac_x0.p;
         d_fac_x0.ensure(2 * mm, 0, st);
@@ -1924,16 +1957,20 @@ bool Engine::fac_refactor(int bump_limit) {
     int* row_lev = level + mm;
     int* claim = row_lev + mm;
     int* cand_row = claim + mm;
+    int* rcnt = cand_row + mm;      // row steps of the peel: active basic columns per row, the bids of the rows, their candidates
+    int* claim_r = rcnt + mm;
+    int* cand_col = claim_r + mm;
     HIPCHECK(hipMemsetAsync(d_fac_counters.p, 0, 4 * sizeof(int), st));
-    launch_fac_peel_init(t, cnt, level, row_lev, claim, st);
+    launch_fac_peel_init(t, cnt, level, row_lev, claim, rcnt, claim_r, st);
     std::vector<int> lptr(1, 0);
     int total = 0;
+    int n_col_steps = 0, n_row_steps = 0;
     static const bool peel_paced = std::getenv("MLP_FACTOR_PEEL_PACED") != nullptr;  // the round-4 first cut: the host paces the levels
     bool device_peel_done = false;
     if (!peel_paced) {
         // one launch for the whole peel (grid barriers between the phases), one read-back of the level counts
         d_fac_lcount.ensure(FAC_MAX_LEVELS + 2, 0, st);
-        launch_fac_peel_all(t, cnt, level, row_lev, claim, cand_row, d_fac_counters.p, d_fac_lcount.p, FAC_MAX_LEVELS, st);
+        launch_fac_peel_all(t, cnt, level, row_lev, claim, cand_row, d_fac_counters.p, d_fac_lcount.p, FAC_MAX_LEVELS, rcnt, claim_r, cand_col, st);
         std::vector<int> lc(FAC_MAX_LEVELS + 2, 0);
         int hc[4] = {0, 0, 0, 0};
         HIPCHECK(hipMemcpyAsync(hc, d_fac_counters.p, sizeof(hc), hipMemcpyDeviceToHost, st));
@@ -1942,16 +1979,29 @@ bool Engine::fac_refactor(int bump_limit) {
         if (hc[2]) throw MlpError(-2, "singular basis matrix: a basic column lost its last unclaimed row in the peel (solver.rs:1301)");
         if (!hc[1]) {
             const int nl = lc[0];
-            if (nl >= 63) {  // (rare: more levels than the first read-back covered)
+            if (nl >= 63) {  // (rare: more steps than the first read-back covered)
                 HIPCHECK(hipMemcpyAsync(lc.data(), d_fac_lcount.p, sizeof(int) * (size_t)(nl + 1), hipMemcpyDeviceToHost, st));
                 HIPCHECK(hipStreamSynchronize(st));
             }
-            for (int l = 1; l <= nl; ++l) lptr.push_back(lc[l]);
-            total = nl > 0 ? lc[nl] : 0;
+            // sizes of the column steps (in order) and of the row steps (in order); the list of levels = column steps, then the row
+            // steps backwards (factor.inc, k_fac_peel_all)
+            std::vector<int> csz, rsz;
+            int run = 0;
+            for (int l = 1; l <= nl; ++l) {
+                const int cum = std::abs(lc[l]);
+                (lc[l] > 0 ? csz : rsz).push_back(cum - run);
+                run = cum;
+            }
+            total = run;
+            n_col_steps = (int)csz.size();
+            n_row_steps = (int)rsz.size();
+            for (int x : csz) lptr.push_back(lptr.back() + x);
+            lptr.push_back(lptr.back());  // the bump: a level of its own in the order, empty in the lists (walked through its dense inverse)
+            for (size_t a = rsz.size(); a-- > 0;) lptr.push_back(lptr.back() + rsz[a]);
             device_peel_done = true;
         } else {  // a grid barrier gave up: redo the peel level by level
             HIPCHECK(hipMemsetAsync(d_fac_counters.p, 0, 4 * sizeof(int), st));
-            launch_fac_peel_init(t, cnt, level, row_lev, claim, st);
+            launch_fac_peel_init(t, cnt, level, row_lev, claim, rcnt, claim_r, st);
         }
     }
     for (int lev = 1; !device_peel_done && lev <= FAC_MAX_LEVELS; ++lev) {
@@ -1963,8 +2013,10 @@ bool Engine::fac_refactor(int bump_limit) {
         if (hc[0] == total) break;
         total = hc[0];
         lptr.push_back(total);
+        n_col_steps += 1;  // (the host-paced fallback runs column steps only: a larger bump, the same order)
         if (total == m_) break;
     }
+    if (!device_peel_done) lptr.push_back(lptr.back());  // the (empty) level of the bump
     // What the peel leaves is the BUMP (columns on cycles of the basis graph).  A small bump is carried along with its explicit
     // inverse (Gauss-Jordan here, b^2 doubles); a large one means this basis is not the shape the representation is for.
     const int b = m_ - total;
@@ -1989,18 +2041,30 @@ bool Engine::fac_refactor(int bump_limit) {
             if (hview.fac_Wb != d_fac_Wb.p) view_dirty = true;
             HIPCHECK(hipMemcpyAsync(d_fac_bpos.p, bpos.data(), sizeof(int) * (size_t)b, hipMemcpyHostToDevice, st));
             HIPCHECK(hipMemcpyAsync(d_fac_brow.p, brow.data(), sizeof(int) * (size_t)b, hipMemcpyHostToDevice, st));
-            DevBuf<double> Kd, scratch;
-            DevBuf<int> flag;
-            Kd.ensure((size_t)b * FAC_BMAX, 0, st);
-            scratch.ensure((size_t)b + 8, 0, st);
-            flag.ensure(2, 0, st);
-            HIPCHECK(hipMemsetAsync(flag.p, 0, 2 * sizeof(int), st));
-            launch_fac_bump_build(t, Kd.p, b, st);
-            launch_gauss_jordan(Kd.p, d_fac_Wb.p, b, FAC_BMAX, flag.p, scratch.p, st);
-            int hflag = 0;
-            HIPCHECK(hipMemcpyAsync(&hflag, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
-            HIPCHECK(hipStreamSynchronize(st));
-            if (hflag) throw MlpError(-2, "singular basis matrix: the bump of the peel is singular (solver.rs:1301)");
+            // work arrays of the inversion, kept across refactorisations (grown in steps of 64 rows)
+            const size_t brows = (size_t)((b + 63) / 64) * 64;
+            d_fac_Kd.ensure(brows * FAC_BMAX, 0, st);
+            d_fac_Wtmp.ensure(brows * FAC_BMAX, 0, st);
+            d_fac_gjval.ensure(2 * 64 + (size_t)b + 8, 0, st);  // partial maxima of the one-launch form | scratch of the per-column form
+            d_fac_gjrow.ensure(2 * 64 + 4, 0, st);               // ... their rows | the two flags
+            int* flag = d_fac_gjrow.p + 2 * 64;
+            HIPCHECK(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
+            launch_fac_bump_build(t, d_fac_Kd.p, b, st);
+            static const bool gj_launches = std::getenv("MLP_FACTOR_GJ_LAUNCHES") != nullptr;  // A/B: the launch-per-column Gauss-Jordan
+            int hflag[2] = {0, 0};
+            if (!gj_launches) {
+                launch_fac_bump_invert(t, d_fac_Kd.p, d_fac_Wtmp.p, d_fac_Wb.p, b, flag, d_fac_gjval.p, d_fac_gjrow.p, st);
+                HIPCHECK(hipMemcpyAsync(hflag, flag, sizeof(hflag), hipMemcpyDeviceToHost, st));
+                HIPCHECK(hipStreamSynchronize(st));
+            }
+            if (gj_launches || hflag[1]) {  // (a grid barrier of the one-launch form gave up: another process holds the CUs)
+                HIPCHECK(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
+                launch_fac_bump_build(t, d_fac_Kd.p, b, st);
+                launch_gauss_jordan(d_fac_Kd.p, d_fac_Wb.p, b, FAC_BMAX, flag, d_fac_gjval.p + 2 * 64, st);
+                HIPCHECK(hipMemcpyAsync(hflag, flag, sizeof(hflag), hipMemcpyDeviceToHost, st));
+                HIPCHECK(hipStreamSynchronize(st));
+            }
+            if (hflag[0]) throw MlpError(-2, "singular basis matrix: the bump of the peel is singular (solver.rs:1301)");
         }
         HIPCHECK(hipStreamSynchronize(st));  // (staged from local vectors)
     }
@@ -2012,7 +2076,7 @@ bool Engine::fac_refactor(int bump_limit) {
     // the tail: the levels from `tail` on all hold at most FAC_TAIL positions (one workgroup walks them: factor.inc)
     int tail = nlev;
     while (tail > 0 && lptr[tail] - lptr[tail - 1] <= 512) tail -= 1;
-    const int meta[4] = {nlev, total, b, tail};
+    const int meta[8] = {nlev, total, b, tail, n_col_steps, n_row_steps, 0, 0};
     HIPCHECK(hipMemcpyAsync(d_fac_meta.p, meta, sizeof(meta), hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)std::max(nlev, 1), st));  // (cnt is free again: the per-level fill cursors)
     launch_fac_peel_fill(t, level, cnt, st);
@@ -2022,8 +2086,7 @@ bool Engine::fac_refactor(int bump_limit) {
     launch_exclusive_scan(d_fac_fptr.p, d_fac_fptr.p, (long)total + 1, d_scan_tmp.p, st);
     launch_exclusive_scan(d_fac_bptr.p, d_fac_bptr.p, (long)total + 1, d_scan_tmp.p, st);
     launch_fac_edges(t, 1, d_fac_fptr.p, d_fac_bptr.p, level, st);
-    if (fac_skip_ && b == 0)  // the level ranges of the solves (factor.inc): reach of every position, levels in descending order
-        for (int lev = nlev - 1; lev >= 0; --lev) launch_fac_reach(t, lev, lptr[lev + 1] - lptr[lev], st);
+    launch_fac_reach_all(t, st);  // the level ranges of the solves (factor.inc): reach of every position, levels in descending order; level of the bump
     {   // level statistics produced before this refactorisation describe the old levels: conservative values until the next producer
         const int stat[4] = {INT_MAX, INT_MAX, 0, INT_MAX};  // fac_aq_hi, fac_rho_hi, fac_aq_lo, fac_aq_reach
         HIPCHECK(hipMemcpyAsync(&d_ctl.p->fac_aq_hi, stat, sizeof(stat), hipMemcpyHostToDevice, st));

@@ -78,7 +78,7 @@ struct Ctl {
     int forced;  // dual iteration with a host-forced row (fix_var): skip dual pricing
     // delayed-update mode: W = W0 + sum_{j<nlow} U[j] V[j]^T
     int nlow;   // number of pending rank-1 terms
-    int fold;   // this pivot's fused pass folds the pending terms into W0 (set by the plan)
+    int fold;   // this pivot's fused pass folds the pending terms into W0 (primal: set by the FTRAN head, dual: by the plan)
     double lr_c[LR_MAX], lr_e[LR_MAX], lr_g[LR_MAX], lr_h[LR_MAX];  // V[j].a_list, U[j].b_list, V[j].rho_K, U[j].t_K
     int ratio_epoch;          // fused primal ratio test: launch counter published by pass 1's last block
     double ratio_max_step;    // ... and the step bound it publishes
@@ -102,7 +102,8 @@ struct Ctl {
     int fac_aq_lo;     // BTRAN of alpha_q (v = B^-T alpha_q): lowest level among supp(alpha_q)           (atomicMin by the FTRAN's epilogue)
     int fac_aq_reach;  // ... and the highest level its dependents reach                                   (atomicMax)
     int kprof_on;    // MLP_KPROF=1: kernels stamp the wall clock into hy_prof (KMARK; state("kernel_timeline"))
-    int str_pad;
+    int side_go;     // v branch of the late primal iteration (engine.hip launch_stage): the iteration was live when its FTRAN head ran — the
+                     // side kernels (t_K, fold, streaming pass) test this instead of `status`, which the ratio test rewrites beside them
     unsigned long long hy_prof[24];  // ticks of the 100 MHz wall clock per stage of the hypersparse iteration (diagnostics)
     PivotRec ring[RING];
 };
@@ -314,14 +315,15 @@ void launch_clear_work(const DevView& dv, hipStream_t st);  // alpha_q, tau, rv 
 void launch_price_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st);  // standalone K1 (first iteration of a batch)
 void launch_price_dual(const DevView& dv, const Geom& g, int use_dse, hipStream_t st);    // standalone K6
 void launch_ftran_prep(const DevView& dv, int derive_primal, hipStream_t st);             // FTRAN head (one wave)
-void launch_ftran_gather(const DevView& dv, const Geom& g, hipStream_t st);               // alpha_q = B^-1 a_q
+void launch_ftran_gather(const DevView& dv, const Geom& g, hipStream_t st, int ys = 0);               // alpha_q = B^-1 a_q
 void launch_ftran_fused(const DevView& dv, const Geom& g, int derive_primal, hipStream_t st);   // FTRAN head + gather in one launch (Geom.head_fused)
 void launch_btran_fused(const DevView& dv, const Geom& g, int with_rhs, int derive_dual, hipStream_t st);  // BTRAN head + gather (dual iteration)
 constexpr int HEAD_LIST_CAP = 1024;  // entries an in-kernel stage head can hold (longest column / row of A)
 void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st);  // K5 p1 (+alpha_sq, y_S), p2 (+BTRAN head, plan)
 void launch_post_ftran(const DevView& dv, const Geom& g, int use_pse, hipStream_t st);    // dual path: alpha_sq, y_S, plan
 void launch_btran_prep(const DevView& dv, int derive_dual, int plan_after, hipStream_t st);  // BTRAN head (one wave)
-void launch_btran(const DevView& dv, const Geom& g, int with_rhs, hipStream_t st);        // rho, rK, rho_sq [| tK]
+void launch_btran(const DevView& dv, const Geom& g, int with_rhs, hipStream_t st, int after_fold = 0);  // rho, rK, rho_sq [| tK]
+void launch_pse_tk(const DevView& dv, const Geom& g, hipStream_t st);  // v branch: tK = alpha_K - F^T y_S straight from alpha_q (y_S formed on the fly)
 void launch_btran_rhs(const DevView& dv, const Geom& g, hipStream_t st);                  // tK alone
 void launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, hipStream_t st, int inline_combine = 0);  // K4 [| partition change]
 // sparse tableau row: touched-column list, then the pull of alpha_r / helper on the listed columns (| partition change)
@@ -329,6 +331,10 @@ void launch_row_sparse(const DevView& dv, const Geom& g, int mode, int with_stru
 void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st);                 // K7 p1, p2 (+FTRAN head)
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int with_tau = 1);  // tauK/vK partials + eta update of W
+// v branch (delayed-update mode, lazy primal iteration): the same pass in two parts on the side stream — part 1 the fold of a
+// folding pivot (its last block clears nlow), part 2 the streaming pass; both gated by Ctl.side_go
+void launch_fused_w_side(const DevView& dv, const Geom& g, int part, hipStream_t st);
+bool vbranch_supported(const DevView& dv, const Geom& g);  // the strip-tiled pass with the default fold kernel is the one that has a side form
 int launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic = 0, int skip_push = 0, int with_tau = 1, int touch = 0);
 void launch_exact_beta(const DevView& dv, hipStream_t st);  // beta_p = ||e_p^T B^-1||^2 for every basic position (lazy dual steepest edge)
 void launch_push_tau(const DevView& dv, hipStream_t st);  // blocked push of -F tau_K alone (runs on a side branch of the graph)  // tau push | v reduce+scatter (classic: partials of k_fused_w's tiling)
@@ -366,13 +372,16 @@ void launch_fac_solve2(const DevView& dv, const Geom& g, int dir, int srcA, int 
 void launch_fac_append(const DevView& dv, hipStream_t st);     // U_nlow, V_nlow from alpha_q / rho of this pivot; nlow += 1
 void launch_fac_gather_cb(const DevView& dv, hipStream_t st);  // alpha_q[p] = c[basic_vars[p]]
 // refactorisation (host-paced peel): init, then claim + commit per level, then the level lists
-void launch_fac_peel_init(const DevView& dv, int* cnt, int* level, int* row_lev, int* claim, hipStream_t st);
+void launch_fac_peel_init(const DevView& dv, int* cnt, int* level, int* row_lev, int* claim, int* rcnt, int* claim_r, hipStream_t st);
 void launch_fac_peel_level(const DevView& dv, int lev, int* cnt, int* level, int* row_lev, int* claim, int* cand_row, int* counters, hipStream_t st);
-void launch_fac_peel_all(const DevView& dv, int* cnt, int* level, int* row_lev, int* claim, int* cand_row, int* counters, int* lcount, int max_levels,
-                         hipStream_t st);  // the whole peel in one launch: lcount[0] = levels, lcount[l] = positions peeled up to level l
+// the whole peel in one launch (column steps and row steps): lsteps[0] = steps that removed something, lsteps[t] = +/- positions peeled
+// up to step t (+ column step, - row step)
+void launch_fac_peel_all(const DevView& dv, int* cnt, int* level, int* row_lev, int* claim, int* cand_row, int* counters, int* lsteps, int max_levels,
+                         int* rcnt, int* claim_r, int* cand_col, hipStream_t st);
 void launch_fac_peel_fill(const DevView& dv, const int* level, int* cursor, hipStream_t st);
 void launch_fac_edges(const DevView& dv, int pass, int* fcnt, int* bcnt, const int* level, hipStream_t st);  // resolved edge lists in level order: pass 0 counts, pass 1 fills
-void launch_fac_reach(const DevView& dv, int lev, int count, hipStream_t st);  // reach_of_pos of one level (levels in descending order)
+void launch_fac_bump_invert(const DevView& dv, double* K, double* W, double* out, int b, int* flag, double* part_val, int* part_row, hipStream_t st);  // K^-1 of the bump, one launch
+void launch_fac_reach_all(const DevView& dv, hipStream_t st);  // reach_of_pos of every position (levels in descending order, one launch); level of the bump
 void launch_fac_bump_build(const DevView& dv, double* Kd, int b, hipStream_t st);  // K = B0[bump rows, bump columns], dense, row-major with pitch FAC_BMAX
 void launch_str_reset(const DevView& dv, hipStream_t st);  // sparse tableau row: new stamp epoch, empty lists
 void launch_checksum_w(const DevView& dv, unsigned long long* out, hipStream_t st);  // order-independent checksum of W[0:k, 0:k] and the slot maps (tests)

@@ -608,7 +608,9 @@ __device__ void plan_update(const DevView& v, Ctl* c, int phase) {
         u.inv_diag_r = 1.0 / v.sdiag_of_pos[r];
     }
     c->it.inv_alpha = 1.0 / v.alpha_q[r];
-    c->fold = (v.lrJ > 0 && c->nlow >= v.lrJ) ? 1 : 0;
+    // (primal iteration: the FTRAN head took the fold decision — with the v branch the fold of this pivot may already be running
+    // beside this plan, and its last block clears nlow)
+    if (phase != 0 || !v.lrJ) c->fold = (v.lrJ > 0 && c->nlow >= v.lrJ) ? 1 : 0;
     u.jn = c->fold ? 0 : c->nlow;
     u.pad0 = 0;
     u.pad = 0;
@@ -690,6 +692,9 @@ __device__ void ftran_prep_wave(const DevView& v, Ctl* c, int lane, int derive_p
             it->entering_other = (dq < 0.0) ? v.var_hi[var] : v.var_lo[var];
             it->r = -1;
             it->leaving_var = -1;
+            // delayed-update mode: a full list of pending terms is folded by this pivot — decided here, ahead of everything
+            // that reads W0, so that the fold may run beside the ratio test (v branch) instead of behind it
+            if (v.lrJ) c->fold = c->nlow >= v.lrJ ? 1 : 0;
         }
     }
     int base = v.csc_ptr[var], end = v.csc_ptr[var + 1];
@@ -945,7 +950,11 @@ __global__ void __launch_bounds__(BLK) k_price_dual(DevView v, int use_dse) {
 //            + push of -F*aK into the singleton positions (CSC columns of the nucleus basics)
 __global__ void __launch_bounds__(64) k_ftran_prep(DevView v, int derive_primal) {
     Ctl* c = v.ctl;
-    if (c->halt || c->it.status != ITER_PIVOT) return;
+    if (c->halt || c->it.status != ITER_PIVOT) {
+        if (threadIdx.x == 0) c->side_go = 0;
+        return;
+    }
+    if (threadIdx.x == 0) c->side_go = 1;
     KMARK0(c, 0);
     ftran_prep_wave(v, c, threadIdx.x, derive_primal);
 }
@@ -1251,7 +1260,7 @@ __global__ void __launch_bounds__(PBB_THREADS) k_push_band(DevView v, int which,
     double* dst = v.push_part + (size_t)cc * v.m + row0;
     for (int t = tid; t < nrows; t += PBB_THREADS) dst[t] = acc[t];
 }
-__global__ void __launch_bounds__(BLK) k_push_combine(DevView v, int which, int nchunks) {
+__global__ void __launch_bounds__(BLK) k_push_combine(DevView v, int which, int nchunks, int ys = 0) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     KMARK0(c, 20);
@@ -1266,6 +1275,14 @@ __global__ void __launch_bounds__(BLK) k_push_combine(DevView v, int which, int 
         for (int u = 0; u < 8; ++u) pp[u] = (c0 + u < nchunks) ? v.push_part[(size_t)(c0 + u) * v.m + i] : 0.0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += pp[u];
+    }
+    if (ys) {
+        // v branch: the singleton part y_S = alpha_S / diag of v = B^-T alpha_q (solver.rs:1114), by row, is left behind for t_K
+        // (the ratio test, which otherwise forms it, now runs beside the kernels that need it: the same quotient, bit for bit)
+        const double a = v.alpha_q[ri.pos] - (s != 0.0 ? s / ri.diag : 0.0);
+        if (s != 0.0) v.alpha_q[ri.pos] = a;
+        v.rv[i].y = a / ri.diag;
+        return;
     }
     if (s != 0.0) {
         double* out = which ? v.tau : v.alpha_q;
@@ -1312,13 +1329,13 @@ static void launch_pull_F(const DevView& dv, const Geom& g, int which, hipStream
     else if (g.lanes <= 16) hipLaunchKernelGGL(k_pull_F<16>, dim3(blocks_for((long)dv.m * 16)), dim3(BLK), 0, st, dv, which);
     else hipLaunchKernelGGL(k_pull_F<64>, dim3(blocks_for((long)dv.m * 64)), dim3(BLK), 0, st, dv, which);
 }
-static void launch_blocked_push(const DevView& dv, int which, hipStream_t st) {
+static void launch_blocked_push(const DevView& dv, int which, hipStream_t st, int ys = 0) {
     // Measured (round 2, k = 20 500): the band form runs in 34.6 + 9.5 us against 34.8 + 6.4 us for the row-block form
     // over the CSC — neither is bound by its traffic (the row-block form moves 196 MB for 27 MB of algorithmic bytes, PMC)
     // but by the serial descriptor / entry chains of its slot tiles.  The row-block form stays the default;
     // MLP_PUSH_BAND=1 selects the band form for experiments.
     static const bool band_push = std::getenv("MLP_PUSH_BAND") != nullptr;
-    if (dv.banded && band_push && !dv.pb_det) {
+    if (dv.banded && band_push && !dv.pb_det && !ys) {
         static bool attr_set = false;
         const size_t lds = sizeof(double) * (BAND_ROWS + PBB_TILE) + sizeof(int) * 2 * PBB_TILE;
         if (!attr_set) {
@@ -1345,7 +1362,7 @@ static void launch_blocked_push(const DevView& dv, int which, hipStream_t st) {
         if (want <= 0) chunks = PBD_CHUNKS_DEFAULT;  // (two workgroups per CU by LDS: row blocks x chunks should fit one round)
         hipLaunchKernelGGL(k_push_stage1_det, dim3(dv.pb_rb, chunks), dim3(BLK), PBD_LDS, st, dv, which);
     } else hipLaunchKernelGGL(k_push_stage1, dim3(dv.pb_rb, chunks), dim3(BLK), 0, st, dv, which);
-    hipLaunchKernelGGL(k_push_combine, dim3((dv.m + BLK - 1) / BLK), dim3(BLK), 0, st, dv, which, chunks);
+    hipLaunchKernelGGL(k_push_combine, dim3((dv.m + BLK - 1) / BLK), dim3(BLK), 0, st, dv, which, chunks, ys);
 }
 
 // ------------------------------------------------------------------- K5: primal Harris ratio test
@@ -1774,7 +1791,7 @@ __global__ void __launch_bounds__(64) k_btran_prep(DevView v, int derive_dual, i
 // Horizontally fused: blocks [0, n_gather) do rK = sum_j blist_a[j] * W[blist_s[j], :], the rho
 // scatter and ||rho||^2; the remaining blocks (PSE) build tK = alpha_K - F^T y_S (solver.rs:1114).
 template <int G>
-__global__ void __launch_bounds__(BLK) k_btran(DevView v, int n_gather) {
+__global__ void __launch_bounds__(BLK) k_btran(DevView v, int n_gather, int after_fold = 0) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     KMARK0(c, 7);
@@ -1785,7 +1802,8 @@ __global__ void __launch_bounds__(BLK) k_btran(DevView v, int n_gather) {
         if (v.lrJ) {
             // delayed-update mode (large nucleus): four lanes share a slot — up to 20 listed rows plus 32 pending terms are
             // 52 loads per slot, a serial chain for one lane (fixed summation order: lane-strided, then two shuffles)
-            const int nlow = c->nlow;
+            // (v branch: this launch waited for the fold of a folding pivot — W0 then holds every term)
+            const int nlow = (after_fold && c->fold) ? 0 : c->nlow;
             for (int g4 = blockIdx.x * BLK + threadIdx.x; g4 < 4 * k; g4 += n_gather * BLK) {  // (whole groups of 4 lanes)
                 const int s = g4 >> 2, gl = g4 & 3;
                 double acc = 0.0;
@@ -1832,6 +1850,28 @@ __global__ void __launch_bounds__(BLK) k_btran(DevView v, int n_gather) {
     }
 }
 
+
+// v branch of the late primal iteration: tK = alpha_K - F^T y_S (solver.rs:1114) on its own, as soon as the FTRAN has landed.
+// y_S[i] = alpha_q[pos] / diag of the singleton covering row i was left in rv.y by the combine of the F push (the same quotient
+// the ratio test forms, so tK is bit-identical to k_btran's), which frees this kernel — and the streaming pass behind it —
+// from the ratio test: v = B^-T alpha_q does not depend on the leaving row.
+template <int G>
+__global__ void __launch_bounds__(BLK) k_pse_tk(DevView v) {
+    Ctl* c = v.ctl;
+    if (!c->side_go) return;
+    const int k = c->k;
+    const int slot = (int)((blockIdx.x * BLK + threadIdx.x) / G);
+    const int gl = threadIdx.x & (G - 1);
+    if (slot >= k) return;
+    const int p = v.pos_of_kslot[slot];
+    const int var = v.basic_vars[p];
+    const int end = v.csc_ptr[var + 1];
+    double acc = 0.0;
+    // (rv.y holds y_S on the singleton rows — the F push's combine left it there — and zeros on the nucleus rows)
+    for (int e = v.csc_ptr[var] + gl; e < end; e += G) acc += v.csc_val[e] * v.rv[v.csc_row[e]].y;
+    acc = group_sum<G>(acc);
+    if (gl == 0) v.tK[slot] = v.alpha_q[p] - acc;
+}
 
 // ------------------------------------------------------------------- stage heads inside the consuming kernel
 // A stage head (one wave: a five-deep chain of dependent loads that turns the pivot column / row into a short list)
@@ -3081,11 +3121,12 @@ __device__ __forceinline__ int sw_strip_rows(const DevView& v, int k, int ch, in
     return max(rb, 32);  // (part_v holds cap / 8 rows of partials)
 }
 template <bool WITH_V, int SW_CH, int SW_RB, int SW_RS>
-__global__ void __launch_bounds__(BLK, 4) k_stream_w(DevView v, int with_tau, int skip_on_fold = 0) {  // 4 waves per SIMD: keep the double buffer within 128 VGPRs
+__global__ void __launch_bounds__(BLK, 4) k_stream_w(DevView v, int with_tau, int skip_on_fold = 0, int side = 0) {  // 4 waves per SIMD: keep the double buffer within 128 VGPRs
     static_assert(SW_CH == 2 * BLK || SW_CH == 4 * BLK, "one or two column pairs per thread");
     constexpr int NP = SW_CH / (2 * BLK);
     Ctl* c = v.ctl;
-    if (c->halt || c->it.status != ITER_PIVOT) return;
+    // (side: v branch — the ratio test runs beside this pass and may rewrite `status`; the pass is then merely unused)
+    if (side ? !c->side_go : (c->halt || c->it.status != ITER_PIVOT)) return;
     if (skip_on_fold && c->fold) return;  // the fold of this pivot produced the v partials itself (k_fold_w, fuse_v)
     KMARK0(c, 21);
     const int k = c->k, ld = v.ld;
@@ -3310,7 +3351,10 @@ typedef double sreg8 __attribute__((ext_vector_type(8)));  // 16 consecutive SGP
 template <int JM>
 __global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : JM <= 32 ? 3 : 2)) k_fold_w2(DevView v, int mode, int fuse_v) {
     Ctl* c = v.ctl;
-    if (mode != 1 && (c->halt || c->it.status != ITER_PIVOT)) return;
+    // mode 3: the fold of a folding pivot on the v branch — it runs beside the ratio test, which may turn the pivot into a bound
+    // flip while the fold is under way: the fold goes through whatever the ratio test decides (W0 + the pending terms is the same
+    // inverse either way) and its last block clears the list itself
+    if (mode == 3 ? !c->side_go : (mode != 1 && (c->halt || c->it.status != ITER_PIVOT))) return;
     if (!(mode == 1 || c->fold)) return;
     const int k = c->k, ld = v.ld;
     const int nlow = min(c->nlow, JM);
@@ -3394,6 +3438,10 @@ __global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : JM <= 32 ? 3 : 2)) k_fold
             for (int a = 0; a < FD_RS; ++a) w[a] = wn[a];
         }
         if (fuse_v && active) v.part_v[(size_t)strip * ld + col] = vacc;
+    }
+    if (mode == 3 && last_block_arrives(&v.ticket[2], gridDim.x) && tid == 0) {
+        v.ticket[2] = 0;
+        c->nlow = 0;  // (lowrank_append of a pivot sets it to 1; a bound flip leaves the folded inverse with an empty list)
     }
 }
 // (Measured and rejected in round 3: the same update on the matrix cores — v_mfma_f64_16x16x4_f64, operands one f64 per lane
@@ -4344,12 +4392,12 @@ void launch_btran_fused(const DevView& dv, const Geom& g, int with_rhs, int deri
     LANES_SWITCH(g.lanes, BTRANF(4), BTRANF(16), BTRANF(64));
 #undef BTRANF
 }
-void launch_ftran_gather(const DevView& dv, const Geom& g, hipStream_t st) {
+void launch_ftran_gather(const DevView& dv, const Geom& g, hipStream_t st, int ys) {
     LANES_SWITCH(g.lanes,
                  hipLaunchKernelGGL(k_ftran_gather<4>, dim3(blocks_for((long)g.cap * 4)), dim3(BLK), 0, st, dv),
                  hipLaunchKernelGGL(k_ftran_gather<16>, dim3(blocks_for((long)g.cap * 16)), dim3(BLK), 0, st, dv),
                  hipLaunchKernelGGL(k_ftran_gather<64>, dim3(blocks_for((long)g.cap * 64)), dim3(BLK), 0, st, dv));
-    if (dv.pb_on) launch_blocked_push(dv, 0, st);
+    if (dv.pb_on) launch_blocked_push(dv, 0, st, ys);
     else if (dv.det_pull) launch_pull_F(dv, g, 0, st);
 }
 // Blocks of `fn` (BLK threads, no dynamic LDS) that the CURRENT device holds at once, halved as a margin for kernels of
@@ -4399,13 +4447,19 @@ void launch_post_ftran(const DevView& dv, const Geom& g, int use_pse, hipStream_
 void launch_btran_prep(const DevView& dv, int derive_dual, int plan_after, hipStream_t st) {
     hipLaunchKernelGGL(k_btran_prep, dim3(1), dim3(64), 0, st, dv, derive_dual, plan_after);
 }
-void launch_btran(const DevView& dv, const Geom& g, int with_rhs, hipStream_t st) {
+void launch_pse_tk(const DevView& dv, const Geom& g, hipStream_t st) {
+    LANES_SWITCH(g.lanes,
+                 hipLaunchKernelGGL(k_pse_tk<4>, dim3(blocks_for((long)g.cap * 4)), dim3(BLK), 0, st, dv),
+                 hipLaunchKernelGGL(k_pse_tk<16>, dim3(blocks_for((long)g.cap * 16)), dim3(BLK), 0, st, dv),
+                 hipLaunchKernelGGL(k_pse_tk<64>, dim3(blocks_for((long)g.cap * 64)), dim3(BLK), 0, st, dv));
+}
+void launch_btran(const DevView& dv, const Geom& g, int with_rhs, hipStream_t st, int after_fold) {
     int n_gather = blocks_for(dv.lrJ ? (long)g.cap * 4 : (long)g.cap);  // delayed-update mode: 4 lanes per slot
     if (n_gather > (dv.lrJ ? 1024 : 512)) n_gather = dv.lrJ ? 1024 : 512;  // (the reduction buffers hold >= 1024 partials)
 #define BTRAN(G)                                                                                           \
     do {                                                                                                   \
         int n_rhs = with_rhs ? blocks_for((long)g.cap * G) : 0;                                            \
-        hipLaunchKernelGGL(k_btran<G>, dim3(n_gather + n_rhs), dim3(BLK), 0, st, dv, n_gather);            \
+        hipLaunchKernelGGL(k_btran<G>, dim3(n_gather + n_rhs), dim3(BLK), 0, st, dv, n_gather, after_fold); \
     } while (0)
     LANES_SWITCH(g.lanes, BTRAN(4), BTRAN(16), BTRAN(64));
 #undef BTRAN
@@ -4550,7 +4604,8 @@ bool fold_fuses_v(const DevView& dv, int with_v, int with_tau, int fold_only) {
     static const bool off = std::getenv("MLP_FOLD_FUSE") && std::getenv("MLP_FOLD_FUSE")[0] == '0';
     return !off && with_v && !with_tau && !fold_only && !dv.wshard && dv.lrJ > 0 && stream_strips_enabled();
 }
-static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fold_only, hipStream_t st, int with_tau = 1) {
+// part / side: the v branch launches the fold (part 1) and the streaming pass (part 2) separately on the side stream
+static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fold_only, hipStream_t st, int with_tau = 1, int part = 0, int side = 0) {
     const int rows = fw_rows(g);
     int nstripes = (g.cap + rows - 1) / rows, nchunks = (g.cap + FW_TC - 1) / FW_TC;
     dim3 b(BLK);
@@ -4570,7 +4625,9 @@ static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fo
             // a folding pivot folds first (mode 2: no partials), then EVERY pivot streams W0 once (k_stream_w)
             static const bool old_fold = std::getenv("MLP_OLD_FOLD") != nullptr;  // A/B: the 16 x 1024 fold kernel
             const int fuse = fold_fuses_v(dv, with_v, with_tau, fold_only) && !old_fold ? 1 : 0;
-            if (old_fold) {
+            if (part == 2) {
+                // (the fold of this pivot was launched on its own)
+            } else if (old_fold) {
                 hipLaunchKernelGGL((k_fused_lr16<false, true>), dim3(nb), b, 0, st, dv, fold_only ? 1 : 2);
             } else {
                 const long ftiles = (long)((g.cap + FD_RB - 1) / FD_RB) * ((g.cap + FD_CH - 1) / FD_CH);
@@ -4578,21 +4635,21 @@ static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fo
                 const char* fs = std::getenv("MLP_FOLD_SCALAR");  // A/B: "0" = the form with U staged in LDS (read per launch: tests toggle it)
                 const bool scalar_u = !(fs && fs[0] == '0');
                 if (scalar_u) {
-                    if (dv.lrJ <= 16) LAUNCH_T(3, k_fold_w2<16>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, fuse);
-                    else LAUNCH_T(3, k_fold_w2<LR_MAX>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, fuse);
+                    if (dv.lrJ <= 16) LAUNCH_T(3, k_fold_w2<16>, dim3(nf), b, 0, st, dv, fold_only ? 1 : (side ? 3 : 2), fuse);
+                    else LAUNCH_T(3, k_fold_w2<LR_MAX>, dim3(nf), b, 0, st, dv, fold_only ? 1 : (side ? 3 : 2), fuse);
                 } else {
                     if (dv.lrJ <= 16) LAUNCH_T(3, k_fold_w<16>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, fuse);
                     else LAUNCH_T(3, k_fold_w<LR_MAX>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, fuse);
                 }
             }
-            if (!fold_only) {
+            if (!fold_only && part != 1) {
                 long tiles = (long)((g.cap + sw_rb() - 1) / sw_rb()) * ((g.cap + sw_ch() - 1) / sw_ch());
                 if (dv.sw_nbal > tiles) tiles = dv.sw_nbal;  // balanced strips: one tile per co-resident block
                 const int nt = (int)(tiles < SW_MAX_BLOCKS ? tiles : SW_MAX_BLOCKS);
 #define SW_LAUNCH(CH, RB, RS)                                                                                     \
     do {                                                                                                          \
-        if (with_v) LAUNCH_T(2, (k_stream_w<true, CH, RB, RS>), dim3(nt + LR_MAX), b, 0, st, dv, with_tau, fuse); \
-        else if (with_tau) LAUNCH_T(2, (k_stream_w<false, CH, RB, RS>), dim3(nt + LR_MAX), b, 0, st, dv, 1, 0);  \
+        if (with_v) LAUNCH_T(2, (k_stream_w<true, CH, RB, RS>), dim3(nt + LR_MAX), b, 0, st, dv, with_tau, fuse, side); \
+        else if (with_tau) LAUNCH_T(2, (k_stream_w<false, CH, RB, RS>), dim3(nt + LR_MAX), b, 0, st, dv, 1, 0, 0);  \
     } while (0)
                 switch (stream_variant()) {
                 case 0: SW_LAUNCH(512, 512, 8); break;
@@ -4625,6 +4682,15 @@ void launch_fold_lowrank(const DevView& dv, const Geom& g, hipStream_t st) {
     if (!dv.lrJ || g.cap <= 0) return;
     launch_fused_lr(dv, g, 0, 1, st);
     hipLaunchKernelGGL(k_reset_nlow, dim3(1), dim3(1), 0, st, dv);
+}
+bool vbranch_supported(const DevView& dv, const Geom& g) {
+    static const bool other_fold = std::getenv("MLP_OLD_FOLD") != nullptr ||
+                                   (std::getenv("MLP_FOLD_SCALAR") && std::getenv("MLP_FOLD_SCALAR")[0] == '0');
+    return dv.lrJ > 0 && g.cap > 0 && fw_rows(g) != 8 && FW_RL == 1 && stream_strips() && !other_fold && !dv.wshard && dv.world <= 1 &&
+           dv.pb_on && !dv.pb_det;
+}
+void launch_fused_w_side(const DevView& dv, const Geom& g, int part, hipStream_t st) {
+    launch_fused_lr(dv, g, 1, 0, st, 0, part, 1);
 }
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int with_tau) {
     if (g.cap <= 0) return;  // a model without kept rows has no nucleus: nothing to stream (and no valid grid)

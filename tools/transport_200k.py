@@ -7,7 +7,7 @@ column-singleton peel leaves no bump) while the STRUCTURAL nucleus — what the 
 holds densely, 8 k^2 bytes — grows to ~0.65 m columns.  At S = D = 100 000 (m = 200 000 rows, n = 400 000 columns, nnz = 800 000)
 that is k = 130 000: 135 GB of inverse and 16 k^2 bytes of traffic per pivot.
 
-    python tools/transport_200k.py [S D deg tight] [--paths oracle,factor,dense] [--dense-pivots N] [--json out.json]
+    python tools/transport_200k.py [S D deg tight] [--paths oracle,factor,dense] [--dense-pivots N] [--json out.json] [--family mixed]
 
   oracle : the single-threaded restatement of the reference (LU + eta file), whole solve, us per pivot per 20 000-pivot chunk
   factor : minilp_amd on the compact factor (auto-selected when the nucleus passes MLP_FACTOR_FROM slots)
@@ -29,7 +29,9 @@ sys.path.insert(0, %r)
 import numpy as np
 from minilp_amd import lpgen
 S, D, deg, tight, path, limit = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), sys.argv[5], int(sys.argv[6])
-lp = lpgen.gen_transport_lp(S, D, deg, tight=tight)
+family = sys.argv[7] if len(sys.argv) > 7 else "transport"
+# (--family mixed: the config-3 generator at scale — S rows, D columns, deg entries per row, E/L/G operators)
+lp = lpgen.gen_mixed_lp(S, D, deg, 3) if family == "mixed" else lpgen.gen_transport_lp(S, D, deg, tight=tight)
 if path == "oracle":
     from oracle import minilp_oracle as B
 else:
@@ -39,7 +41,7 @@ t0 = time.perf_counter()
 rec = dict(path=path, m=lp["m"], n=lp["n"], nnz=int(len(lp["data"])), chunks=[])
 try:
     s = prob.solve(budget=0)
-    chunk = 20000
+    chunk = int(sys.argv[8]) if len(sys.argv) > 8 else 20000
     done = 0
     while True:
         t1 = time.perf_counter()
@@ -50,7 +52,7 @@ try:
         e = dict(pivots=piv, us_per_pivot=round(dt * 1e6 / max(1, piv - done), 1), objective=s.objective())
         if path != "oracle":
             e.update(nucleus=int(st["nucleus_size"]), capacity=int(st["nucleus_capacity"]), factor=int(st["factor_active"]), levels=int(st["factor_levels"]),
-                     refactorisations=int(st["factor_refactors"]))
+                     refactorisations=int(st["factor_refactors"]), bump=int(st["factor_bump"]), switches=int(st["factor_switches"]))
         rec["chunks"].append(e)
         print(json.dumps(e), file=sys.stderr, flush=True)
         done = piv
@@ -76,14 +78,16 @@ def main():
         return sys.argv[sys.argv.index(name) + 1] if name in sys.argv else default
     paths = opt("--paths", "oracle,factor,dense").split(",")
     dense_pivots = int(opt("--dense-pivots", "60000"))
-    out = dict(family="transport (network with gains)", S=S, D=D, deg=deg, tight=tight, runs={})
+    family = opt("--family", "transport")
+    out = dict(family="transport (network with gains)" if family == "transport" else "mixed (config-3 generator at scale: S rows, D columns, deg per row)",
+               S=S, D=D, deg=deg, tight=tight, runs={})
     for path in paths:
         env = dict(os.environ)
         if path == "dense":
             env["MLP_FACTOR"] = "0"
         limit = dense_pivots if path == "dense" else 0
         t0 = time.time()
-        r = subprocess.run([sys.executable, "-c", CODE, str(S), str(D), str(deg), str(tight), path, str(limit)], env=env, capture_output=True, text=True)
+        r = subprocess.run([sys.executable, "-c", CODE, str(S), str(D), str(deg), str(tight), path, str(limit), family, opt("--chunk", "20000")], env=env, capture_output=True, text=True)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         rec = json.loads(lines[-1]) if lines else dict(error=(r.stderr or "")[-400:])
         out["runs"][path] = rec
