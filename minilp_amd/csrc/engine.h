@@ -245,6 +245,10 @@ private:
     DevBuf<int> d_fac_lcount;
     DevBuf<double> d_fac_Kd, d_fac_Wtmp, d_fac_gjval;  // bump inversion: K, the work copy of the inverse, partial maxima | scratch
     DevBuf<int> d_fac_gjrow;
+    DevBuf<int> d_fac_eslot;  // 2 nz: slots of the targets of the long edge lists (FTRAN | BTRAN)
+    DevBuf<int> d_fac_ltslot, d_fac_segs;  // per level: first LDS slot (small levels) | the segments of a solve's walk
+    DevBuf<double> d_fac_WbT;               // transpose of the bump inverse
+    DevBuf<FacTailRec> d_fac_tprog;  // the tail of the solves as records: FTRAN | BTRAN, FAC_TAIL_CAP each
     DevBuf<int> d_fac_lev3;   // 3 m: level of a position | level of a row's pivot position | reach of a position
     bool fac_skip_ = true;    // MLP_FACTOR_SKIP=0: every solve walks every level (A/B)
     DevBuf<double> d_fac_Wb;   // allocated with the first bump

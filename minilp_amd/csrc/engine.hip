@@ -1908,8 +1908,10 @@ void Engine::fac_alloc() {
         d_fac_irow.ensure(mm, 0, st); d_fac_ipiv.ensure(mm, 0, st);
         d_fac_fptr.ensure(mm + 2, 0, st); d_fac_bptr.ensure(mm + 2, 0, st);
         d_fac_fidx.ensure(nz, 0, st); d_fac_fval.ensure(nz, 0, st); d_fac_bidx.ensure(nz, 0, st); d_fac_bval.ensure(nz, 0, st);
+        d_fac_eslot.ensure(2 * nz, 0, st);
         d_scan_tmp.ensure((mm + 2) / 4096 + 8, 0, st);
-        d_fac_lev3.ensure(3 * mm, 0, st);
+        d_fac_lev3.ensure(5 * mm, 0, st);  // (+ 2 m: place of a position / of a row's pivot position in the item list)
+        d_fac_tprog.ensure(2 * mm, 0, st);  // (records of the small levels' items, both directions)
     }
     {   // (no bump yet: every row is a pivot row of the peel)
         const int* before = d_fac_bslot_of_row.p;
@@ -1935,6 +1937,11 @@ void Engine::fac_fill_view(DevView& v) const {
     v.fac_lev_of_pos = d_fac_lev3.p; v.fac_lev_of_row = d_fac_lev3.p ? d_fac_lev3.p + (size_t)std::max(m_, 1) : nullptr;
     v.fac_reach_of_pos = d_fac_lev3.p ? d_fac_lev3.p + 2 * (size_t)std::max(m_, 1) : nullptr;
     v.fac_skip = fac_skip_ ? 1 : 0; v.fac_pad1 = 0;
+    v.fac_idx_of_pos = d_fac_lev3.p ? d_fac_lev3.p + 3 * (size_t)std::max(m_, 1) : nullptr;
+    v.fac_idx_of_row = d_fac_lev3.p ? d_fac_lev3.p + 4 * (size_t)std::max(m_, 1) : nullptr;
+    v.fac_tprog_f = d_fac_tprog.p; v.fac_tprog_b = d_fac_tprog.p ? d_fac_tprog.p + (size_t)std::max(m_, 1) : nullptr;
+    v.fac_ltslot = d_fac_ltslot.p; v.fac_segs = d_fac_segs.p; v.fac_WbT = d_fac_WbT.p;
+    v.fac_fslot = d_fac_eslot.p; v.fac_bslot = d_fac_eslot.p ? d_fac_eslot.p + h_rcol.size() + 8 : nullptr;
     v.fac_irow = d_fac_irow.p; v.fac_ipiv = d_fac_ipiv.p; v.fac_fptr = d_fac_fptr.p; v.fac_fidx = d_fac_fidx.p; v.fac_fval = d_fac_fval.p;
     v.fac_bptr = d_fac_bptr.p; v.fac_bidx = d_fac_bidx.p; v.fac_bval = d_fac_bval.p;
     v.fac_bpos = d_fac_bpos.p; v.fac_brow = d_fac_brow.p; v.fac_bslot_of_row = d_fac_bslot_of_row.p; v.fac_Wb = d_fac_Wb.p;
@@ -2037,8 +2044,10 @@ bool Engine::fac_refactor(int bump_limit) {
         HIPCHECK(hipMemcpyAsync(d_fac_bslot_of_row.p, bslot.data(), sizeof(int) * mm, hipMemcpyHostToDevice, st));
         if (b > 0) {
             d_fac_Wb.ensure((size_t)FAC_BMAX * FAC_BMAX, 0, st);
+            d_fac_WbT.ensure((size_t)FAC_BMAX * FAC_BMAX, 0, st);
             t.fac_Wb = d_fac_Wb.p;
-            if (hview.fac_Wb != d_fac_Wb.p) view_dirty = true;
+            t.fac_WbT = d_fac_WbT.p;
+            if (hview.fac_Wb != d_fac_Wb.p || hview.fac_WbT != d_fac_WbT.p) view_dirty = true;
             HIPCHECK(hipMemcpyAsync(d_fac_bpos.p, bpos.data(), sizeof(int) * (size_t)b, hipMemcpyHostToDevice, st));
             HIPCHECK(hipMemcpyAsync(d_fac_brow.p, brow.data(), sizeof(int) * (size_t)b, hipMemcpyHostToDevice, st));
             // work arrays of the inversion, kept across refactorisations (grown in steps of 64 rows)
@@ -2053,7 +2062,7 @@ bool Engine::fac_refactor(int bump_limit) {
             static const bool gj_launches = std::getenv("MLP_FACTOR_GJ_LAUNCHES") != nullptr;  // A/B: the launch-per-column Gauss-Jordan
             int hflag[2] = {0, 0};
             if (!gj_launches) {
-                launch_fac_bump_invert(t, d_fac_Kd.p, d_fac_Wtmp.p, d_fac_Wb.p, b, flag, d_fac_gjval.p, d_fac_gjrow.p, st);
+                launch_fac_bump_invert(t, d_fac_Kd.p, d_fac_Wtmp.p, d_fac_Wb.p, d_fac_WbT.p, b, flag, d_fac_gjval.p, d_fac_gjrow.p, st);
                 HIPCHECK(hipMemcpyAsync(hflag, flag, sizeof(hflag), hipMemcpyDeviceToHost, st));
                 HIPCHECK(hipStreamSynchronize(st));
             }
@@ -2061,6 +2070,7 @@ bool Engine::fac_refactor(int bump_limit) {
                 HIPCHECK(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
                 launch_fac_bump_build(t, d_fac_Kd.p, b, st);
                 launch_gauss_jordan(d_fac_Kd.p, d_fac_Wb.p, b, FAC_BMAX, flag, d_fac_gjval.p + 2 * 64, st);
+                launch_fac_bump_transpose(d_fac_Wb.p, d_fac_WbT.p, b, st);
                 HIPCHECK(hipMemcpyAsync(hflag, flag, sizeof(hflag), hipMemcpyDeviceToHost, st));
                 HIPCHECK(hipStreamSynchronize(st));
             }
@@ -2074,18 +2084,27 @@ bool Engine::fac_refactor(int bump_limit) {
     const int nlev = (int)lptr.size() - 1;
     HIPCHECK(hipMemcpyAsync(d_fac_lptr.p, lptr.data(), sizeof(int) * lptr.size(), hipMemcpyHostToDevice, st));
     // the tail: the levels from `tail` on all hold at most FAC_TAIL positions (one workgroup walks them: factor.inc)
-    int tail = nlev;
-    while (tail > 0 && lptr[tail] - lptr[tail - 1] <= 512) tail -= 1;
-    const int meta[8] = {nlev, total, b, tail, n_col_steps, n_row_steps, 0, 0};
+    // (the walk of a solve — which levels one workgroup walks alone, their LDS slots, the segments — is planned on the device after the
+    // edge lists exist: launch_fac_plan below; meta[3], [6], [7] are its outputs)
+    d_fac_ltslot.ensure(2 * ((size_t)FAC_MAX_LEVELS + 2), 0, st);  // LDS slot per level | "has an item with a long edge list" per level
+    d_fac_segs.ensure(3 * ((size_t)FAC_MAX_LEVELS + 2), 0, st);
+    if (t.fac_ltslot != d_fac_ltslot.p || t.fac_segs != d_fac_segs.p) {
+        t.fac_ltslot = d_fac_ltslot.p;
+        t.fac_segs = d_fac_segs.p;
+        view_dirty = true;
+    }
+    const int meta[8] = {nlev, total, b, nlev, n_col_steps, n_row_steps, 0, 0};
     HIPCHECK(hipMemcpyAsync(d_fac_meta.p, meta, sizeof(meta), hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)std::max(nlev, 1), st));  // (cnt is free again: the per-level fill cursors)
     launch_fac_peel_fill(t, level, cnt, st);
     // resolved edge lists of the two solves in level order: counts -> exclusive scans -> fill
-    HIPCHECK(hipMemsetAsync(d_fac_lev3.p, 0xFF, sizeof(int) * 3 * mm, st));  // (-1: bump positions / rows keep it)
+    HIPCHECK(hipMemsetAsync(d_fac_lev3.p, 0xFF, sizeof(int) * 5 * mm, st));  // (-1: bump positions / rows keep it)
     launch_fac_edges(t, 0, d_fac_fptr.p, d_fac_bptr.p, level, st);
     launch_exclusive_scan(d_fac_fptr.p, d_fac_fptr.p, (long)total + 1, d_scan_tmp.p, st);
     launch_exclusive_scan(d_fac_bptr.p, d_fac_bptr.p, (long)total + 1, d_scan_tmp.p, st);
     launch_fac_edges(t, 1, d_fac_fptr.p, d_fac_bptr.p, level, st);
+    launch_fac_plan(t, d_fac_ltslot.p, d_fac_segs.p, st);
+    launch_fac_tail_prog(t, d_fac_tprog.p, d_fac_tprog.p + mm, nlev, st);  // the items of the small levels as records, both directions
     launch_fac_reach_all(t, st);  // the level ranges of the solves (factor.inc): reach of every position, levels in descending order; level of the bump
     {   // level statistics produced before this refactorisation describe the old levels: conservative values until the next producer
         const int stat[4] = {INT_MAX, INT_MAX, 0, INT_MAX};  // fac_aq_hi, fac_rho_hi, fac_aq_lo, fac_aq_reach
@@ -3065,6 +3084,22 @@ uint64_t Engine::state(const char* what, double* out, uint64_t cap) {
         unsigned long long t0 = ~0ull;
         for (int i = 0; i < 24; ++i) if (h_ctl->hy_prof[i] && h_ctl->hy_prof[i] < t0) t0 = h_ctl->hy_prof[i];
         for (int i = 0; i < 24; ++i) tmp.push_back(h_ctl->hy_prof[i] ? (double)(h_ctl->hy_prof[i] - t0) * 0.01 : -1.0);
+    }
+    else if (w == "factor_plan") {  // compact factor: fac_meta[0..8), then the segments of the walk (kind, first level, last level) and their positions
+        if (fac_on_ && d_fac_meta.p && d_fac_segs.p) {
+            int meta[8] = {0};
+            HIPCHECK(hipStreamSynchronize(st));
+            HIPCHECK(hipMemcpy(meta, d_fac_meta.p, sizeof(meta), hipMemcpyDeviceToHost));
+            const int nseg = std::max(0, std::min(meta[7], FAC_MAX_LEVELS));
+            std::vector<int> sg((size_t)3 * nseg), lp((size_t)meta[0] + 1);
+            if (nseg) HIPCHECK(hipMemcpy(sg.data(), d_fac_segs.p, sizeof(int) * sg.size(), hipMemcpyDeviceToHost));
+            HIPCHECK(hipMemcpy(lp.data(), d_fac_lptr.p, sizeof(int) * lp.size(), hipMemcpyDeviceToHost));
+            for (int i = 0; i < 8; ++i) tmp.push_back((double)meta[i]);
+            for (int q = 0; q < nseg; ++q) {
+                tmp.push_back((double)sg[3 * q]); tmp.push_back((double)sg[3 * q + 1]); tmp.push_back((double)sg[3 * q + 2]);
+                tmp.push_back((double)(lp[sg[3 * q + 2] + 1] - lp[sg[3 * q + 1]]));
+            }
+        }
     }
     else if (w == "hyper_bail_reasons") {
         for (int i = 0; i < 10; ++i) tmp.push_back((double)stats.hyper_bail_reason[i]);

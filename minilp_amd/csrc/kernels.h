@@ -130,6 +130,24 @@ struct alignas(16) RowInfo {
     int kslot;
 };
 
+// One item of a small level of a compact-factor solve, ready to execute: where the result goes (FTRAN: position, BTRAN: row) with the
+// number of edges in the top byte, the index of its right-hand-side entry, the pivot, and its (at most six) edges — for each the index
+// of the target in the solve vector, the target's slot among the items of the small levels (-1: not one of them), the coefficient.
+constexpr int FAC_TAIL = 256;       // levels of at most this many positions are walked by one workgroup (one item per lane)
+constexpr int FAC_TAIL_CAP = 1024;  // ... in pieces of at most this many positions: the piece's part of the solve vectors and its inner edges live in LDS
+constexpr int FAC_TAIL_K = 4;       // inner edges per position kept in LDS (more: that position walks its record)
+constexpr int FAC_TAIL_INLINE = 6;
+struct alignas(16) FacTailRec {
+    int out_n;   // (n << 24) | out
+    int rhs;
+    double piv;
+    int tgt[FAC_TAIL_INLINE];
+    int slot[FAC_TAIL_INLINE];
+    double val[FAC_TAIL_INLINE];
+    int ovf;     // a longer edge list: place of edge number FAC_TAIL_INLINE in the lists in memory (fac_fidx / fac_fslot / fac_fval ...), else -1
+    int pad[3];
+};
+static_assert(sizeof(FacTailRec) == 128, "16 + 6 x 16 + 16 bytes");
 struct DevView {
     int m, n;  // constraints (= basic positions), non-basic positions (= num_vars)
     int ld;    // leading dimension (= capacity) of W
@@ -256,6 +274,7 @@ struct DevView {
     // (basic_vars / var_loc move on with every pivot).
     int fac_on, fac_J;
     int* fac_meta;           // [0] number of levels, [1] peeled positions, [2] bump columns, [3] first level of the single-workgroup tail
+                             // [4] column steps of the peel (= level of the bump), [5] row steps, [6] positions in small levels, [7] segments of the walk
     int* fac_pos_of_var;     // N: position of a variable in B0, -1 when it was non-basic
     int* fac_var_of_pos;     // m: variable at a position in B0
     int* fac_prow;           // m: pivot row of a position
@@ -268,6 +287,14 @@ struct DevView {
     int* fac_lev_of_row;     // m: level of the position that pivots on a row (-1: bump row)
     int* fac_reach_of_pos;   // m: highest level any BTRAN dependent of the position reaches
     int fac_skip, fac_pad1;  // MLP_FACTOR_SKIP: walk only the levels a right-hand side can reach
+    // the single-workgroup tail of the solves (factor.inc): place of a position / of a row's pivot position in fac_items (-1: bump),
+    // and the tail's items as fixed-size records in walking order (one per direction)
+    int* fac_idx_of_pos; int* fac_idx_of_row;
+    const FacTailRec* fac_tprog_f; const FacTailRec* fac_tprog_b;
+    int* fac_fslot; int* fac_bslot;  // per edge of the lists in memory: slot of the target among the items of the small levels (-1: not one); filled for the long lists only
+    int* fac_ltslot;   // per level: first LDS slot of its positions when workgroup 0 walks it alone (a small level), else -1
+    int* fac_segs;     // the walk of a solve as fac_meta[7] segments (kind, first level, last level), ascending: 0 grid, 1 small levels, 2 bump
+    const double* fac_WbT;   // transpose of fac_Wb (the FTRAN walks columns)
     int* fac_irow; double* fac_ipiv;
     int* fac_fptr; int* fac_fidx; double* fac_fval;   // m + 1 | entries of the basis
     int* fac_bptr; int* fac_bidx; double* fac_bval;
@@ -380,7 +407,10 @@ void launch_fac_peel_all(const DevView& dv, int* cnt, int* level, int* row_lev, 
                          int* rcnt, int* claim_r, int* cand_col, hipStream_t st);
 void launch_fac_peel_fill(const DevView& dv, const int* level, int* cursor, hipStream_t st);
 void launch_fac_edges(const DevView& dv, int pass, int* fcnt, int* bcnt, const int* level, hipStream_t st);  // resolved edge lists in level order: pass 0 counts, pass 1 fills
-void launch_fac_bump_invert(const DevView& dv, double* K, double* W, double* out, int b, int* flag, double* part_val, int* part_row, hipStream_t st);  // K^-1 of the bump, one launch
+void launch_fac_bump_invert(const DevView& dv, double* K, double* W, double* out, double* outT, int b, int* flag, double* part_val, int* part_row, hipStream_t st);
+void launch_fac_bump_transpose(const double* in, double* outT, int b, hipStream_t st);  // K^-1 of the bump, one launch
+void launch_fac_tail_prog(const DevView& dv, FacTailRec* pf, FacTailRec* pb, int nlev, hipStream_t st);
+void launch_fac_plan(const DevView& dv, int* ltslot, int* segs, hipStream_t st);  // small levels, their LDS slots, the segments of a solve's walk (device-side)  // the tail's items as records (both directions)
 void launch_fac_reach_all(const DevView& dv, hipStream_t st);  // reach_of_pos of every position (levels in descending order, one launch); level of the bump
 void launch_fac_bump_build(const DevView& dv, double* Kd, int b, hipStream_t st);  // K = B0[bump rows, bump columns], dense, row-major with pitch FAC_BMAX
 void launch_str_reset(const DevView& dv, hipStream_t st);  // sparse tableau row: new stamp epoch, empty lists

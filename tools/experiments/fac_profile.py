@@ -7,7 +7,7 @@ if os.environ.get("MLP_IMPORT_TORCH"):
 import minilp_amd as M
 from minilp_amd import lpgen
 S, D, deg, tight, skip, run = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
-lp = lpgen.gen_transport_lp(S, D, deg, tight=tight)
+lp = lpgen.gen_mixed_lp(S, D, deg, 3) if os.environ.get("FAMILY") == "mixed" else lpgen.gen_transport_lp(S, D, deg, tight=tight)
 s = lpgen.build_problem(M.Problem, lp).solve(budget=skip)
 t0 = time.perf_counter(); s.continue_solve(run); dt = time.perf_counter() - t0
 st = s.stats()
