@@ -393,7 +393,7 @@ private:
     bool values_dirty = true;
 
     // --- iteration graphs: [phase][pse]
-    bool use_graph = true, use_branches = false, use_vbranch = true;
+    bool use_graph = true, use_branches = false, use_vbranch = false;
     int batch = 32;  // (round 4: 16 -> 32: one host round trip per 32 replayed iterations; the driver's 20-pivot window is then ONE batch)
     long final_refresh_pivots = 50000;  // MLP_FINAL_REFRESH: re-examine optimality on recomputed reduced costs after this many pivots (0 = never)
     uint64_t iters_since_recalc = 0, iters_since_polish = 0;

@@ -80,8 +80,12 @@ Engine::Engine() {
     // pivot at k = 20 500 and 367.7 vs 358.6 us at k = 10 000 — the two kernels do not overlap usefully with the sweep and
     // the fork / join costs a little; off unless MLP_BRANCH=1
     use_branches = br && br[0] == '1';
+    // v branch of the late primal iteration (launch_stage): measured in round 4 at k = 20 500 — 708.9 / 711.9 us per pivot
+    // with the branch against 683.3 / 686.6 without (k = 10 000: 271.3 against 264.1).  The streaming pass saturates HBM,
+    // so the latency-bound ratio test and BTRAN beside it see loaded-memory latencies and the pass itself loses bandwidth to
+    // them: the overlap costs more than the 42 us it hides.  Off unless MLP_VBRANCH=1.
     const char* vb = std::getenv("MLP_VBRANCH");
-    use_vbranch = !(vb && vb[0] == '0');
+    use_vbranch = vb && vb[0] == '1';
     const char* rt = std::getenv("MLP_REFRESH_TOL");
     if (rt) refresh_tol = std::atof(rt);
     const char* lr = std::getenv("MLP_LOWRANK");
@@ -1305,7 +1309,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     // v branch (round 4): in the lazy primal iteration of the delayed-update mode the pass over the nucleus inverse computes
     // v = B^-T alpha_q only — it needs alpha_q, not the leaving row — so it leaves the chain FTRAN -> ratio test -> BTRAN -> pass
     // and runs on the side stream beside the ratio test and the BTRAN (t_K, the fold of a folding pivot, the streaming pass);
-    // the BTRAN waits for the fold (W0 must be whole), the tails of the pass wait for the stream.  MLP_VBRANCH=0: the serial order.
+    // the BTRAN waits for the fold (W0 must be whole), the tails of the pass wait for the stream.  Off by default (MLP_VBRANCH=1).
     const bool vbr = use_vbranch && phase == 0 && pse && lazy && !stepping && shard_world == 1 && !g.head_fused && vbranch_supported(dv, g);
     if (stage == STAGE_BASIS) touch_done = false;
     // The pricing decision (q for primal, r for dual) is already in Ctl: it was taken by the
