@@ -37,8 +37,7 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-L/opt/rocm/lib", "-lrocsolver", "-lrocblas",
-                                                                                "-Wl,-rpath,/opt/rocm/lib"]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -130,7 +130,7 @@ struct Stats {
     uint64_t update_launches = 0;
     double solve_wall_s = 0;
     double max_pivot_err = 0;
-    uint64_t reinversion_fallbacks = 0;  // blocked (rocSOLVER) inversions that reported a zero pivot and were redone by the Gauss-Jordan kernels
+    uint64_t reinversion_fallbacks = 0;  // (rounds 1-3: rocSOLVER inversions that reported a false zero pivot and were redone; always 0 since the blocked inversion is hand-written)
     double str_ms = 0;  // sampled sparse tableau rows (k_row_touch + k_row_pull, launch-bracketed HIP events)
     uint64_t str_launches = 0;
     uint64_t hyper_bail_reason[10] = {};  // by reason code of the kernel (hyper.inc)
@@ -215,6 +215,8 @@ private:
     bool ranks_share_device = false;
     // sparse tableau row (k_row_touch / k_row_pull) while the nucleus is small
     int str_kmax = 230;                      // MLP_STR_K: largest nucleus the sparse form is used for (0: never)
+    int sb_kmax = 128;                       // MLP_SMALL_BASIS_K: largest nucleus (at the end of a batch) k_small_basis is used for
+    bool sb_now = false;                     // ... decided per batch like str_now (the geometry is baked into the graphs)
     bool touch_done = false;                 // the BASIS stage of the iteration being recorded carried the touched-column list
     bool str_now = false, str_clean = false; // geometry of the batch being run; alpha_r / helper are zero outside touched entries
     DevBuf<int> d_str_list;
@@ -375,7 +377,6 @@ private:
   public:
     std::string transport = "none";        // human-readable name of the exchange transport
   private:
-    void* blas = nullptr;  // rocblas_handle for the blocked re-inversion
     size_t mail_bytes = 0;
     double refresh_tol = 1e-7;  // re-invert W when the two-way pivot check disagrees by more than this
     DevBuf<double> d_aK, d_rK, d_tK, d_tauK, d_vK, d_klist_a, d_blist_a, d_part_tau, d_part_v;

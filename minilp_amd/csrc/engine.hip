@@ -5,8 +5,6 @@
 // reads back one small record per pivot, once per batch.
 #include "engine.h"
 
-#include <rocblas/rocblas.h>
-#include <rocsolver/rocsolver.h>
 
 #include <algorithm>
 #include <chrono>
@@ -115,6 +113,7 @@ Engine::Engine() {
     lazy_dse = !(lz && lz[0] == '0');
     ratio_two = std::getenv("MLP_RATIO_TWO_KERNELS") != nullptr;
     if (const char* hy = std::getenv("MLP_HYPER")) hyper_mode = std::atoi(hy) > 0 ? 1 : 0;  // 1: whenever the kernel applies, 0: never
+    if (const char* sbk = std::getenv("MLP_SMALL_BASIS_K")) sb_kmax = std::max(0, std::min(256, std::atoi(sbk)));
     if (const char* sk = std::getenv("MLP_STR_K")) str_kmax = std::atoi(sk);  // sparse tableau row up to this nucleus size (0: never)
     if (const char* hh = std::getenv("MLP_HYPER_HEAVY")) hyper_heavy = std::atol(hh);        // work bound per iteration (tests force bail-outs)
     if (const char* rs = std::getenv("MLP_RATIO_SPIN_LIMIT")) ratio_spin_limit = std::atoll(rs);
@@ -305,7 +304,6 @@ Engine::~Engine() {
     drop_graphs();
     for (auto& e : ev)
         if (e) (void)hipEventDestroy(e);
-    if (blas) (void)rocblas_destroy_handle(reinterpret_cast<rocblas_handle>(blas));
     release_mailboxes();
     release_runtime();
 }
@@ -340,6 +338,7 @@ Geom Engine::geom() const {
     // compete for the same CUs), never again after a wait has timed out once
     g.ratio_two = (ratio_two || (shard_world > 1 && ranks_share_device)) ? 1 : 0;
     g.str = (str_now && !stepping && !fac_on_) ? 1 : 0;
+    g.sb = (g.str && sb_now) ? 1 : 0;
     return g;
 }
 
@@ -1311,6 +1310,9 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     // and runs on the side stream beside the ratio test and the BTRAN (t_K, the fold of a folding pivot, the streaming pass);
     // the BTRAN waits for the fold (W0 must be whole), the tails of the pass wait for the stream.  Off by default (MLP_VBRANCH=1).
     const bool vbr = use_vbranch && phase == 0 && pse && lazy && !stepping && shard_world == 1 && !g.head_fused && vbranch_supported(dv, g);
+    // small nucleus (first capacity of the inverse), lazy primal iteration: BTRAN, pass over W, v tail and touched-column list are
+    // ONE launch (k_small_basis) issued at the BASIS stage; the BTRAN stage is empty.  MLP_SMALL_BASIS=0: the three launches.
+    const bool smallb = phase == 0 && pse && lazy && !stepping && shard_world == 1 && !vbr && !tau_branch && small_basis_supported(dv, g);
     if (stage == STAGE_BASIS) touch_done = false;
     // The pricing decision (q for primal, r for dual) is already in Ctl: it was taken by the
     // previous iteration's update kernel, or by the standalone pricing kernel at batch start.
@@ -1351,6 +1353,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         else launch_ratio_dual(dv, g, st);                    // K7 p1, p2 (+ K2 head)
         break;
     case STAGE_BTRAN:
+        if (smallb) break;
         if (phase == 1 && g.head_fused) {
             launch_btran_fused(dv, g, 0, 1, st);                  // K3 head inside the BTRAN kernel (one launch)
         } else {
@@ -1364,6 +1367,13 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         }
         break;
     case STAGE_BASIS:
+        if (smallb) {
+            if (with_events) arm_kernel_timing(2, ev[2], ev[3]);  // (sampled iteration: the slot of the pass over the nucleus inverse)
+            launch_small_basis(dv, g, st);
+            if (with_events) arm_kernel_timing(2, nullptr, nullptr);
+            touch_done = true;
+            break;
+        }
         if (vbr) {
             HIPCHECK(hipStreamWaitEvent(st, evJoin[1], 0));   // the v partials have landed
         } else {
@@ -1707,6 +1717,10 @@ int Engine::run_loop(int phase) {
                 str_now = want;
                 view_dirty = true;
             }
+            // (one workgroup walks all of W in k_small_basis: it pays while the nucleus is small — 8 us against 16.8 for the three
+            // launches at k <= 25, 50 against ~20 at k = 190 as first built — so the form is chosen per batch by the size the
+            // nucleus can reach in it)
+            sb_now = want && k_ + RING + 1 <= sb_kmax;
             if (str_now) {
                 ensure_hyper();  // the epoch stamps
                 d_str_list.ensure((size_t)num_vars + (size_t)m_ + 192, 0, st);  // touched columns | positions of supp(alpha_q)
@@ -2669,40 +2683,27 @@ void Engine::rebuild_inverse() {
         flag.ensure(2, 0, st);
         HIPCHECK(hipMemsetAsync(flag.p, 0, 2 * sizeof(int), st));
         int hflag = 0;
-        static const bool force_gj = std::getenv("MLP_REINVERT_GJ") != nullptr;  // (debugging: the hand-written Gauss-Jordan at any size)
-        bool blocked_failed = false;
-        int hf[2] = {0, 0};
+        static const bool force_gj = std::getenv("MLP_REINVERT_GJ") != nullptr;  // (debugging: the unblocked Gauss-Jordan at any size)
         if (k >= 384 && !force_gj) {
-            // Large nucleus: blocked LU + inverse from rocSOLVER (GEMM-based, O(k^3) flops at library
-            // speed).  K is assembled row-major straight into W; a row-major matrix handed over as
-            // column-major is its transpose, and (K^T)^-1 read back row-major is K^-1, so no transposes.
+            // Large nucleus: blocked in-place Gauss-Jordan with partial pivoting (inverse.inc) — K is assembled row-major
+            // straight into W and inverted there; the rank-32 update of a block step is the fold kernel of the delayed-update
+            // mode.  (Rounds 1-3 called rocSOLVER's dgetrf + dgetri here: the product links no vendor library any more.)
             launch_build_nucleus(hview, geom(), d_W.p, k, st);
-            if (!blas) {
-                if (rocblas_create_handle(reinterpret_cast<rocblas_handle*>(&blas)) != rocblas_status_success)
-                    throw MlpError(-3, "rocblas_create_handle failed");
-            }
-            rocblas_handle h = reinterpret_cast<rocblas_handle>(blas);
-            rocblas_set_stream(h, st);
-            DevBuf<int> ipiv;
-            ipiv.ensure((size_t)k, 0, st);
-            if (rocsolver_dgetrf(h, k, k, d_W.p, ld(), ipiv.p, flag.p) != rocblas_status_success)
-                throw MlpError(-3, "rocsolver_dgetrf failed");
-            if (rocsolver_dgetri(h, k, d_W.p, ld(), ipiv.p, flag.p + 1) != rocblas_status_success)
-                throw MlpError(-3, "rocsolver_dgetri failed");
-            HIPCHECK(hipMemcpyAsync(hf, flag.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+            DevBuf<int> piv, src, cidx;
+            DevBuf<double> prow, ckey;
+            piv.ensure((size_t)k, 0, st);
+            src.ensure((size_t)k, 0, st);
+            prow.ensure(64, 0, st);
+            ckey.ensure((size_t)k / 32 + 8, 0, st);
+            cidx.ensure((size_t)k / 32 + 8, 0, st);
+            const int nrowbuf = (int)std::min<size_t>(4096, d_part_v.cap / (size_t)ld());
+            if (nrowbuf < 1) throw MlpError(-3, "blocked inversion: no row buffer");
+            launch_blocked_inverse(hview, k, d_part_v.p, nrowbuf, piv.p, src.p, prow.p, ckey.p, cidx.p, flag.p, st);
+            HIPCHECK(hipMemcpyAsync(&hflag, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHECK(hipStreamSynchronize(st));
-            // Observed (round 3, covering LPs with 3 non-zeros per row, k = 564 ... 2 254): the library reports a zero pivot
-            // (info > 0) on nuclei that are well conditioned (numpy: cond 82, min |U_ii| 0.05) and that the Gauss-Jordan below
-            // inverts to 3e-14.  A reported zero pivot is therefore re-examined by the hand-written kernel before it
-            // counts as a singular basis.
-            blocked_failed = (hf[0] | hf[1]) != 0;
-            if (blocked_failed) {
-                stats.reinversion_fallbacks += 1;
-                HIPCHECK(hipMemsetAsync(flag.p, 0, 2 * sizeof(int), st));
-            }
         }
-        if (k < 384 || force_gj || blocked_failed) {
-            // Small nucleus (or a blocked inversion that reported a zero pivot): hand-written Gauss-Jordan with partial pivoting
+        if (k < 384 || force_gj) {
+            // Small nucleus: unblocked Gauss-Jordan with partial pivoting
             DevBuf<double> Kd, scratch;
             Kd.ensure((size_t)k * ld(), 0, st);
             scratch.ensure((size_t)k + 8, 0, st);
@@ -2712,8 +2713,7 @@ void Engine::rebuild_inverse() {
             HIPCHECK(hipStreamSynchronize(st));
         }
         if (hflag)
-            throw MlpError(-2, "singular basis matrix (solver.rs:1301)" +
-                                   (blocked_failed ? " (getrf info " + std::to_string(hf[0]) + ", getri info " + std::to_string(hf[1]) + ")" : std::string()));
+            throw MlpError(-2, "singular basis matrix (solver.rs:1301)");
     }
     stats.reinversions += 1;
 }
@@ -2971,7 +2971,7 @@ Engine* Engine::clone() {
     e->h_rptr = h_rptr; e->h_rcol = h_rcol; e->h_rval = h_rval;
     e->h_colnnz = h_colnnz; e->h_single_row = h_single_row; e->h_single_val = h_single_val;
     e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->amax_ = amax_; e->no_head_fusion = no_head_fusion;
-    e->sw_balanced = sw_balanced; e->str_kmax = str_kmax; e->hyper_mode = hyper_mode; e->hyper_heavy = hyper_heavy; e->ratio_two = ratio_two; e->ratio_spin_limit = ratio_spin_limit; e->ranks_share_device = false; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->use_pack = use_pack; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
+    e->sw_balanced = sw_balanced; e->str_kmax = str_kmax; e->sb_kmax = sb_kmax; e->hyper_mode = hyper_mode; e->hyper_heavy = hyper_heavy; e->ratio_two = ratio_two; e->ratio_spin_limit = ratio_spin_limit; e->ranks_share_device = false; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->use_pack = use_pack; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
     e->h_basic_vars = h_basic_vars; e->h_nb_vars = h_nb_vars; e->h_var_loc = h_var_loc;
     e->h_kslot_of_pos = h_kslot_of_pos; e->h_srow_of_pos = h_srow_of_pos; e->h_kslot_of_row = h_kslot_of_row;
     e->h_pos_of_srow = h_pos_of_srow; e->h_sdiag_of_pos = h_sdiag_of_pos; e->h_nb_fixed = h_nb_fixed;
@@ -3075,6 +3075,10 @@ uint64_t Engine::state(const char* what, double* out, uint64_t cap) {
     else if (w == "orig_var_maxs") tmp = h_hi;
     else if (w == "orig_rhs") tmp = h_rhs;
     else if (w == "flags") tmp = {(double)primal_feasible, (double)dual_feasible, (double)enable_pse, (double)enable_dse};
+    else if (w == "small_basis_launches") {  // iterations that ran BTRAN + pass + v tail + touch as one launch (k_small_basis)
+        pull_ctl();
+        tmp = {(double)h_ctl->sb_count};
+    }
     else if (w == "hyper_profile") {  // microseconds per stage of the hypersparse iteration, accumulated since try_new
         pull_ctl();
         for (int i = 0; i < 13; ++i) tmp.push_back((double)h_ctl->hy_prof[i] * 0.01);

@@ -104,6 +104,9 @@ struct Ctl {
     int kprof_on;    // MLP_KPROF=1: kernels stamp the wall clock into hy_prof (KMARK; state("kernel_timeline"))
     int side_go;     // v branch of the late primal iteration (engine.hip launch_stage): the iteration was live when its FTRAN head ran — the
                      // side kernels (t_K, fold, streaming pass) test this instead of `status`, which the ratio test rewrites beside them
+    double sb_obj0;  // running objective before the primal ratio test added this iteration's step (k_small_basis restores it when its wait stalls:
+                     // the iteration is then re-run from the top)
+    int sb_count;    // launches of k_small_basis that ran an iteration (state("small_basis_launches"): tests check the path was taken)
     unsigned long long hy_prof[24];  // ticks of the 100 MHz wall clock per stage of the hypersparse iteration (diagnostics)
     PivotRec ring[RING];
 };
@@ -333,6 +336,7 @@ struct Geom {
     int big;            // fused W pass: 64-row x 1024-column blocks, non-temporal (cap > 4096, or forced by MLP_BIGTILE)
     int head_fused;     // stage heads run inside the consuming kernel (delayed-update mode off, every column / row fits the LDS list)
     int str;            // sparse tableau row instead of the sweep over all of A (nucleus of at most MLP_STR_K columns, one GPU)
+    int sb;             // nucleus small enough for the one-launch BTRAN + pass + v tail + touch of the lazy primal iteration (k_small_basis; MLP_SMALL_BASIS_K)
     int fac;            // compact factor of the basis instead of the explicit nucleus inverse (factor.inc)
     int ratio_two;      // the two Harris passes as two launches (no in-kernel wait): MLP_RATIO_TWO_KERNELS, ranks sharing a device, after an ITER_STALL
 };
@@ -355,6 +359,9 @@ void launch_btran_rhs(const DevView& dv, const Geom& g, hipStream_t st);        
 void launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, hipStream_t st, int inline_combine = 0);  // K4 [| partition change]
 // sparse tableau row: touched-column list, then the pull of alpha_r / helper on the listed columns (| partition change)
 void launch_row_sparse(const DevView& dv, const Geom& g, int mode, int with_struct, int touch, hipStream_t st);
+// small nucleus (first capacity), lazy primal iteration: BTRAN + pass over W + v tail + touched-column list in ONE launch
+bool small_basis_supported(const DevView& dv, const Geom& g);
+void launch_small_basis(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st);                 // K7 p1, p2 (+FTRAN head)
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int with_tau = 1);  // tauK/vK partials + eta update of W
@@ -417,6 +424,9 @@ void launch_str_reset(const DevView& dv, hipStream_t st);  // sparse tableau row
 void launch_checksum_w(const DevView& dv, unsigned long long* out, hipStream_t st);  // order-independent checksum of W[0:k, 0:k] and the slot maps (tests)
 void launch_fold_lowrank(const DevView& dv, const Geom& g, hipStream_t st);  // W0 += U^T V, nlow := 0 (host-requested flush)
 void launch_gauss_jordan(double* Kd, double* Winv, int k, int ld, int* d_flag, double* d_scratch, hipStream_t st);
+// blocked in-place Gauss-Jordan inversion of the nucleus held in dv.W (inverse.inc); *flag = 1: singular
+void launch_blocked_inverse(const DevView& dv, int k, double* rowbuf, int nrowbuf, int* piv, int* src, double* prow, double* ckey,
+                            int* cidx, int* flag, hipStream_t st);
 
 // device-side matrix maintenance (add_constraint without a host pass over the non-zeros; also the initial builds)
 void launch_csc_append_row(const int* optr, const int* orow, const double* oval, int n_old, int new_row, const int* ncols,

@@ -1324,7 +1324,52 @@ __global__ void __launch_bounds__(BLK) k_pull_F(DevView v, int which) {
         out[p] -= acc / v.sdiag_of_pos[p];
     }
 }
+// The marked pull of the FTRAN (which = 0 with marks) at 64 lanes per row, in scan form: k_pull_F<64> launches m / 4 blocks — 25 000
+// on config 4 — of which all but the few holding a marked row return at once; the grid alone made the sharded early FTRAN cost 64 us
+// against 11 unsharded (round-3 review, weak 9).  Here 2 048 waves stride over the positions 64 at a time: one coalesced read of the
+// mark bytes, a ballot, then the whole wave walks each marked row exactly as the 64 lanes of k_pull_F<64> do (same lane -> entry
+// assignment, same xor tree: the same bits).
+__global__ void __launch_bounds__(BLK) k_pull_F_scan(DevView v) {
+    const Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    const int lane = threadIdx.x & 63;
+    const int nw = (int)gridDim.x * (BLK / 64);
+    for (int chunk = (int)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6); chunk * 64 < v.m; chunk += nw) {
+        const int p0 = chunk * 64 + lane;
+        unsigned char mk = 0;
+        if (p0 < v.m) {
+            mk = v.fmark[p0];
+            if (mk) {
+                v.fmark[p0] = 0;
+                if (v.kslot_of_pos[p0] >= 0) mk = 0;  // (k_pull_F leaves such a mark in place; nothing sets one)
+            }
+        }
+        unsigned long long mask = __ballot(mk != 0);
+        while (mask) {
+            const int b = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int p = chunk * 64 + b;
+            const int i = v.srow_of_pos[p];
+            double acc = 0.0;
+            const int end = v.csr_ptr[i + 1];
+            for (int e = v.csr_ptr[i] + lane; e < end; e += 64) {
+                const int loc = v.var_loc[v.csr_col[e]];
+                if (loc >= 0) {
+                    const int s = v.kslot_of_pos[loc];
+                    if (s >= 0) acc += v.csr_val[e] * v.aK[s];
+                }
+            }
+            acc = group_sum<64>(acc);
+            if (lane == 0 && acc != 0.0) v.alpha_q[p] -= acc / v.sdiag_of_pos[p];
+        }
+    }
+}
 static void launch_pull_F(const DevView& dv, const Geom& g, int which, hipStream_t st) {
+    static const bool scan_off = std::getenv("MLP_PULL_SCAN") && std::getenv("MLP_PULL_SCAN")[0] == '0';
+    if (!which && dv.fmark && g.lanes > 16 && !scan_off && dv.m >= 16384) {
+        hipLaunchKernelGGL(k_pull_F_scan, dim3(512), dim3(BLK), 0, st, dv);
+        return;
+    }
     if (g.lanes <= 4) hipLaunchKernelGGL(k_pull_F<4>, dim3(blocks_for((long)dv.m * 4)), dim3(BLK), 0, st, dv, which);
     else if (g.lanes <= 16) hipLaunchKernelGGL(k_pull_F<16>, dim3(blocks_for((long)dv.m * 16)), dim3(BLK), 0, st, dv, which);
     else hipLaunchKernelGGL(k_pull_F<64>, dim3(blocks_for((long)dv.m * 64)), dim3(BLK), 0, st, dv, which);
@@ -1464,6 +1509,7 @@ __device__ void ratio_primal_finish(const DevView& v, Ctl* c, Cand best) {
                 c->halt = 1;
                 push_rec(c, 0);
             } else {
+                c->sb_obj0 = it->obj;
                 it->obj += dq * diff;  // solver.rs:1027
                 if (status == ITER_PIVOT) {
                     it->leaving_var = v.basic_vars[r];
@@ -3539,7 +3585,8 @@ __global__ void __launch_bounds__(BLK) k_post_exchange(DevView v, int with_v, in
 // After the fused pass (horizontally fused): blocks [0, n_push) finish tau = B^-1 rho by position
 // (tau_K from the per-chunk partials in a fixed order, then the push of -F tau_K, solver.rs:1157);
 // the remaining blocks reduce the v partials in a fixed order and scatter v_K by row (solver.rs:1114).
-__device__ __forceinline__ void row_touch_body(const DevView& v, Ctl* c, int block);  // (sparse tableau row, below)
+template <bool OWN_RK = false>
+__device__ __forceinline__ void row_touch_body(const DevView& v, Ctl* c, int block, double own_rk = 0.0);  // (sparse tableau row, below)
 template <int G, bool WITH_V, int TR, int TC = FW_TC>
 __global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push, int touch_from = -1, int fold_fused = 0) {
     Ctl* c = v.ctl;
@@ -4270,13 +4317,14 @@ void launch_build_colblk(const int* cptr, const int* crow, int N, int rb, int* c
 // helper N^T v (solver.rs:1126-1132) is needed on the columns with alpha_rj != 0 only, i.e. on the same list.
 //   k_row_touch: one wave per row of supp(rho): its CSR entries -> non-basic positions, each listed once (epoch stamp);
 //   k_row_pull : G lanes per listed column pull alpha_rj (and helper_j) from the CSC in storage order (no float atomics).
-__device__ __forceinline__ void row_touch_body(const DevView& v, Ctl* c, int block) {
+template <bool OWN_RK>
+__device__ __forceinline__ void row_touch_body(const DevView& v, Ctl* c, int block, double own_rk) {
     const int k = c->k;
     const int w = (int)((block * BLK + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     if (w > k) return;
     int row;
     if (w < k) {
-        if (v.rK[w] == 0.0) return;
+        if ((OWN_RK ? own_rk : v.rK[w]) == 0.0) return;  // (k_small_basis: the wave formed its own entry of rho_K)
         row = v.row_of_kslot[w];
     } else {  // the leaving singleton's own row (rho there is 1 / its diagonal entry)
         const int r = c->it.r;
@@ -4310,6 +4358,204 @@ __global__ void __launch_bounds__(BLK) k_row_touch(DevView v) {
     KMARK0(c, 10);
     row_touch_body(v, c, (int)blockIdx.x);
 }
+// ------------------------------------------------------------------- small nucleus: BTRAN + pass over W + v tail + touch, one launch
+// While the nucleus inverse still has its first capacity (256 slots) the lazy primal iteration's three launches between the
+// ratio test and the tableau row — k_btran (rho_K, ||rho||^2 | t_K), k_fused_w<8> (v partials + eta update of W),
+// k_post_fused (v_K reduce + scatter | touched-column list) — move a few kilobytes each and cost 4.9 + 6.2 + 5.7 us of
+// launch ramps, boundaries and dependent-load chains (profiles/r04_early_kernel_stats.csv).  Here they are ONE launch:
+//   block 0            rho_K from the listed rows of W (as k_btran), then — once the t_K blocks have arrived — the whole pass
+//                      over W from LDS-staged vectors, the v_K reduction and its scatter by row;
+//   blocks 1..n_rhs    t_K = alpha_K - F^T y_S, G lanes per slot (as k_btran's second part), write-through, then a ticket;
+//   the rest           the touched-column list of the sparse tableau row; each wave forms its own rho_K entry, so these
+//                      blocks wait for nobody.
+// The only in-kernel wait is block 0's for the t_K tickets, BEFORE anything of the iteration has been applied to W: if it
+// times out (grid not co-resident) the batch ends with ITER_STALL like a fused ratio test and the engine goes back to the
+// three launches for good (Geom.ratio_two).  Every sum is formed in the order of the kernels it replaces — the stripes of
+// eight rows, then k_post_fused's eight groups — so the results are bit-identical to theirs (tests/test_small_basis.py).
+constexpr int SB_CAP = 256;  // capacity this kernel serves (one workgroup walks all of W: 512 KB at most)
+template <int G>
+__global__ void __launch_bounds__(BLK) k_small_basis(DevView v, int n_rhs) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
+    const int k = c->k, ld = v.ld;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x > n_rhs) {
+        // rho_K is being formed by block 0 of this launch: each wave forms its own entry (the same sum in the same order,
+        // hence the same bits — only "is it zero" is needed) from the rows of W block 0 is going to update, so block 0 waits
+        // for this block's ticket before it writes W
+        const int tb = (int)blockIdx.x - 1 - n_rhs;
+        if (tb * (BLK / 64) > k) return;  // (no wave of this block has a row: block 0 does not count it)
+        const int w = (tb * BLK + tid) >> 6;
+        double acc = 0.0;
+        if (w < k) {
+            const int n = c->it.blist_n;
+            for (int j = 0; j < n; ++j) acc += v.blist_a[j] * v.W[(size_t)v.blist_s[j] * ld + w];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(&v.ticket[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        row_touch_body<true>(v, c, tb, acc);
+        return;
+    }
+    if (blockIdx.x > 0) {  // t_K (solver.rs:1114), as k_btran
+        const int slot = (((int)blockIdx.x - 1) * BLK + tid) / G;
+        const int gl = tid & (G - 1);
+        if (((int)blockIdx.x - 1) * (BLK / G) >= k) return;  // (whole block beyond the nucleus: block 0 does not count it)
+        if (slot < k) {
+            const int p = v.pos_of_kslot[slot];
+            const int var = v.basic_vars[p];
+            const int end = v.csc_ptr[var + 1];
+            double acc = 0.0;
+            for (int e = v.csc_ptr[var] + gl; e < end; e += G) acc += v.csc_val[e] * v.rv[v.csc_row[e]].y;
+            acc = group_sum<G>(acc);
+            if (gl == 0) {
+                st_agent(&v.tK[slot], v.alpha_q[p] - acc);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(&v.ticket[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    KMARK0(c, 7);
+    __shared__ double s_part[32][128];  // per-stripe v partials of one half of the columns
+    __shared__ double s_rk[SB_CAP], s_tk[SB_CAP], s_u[SB_CAP];
+    __shared__ int s_state;
+    // (1) rho_K = sum_j blist_a[j] W[blist_s[j], :], rho by row, ||rho||^2
+    {
+        const int n = c->it.blist_n;
+        double sq = 0.0;
+        if (tid < k) {
+            double acc = 0.0;
+            for (int j = 0; j < n; ++j) acc += v.blist_a[j] * v.W[(size_t)v.blist_s[j] * ld + tid];
+            v.rK[tid] = acc;
+            v.rv[v.row_of_kslot[tid]].x = acc;
+            s_rk[tid] = acc;
+            sq += acc * acc;
+        }
+        sq = block_sum(sq);
+        {   // (the detour of k_btran's one-block grid reduction: a second tree over (sq, 0, 0, ...) — the same bits)
+            double y = tid == 0 ? sq : 0.0;
+            sq = block_sum(y);
+        }
+        if (tid == 0) {
+            const int r = c->it.r;
+            if (v.kslot_of_pos[r] < 0) {
+                const double inv = 1.0 / v.sdiag_of_pos[r];
+                sq += inv * inv;
+            }
+            c->it.rho_sq = sq;
+        }
+    }
+    // (2) the eta column by slot while the t_K blocks finish, then wait for their tickets
+    const double inv_alpha = c->it.inv_alpha;
+    const int rslot = c->up.sr;
+    if (tid < k) s_u[tid] = (v.aK[tid] - (tid == rslot ? 1.0 : 0.0)) * inv_alpha;
+    const int row_of_mine = tid < k ? v.row_of_kslot[tid] : 0;  // (128 columns per half: thread i serves column cb + i below)
+    const int row_of_mine2 = tid + 128 < k && tid < 128 ? v.row_of_kslot[tid + 128] : 0;
+    if (tid == 0) {
+        const unsigned want = (unsigned)((k + BLK / G - 1) / (BLK / G));  // t_K blocks with a slot below k
+        const unsigned want_touch = (unsigned)(k / (BLK / 64) + 1);          // touch blocks with a wave at or below k
+        int state = 0;
+        long long spins = 0;
+        while (__hip_atomic_load(&v.ticket[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want ||
+               __hip_atomic_load(&v.ticket[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want_touch) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > c->ratio_spin_limit) {
+                state = 1;
+                break;
+            }
+        }
+        if (!state) {
+            __hip_atomic_store(&v.ticket[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&v.ticket[3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_state = state;
+    }
+    __syncthreads();
+    if (s_state) {
+        if (tid == 0 && atomicExch(&c->halt, 1) == 0) {
+            c->it.obj = c->sb_obj0;  // (the ratio test of this iteration has already added its step: the iteration is re-run from the top)
+            c->it.status = ITER_STALL;
+            push_rec(c, 0);
+        }
+        return;
+    }
+    KMARK0(c, 8);
+    if (tid < k) s_tk[tid] = ld_agent(&v.tK[tid]);
+    __syncthreads();
+    // (3) v partials per stripe of eight rows + eta update of W (k_fused_w<8>), reduced in k_post_fused's order
+    const int nstripes = (k + 7) / 8;
+    const int cp = tid & 63, wv = tid >> 6;
+    for (int cb = 0; cb < k; cb += 128) {
+        const int c0 = cb + 2 * cp;
+        const bool pair = c0 + 1 < k, one = c0 < k;
+        const double rk0 = one ? s_rk[c0] : 0.0, rk1 = pair ? s_rk[c0 + 1] : 0.0;
+        // (two stripes of the wave per trip: 32 independent loads in flight per lane — the pass is one workgroup's chain of
+        // load -> use -> store round trips, not bandwidth)
+        for (int st0 = wv; st0 < nstripes; st0 += 2 * (BLK / 64)) {
+            double w0[16], w1[16];
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                const int row = (st0 + (a >> 3) * (BLK / 64)) * 8 + (a & 7);
+                w0[a] = 0.0;
+                w1[a] = 0.0;
+                if (row < k && st0 + (a >> 3) * (BLK / 64) < nstripes) {
+                    const double* wp = v.W + (size_t)row * ld;
+                    if (pair) {
+                        const double2 t = *reinterpret_cast<const double2*>(wp + c0);
+                        w0[a] = t.x;
+                        w1[a] = t.y;
+                    } else if (one) {
+                        w0[a] = wp[c0];
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int stripe = st0 + h * (BLK / 64);
+                if (stripe >= nstripes) break;
+                double va0 = 0.0, va1 = 0.0;
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    const int row = stripe * 8 + a;
+                    if (row >= k) continue;
+                    const double t = s_tk[row], u = s_u[row];
+                    va0 += w0[h * 8 + a] * t;
+                    va1 += w1[h * 8 + a] * t;
+                    double* wp = v.W + (size_t)row * ld;
+                    const double n0 = w0[h * 8 + a] - u * rk0, n1 = w1[h * 8 + a] - u * rk1;
+                    if (pair) *reinterpret_cast<double2*>(wp + c0) = make_double2(n0, n1);
+                    else if (one) wp[c0] = n0;
+                }
+                s_part[stripe][2 * cp] = va0;
+                s_part[stripe][2 * cp + 1] = va1;
+            }
+        }
+        __syncthreads();
+        if (tid < 128 && cb + tid < k) {
+            double sv = 0.0;
+#pragma unroll 1
+            for (int grp = 0; grp < 8; ++grp) {
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                int t = grp;
+                for (; t + 24 < nstripes; t += 32) {
+                    s0 += s_part[t][tid];
+                    s1 += s_part[t + 8][tid];
+                    s2 += s_part[t + 16][tid];
+                    s3 += s_part[t + 24][tid];
+                }
+                for (; t < nstripes; t += 8) s0 += s_part[t][tid];
+                const double g = (s0 + s1) + (s2 + s3);
+                sv = grp == 0 ? g : sv + g;
+            }
+            v.vK[cb + tid] = sv;
+            v.rv[cb == 0 ? row_of_mine : row_of_mine2].y = sv;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) c->sb_count += 1;
+}
 template <int G, int MODE>  // MODE 0: alpha_r, 1: alpha_r + helper, 2: helper
 __global__ void __launch_bounds__(BLK) k_row_pull(DevView v, int n_pull) {
     Ctl* c = v.ctl;
@@ -4342,6 +4588,7 @@ __global__ void __launch_bounds__(BLK) k_row_pull(DevView v, int n_pull) {
 
 #include "hyper.inc"  // the hypersparse single-workgroup iteration (uses the stage helpers above)
 #include "factor.inc"  // the compact factor of the basis: peel, level-scheduled solves, additive eta terms
+#include "inverse.inc"  // blocked in-place inversion of a dense-filling nucleus (the refactorisation of the explicit inverse)
 
 // ===================================================================================== launchers
 #define LANES_SWITCH(L, STMT4, STMT16, STMT32) \
@@ -4543,6 +4790,21 @@ void launch_row_sparse(const DevView& dv, const Geom& g, int mode, int with_stru
     } while (0)
     LANES_SWITCH(g.lanes, ROWPULL(4), ROWPULL(16), ROWPULL(32));
 #undef ROWPULL
+}
+bool small_basis_supported(const DevView& dv, const Geom& g) {
+    const char* sb = std::getenv("MLP_SMALL_BASIS");  // (read per call, i.e. per captured graph: tests toggle it inside one process)
+    const bool off = sb && sb[0] == '0';
+    return !off && g.sb && g.cap > 0 && g.cap <= SB_CAP && !g.big && !dv.lrJ && g.str && !g.ratio_two && !g.fac && dv.world <= 1;
+}
+void launch_small_basis(const DevView& dv, const Geom& g, hipStream_t st) {
+    const int n_touch = blocks_for((long)(g.cap + 1) * 64);
+#define SMALLB(G)                                                                                                  \
+    do {                                                                                                           \
+        const int n_rhs = blocks_for((long)g.cap * G);                                                             \
+        LAUNCH_T(2, k_small_basis<G>, dim3(1 + n_rhs + n_touch), dim3(BLK), 0, st, dv, n_rhs);                      \
+    } while (0)
+    LANES_SWITCH(g.lanes, SMALLB(4), SMALLB(16), SMALLB(64));
+#undef SMALLB
 }
 void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st) {
     hipLaunchKernelGGL(k_init_nb_rng, dim3(blocks_for(g.n)), dim3(BLK), 0, st, dv);

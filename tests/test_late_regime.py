@@ -87,19 +87,21 @@ def test_both_forms_of_the_fold_kernel_give_the_same_inverse(cfg4, monkeypatch):
     assert runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
 
 
-def test_the_v_branch_of_the_late_pivot_is_an_ordering_not_a_different_computation(cfg4, monkeypatch):
+def test_the_v_branch_of_the_late_pivot_takes_the_same_pivots(cfg4, monkeypatch):
     """MLP_VBRANCH=1 runs the pass v_K = W^T t_K on a side stream beside the ratio test and the BTRAN (off by default: it is
-    slower, engine.hip).  It reorders launches only — t_K is formed from the same quotients — so 96 pivots from the mid
-    basis (three folds) must give the same trace and bit-identical values as the serial order."""
+    slower, engine.hip).  On a folding pivot the branch takes v from the fold's own partials, so from the first fold on the
+    two orders differ at rounding level (pivot element 1.1118724973741045 against ...028 at pivot 33) — nothing more: 96
+    pivots from the mid basis (three folds) must choose the same (entering, leaving) pairs and end at the same point."""
     lp, prob = cfg4
     runs = []
     for on in ("0", "1"):
         monkeypatch.setenv("MLP_VBRANCH", on)
         s = _load(prob, MID, trace=True)
         s.continue_solve(96)
-        runs.append((s.trace(), s.objective(), s.values().tobytes()))
-    assert runs[0][0] == runs[1][0]
-    assert runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
+        runs.append((s.trace(), s.objective(), s.values()))
+    assert [t[:5] for t in runs[0][0]] == [t[:5] for t in runs[1][0]]
+    assert abs(runs[0][1] - runs[1][1]) <= 1e-11 * abs(runs[0][1])
+    assert np.abs(runs[0][2] - runs[1][2]).max() <= 1e-9
 
 
 def _backward_error(resid, *abs_terms):

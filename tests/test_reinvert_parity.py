@@ -4,7 +4,9 @@ LU (lu.rs:118-304 restated, pinned by the reference's lu_simple / lu_rand KATs) 
 After `mlp_solution_reinvert` (and after `mlp_problem_solve_from_basis`, which rebuilds the inverse from A as well)
 one iteration is stepped through the C ABI and its two solves are compared with the oracle's LU solves on the same
 basis matrix:  alpha_q = B^-1 a_q  (LUFactors::solve, lu.rs:79-106)  and  rho_r = B^-T e_r  (the transposed factors).
-Both re-inversion back ends are covered: the hand-written Gauss-Jordan (nucleus < 384) and rocSOLVER getrf + getri."""
+Both hand-written back ends are covered: the unblocked Gauss-Jordan (nucleus < 384) and the blocked in-place Gauss-Jordan
+whose rank-32 update is the fold kernel (csrc/inverse.inc; rounds 1-3 called rocSOLVER there), the latter also against the former
+on the same nucleus (MLP_REINVERT_GJ=1)."""
 import numpy as np
 import pytest
 
@@ -69,7 +71,7 @@ def _check_one_iteration_against_lu(lp, s, tol=1e-9):
 
 
 @pytest.mark.parametrize("fam,args,pivots,min_k,max_k", [("sparse", (300, 260, 10, 51), 150, 20, 383),
-                                                         ("sparse", (1500, 1500, 30, 52), 1500, 384, 10 ** 9)], ids=["gauss_jordan", "rocsolver"])
+                                                         ("sparse", (1500, 1500, 30, 52), 1500, 384, 10 ** 9)], ids=["gauss_jordan", "blocked"])
 def test_reinverted_basis_solves_like_the_oracle_lu(fam, args, pivots, min_k, max_k):
     lp = GEN[fam](*args)
     s = lpgen.build_problem(M.Problem, lp).solve(budget=pivots)
@@ -94,3 +96,23 @@ def test_basis_loaded_from_a_checkpoint_solves_like_the_oracle_lu():
     s = prob.solve_from_basis(blob, budget=0)                   # load = classify columns + invert the nucleus from A
     assert s.stats()["reinversions"] == 1 and s.stats()["nucleus_size"] >= 384
     assert _check_one_iteration_against_lu(lp, s) in (True, False)
+
+
+def test_blocked_and_unblocked_inversion_agree_on_the_same_nucleus(monkeypatch):
+    """k = 1 0xx is not a multiple of the panel width (a ragged last block) and the nucleus of this family needs row swaps in
+    most panels; both kernels pivot by the same rule, so the two inverses agree to rounding."""
+    lp = GEN["sparse"](1500, 1500, 30, 52)
+    prob = lpgen.build_problem(M.Problem, lp)
+    blob = prob.solve(budget=1200).save_basis(2)
+    runs = []
+    for gj in ("", "1"):
+        if gj:
+            monkeypatch.setenv("MLP_REINVERT_GJ", gj)
+        s = prob.solve_from_basis(blob, budget=0)
+        k = s.stats()["nucleus_size"]
+        assert k >= 384 and k % 32 != 0, k
+        s.continue_solve(40)
+        runs.append((s.trace(), s.objective(), s.values()))
+    assert [t[:5] for t in runs[0][0]] == [t[:5] for t in runs[1][0]]
+    assert abs(runs[0][1] - runs[1][1]) <= 1e-10 * max(1.0, abs(runs[1][1]))
+    assert np.abs(runs[0][2] - runs[1][2]).max() <= 1e-8
