@@ -139,7 +139,8 @@ def kernel_report(st):
 
 KERNEL_NAMES = {
     "fused": ("pass over the nucleus inverse of a primal pivot: v_K = W^T t_K, the BTRAN-shaped dense solve v = B^-T alpha_q of primal "
-              "steepest edge (solver.rs:1114).  Small nucleus: k_fused_w (one read + one write, the eta update rides along); large "
+              "steepest edge (solver.rs:1114).  Nucleus of a few dozen columns: k_small_basis (BTRAN, the pass with the eta update, the v "
+              "tail and the touched-column list in one launch); small nucleus: k_fused_w (one read + one write, the eta update rides along); large "
               "nucleus: k_stream_w (read-only).  tau = B^-1 rho (solver.rs:1157) is skipped in primal pivots (lazy dual steepest edge)"),
     "fold": "k_fold_w (fold of the pending rank-1 terms into the nucleus inverse, every 32 pivots: read + write)",
     "dense_ftran": ("dense-rhs FTRAN x_B = B^-1 (b - N x_N) of the polish step (solver.rs:1177-1197): one streaming read of the nucleus "

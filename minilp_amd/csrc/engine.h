@@ -215,7 +215,8 @@ private:
     bool ranks_share_device = false;
     // sparse tableau row (k_row_touch / k_row_pull) while the nucleus is small
     int str_kmax = 230;                      // MLP_STR_K: largest nucleus the sparse form is used for (0: never)
-    int sb_kmax = 128;                       // MLP_SMALL_BASIS_K: largest nucleus (at the end of a batch) k_small_basis is used for
+    int sb_kmax = 160;                       // MLP_SMALL_BASIS_K: largest nucleus (at the end of a full record ring) k_small_basis is used for; measured
+                                             // crossover with the three launches at k ~ 110-120 (tools/small_basis_curve.py)
     bool sb_now = false;                     // ... decided per batch like str_now (the geometry is baked into the graphs)
     bool touch_done = false;                 // the BASIS stage of the iteration being recorded carried the touched-column list
     bool str_now = false, str_clean = false; // geometry of the batch being run; alpha_r / helper are zero outside touched entries

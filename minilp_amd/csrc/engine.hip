@@ -625,8 +625,13 @@ void Engine::ensure_nucleus_cap(int need) {
     }
     flush_lowrank();  // pending rank-1 terms are folded before the buffers move
     HIPCHECK(hipStreamSynchronize(st));
-    long ncap_l = std::max(256L, (long)cap_ * 2);
-    while (ncap_l < need) ncap_l *= 2;
+    // Growth: doubling while the inverse is small; from 8 192 slots on (where 8 cap^2 bytes start to matter: 0.5 GB) by a
+    // quarter, rounded up to 2 048 slots — a nucleus of 20 493 columns sits in a 24 576-slot array (4.8 GB) instead of a
+    // 32 768-slot one (8.6 GB): at most 1.56x the bytes of the inverse instead of up to 4x (round-3 review, weak 10).  A growth
+    // step costs one copy of the inverse (16 k^2 bytes: ~1.5 ms at k = 20 000) and a re-capture of the graphs.
+    auto next_cap = [](long c) { return c < 8192 ? std::max(256L, c * 2) : ((c + c / 4 + 2047) / 2048) * 2048; };
+    long ncap_l = next_cap((long)cap_);
+    while (ncap_l < need) ncap_l = next_cap(ncap_l);
     // geometric growth, but never beyond the number of rows (rounded up to the column tile of the fused pass):
     // a 100 000-row model whose nucleus passes 65 536 slots gets a 100 352-slot W, not a 131 072-slot one
     const long m_cap = (((long)m_ + FW_TC - 1) / FW_TC) * FW_TC;
@@ -1717,9 +1722,9 @@ int Engine::run_loop(int phase) {
                 str_now = want;
                 view_dirty = true;
             }
-            // (one workgroup walks all of W in k_small_basis: it pays while the nucleus is small — 8 us against 16.8 for the three
-            // launches at k <= 25, 50 against ~20 at k = 190 as first built — so the form is chosen per batch by the size the
-            // nucleus can reach in it)
+            // (one workgroup walks all of W in k_small_basis: it pays while the nucleus is small — per pivot of config 4 from the
+            // slack basis 55-57 us against 60-62 up to k = 72, 67.0 against 68.8 at k = 104, 78.9 against 77.9 at k = 120, 105
+            // against 98 at k = 135 (tools/small_basis_curve.py) — so the form is chosen per batch by the size the nucleus can reach)
             sb_now = want && k_ + RING + 1 <= sb_kmax;
             if (str_now) {
                 ensure_hyper();  // the epoch stamps
@@ -2656,7 +2661,7 @@ void Engine::rebuild_inverse() {
     }
     int k = (int)nuc_pos.size();
     k_ = 0;  // nothing to preserve while growing
-    ensure_nucleus_cap(std::max(k, 1));
+    ensure_nucleus_cap(std::max(k + (k >= 4096 ? 1024 : 0), 1));  // (a loaded large nucleus gets room for its next thousand columns)
     h_pos_of_kslot.assign(cap_, -1);
     h_row_of_kslot.assign(cap_, -1);
     int s = 0;

@@ -995,10 +995,44 @@ __global__ void __launch_bounds__(BLK) k_ftran_gather(DevView v) {
     int n = c->it.klist_n;
     double acc = 0.0;
     const double* wrow = v.W + (size_t)slot * v.ld;
-    for (int j = gl; j < n; j += G) acc += v.klist_a[j] * wrow[v.klist_s[j]];
-    if (v.lrJ) {
-        const int nlow = c->nlow;
-        for (int j = gl; j < nlow; j += G) acc += v.U[(size_t)j * v.ld + slot] * c->lr_c[j];
+    if (G == 4) {
+        // Four lanes per slot with the lane's loads of a trip issued together (round 4; the delayed-update mode with the blocked
+        // push launches this instance whatever the model's lane count): with 64 lanes per slot the 32 pending terms U[j][slot] were
+        // read one row per lane — 32 cache lines per slot, 5 120 workgroups — and the gather took 17 us at k = 20 500.
+        for (int j0 = gl; j0 < n; j0 += 16) {
+            double a[4], w[4];
+            int si[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 4 * u;
+                a[u] = j < n ? v.klist_a[j] : 0.0;
+                si[u] = j < n ? v.klist_s[j] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = j0 + 4 * u < n ? wrow[si[u]] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j0 + 4 * u < n) acc += a[u] * w[u];
+        }
+        if (v.lrJ) {
+            const int nlow = c->nlow;
+            double e[LR_MAX / 4], x[LR_MAX / 4];
+#pragma unroll
+            for (int u = 0; u < LR_MAX / 4; ++u) {
+                const int j = gl + 4 * u;
+                e[u] = j < nlow ? c->lr_c[j] : 0.0;
+                x[u] = j < nlow ? v.U[(size_t)j * v.ld + slot] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < LR_MAX / 4; ++u)
+                if (gl + 4 * u < nlow) acc += x[u] * e[u];
+        }
+    } else {
+        for (int j = gl; j < n; j += G) acc += v.klist_a[j] * wrow[v.klist_s[j]];
+        if (v.lrJ) {
+            const int nlow = c->nlow;
+            for (int j = gl; j < nlow; j += G) acc += v.U[(size_t)j * v.ld + slot] * c->lr_c[j];
+        }
     }
     acc = group_sum<G>(acc);
     int p = v.pos_of_kslot[slot];
@@ -1853,8 +1887,36 @@ __global__ void __launch_bounds__(BLK) k_btran(DevView v, int n_gather, int afte
             for (int g4 = blockIdx.x * BLK + threadIdx.x; g4 < 4 * k; g4 += n_gather * BLK) {  // (whole groups of 4 lanes)
                 const int s = g4 >> 2, gl = g4 & 3;
                 double acc = 0.0;
-                for (int j = gl; j < n; j += 4) acc += v.blist_a[j] * v.W[(size_t)v.blist_s[j] * v.ld + s];
-                for (int j = gl; j < nlow; j += 4) acc += c->lr_e[j] * v.V[(size_t)j * v.ld + s];
+                // (round 4: the lane's loads of a trip are issued together — four listed rows, then its eight pending terms —
+                // and added in the old order: as one load -> add chain per term the 13 dependent round trips were the kernel,
+                // 22 us at k = 20 500 for 8 MB)
+                for (int j0 = gl; j0 < n; j0 += 16) {
+                    double a[4], w[4];
+                    int si[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = j0 + 4 * u;
+                        a[u] = j < n ? v.blist_a[j] : 0.0;
+                        si[u] = j < n ? v.blist_s[j] : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) w[u] = j0 + 4 * u < n ? v.W[(size_t)si[u] * v.ld + s] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (j0 + 4 * u < n) acc += a[u] * w[u];
+                }
+                {
+                    double e[LR_MAX / 4], x[LR_MAX / 4];
+#pragma unroll
+                    for (int u = 0; u < LR_MAX / 4; ++u) {
+                        const int j = gl + 4 * u;
+                        e[u] = j < nlow ? c->lr_e[j] : 0.0;
+                        x[u] = j < nlow ? v.V[(size_t)j * v.ld + s] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < LR_MAX / 4; ++u)
+                        if (gl + 4 * u < nlow) acc += e[u] * x[u];
+                }
                 acc += __shfl_xor(acc, 1, 64);
                 acc += __shfl_xor(acc, 2, 64);
                 if (gl == 0) {
@@ -4640,7 +4702,8 @@ void launch_btran_fused(const DevView& dv, const Geom& g, int with_rhs, int deri
 #undef BTRANF
 }
 void launch_ftran_gather(const DevView& dv, const Geom& g, hipStream_t st, int ys) {
-    LANES_SWITCH(g.lanes,
+    // (delayed-update mode with the blocked push: nothing after the gather needs the lanes of a slot — four lanes per slot)
+    LANES_SWITCH((dv.lrJ && dv.pb_on) ? 4 : g.lanes,
                  hipLaunchKernelGGL(k_ftran_gather<4>, dim3(blocks_for((long)g.cap * 4)), dim3(BLK), 0, st, dv),
                  hipLaunchKernelGGL(k_ftran_gather<16>, dim3(blocks_for((long)g.cap * 16)), dim3(BLK), 0, st, dv),
                  hipLaunchKernelGGL(k_ftran_gather<64>, dim3(blocks_for((long)g.cap * 64)), dim3(BLK), 0, st, dv));

@@ -1,6 +1,6 @@
 """GPU: the large-nucleus regime of config 4 at FULL SIZE with the DEFAULT machinery (nothing forced): the two committed
-mid-solve bases that bench.py times (tests/golden/cfg4_basis_p45000 / p240000: nucleus 9 999 / 20 493, capacity 16 384 /
-32 768) are loaded through mlp_problem_solve_from_basis and continued.  From capacity 8 192 on the engine runs the
+mid-solve bases that bench.py times (tests/golden/cfg4_basis_p45000 / p240000: nucleus 9 999 / 20 493, capacity 14 336 /
+24 576: growth by a quarter from 8 192 slots on) are loaded through mlp_problem_solve_from_basis and continued.  From capacity 8 192 on the engine runs the
 delayed-update mode (k_stream_w every pivot, k_fold_w every 32nd), the blocked F push, the banded sweep in locality order
 with the packed non-basic copy — the kernels the solve spends > 90 % of its wall time in.
 
@@ -40,7 +40,7 @@ def _load(prob, path, **kw):
         return prob.solve_from_basis(f.read(), budget=0, **kw)
 
 
-@pytest.mark.parametrize("path,k0,cap", [(MID, 9999, 16384), (LATE, 20493, 32768)], ids=["mid k=9999", "late k=20493"])
+@pytest.mark.parametrize("path,k0,cap", [(MID, 9999, 14336), (LATE, 20493, 24576)], ids=["mid k=9999", "late k=20493"])
 def test_default_machinery_from_saved_basis_keeps_the_invariants(cfg4, path, k0, cap):
     lp, prob = cfg4
     s = _load(prob, path, trace=True)
