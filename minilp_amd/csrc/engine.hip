@@ -1318,6 +1318,9 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     // small nucleus (first capacity of the inverse), lazy primal iteration: BTRAN, pass over W, v tail and touched-column list are
     // ONE launch (k_small_basis) issued at the BASIS stage; the BTRAN stage is empty.  MLP_SMALL_BASIS=0: the three launches.
     const bool smallb = phase == 0 && pse && lazy && !stepping && shard_world == 1 && !vbr && !tau_branch && small_basis_supported(dv, g);
+    // large nucleus, lazy primal iteration: t_K = alpha_K - F^T y_S rides in the ratio test's launch (blocks behind the ratio blocks);
+    // the FTRAN's push combine leaves y_S by row, the BTRAN launch forms rho_K only.  MLP_TK_RIDE=0: t_K in the BTRAN launch.
+    const bool tkr = phase == 0 && pse && lazy && !stepping && shard_world == 1 && !vbr && !smallb && !g.head_fused && !dv.pb_det && tk_rides_ratio(dv, g);
     if (stage == STAGE_BASIS) touch_done = false;
     // The pricing decision (q for primal, r for dual) is already in Ctl: it was taken by the
     // previous iteration's update kernel, or by the standalone pricing kernel at batch start.
@@ -1328,7 +1331,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
             launch_ftran_fused(dv, g, 1, st);              // K2 head inside the gather kernel (one launch)
         } else {
             if (phase == 0) launch_ftran_prep(dv, 1, st);  // K2 head: entering column scalars, singleton rows, list
-            launch_ftran_gather(dv, g, st, vbr ? 1 : 0);   // K2: alpha_q = B^-1 a_q (dual: the head ran in RATIO); v branch: + y_S by row
+            launch_ftran_gather(dv, g, st, (vbr || tkr) ? 1 : 0);   // K2: alpha_q = B^-1 a_q (dual: the head ran in RATIO); v branch / t_K ride: + y_S by row
         }
         if (with_events) HIPCHECK(hipEventRecord(ev[7], st));
         if (phase == 1) {
@@ -1354,7 +1357,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         }
         break;
     case STAGE_RATIO:
-        if (phase == 0) launch_ratio_primal(dv, g, pse, st);  // K5 p1 (+ ||alpha||^2, y_S), p2 (+ K3 head + plan)
+        if (phase == 0) launch_ratio_primal(dv, g, pse, st, tkr ? 1 : 0);  // K5 p1 (+ ||alpha||^2, y_S), p2 (+ K3 head + plan) [| t_K]
         else launch_ratio_dual(dv, g, st);                    // K7 p1, p2 (+ K2 head)
         break;
     case STAGE_BTRAN:
@@ -1367,7 +1370,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
                 HIPCHECK(hipStreamWaitEvent(st, evFork[2], 0));   // a folding pivot: rho is a row of the folded W0
                 launch_btran(dv, g, 0, st, 1);                    // K3: rho, rK, ||rho||^2 (tK was built on the side stream)
             } else {
-                launch_btran(dv, g, phase == 0 ? pse : 0, st);    // K3: rho, rK, ||rho||^2  |  tK = alpha_K - F^T y_S
+                launch_btran(dv, g, (phase == 0 && !tkr) ? pse : 0, st);    // K3: rho, rK, ||rho||^2  |  tK = alpha_K - F^T y_S (unless it rode in the ratio launch)
             }
         }
         break;

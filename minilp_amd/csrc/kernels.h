@@ -350,7 +350,8 @@ void launch_ftran_gather(const DevView& dv, const Geom& g, hipStream_t st, int y
 void launch_ftran_fused(const DevView& dv, const Geom& g, int derive_primal, hipStream_t st);   // FTRAN head + gather in one launch (Geom.head_fused)
 void launch_btran_fused(const DevView& dv, const Geom& g, int with_rhs, int derive_dual, hipStream_t st);  // BTRAN head + gather (dual iteration)
 constexpr int HEAD_LIST_CAP = 1024;  // entries an in-kernel stage head can hold (longest column / row of A)
-void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st);  // K5 p1 (+alpha_sq, y_S), p2 (+BTRAN head, plan)
+void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st, int tk_ride = 0);  // K5 p1 (+alpha_sq, y_S), p2 (+BTRAN head, plan) [| t_K blocks]
+bool tk_rides_ratio(const DevView& dv, const Geom& g);  // large nucleus, lazy primal iteration: t_K is formed by blocks riding behind the ratio blocks
 void launch_post_ftran(const DevView& dv, const Geom& g, int use_pse, hipStream_t st);    // dual path: alpha_sq, y_S, plan
 void launch_btran_prep(const DevView& dv, int derive_dual, int plan_after, hipStream_t st);  // BTRAN head (one wave)
 void launch_btran(const DevView& dv, const Geom& g, int with_rhs, hipStream_t st, int after_fold = 0);  // rho, rK, rho_sq [| tK]

@@ -155,15 +155,16 @@ __device__ __forceinline__ int ld_agent(const int* p) {
 }
 
 // grid-wide arg-best; returns true for every thread of the finalising block, result in thread 0
-__device__ __forceinline__ bool grid_best(Cand& c, const DevView& v) {
+__device__ __forceinline__ bool grid_best(Cand& c, const DevView& v, int nblocks = -1) {
+    if (nblocks < 0) nblocks = (int)gridDim.x;  // (a launch may carry extra, horizontally fused blocks behind the reducing ones)
     c = block_best(c);
     if (threadIdx.x == 0) {
         st_agent(&v.red_key[blockIdx.x], c.key);
         st_agent(&v.red_idx[blockIdx.x], c.idx);
     }
-    if (!last_block_arrives(v.ticket, gridDim.x)) return false;
+    if (!last_block_arrives(v.ticket, (unsigned)nblocks)) return false;
     Cand x = cand_none();
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) {
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
         Cand t{ld_agent(&v.red_key[i]), ld_agent(&v.red_idx[i])};
         if (cand_better(t, x)) x = t;
     }
@@ -235,16 +236,17 @@ __device__ __forceinline__ bool grid_best_p(Cand& c, double& pay, const DevView&
     return true;
 }
 // grid-wide (min, sum) pair in one pass
-__device__ __forceinline__ bool grid_min_sum(double& mn, double& sm, const DevView& v) {
+__device__ __forceinline__ bool grid_min_sum(double& mn, double& sm, const DevView& v, int nblocks = -1) {
+    if (nblocks < 0) nblocks = (int)gridDim.x;
     mn = block_min(mn);
     sm = block_sum(sm);
     if (threadIdx.x == 0) {
         st_agent(&v.red_key[blockIdx.x], mn);
         st_agent(&v.red_key2[blockIdx.x], sm);
     }
-    if (!last_block_arrives(v.ticket, gridDim.x)) return false;
+    if (!last_block_arrives(v.ticket, (unsigned)nblocks)) return false;
     double y = INFINITY, z = 0.0;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) {
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
         double t = ld_agent(&v.red_key[i]);
         if (t < y) y = t;
         z += ld_agent(&v.red_key2[i]);
@@ -1667,9 +1669,37 @@ constexpr int AQ_CAP = 1024;  // positions of supp(alpha_q) the single-block for
 // block, every block waits for it (a 98-block grid is always co-resident) and runs pass 2 on the elements it
 // still holds in registers; the second ticketed reduction ends in ratio_primal_finish as before.  Saves a
 // kernel boundary and the second read of alpha_q / x_B / bounds.
-__global__ void __launch_bounds__(BLK) k_ratio_primal_fused(DevView v, int use_pse) {
+// t_K = alpha_K - F^T y_S (solver.rs:1114) for the slots of one block, G lanes per slot, as k_btran's second part — for the
+// blocks that ride behind the ratio blocks of k_ratio_primal_fused (below)
+template <int G>
+__device__ __forceinline__ void tk_ride_body(const DevView& v, const Ctl* c, int block) {
+    const int slot = (block * BLK + (int)threadIdx.x) / G;
+    const int gl = threadIdx.x & (G - 1);
+    if (slot >= c->k) return;
+    const int p = v.pos_of_kslot[slot];
+    const int var = v.basic_vars[p];
+    const int end = v.csc_ptr[var + 1];
+    double acc = 0.0;
+    for (int e = v.csc_ptr[var] + gl; e < end; e += G) acc += v.csc_val[e] * v.rv[v.csc_row[e]].y;  // (zero on nucleus rows, see k_btran)
+    acc = group_sum<G>(acc);
+    if (gl == 0) v.tK[slot] = v.alpha_q[p] - acc;
+}
+// n_ratio > 0 (large nucleus, lazy primal iteration; launch_ratio_primal): only the first n_ratio blocks run the ratio test; the
+// blocks behind them form t_K, which needs alpha_q and y_S but not the leaving row — the combine of the blocked F push has left
+// y_S by row (its ys form: the quotient the ratio test would write, use_pse = 2 tells pass 1 not to), so the 2 M-entry pull that
+// made k_btran a 23 us kernel runs in the shadow of the ratio test's two grid-wide hand-offs.  The ratio blocks come first in
+// dispatch order and wait only for each other: the co-residency argument of the in-kernel wait is unchanged.
+__global__ void __launch_bounds__(BLK) k_ratio_primal_fused(DevView v, int use_pse, int n_ratio = 0, int tk_lanes = 0) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
+    const int nrb = n_ratio > 0 ? n_ratio : (int)gridDim.x;
+    if ((int)blockIdx.x >= nrb) {
+        const int tb = (int)blockIdx.x - nrb;
+        if (tk_lanes <= 4) tk_ride_body<4>(v, c, tb);
+        else if (tk_lanes <= 16) tk_ride_body<16>(v, c, tb);
+        else tk_ride_body<64>(v, c, tb);
+        return;
+    }
     const int sign = c->it.sign;
     KMARK0(c, 1);
     if (aq_listing(v) && c->aq_n <= AQ_CAP) {
@@ -1762,7 +1792,7 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_fused(DevView v, int use_p
     double mn = INFINITY, sq = 0.0;
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
-        const int p = (int)blockIdx.x * BLK + threadIdx.x + u * (int)gridDim.x * BLK;
+        const int p = (int)blockIdx.x * BLK + threadIdx.x + u * nrb * BLK;
         pos[u] = -1;
         ca[u] = 0.0;
         stp[u] = 0.0;
@@ -1775,7 +1805,7 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_fused(DevView v, int use_p
         const double xb = v.xB[p], lob = v.loB[p], hib = v.hiB[p];
         if (use_pse) {
             sq += coeff * coeff;
-            if (ks < 0) v.rv[sr].y = coeff / sd;
+            if (ks < 0 && use_pse != 2) v.rv[sr].y = coeff / sd;
         }
         const double a = fabs(coeff);
         if (a < EPS) continue;
@@ -1788,7 +1818,7 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_fused(DevView v, int use_p
         if (cur < mn) mn = cur;
     }
     __shared__ double s_max_step;
-    if (grid_min_sum(mn, sq, v)) {  // last arriver of pass 1: publish the step bound
+    if (grid_min_sum(mn, sq, v, nrb)) {  // last arriver of pass 1: publish the step bound
         if (threadIdx.x == 0) {
             double max_step = fabs(c->it.entering_other - c->it.entering_cur);
             if (mn < max_step) max_step = mn;
@@ -1836,7 +1866,7 @@ __global__ void __launch_bounds__(BLK) k_ratio_primal_fused(DevView v, int use_p
             if (cand_better(t, best)) best = t;
         }
     }
-    if (!grid_best(best, v)) return;
+    if (!grid_best(best, v, nrb)) return;
     ratio_primal_finish(v, c, best);
 }
 
@@ -4732,7 +4762,24 @@ static bool ratio_one_enabled() {  // MLP_RATIO_ONE=0: the grid forms at any siz
     const char* e = std::getenv("MLP_RATIO_ONE");  // (read per launch: tests switch it inside one process)
     return !(e && e[0] == '0');
 }
-void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st) {
+// t_K rides in the ratio launch (k_ratio_primal_fused, n_ratio > 0): the one-launch grid form of the test is the one that runs,
+// the blocked F push is on (its combine leaves y_S by row) and the delayed-update mode is on (large nucleus)
+bool tk_rides_ratio(const DevView& dv, const Geom& g) {
+    const char* e = std::getenv("MLP_TK_RIDE");
+    if (e && e[0] == '0') return false;
+    if (dv.world > 1 || !dv.pb_on || !dv.lrJ || g.ratio_two || g.cap <= 0) return false;
+    if (g.m <= 16384 && ratio_one_enabled()) return false;
+    const int nb = grid_for(g.m);
+    const int max_coresident = coresident_half(reinterpret_cast<const void*>(k_ratio_primal_fused), 0);
+    return nb <= max_coresident && (long)nb * BLK * 4 >= (long)g.m;
+}
+void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st, int tk_ride) {
+    if (tk_ride) {  // (the caller asked tk_rides_ratio first)
+        const int nb = grid_for(g.m);
+        const int lanes = g.lanes <= 4 ? 4 : (g.lanes <= 16 ? 16 : 64);
+        hipLaunchKernelGGL(k_ratio_primal_fused, dim3(nb + blocks_for((long)g.cap * lanes)), dim3(BLK), 0, st, dv, 2, nb, lanes);
+        return;
+    }
     if (dv.world <= 1 && g.m <= 16384 && ratio_one_enabled()) {  // small model: one block, no grid-wide reduction (RATIO_ONE_MAX)
         hipLaunchKernelGGL(k_ratio_primal_one, dim3(1), dim3(BLK), 0, st, dv, use_pse);
         return;
@@ -4745,7 +4792,7 @@ void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStrea
     // share one device, and for good after a wait has ever timed out (ITER_STALL).
     const int max_coresident = g.ratio_two ? 0 : coresident_half(reinterpret_cast<const void*>(k_ratio_primal_fused), 0);
     if (nb <= max_coresident && (long)nb * BLK * 4 >= (long)g.m) {  // every element fits the fused kernel's registers
-        hipLaunchKernelGGL(k_ratio_primal_fused, dim3(nb), dim3(BLK), 0, st, dv, use_pse);  // both passes + BTRAN head + plan
+        hipLaunchKernelGGL(k_ratio_primal_fused, dim3(nb), dim3(BLK), 0, st, dv, use_pse, 0, 0);  // both passes + BTRAN head + plan
         return;
     }
     hipLaunchKernelGGL(k_ratio_primal_p1, dim3(nb), dim3(BLK), 0, st, dv, use_pse);

@@ -87,6 +87,21 @@ def test_both_forms_of_the_fold_kernel_give_the_same_inverse(cfg4, monkeypatch):
     assert runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
 
 
+def test_t_K_riding_in_the_ratio_launch_changes_no_bit(cfg4, monkeypatch):
+    """Large nucleus, lazy primal iteration: t_K = alpha_K - F^T y_S is formed by blocks that ride behind the ratio blocks of
+    k_ratio_primal_fused (y_S left by row by the F push's combine) instead of in the BTRAN launch (MLP_TK_RIDE=0).  The same
+    quotients, the same sums in the same order: 96 pivots from the mid basis must agree bit for bit."""
+    lp, prob = cfg4
+    runs = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("MLP_TK_RIDE", on)
+        s = _load(prob, MID, trace=True)
+        s.continue_solve(96)
+        runs.append((s.trace(), s.objective(), s.values().tobytes()))
+    assert runs[0][0] == runs[1][0]
+    assert runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
+
+
 def test_the_v_branch_of_the_late_pivot_takes_the_same_pivots(cfg4, monkeypatch):
     """MLP_VBRANCH=1 runs the pass v_K = W^T t_K on a side stream beside the ratio test and the BTRAN (off by default: it is
     slower, engine.hip).  On a folding pivot the branch takes v from the fold's own partials, so from the first fold on the
