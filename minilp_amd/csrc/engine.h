@@ -224,6 +224,7 @@ private:
     // hypersparse single-workgroup iteration (hyper.inc)
     int hyper_mode = -1;                     // MLP_HYPER: 1 on wherever the kernel applies, 0 off, -1 auto (<= 16 non-zeros per row on average)
     long hyper_heavy = 0;                    // MLP_HYPER_HEAVY: eta-update entries one workgroup takes on (0: the kernel's default)
+    int hyper_backoff_max = 8;   // MLP_HYPER_BACKOFF: after bail-outs in a row the multi-kernel path keeps going for up to 2 << this pivots
     uint64_t hyper_off_until = 0;            // lifetime pivot count until which the multi-kernel path runs (after bail-outs)
     int hyper_bail_streak = 0;
     DevBuf<int> d_hy_stamp;                  // n + m epoch stamps (alpha_r list / singleton part of the alpha_q list) + the kernel's derived maps

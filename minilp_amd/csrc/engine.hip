@@ -115,6 +115,7 @@ Engine::Engine() {
     if (const char* hy = std::getenv("MLP_HYPER")) hyper_mode = std::atoi(hy) > 0 ? 1 : 0;  // 1: whenever the kernel applies, 0: never
     if (const char* sbk = std::getenv("MLP_SMALL_BASIS_K")) sb_kmax = std::max(0, std::min(256, std::atoi(sbk)));
     if (const char* sk = std::getenv("MLP_STR_K")) str_kmax = std::atoi(sk);  // sparse tableau row up to this nucleus size (0: never)
+    if (const char* hb = std::getenv("MLP_HYPER_BACKOFF")) hyper_backoff_max = std::max(0, std::min(16, std::atoi(hb)));  // longest stay on the multi-kernel path after bail-outs in a row: 2 << this pivots
     if (const char* hh = std::getenv("MLP_HYPER_HEAVY")) hyper_heavy = std::atol(hh);        // work bound per iteration (tests force bail-outs)
     if (const char* rs = std::getenv("MLP_RATIO_SPIN_LIMIT")) ratio_spin_limit = std::atoll(rs);
     if (const char* sb = std::getenv("MLP_STREAM_BALANCED")) sw_balanced = std::atoi(sb);
@@ -1704,7 +1705,7 @@ int Engine::run_loop(int phase) {
                     hyper_bail_streak = 0;
                     hyper_off_until = lifetime_pivots + 1;
                 } else {
-                    hyper_bail_streak = std::min(hyper_bail_streak + 1, 8);
+                    hyper_bail_streak = std::min(hyper_bail_streak + 1, hyper_backoff_max);
                     hyper_off_until = lifetime_pivots + ((uint64_t)2 << hyper_bail_streak);
                 }
             } else if (stats.iterations - before >= 16) {
@@ -2979,7 +2980,7 @@ Engine* Engine::clone() {
     e->h_rptr = h_rptr; e->h_rcol = h_rcol; e->h_rval = h_rval;
     e->h_colnnz = h_colnnz; e->h_single_row = h_single_row; e->h_single_val = h_single_val;
     e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->amax_ = amax_; e->no_head_fusion = no_head_fusion;
-    e->sw_balanced = sw_balanced; e->str_kmax = str_kmax; e->sb_kmax = sb_kmax; e->hyper_mode = hyper_mode; e->hyper_heavy = hyper_heavy; e->ratio_two = ratio_two; e->ratio_spin_limit = ratio_spin_limit; e->ranks_share_device = false; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->use_pack = use_pack; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
+    e->sw_balanced = sw_balanced; e->str_kmax = str_kmax; e->sb_kmax = sb_kmax; e->hyper_mode = hyper_mode; e->hyper_heavy = hyper_heavy; e->hyper_backoff_max = hyper_backoff_max; e->ratio_two = ratio_two; e->ratio_spin_limit = ratio_spin_limit; e->ranks_share_device = false; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->use_pack = use_pack; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
     e->h_basic_vars = h_basic_vars; e->h_nb_vars = h_nb_vars; e->h_var_loc = h_var_loc;
     e->h_kslot_of_pos = h_kslot_of_pos; e->h_srow_of_pos = h_srow_of_pos; e->h_kslot_of_row = h_kslot_of_row;
     e->h_pos_of_srow = h_pos_of_srow; e->h_sdiag_of_pos = h_sdiag_of_pos; e->h_nb_fixed = h_nb_fixed;

@@ -345,3 +345,16 @@ def test_rust_api_surface_document_matches_the_crate_source():
         section = doc.split("## `%s`" % fname)[1].split("\n## `")[0]
         listed = re.findall(r"^\* `(.*)`$", section.split("### identical")[1].split("###")[0], flags=re.M)
         assert listed and all(sig in set(ours.values()) for sig in listed), [s for s in listed if s not in set(ours.values())]
+
+
+def test_product_library_links_no_vendor_math_library():
+    """Every kernel on the product path is hand-written — since round 4 also the blocked re-inversion of a large nucleus
+    (csrc/inverse.inc; rounds 1-3 linked rocSOLVER / rocBLAS for it).  The shared library may depend on the HIP runtime and
+    the C / C++ runtimes only (RCCL is dlopen'ed when a sharded solve asks for that transport)."""
+    import subprocess
+    out = subprocess.run(["readelf", "-d", mbuild.SO], capture_output=True, text=True, check=True).stdout
+    needed = re.findall(r"\(NEEDED\)\s+Shared library: \[([^\]]+)\]", out)
+    assert needed, out
+    banned = [n for n in needed if re.search(r"rocsolver|rocblas|hipblas|rocsparse|hipsparse|MIOpen|rccl|torch", n, re.I)]
+    assert not banned, needed
+    assert any("amdhip64" in n for n in needed), needed
