@@ -3248,6 +3248,12 @@ __global__ void __launch_bounds__(BLK) k_fused_lr16(DevView v, int fold_only) {
 // pivot k_fused_lr16 (mode 2) has already applied the pending terms to W0, so the dots are skipped and the pass
 // reads the folded matrix.
 constexpr int SW_MAX_BLOCKS = 8192;
+// grid of the fold (tiles are strided over by its blocks): MLP_FOLD_BLOCKS for A/B runs (tools/rw_bench.hip: a bare in-place
+// read + write pass over the same matrix runs in 1 140 us with 4 096 blocks against 1 237 / 1 265 with 2 048 / 8 192)
+static int fold_max_blocks() {
+    static const int v = std::getenv("MLP_FOLD_BLOCKS") ? std::max(256, std::atoi(std::getenv("MLP_FOLD_BLOCKS"))) : SW_MAX_BLOCKS;
+    return v;
+}
 // rows per strip of the streaming pass: fixed (template value) or balanced over the co-resident blocks (DevView.sw_nbal)
 __device__ __forceinline__ int sw_strip_rows(const DevView& v, int k, int ch, int rs, int rb_fixed) {
     if (!v.sw_nbal || rb_fixed != 128) return rb_fixed;  // (only the partials of k_stream_w's default geometry are balanced)
@@ -5003,7 +5009,7 @@ static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fo
                 hipLaunchKernelGGL((k_fused_lr16<false, true>), dim3(nb), b, 0, st, dv, fold_only ? 1 : 2);
             } else {
                 const long ftiles = (long)((g.cap + FD_RB - 1) / FD_RB) * ((g.cap + FD_CH - 1) / FD_CH);
-                const int nf = (int)(ftiles < SW_MAX_BLOCKS ? ftiles : SW_MAX_BLOCKS);
+                const int nf = (int)(ftiles < fold_max_blocks() ? ftiles : fold_max_blocks());
                 const char* fs = std::getenv("MLP_FOLD_SCALAR");  // A/B: "0" = the form with U staged in LDS (read per launch: tests toggle it)
                 const bool scalar_u = !(fs && fs[0] == '0');
                 if (scalar_u) {
