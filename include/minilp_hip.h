@@ -174,8 +174,9 @@ typedef struct mlp_stats {
     uint64_t ratio_stalls; /* in-kernel waits of the one-launch Harris tests that timed out (grid not co-resident); each one is
                               retried with the two-launch form, which then stays selected */
     /* ---- appended in ABI version 4 ---- */
-    uint64_t reinversion_fallbacks; /* re-inversions of the nucleus that a first attempt reported singular and the Gauss-Jordan
-                                       kernels then re-examined (0 in a healthy run) */
+    uint64_t reinversion_fallbacks; /* rounds 1-3: re-inversions a library call reported singular and the Gauss-Jordan kernels then
+                                       re-examined; always 0 since the blocked inversion is hand-written (kept for the layout);
+                                       ratio_stalls also counts a stalled wait of the one-launch small-nucleus form */
     /* compact factor of the basis (a peeled triangular factor + additive eta terms instead of the explicit
      * nucleus inverse; selected by the measured shape of the basis, MLP_FACTOR=1 / 0 forces it on / off) */
     uint64_t factor_active;     /* 1 while B^-1 is held as the compact factor */
