@@ -1322,6 +1322,8 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     // large nucleus, lazy primal iteration: t_K = alpha_K - F^T y_S rides in the ratio test's launch (blocks behind the ratio blocks);
     // the FTRAN's push combine leaves y_S by row, the BTRAN launch forms rho_K only.  MLP_TK_RIDE=0: t_K in the BTRAN launch.
     const bool tkr = phase == 0 && pse && lazy && !stepping && shard_world == 1 && !vbr && !smallb && !g.head_fused && !dv.pb_det && tk_rides_ratio(dv, g);
+    // ... and rho_K rides behind the v tail of the pass (k_post_fused): the BTRAN stage is then empty.  MLP_RK_RIDE=0: its own launch.
+    const bool rkr = tkr && rk_rides_post(dv, g);
     if (stage == STAGE_BASIS) touch_done = false;
     // The pricing decision (q for primal, r for dual) is already in Ctl: it was taken by the
     // previous iteration's update kernel, or by the standalone pricing kernel at batch start.
@@ -1362,7 +1364,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         else launch_ratio_dual(dv, g, st);                    // K7 p1, p2 (+ K2 head)
         break;
     case STAGE_BTRAN:
-        if (smallb) break;
+        if (smallb || rkr) break;
         if (phase == 1 && g.head_fused) {
             launch_btran_fused(dv, g, 0, 1, st);                  // K3 head inside the BTRAN kernel (one launch)
         } else {
@@ -1407,7 +1409,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
             HIPCHECK(hipEventRecord(evJoin[0], st2));
         } else {
             // tau by position (F push)  |  v reduce + scatter  |  (sparse tableau row, primal: its touched-column list)
-            touch_done = launch_post_fused(dv, g, pse, st, 0, 0, wtau, (g.str && phase == 0) ? 1 : 0) != 0;
+            touch_done = launch_post_fused(dv, g, pse, st, 0, 0, wtau, (g.str && phase == 0) ? 1 : 0, rkr ? 1 : 0) != 0;
         }
         break;
     case STAGE_ROW:

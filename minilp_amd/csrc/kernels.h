@@ -370,7 +370,8 @@ void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st
 // folding pivot (its last block clears nlow), part 2 the streaming pass; both gated by Ctl.side_go
 void launch_fused_w_side(const DevView& dv, const Geom& g, int part, hipStream_t st);
 bool vbranch_supported(const DevView& dv, const Geom& g);  // the strip-tiled pass with the default fold kernel is the one that has a side form
-int launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic = 0, int skip_push = 0, int with_tau = 1, int touch = 0);
+int launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic = 0, int skip_push = 0, int with_tau = 1, int touch = 0, int rk_ride = 0);
+bool rk_rides_post(const DevView& dv, const Geom& g);  // (strip-tiled tail of the large-nucleus pass: the form that carries the rho_K blocks)
 void launch_exact_beta(const DevView& dv, hipStream_t st);  // beta_p = ||e_p^T B^-1||^2 for every basic position (lazy dual steepest edge)
 void launch_push_tau(const DevView& dv, hipStream_t st);  // blocked push of -F tau_K alone (runs on a side branch of the graph)  // tau push | v reduce+scatter (classic: partials of k_fused_w's tiling)
 // hypersparse iteration (hyper.inc): up to max_iters dual iterations (no primal steepest edge) in ONE launch of one workgroup

@@ -256,10 +256,11 @@ __device__ __forceinline__ bool grid_min_sum(double& mn, double& sm, const DevVi
     if (threadIdx.x == 0) *v.ticket = 0;
     return true;
 }
-__device__ __forceinline__ bool grid_sum(double& x, const DevView& v, int nblocks = -1) {
+__device__ __forceinline__ bool grid_sum(double& x, const DevView& v, int nblocks = -1, int my = -1) {
     if (nblocks < 0) nblocks = (int)gridDim.x;
+    if (my < 0) my = (int)blockIdx.x;  // (the reducing blocks may sit behind other blocks of the launch: their own index then)
     x = block_sum(x);
-    if (threadIdx.x == 0) st_agent(&v.red_key[blockIdx.x], x);
+    if (threadIdx.x == 0) st_agent(&v.red_key[my], x);
     if (!last_block_arrives(v.ticket, (unsigned)nblocks)) return false;
     double y = 0.0;
     for (int i = threadIdx.x; i < nblocks; i += blockDim.x) y += ld_agent(&v.red_key[i]);
@@ -1900,6 +1901,76 @@ __global__ void __launch_bounds__(64) k_btran_prep(DevView v, int derive_dual, i
 }
 // Horizontally fused: blocks [0, n_gather) do rK = sum_j blist_a[j] * W[blist_s[j], :], the rho
 // scatter and ||rho||^2; the remaining blocks (PSE) build tK = alpha_K - F^T y_S (solver.rs:1114).
+// rho_K = sum_j blist_a[j] W[blist_s[j], :] (+ the pending terms of the delayed-update mode), rho by row, ||rho||^2: the first part
+// of k_btran, for `n_gather` blocks numbered `block` — of k_btran itself, or riding behind the v tail of k_post_fused (round 4)
+__device__ __forceinline__ void btran_rk_body(const DevView& v, Ctl* c, int block, int n_gather, int after_fold) {
+    const int k = c->k;
+    const int n = c->it.blist_n;
+    double sq = 0.0;
+    if (v.lrJ) {
+        // delayed-update mode (large nucleus): four lanes share a slot — up to 20 listed rows plus 32 pending terms are
+        // 52 loads per slot, a serial chain for one lane (fixed summation order: lane-strided, then two shuffles)
+        // (v branch: this launch waited for the fold of a folding pivot — W0 then holds every term)
+        const int nlow = (after_fold && c->fold) ? 0 : c->nlow;
+        for (int g4 = block * BLK + (int)threadIdx.x; g4 < 4 * k; g4 += n_gather * BLK) {  // (whole groups of 4 lanes)
+            const int s = g4 >> 2, gl = g4 & 3;
+            double acc = 0.0;
+            // (round 4: the lane's loads of a trip are issued together — four listed rows, then its eight pending terms —
+            // and added in the old order: as one load -> add chain per term the 13 dependent round trips were the kernel,
+            // 22 us at k = 20 500 for 8 MB)
+            for (int j0 = gl; j0 < n; j0 += 16) {
+                double a[4], w[4];
+                int si[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + 4 * u;
+                    a[u] = j < n ? v.blist_a[j] : 0.0;
+                    si[u] = j < n ? v.blist_s[j] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w[u] = j0 + 4 * u < n ? v.W[(size_t)si[u] * v.ld + s] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (j0 + 4 * u < n) acc += a[u] * w[u];
+            }
+            {
+                double e[LR_MAX / 4], x[LR_MAX / 4];
+#pragma unroll
+                for (int u = 0; u < LR_MAX / 4; ++u) {
+                    const int j = gl + 4 * u;
+                    e[u] = j < nlow ? c->lr_e[j] : 0.0;
+                    x[u] = j < nlow ? v.V[(size_t)j * v.ld + s] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < LR_MAX / 4; ++u)
+                    if (gl + 4 * u < nlow) acc += e[u] * x[u];
+            }
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            if (gl == 0) {
+                v.rK[s] = acc;
+                v.rv[v.row_of_kslot[s]].x = acc;
+                sq += acc * acc;
+            }
+        }
+    } else
+    for (int s = block * BLK + (int)threadIdx.x; s < k; s += n_gather * BLK) {
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc += v.blist_a[j] * v.W[(size_t)v.blist_s[j] * v.ld + s];
+        v.rK[s] = acc;
+        v.rv[v.row_of_kslot[s]].x = acc;
+        sq += acc * acc;
+    }
+    if (!grid_sum(sq, v, n_gather, block)) return;
+    if (threadIdx.x == 0) {
+        int r = c->it.r;
+        if (v.kslot_of_pos[r] < 0) {
+            double inv = 1.0 / v.sdiag_of_pos[r];
+            sq += inv * inv;
+        }
+        c->it.rho_sq = sq;
+    }
+}
 template <int G>
 __global__ void __launch_bounds__(BLK) k_btran(DevView v, int n_gather, int after_fold = 0) {
     Ctl* c = v.ctl;
@@ -1907,71 +1978,7 @@ __global__ void __launch_bounds__(BLK) k_btran(DevView v, int n_gather, int afte
     KMARK0(c, 7);
     const int k = c->k;
     if ((int)blockIdx.x < n_gather) {
-        const int n = c->it.blist_n;
-        double sq = 0.0;
-        if (v.lrJ) {
-            // delayed-update mode (large nucleus): four lanes share a slot — up to 20 listed rows plus 32 pending terms are
-            // 52 loads per slot, a serial chain for one lane (fixed summation order: lane-strided, then two shuffles)
-            // (v branch: this launch waited for the fold of a folding pivot — W0 then holds every term)
-            const int nlow = (after_fold && c->fold) ? 0 : c->nlow;
-            for (int g4 = blockIdx.x * BLK + threadIdx.x; g4 < 4 * k; g4 += n_gather * BLK) {  // (whole groups of 4 lanes)
-                const int s = g4 >> 2, gl = g4 & 3;
-                double acc = 0.0;
-                // (round 4: the lane's loads of a trip are issued together — four listed rows, then its eight pending terms —
-                // and added in the old order: as one load -> add chain per term the 13 dependent round trips were the kernel,
-                // 22 us at k = 20 500 for 8 MB)
-                for (int j0 = gl; j0 < n; j0 += 16) {
-                    double a[4], w[4];
-                    int si[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int j = j0 + 4 * u;
-                        a[u] = j < n ? v.blist_a[j] : 0.0;
-                        si[u] = j < n ? v.blist_s[j] : 0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) w[u] = j0 + 4 * u < n ? v.W[(size_t)si[u] * v.ld + s] : 0.0;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (j0 + 4 * u < n) acc += a[u] * w[u];
-                }
-                {
-                    double e[LR_MAX / 4], x[LR_MAX / 4];
-#pragma unroll
-                    for (int u = 0; u < LR_MAX / 4; ++u) {
-                        const int j = gl + 4 * u;
-                        e[u] = j < nlow ? c->lr_e[j] : 0.0;
-                        x[u] = j < nlow ? v.V[(size_t)j * v.ld + s] : 0.0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < LR_MAX / 4; ++u)
-                        if (gl + 4 * u < nlow) acc += e[u] * x[u];
-                }
-                acc += __shfl_xor(acc, 1, 64);
-                acc += __shfl_xor(acc, 2, 64);
-                if (gl == 0) {
-                    v.rK[s] = acc;
-                    v.rv[v.row_of_kslot[s]].x = acc;
-                    sq += acc * acc;
-                }
-            }
-        } else
-        for (int s = blockIdx.x * BLK + threadIdx.x; s < k; s += n_gather * BLK) {
-            double acc = 0.0;
-            for (int j = 0; j < n; ++j) acc += v.blist_a[j] * v.W[(size_t)v.blist_s[j] * v.ld + s];
-            v.rK[s] = acc;
-            v.rv[v.row_of_kslot[s]].x = acc;
-            sq += acc * acc;
-        }
-        if (!grid_sum(sq, v, n_gather)) return;
-        if (threadIdx.x == 0) {
-            int r = c->it.r;
-            if (v.kslot_of_pos[r] < 0) {
-                double inv = 1.0 / v.sdiag_of_pos[r];
-                sq += inv * inv;
-            }
-            c->it.rho_sq = sq;
-        }
+        btran_rk_body(v, c, (int)blockIdx.x, n_gather, after_fold);
     } else {
         int slot = (((int)blockIdx.x - n_gather) * BLK + threadIdx.x) / G;
         int gl = threadIdx.x & (G - 1);
@@ -3686,10 +3693,17 @@ __global__ void __launch_bounds__(BLK) k_post_exchange(DevView v, int with_v, in
 template <bool OWN_RK = false>
 __device__ __forceinline__ void row_touch_body(const DevView& v, Ctl* c, int block, double own_rk = 0.0);  // (sparse tableau row, below)
 template <int G, bool WITH_V, int TR, int TC = FW_TC>
-__global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push, int touch_from = -1, int fold_fused = 0) {
+__global__ void __launch_bounds__(BLK) k_post_fused(DevView v, int n_push, int touch_from = -1, int fold_fused = 0, int rk_from = -1) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     KMARK0(c, 9);
+    if (rk_from >= 0 && (int)blockIdx.x >= rk_from) {
+        // rho_K rides behind the v tail (round 4; large nucleus, lazy primal iteration): nothing between the ratio test and the
+        // tableau row reads rho — the streaming pass forms v only — so the BTRAN launch (10.6 us at k = 20 500) is gone and its
+        // blocks run beside this 6 us reduction.  On a folding pivot the fold has already run: W0 holds every term (after_fold).
+        btran_rk_body(v, c, (int)blockIdx.x - rk_from, (int)gridDim.x - rk_from, 1);
+        return;
+    }
     if (touch_from >= 0 && (int)blockIdx.x >= touch_from) {  // horizontally fused: the touched-column list of the sparse tableau
         row_touch_body(v, c, (int)blockIdx.x - touch_from);   // row needs rho only (the BTRAN before this launch), nothing of this pass
         return;
@@ -5093,7 +5107,12 @@ void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st
         else LAUNCH_T(2, (k_fused_w<16, false, false, true, true, false, FW_RL, true>), dim3(nb), b, 0, st, dv);
     }
 }
-int launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic, int skip_push, int with_tau, int touch) {
+bool rk_rides_post(const DevView& dv, const Geom& g) {
+    const char* e = std::getenv("MLP_RK_RIDE");
+    if (e && e[0] == '0') return false;
+    return dv.lrJ && fw_rows(g) != 8 && FW_RL == 1 && stream_strips() && !dv.wshard && dv.world <= 1;
+}
+int launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic, int skip_push, int with_tau, int touch, int rk_ride) {
     // touch: also build the touched-column list of the sparse tableau row in this launch (extra blocks); returns 1 when it
     // did, 0 when the caller still has to launch k_row_touch on its own
     if (!with_tau) skip_push = 1;  // lazy dual steepest edge: no tau, hence no push of -F tau_K
@@ -5108,7 +5127,12 @@ int launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t 
 #undef POSTX
 #define POSTS2(G, RB, CH)                                                                                         \
     if (sw_rb() == RB && sw_ch() == CH) {                                                                         \
-        if (with_v) hipLaunchKernelGGL((k_post_fused<G, true, RB, CH>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push, -1, fold_fuses_v(dv, with_v, with_tau, 0) ? 1 : 0); \
+        if (with_v && rk_ride) {                                                                                  \
+            const int n_tail = n_push + blocks_for(g.cap, 32);                                                    \
+            int n_rk = blocks_for((long)g.cap * 4);                                                               \
+            if (n_rk > 1024) n_rk = 1024;                                                                         \
+            hipLaunchKernelGGL((k_post_fused<G, true, RB, CH>), dim3(n_tail + n_rk), dim3(BLK), 0, st, dv, n_push, -1, fold_fuses_v(dv, with_v, with_tau, 0) ? 1 : 0, n_tail); \
+        } else if (with_v) hipLaunchKernelGGL((k_post_fused<G, true, RB, CH>), dim3(n_push + blocks_for(g.cap, 32)), dim3(BLK), 0, st, dv, n_push, -1, fold_fuses_v(dv, with_v, with_tau, 0) ? 1 : 0, -1); \
         else hipLaunchKernelGGL((k_post_fused<G, false, RB, CH>), dim3(n_push), dim3(BLK), 0, st, dv, n_push);    \
     }
 #define POSTS(G)                                                                                                  \

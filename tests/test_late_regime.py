@@ -92,6 +92,7 @@ def test_t_K_riding_in_the_ratio_launch_changes_no_bit(cfg4, monkeypatch):
     k_ratio_primal_fused (y_S left by row by the F push's combine) instead of in the BTRAN launch (MLP_TK_RIDE=0).  The same
     quotients, the same sums in the same order: 96 pivots from the mid basis must agree bit for bit."""
     lp, prob = cfg4
+    monkeypatch.setenv("MLP_RK_RIDE", "0")  # (rho_K riding behind the v tail needs the t_K ride and is not bit-neutral on folding pivots: next test)
     runs = []
     for on in ("1", "0"):
         monkeypatch.setenv("MLP_TK_RIDE", on)
@@ -100,6 +101,25 @@ def test_t_K_riding_in_the_ratio_launch_changes_no_bit(cfg4, monkeypatch):
         runs.append((s.trace(), s.objective(), s.values().tobytes()))
     assert runs[0][0] == runs[1][0]
     assert runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
+
+
+def test_rho_K_riding_behind_the_v_tail_takes_the_same_pivots(cfg4, monkeypatch):
+    """Large nucleus, lazy primal iteration: nothing between the ratio test and the tableau row reads rho, so rho_K is formed by
+    blocks riding behind the v tail of the pass (k_post_fused) instead of in a BTRAN launch of its own (MLP_RK_RIDE=0).  On a
+    folding pivot those blocks read the FOLDED inverse (W0 with the 32 terms added in) where the BTRAN launch read W0 and the
+    terms separately: rounding-level differences from the first fold on, the same pivots and the same end point (96 pivots)."""
+    lp, prob = cfg4
+    runs = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("MLP_RK_RIDE", on)
+        s = _load(prob, MID, trace=True)
+        s.continue_solve(96)
+        runs.append((s.trace(), s.objective(), s.values(), s.stats()["max_pivot_err"]))
+    assert [t[:5] for t in runs[0][0]] == [t[:5] for t in runs[1][0]]
+    assert runs[0][0][:30] == runs[1][0][:30]          # bit for bit until the first fold
+    assert abs(runs[0][1] - runs[1][1]) <= 1e-11 * abs(runs[0][1])
+    assert np.abs(runs[0][2] - runs[1][2]).max() <= 1e-9
+    assert runs[0][3] < 1e-9 and runs[1][3] < 1e-9
 
 
 def test_the_v_branch_of_the_late_pivot_takes_the_same_pivots(cfg4, monkeypatch):
