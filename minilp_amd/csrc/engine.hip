@@ -1322,6 +1322,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     // large nucleus, lazy primal iteration: t_K = alpha_K - F^T y_S rides in the ratio test's launch (blocks behind the ratio blocks);
     // the FTRAN's push combine leaves y_S by row, the BTRAN launch forms rho_K only.  MLP_TK_RIDE=0: t_K in the BTRAN launch.
     const bool tkr = phase == 0 && pse && lazy && !stepping && shard_world == 1 && !vbr && !smallb && !g.head_fused && !dv.pb_det && tk_rides_ratio(dv, g);
+    const bool tkr_s = smallb && tk_rides_ratio_small(dv, g);  // small nucleus: t_K rides in the ratio launch too (y_S on the fly)
     // ... and rho_K rides behind the v tail of the pass (k_post_fused): the BTRAN stage is then empty.  MLP_RK_RIDE=0: its own launch.
     const bool rkr = tkr && rk_rides_post(dv, g);
     if (stage == STAGE_BASIS) touch_done = false;
@@ -1360,7 +1361,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         }
         break;
     case STAGE_RATIO:
-        if (phase == 0) launch_ratio_primal(dv, g, pse, st, tkr ? 1 : 0);  // K5 p1 (+ ||alpha||^2, y_S), p2 (+ K3 head + plan) [| t_K]
+        if (phase == 0) launch_ratio_primal(dv, g, pse, st, tkr ? 1 : (tkr_s ? 2 : 0));  // K5 p1 (+ ||alpha||^2, y_S), p2 (+ K3 head + plan) [| t_K]
         else launch_ratio_dual(dv, g, st);                    // K7 p1, p2 (+ K2 head)
         break;
     case STAGE_BTRAN:
@@ -1380,7 +1381,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     case STAGE_BASIS:
         if (smallb) {
             if (with_events) arm_kernel_timing(2, ev[2], ev[3]);  // (sampled iteration: the slot of the pass over the nucleus inverse)
-            launch_small_basis(dv, g, st);
+            launch_small_basis(dv, g, st, tkr_s ? 0 : 1);
             if (with_events) arm_kernel_timing(2, nullptr, nullptr);
             touch_done = true;
             break;

@@ -351,7 +351,8 @@ void launch_ftran_fused(const DevView& dv, const Geom& g, int derive_primal, hip
 void launch_btran_fused(const DevView& dv, const Geom& g, int with_rhs, int derive_dual, hipStream_t st);  // BTRAN head + gather (dual iteration)
 constexpr int HEAD_LIST_CAP = 1024;  // entries an in-kernel stage head can hold (longest column / row of A)
 void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st, int tk_ride = 0);  // K5 p1 (+alpha_sq, y_S), p2 (+BTRAN head, plan) [| t_K blocks]
-bool tk_rides_ratio(const DevView& dv, const Geom& g);  // large nucleus, lazy primal iteration: t_K is formed by blocks riding behind the ratio blocks
+bool tk_rides_ratio(const DevView& dv, const Geom& g);
+bool tk_rides_ratio_small(const DevView& dv, const Geom& g);  // the same for a small nucleus (k_small_basis), y_S formed on the fly  // large nucleus, lazy primal iteration: t_K is formed by blocks riding behind the ratio blocks
 void launch_post_ftran(const DevView& dv, const Geom& g, int use_pse, hipStream_t st);    // dual path: alpha_sq, y_S, plan
 void launch_btran_prep(const DevView& dv, int derive_dual, int plan_after, hipStream_t st);  // BTRAN head (one wave)
 void launch_btran(const DevView& dv, const Geom& g, int with_rhs, hipStream_t st, int after_fold = 0);  // rho, rK, rho_sq [| tK]
@@ -362,7 +363,7 @@ void launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, h
 void launch_row_sparse(const DevView& dv, const Geom& g, int mode, int with_struct, int touch, hipStream_t st);
 // small nucleus (first capacity), lazy primal iteration: BTRAN + pass over W + v tail + touched-column list in ONE launch
 bool small_basis_supported(const DevView& dv, const Geom& g);
-void launch_small_basis(const DevView& dv, const Geom& g, hipStream_t st);
+void launch_small_basis(const DevView& dv, const Geom& g, hipStream_t st, int tk_inside = 1);  // tk_inside = 0: t_K rode in the ratio launch
 void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st);                 // K7 p1, p2 (+FTRAN head)
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int with_tau = 1);  // tauK/vK partials + eta update of W

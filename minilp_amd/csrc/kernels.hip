@@ -1672,7 +1672,9 @@ constexpr int AQ_CAP = 1024;  // positions of supp(alpha_q) the single-block for
 // kernel boundary and the second read of alpha_q / x_B / bounds.
 // t_K = alpha_K - F^T y_S (solver.rs:1114) for the slots of one block, G lanes per slot, as k_btran's second part — for the
 // blocks that ride behind the ratio blocks of k_ratio_primal_fused (below)
-template <int G>
+// ONFLY (small nucleus: the ratio test of the SAME launch is the one that writes y_S by row): y_S[i] = alpha_q[pos] / diag of the
+// singleton covering row i is formed from the packed row map — the quotient the ratio test writes, zero where alpha_q is zero
+template <int G, bool ONFLY>
 __device__ __forceinline__ void tk_ride_body(const DevView& v, const Ctl* c, int block) {
     const int slot = (block * BLK + (int)threadIdx.x) / G;
     const int gl = threadIdx.x & (G - 1);
@@ -1681,7 +1683,17 @@ __device__ __forceinline__ void tk_ride_body(const DevView& v, const Ctl* c, int
     const int var = v.basic_vars[p];
     const int end = v.csc_ptr[var + 1];
     double acc = 0.0;
-    for (int e = v.csc_ptr[var] + gl; e < end; e += G) acc += v.csc_val[e] * v.rv[v.csc_row[e]].y;  // (zero on nucleus rows, see k_btran)
+    for (int e = v.csc_ptr[var] + gl; e < end; e += G) {
+        double y;
+        if (ONFLY) {
+            const RowInfo ri = v.rowinfo[v.csc_row[e]];
+            const double a = ri.kslot < 0 ? v.alpha_q[ri.pos] : 0.0;
+            y = a != 0.0 ? a / ri.diag : 0.0;
+        } else {
+            y = v.rv[v.csc_row[e]].y;  // (zero on nucleus rows, see k_btran)
+        }
+        acc += v.csc_val[e] * y;
+    }
     acc = group_sum<G>(acc);
     if (gl == 0) v.tK[slot] = v.alpha_q[p] - acc;
 }
@@ -1690,15 +1702,21 @@ __device__ __forceinline__ void tk_ride_body(const DevView& v, const Ctl* c, int
 // y_S by row (its ys form: the quotient the ratio test would write, use_pse = 2 tells pass 1 not to), so the 2 M-entry pull that
 // made k_btran a 23 us kernel runs in the shadow of the ratio test's two grid-wide hand-offs.  The ratio blocks come first in
 // dispatch order and wait only for each other: the co-residency argument of the in-kernel wait is unchanged.
-__global__ void __launch_bounds__(BLK) k_ratio_primal_fused(DevView v, int use_pse, int n_ratio = 0, int tk_lanes = 0) {
+__global__ void __launch_bounds__(BLK) k_ratio_primal_fused(DevView v, int use_pse, int n_ratio = 0, int tk_lanes = 0, int tk_onfly = 0) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     const int nrb = n_ratio > 0 ? n_ratio : (int)gridDim.x;
     if ((int)blockIdx.x >= nrb) {
         const int tb = (int)blockIdx.x - nrb;
-        if (tk_lanes <= 4) tk_ride_body<4>(v, c, tb);
-        else if (tk_lanes <= 16) tk_ride_body<16>(v, c, tb);
-        else tk_ride_body<64>(v, c, tb);
+        if (tk_onfly) {  // (small nucleus: k_small_basis then carries no t_K blocks and waits for none)
+            if (tk_lanes <= 4) tk_ride_body<4, true>(v, c, tb);
+            else if (tk_lanes <= 16) tk_ride_body<16, true>(v, c, tb);
+            else tk_ride_body<64, true>(v, c, tb);
+        } else {
+            if (tk_lanes <= 4) tk_ride_body<4, false>(v, c, tb);
+            else if (tk_lanes <= 16) tk_ride_body<16, false>(v, c, tb);
+            else tk_ride_body<64, false>(v, c, tb);
+        }
         return;
     }
     const int sign = c->it.sign;
@@ -4486,7 +4504,7 @@ __global__ void __launch_bounds__(BLK) k_row_touch(DevView v) {
 // eight rows, then k_post_fused's eight groups — so the results are bit-identical to theirs (tests/test_small_basis.py).
 constexpr int SB_CAP = 256;  // capacity this kernel serves (one workgroup walks all of W: 512 KB at most)
 template <int G>
-__global__ void __launch_bounds__(BLK) k_small_basis(DevView v, int n_rhs) {
+__global__ void __launch_bounds__(BLK) k_small_basis(DevView v, int n_rhs) {  // n_rhs = 0: t_K was formed by blocks riding in the ratio launch
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     const int k = c->k, ld = v.ld;
@@ -4566,7 +4584,7 @@ __global__ void __launch_bounds__(BLK) k_small_basis(DevView v, int n_rhs) {
     const int row_of_mine = tid < k ? v.row_of_kslot[tid] : 0;  // (128 columns per half: thread i serves column cb + i below)
     const int row_of_mine2 = tid + 128 < k && tid < 128 ? v.row_of_kslot[tid + 128] : 0;
     if (tid == 0) {
-        const unsigned want = (unsigned)((k + BLK / G - 1) / (BLK / G));  // t_K blocks with a slot below k
+        const unsigned want = n_rhs > 0 ? (unsigned)((k + BLK / G - 1) / (BLK / G)) : 0u;  // t_K blocks with a slot below k
         const unsigned want_touch = (unsigned)(k / (BLK / 64) + 1);          // touch blocks with a wave at or below k
         int state = 0;
         long long spins = 0;
@@ -4793,11 +4811,22 @@ bool tk_rides_ratio(const DevView& dv, const Geom& g) {
     const int max_coresident = coresident_half(reinterpret_cast<const void*>(k_ratio_primal_fused), 0);
     return nb <= max_coresident && (long)nb * BLK * 4 >= (long)g.m;
 }
+// ... and for a small nucleus (k_small_basis): the grid form of the test runs (in its sparse form block 0 alone works), t_K with y_S on the fly
+bool tk_rides_ratio_small(const DevView& dv, const Geom& g) {
+    const char* e = std::getenv("MLP_TK_RIDE");
+    if (e && e[0] == '0') return false;
+    if (dv.world > 1 || g.ratio_two || g.cap <= 0 || !dv.rowinfo) return false;
+    if (g.m <= 16384 && ratio_one_enabled()) return false;
+    const int nb = grid_for(g.m);
+    const int max_coresident = coresident_half(reinterpret_cast<const void*>(k_ratio_primal_fused), 0);
+    return nb <= max_coresident && (long)nb * BLK * 4 >= (long)g.m;
+}
 void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st, int tk_ride) {
-    if (tk_ride) {  // (the caller asked tk_rides_ratio first)
+    if (tk_ride) {  // (the caller asked tk_rides_ratio / tk_rides_ratio_small first); 2: small nucleus, y_S on the fly
         const int nb = grid_for(g.m);
         const int lanes = g.lanes <= 4 ? 4 : (g.lanes <= 16 ? 16 : 64);
-        hipLaunchKernelGGL(k_ratio_primal_fused, dim3(nb + blocks_for((long)g.cap * lanes)), dim3(BLK), 0, st, dv, 2, nb, lanes);
+        hipLaunchKernelGGL(k_ratio_primal_fused, dim3(nb + blocks_for((long)g.cap * lanes)), dim3(BLK), 0, st, dv, tk_ride == 2 ? use_pse : 2, nb, lanes,
+                           tk_ride == 2 ? 1 : 0);
         return;
     }
     if (dv.world <= 1 && g.m <= 16384 && ratio_one_enabled()) {  // small model: one block, no grid-wide reduction (RATIO_ONE_MAX)
@@ -4812,7 +4841,7 @@ void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStrea
     // share one device, and for good after a wait has ever timed out (ITER_STALL).
     const int max_coresident = g.ratio_two ? 0 : coresident_half(reinterpret_cast<const void*>(k_ratio_primal_fused), 0);
     if (nb <= max_coresident && (long)nb * BLK * 4 >= (long)g.m) {  // every element fits the fused kernel's registers
-        hipLaunchKernelGGL(k_ratio_primal_fused, dim3(nb), dim3(BLK), 0, st, dv, use_pse, 0, 0);  // both passes + BTRAN head + plan
+        hipLaunchKernelGGL(k_ratio_primal_fused, dim3(nb), dim3(BLK), 0, st, dv, use_pse, 0, 0, 0);  // both passes + BTRAN head + plan
         return;
     }
     hipLaunchKernelGGL(k_ratio_primal_p1, dim3(nb), dim3(BLK), 0, st, dv, use_pse);
@@ -4926,11 +4955,11 @@ bool small_basis_supported(const DevView& dv, const Geom& g) {
     const bool off = sb && sb[0] == '0';
     return !off && g.sb && g.cap > 0 && g.cap <= SB_CAP && !g.big && !dv.lrJ && g.str && !g.ratio_two && !g.fac && dv.world <= 1;
 }
-void launch_small_basis(const DevView& dv, const Geom& g, hipStream_t st) {
+void launch_small_basis(const DevView& dv, const Geom& g, hipStream_t st, int tk_inside) {
     const int n_touch = blocks_for((long)(g.cap + 1) * 64);
 #define SMALLB(G)                                                                                                  \
     do {                                                                                                           \
-        const int n_rhs = blocks_for((long)g.cap * G);                                                             \
+        const int n_rhs = tk_inside ? blocks_for((long)g.cap * G) : 0;                                             \
         LAUNCH_T(2, k_small_basis<G>, dim3(1 + n_rhs + n_touch), dim3(BLK), 0, st, dv, n_rhs);                      \
     } while (0)
     LANES_SWITCH(g.lanes, SMALLB(4), SMALLB(16), SMALLB(64));

@@ -24,8 +24,13 @@ CASES = [("sparse", (700, 600, 12, 6)), ("dense", (150, 100, 3)), ("sparse", (10
 
 
 @pytest.mark.parametrize("fam,args", CASES, ids=str)
-def test_one_launch_form_is_bit_identical_to_the_three_launches(monkeypatch, fam, args):
+@pytest.mark.parametrize("grid_ratio", [0, 1], ids=["t_K inside", "t_K riding in the grid-form ratio launch"])
+def test_one_launch_form_is_bit_identical_to_the_three_launches(monkeypatch, fam, args, grid_ratio):
     monkeypatch.setenv("MLP_HYPER", "0")
+    if grid_ratio:
+        # models above 16 384 rows (config 4) run the grid form of the ratio test, and t_K then rides behind its blocks with y_S formed
+        # on the fly (k_small_basis carries no t_K blocks and waits for none); forced here at small sizes
+        monkeypatch.setenv("MLP_RATIO_ONE", "0")
     monkeypatch.setenv("MLP_SMALL_BASIS_K", "256")  # (every size the sparse tableau row allows, not just the sizes at which the form pays)
     lp = GEN[fam](*args)
     runs = []
