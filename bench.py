@@ -86,6 +86,25 @@ def pmc_traffic(a, which):
 
 
 def cpu_baseline(lp, warmup, steps, cap):
+    """One core, pinned (minilp is single-threaded: SURVEY §8d); the affinity mask is restored afterwards."""
+    old_mask = pinned = None
+    try:
+        old_mask = os.sched_getaffinity(0)
+        pinned = max(old_mask)
+        os.sched_setaffinity(0, {pinned})
+    except (AttributeError, OSError):
+        old_mask = pinned = None
+    try:
+        return cpu_baseline_pinned(lp, warmup, steps, cap, pinned)
+    finally:
+        if old_mask is not None:
+            try:
+                os.sched_setaffinity(0, old_mask)
+            except OSError:
+                pass
+
+
+def cpu_baseline_pinned(lp, warmup, steps, cap, pinned):
     """The oracle (single-threaded C++ restatement of minilp 0.2.2) timed on this box's host cores on the same
     instance.  `value`: exactly the pivots the GPU figure was timed on, warmup..warmup+steps (bounded by `cap` pivots so
     that a long timed region costs ~20 s of CPU at most); `window_200_700`: pivots 200..700, its fastest sustained
@@ -95,17 +114,27 @@ def cpu_baseline(lp, warmup, steps, cap):
 
     def count(st):
         return st["primal_iters"] + st["dual_iters"]
-    s = lpgen.build_problem(O.Problem, lp).solve(budget=warmup)
+    s0 = lpgen.build_problem(O.Problem, lp).solve(budget=warmup)
     n_same = min(steps, cap)
-    it0 = count(s.stats())
-    t0 = time.perf_counter()
-    s.continue_solve(n_same)
-    dt = time.perf_counter() - t0
-    n = count(s.stats()) - it0
+    # the same-window sample is short when the window is (20 pivots ~ 14 ms): timed REPEATS times on clones of the
+    # warm state, median reported (a single read of a 14 ms interval is noise)
+    reps = 7 if n_same <= 200 else 1
+    samples = []
+    for i in range(reps):
+        s = s0.clone() if i + 1 < reps else s0
+        it0 = count(s.stats())
+        t0 = time.perf_counter()
+        s.continue_solve(n_same)
+        samples.append((time.perf_counter() - t0, count(s.stats()) - it0))
+        if i + 1 < reps:
+            del s
+    samples_sorted = sorted(samples, key=lambda x: x[0] / max(x[1], 1))
+    dt, n = samples_sorted[len(samples_sorted) // 2]
     out = dict(value=n / dt, unit="pivots/s", cores=1, kind="port", measured="live",
-               sample=f"oracle (C++ restatement of minilp 0.2.2, 1 thread), same instance, pivots {warmup}..{warmup + n} from the slack "
-                      f"basis in {dt:.2f}s" + ("" if n_same == steps else f" (the first {n_same} of the {steps} timed pivots)"),
-               host_cpus=os.cpu_count())
+               sample=f"oracle (C++ restatement of minilp 0.2.2, 1 thread pinned to core {pinned}), same instance, pivots {warmup}..{warmup + n} "
+                      f"from the slack basis: median of {reps} repeats, {dt * 1e3:.1f} ms" + ("" if n_same == steps else f" (the first {n_same} of the {steps} timed pivots)"),
+               host_cpus=os.cpu_count(), cpu_model=cpu_model(), pinned_core=pinned, repeats=reps,
+               repeat_pivots_per_s=[round(n_ / t_, 1) for t_, n_ in samples])
     done = warmup + n
     if done <= 200:   # the 200..700 figure quoted in DESIGN.md, separately
         s.continue_solve(200 - done)
@@ -393,14 +422,15 @@ def compact_line(out):
     cb = out.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = dict(value=r(cb["value"], 2), unit=cb["unit"], cores=cb["cores"], kind=cb["kind"], measured=cb.get("measured", "live"),
-                                    sample=cb["sample"][:200])
+                                    sample=cb["sample"][:240], host_cpus=cb.get("host_cpus"), cpu_model=cb.get("cpu_model"),
+                                    repeats=cb.get("repeats"))
         if cb.get("window_200_700"):
             line["cpu_baseline"]["pivots_200_700"] = r(cb["window_200_700"]["value"], 2)
         if cb.get("gpu_over_cpu_same_window"):
             line["cpu_baseline"]["gpu_over_cpu_same_window"] = r(cb["gpu_over_cpu_same_window"], 2)
     if out.get("parity"):
         line["parity"] = dict(oracle_identical_through_pivot=out["parity"]["oracle_identical_through_pivot"], beyond="defining equations vs A at k = 9 999 / 20 493 + live duality certificate")
-    for key in ("value_vs_1gpu", "pricing_speedup_vs_1gpu", "unsharded_same_run"):
+    for key in ("ranks", "value_vs_1gpu", "pricing_speedup_vs_1gpu", "unsharded_same_run"):
         if out.get(key) is not None:
             line[key] = out[key] if isinstance(out[key], dict) else r(out[key], 3)
     if out.get("factor_transport"):
@@ -409,10 +439,51 @@ def compact_line(out):
     return line
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N ranks here, one process per
+    GPU, exactly as the driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` would, hand their stdout
+    through (rank 0 prints the ONE line) and leave with the launcher's return code.  Fewer visible GPUs than ranks is an ERROR
+    (rc 2) unless MLP_OVERSUBSCRIBE=1 (test rigs: every rank on the one device)."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < a.gpus and os.environ.get("MLP_OVERSUBSCRIBE") != "1":
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} but {ndev} GPU(s) visible; refusing to run {a.gpus} ranks on fewer devices "
+                         f"(set MLP_OVERSUBSCRIBE=1 for an oversubscribed test rig)\n")
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MLP_BENCH_SELF_LAUNCHED="1")
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def main():
     T_START = time.perf_counter()
     a = parse()
+    if a.gpus < 1:
+        sys.stderr.write("bench.py: --gpus must be >= 1\n")
+        sys.exit(2)
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:   # a world that is not what --gpus says is a mis-launch, not something to measure under another name
+        if int(os.environ.get("RANK", "0")) == 0:
+            sys.stderr.write(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing\n")
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # The contract is ONE JSON line on stdout.  Native libraries (Gloo's "Rank 0 is connected ...", RCCL warnings, the HIP
@@ -425,6 +496,11 @@ def main():
     import torch
     import torch.distributed as dist
     oversub = world > 1 and torch.cuda.device_count() < world  # test rigs with fewer GPUs than ranks
+    if oversub and os.environ.get("MLP_OVERSUBSCRIBE") != "1":
+        if rank == 0:
+            sys.stderr.write(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s) visible; refusing (MLP_OVERSUBSCRIBE=1 allows "
+                             f"an oversubscribed test rig)\n")
+        sys.exit(2)
     dev_index = 0 if oversub else (local_rank if world > 1 else 0)
     if world > 1:
         torch.cuda.set_device(dev_index)
@@ -458,6 +534,18 @@ def main():
         # raises on EVERY rank when any rank cannot join (setup_sharding all-gathers the errors): a sharded run
         # that cannot be set up is a failed run, not a run of something else
         mailbox = mdist.setup_sharding(s, dist)
+    ranks_info = None
+    if world > 1:
+        # what actually ran: every rank reports itself (rank, device index, device uuid-ish name, pid); rank 0 puts it into the line
+        mine = dict(rank=rank, device=dev_index, device_name=torch.cuda.get_device_name(dev_index), pid=os.getpid(),
+                    transport=(s.transport() if sharded else "none"))
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        ranks_info = dict(ranks_seen=len({r_["rank"] for r_ in allr}), devices=[r_["device"] for r_ in allr],
+                          distinct_devices=len({r_["device"] for r_ in allr}), pids_distinct=len({r_["pid"] for r_ in allr}) == world,
+                          transport=sorted({r_["transport"] for r_ in allr}),
+                          process_group=dict(backend=dist.get_backend(), size=dist.get_world_size()),
+                          self_launched=os.environ.get("MLP_BENCH_SELF_LAUNCHED") == "1", oversubscribed=bool(oversub))
     t0 = time.perf_counter()
     s.continue_solve(a.warmup)       # W untimed warm-up pivots
     solve_s += time.perf_counter() - t0
@@ -528,6 +616,8 @@ def main():
                                pricing_path_us_per_pivot=pricing_us,
                                vs_baseline_note="BASELINE.md §1: the reference publishes no number for this metric"),
                    roofline=roofline)
+        if ranks_info:
+            out["ranks"] = ranks_info
         out["provenance"] = dict(value="live", roofline_achieved="live (HIP events stamped by the kernels, this run)",
                                  roofline_traffic="committed (PMC passes cannot run inside the timed run)", windows="live",
                                  full_solve="live", cpu_baseline="live")

@@ -108,7 +108,9 @@ int mlp_problem_solve_from_basis(const mlp_problem* p, const void* blob, uint64_
 int mlp_solution_set_sampling(mlp_solution* s, int every_iteration);
 int mlp_solution_budget_exhausted(const mlp_solution* s);
 /* Recompute the dense nucleus inverse from A (the counterpart of BasisSolver::reset,
- * solver.rs:1286-1303); returns max |W_incremental - W_fresh| through *max_diff when non-NULL. */
+ * solver.rs:1286-1303); returns max |W_incremental - W_fresh| through *max_diff when non-NULL.  While the basis is held as the
+ * compact factor (mlp_stats.factor_active) there is no incremental inverse to compare with: the factor is rebuilt from the basis
+ * and *max_diff is NaN ("nothing compared"), never a false 0. */
 int mlp_solution_reinvert(mlp_solution* s, double* max_diff);
 
 /* The objective value and the reduced costs are recomputed for the new point as well (solver.rs:1199-1231).

@@ -214,8 +214,10 @@ int mlp_solution_recompute_basic_values(mlp_solution* s) {
         if (!s) throw MlpError(MLP_EINVAL, "NULL solution");
         // x_B, then the objective of the recomputed point (and the reduced costs with it: solver.rs:1199-1231), so that
         // mlp_solution_objective and the values agree afterwards
+        // — except inside the artificial-objective feasibility phase of a budget-paused solve (d = +-1 / 0 there: initial_solve
+        // itself never recomputes d on a budget resume); the basic values are recomputed, d and the objective are left alone
         s->eng->recalc_basic_vals();
-        s->eng->refresh_objective();
+        if (!s->eng->in_artificial_phase()) s->eng->refresh_objective();
     });
 }
 uint32_t mlp_abi_version(void) { return MLP_ABI_VERSION; }

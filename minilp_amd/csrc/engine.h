@@ -442,6 +442,9 @@ private:
     int step_phase = 0, step_pos = -1;
     bool stepping = false;
     void recalc_basic_vals();  // x_B recomputed from the basis (polish of long runs)
+    // solver.rs:261-270: neither primal nor dual feasible => the feasibility phase runs on an ARTIFICIAL objective (d = +-1 / 0 from
+    // try_new); recomputing d from the real costs inside that phase would resume the dual loop on dual-infeasible reduced costs
+    bool in_artificial_phase() const { return !primal_feasible && !dual_feasible; }
     void refresh_objective() { recalc_obj_coeffs(); }  // objective + reduced costs of the current point, from the basis (solver.rs:1199-1231)
     int step_open(StepInfo* out);
     int step_stage(int stage, StepInfo* out);

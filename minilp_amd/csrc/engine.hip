@@ -830,6 +830,19 @@ void Engine::enable_pump(int rank, int world, void* shm, size_t host_bytes, int 
         if (!rccl_id) throw MlpError(-1, "enable_sharding: the rccl transport needs rank 0's ncclUniqueId (mlp_rccl_unique_id)");
         NcclId id;
         std::memcpy(&id, rccl_id, sizeof(id));
+        (void)rccl_api();  // dlopen before the readiness vote: a rank without librccl fails HERE, not inside the collective
+        // ncclCommInitRank is a blocking collective without a timeout: a rank that failed above (allocation, dlopen) would leave the
+        // others inside it forever.  Every rank therefore first publishes "ready" through the rendezvous object and waits — bounded —
+        // for every peer's flag; a failed rank publishes all-ones (enable_sharding's catch) and every rank leaves through the same door.
+        Rendezvous* rvr = reinterpret_cast<Rendezvous*>(static_cast<uint8_t*>(shm) + host_bytes);
+        __atomic_store_n(&rvr[rank].ready, (uint64_t)1, __ATOMIC_RELEASE);
+        for (int r = 0; r < world; ++r) {
+            if (r == rank) continue;
+            if (!wait_flag(&rvr[r].ready, 1, 120.0))
+                throw MlpError(-3, "enable_sharding: rank " + std::to_string(r) + " did not get ready for ncclCommInitRank within 120 s");
+            if (__atomic_load_n(&rvr[r].ready, __ATOMIC_ACQUIRE) == ~(uint64_t)0)
+                throw MlpError(-3, "enable_sharding: rank " + std::to_string(r) + " failed before ncclCommInitRank");
+        }
         rccl_check(rccl_api().CommInitRank(&rccl_comm_, world, id, rank), "ncclCommInitRank");
         ranks_share_device = false;  // (RCCL refuses two ranks on one device)
         transport = "RCCL: the ranks' mailbox records delivered by ncclAllGather over xGMI, pumped on a second stream while a batch of pivots is in flight";
@@ -1921,6 +1934,9 @@ void Engine::ensure_hyper() {
 // ------------------------------------------------------------------ compact factor of the basis (factor.inc)
 constexpr int FAC_MAX_LEVELS = 4096;
 void Engine::fac_alloc() {
+    // workgroup j of k_fac_solve reduces the coefficient of pending term j: never more terms than workgroups (a partitioned device —
+    // CPX mode, ~32 CUs — with MLP_FACTOR_J=64 would silently drop the terms beyond the grid: ADVICE r4)
+    fac_J_ = std::max(1, std::min(fac_J_, fac_solve_grid_blocks()));
     const size_t mm = (size_t)std::max(m_, 1), NN = (size_t)std::max(N_, 1), J = (size_t)fac_J_;
     d_fac_pos_of_var.ensure(NN, 0, st); d_fac_var_of_pos.ensure(mm, 0, st); d_fac_prow.ensure(mm, 0, st);
     d_fac_items.ensure(mm, 0, st); d_fac_lptr.ensure(FAC_MAX_LEVELS + 2, 0, st); d_fac_meta.ensure(8, 0, st);
@@ -2732,9 +2748,12 @@ void Engine::rebuild_inverse() {
 
 double Engine::reinvert(bool replace) {
     if (fac_on_) {  // compact factor: a fresh peel of the current basis (there is no incremental inverse to compare with)
+        // The return value is NaN — "nothing was compared" — so that a host using reinvert() as a drift probe cannot read a
+        // false "no drift" (ADVICE r4); last_reinvert_scale = 0 says the same.
         (void)replace;
         rebuild_inverse();
-        return 0.0;
+        last_reinvert_scale = 0.0;
+        return std::nan("");
     }
     flush_lowrank();
     pull_maps();

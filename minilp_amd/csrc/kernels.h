@@ -406,6 +406,7 @@ void launch_build_nucleus(const DevView& dv, const Geom& g, double* Kd, int k, h
 // dir 1 BTRAN (src 0 e_r | 1 alpha_q | 2 src_ptr by position; dst 0 rho + ||rho||^2 | 1 v); always: whatever the iteration status
 void launch_fac_solve(const DevView& dv, const Geom& g, int dir, int src, int dst, const double* src_ptr, int always, hipStream_t st);
 void launch_fac_solve2(const DevView& dv, const Geom& g, int dir, int srcA, int dstA, int srcB, int dstB, hipStream_t st);  // two right-hand sides, one walk over the levels
+int fac_solve_grid_blocks();  // workgroups of k_fac_solve's grid: workgroup j reduces the coefficient of pending term j, so fac_J must not exceed it
 void launch_fac_append(const DevView& dv, hipStream_t st);     // U_nlow, V_nlow from alpha_q / rho of this pivot; nlow += 1
 void launch_fac_gather_cb(const DevView& dv, hipStream_t st);  // alpha_q[p] = c[basic_vars[p]]
 // refactorisation (host-paced peel): init, then claim + commit per level, then the level lists

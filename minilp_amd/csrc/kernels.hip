@@ -1175,15 +1175,23 @@ __global__ void __launch_bounds__(BLK) k_push_stage1_det(DevView v, int which) {
     const double* xK = which ? v.tauK : v.aK;
     {   // bound of the chunk: max |x_K| over its slots (max is order-independent: every row block of the chunk finds the same)
         double mx = 0.0;
-        for (int s = s_lo + tid; s < s_hi; s += BLK) mx = fmax(mx, fabs(xK[s]));
+        for (int s = s_lo + tid; s < s_hi; s += BLK) {
+            const double ax = fabs(xK[s]);
+            mx = (ax == ax) ? fmax(mx, ax) : INFINITY;  // (fmax drops a NaN: a NaN slot must poison the bound like an infinite one)
+        }
         mx = block_max(mx);
         if (tid == 0) s_bound = mx * v.pb_amax;
     }
     __syncthreads();
     const double bound = s_bound;
     double* dst = v.push_part + (size_t)cc * v.m + row0;
-    if (!(bound > 0.0) || !(bound < INFINITY)) {  // nothing to push (or a non-finite x: the float form would propagate it; report zero)
+    if (!(bound > 0.0)) {  // nothing to push
         for (int t = tid; t < nrows; t += BLK) dst[t] = 0.0;
+        return;
+    }
+    if (!(bound < INFINITY)) {  // a non-finite x_K (broken inverse, overflow): PROPAGATE it as the float form would, so that the
+                                // drift monitor / polish checks see the breakdown instead of a silent zero
+        for (int t = tid; t < nrows; t += BLK) dst[t] = NAN;
         return;
     }
     int e;

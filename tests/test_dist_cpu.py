@@ -94,3 +94,23 @@ def test_mailbox_protocol_two_ranks_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _bench_cli(args, env_extra):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MLP_OVERSUBSCRIBE")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=300, env=env)
+
+
+def test_bench_gpus_flag_is_read_and_a_mismatched_world_is_refused():
+    """`--gpus N` is the number of ranks that run, not a label: (i) N > 1 without a launcher makes bench.py start N ranks itself,
+    which on a box with fewer GPUs (here: none) is refused with rc 2 unless MLP_OVERSUBSCRIBE=1; (ii) a launcher whose WORLD_SIZE
+    differs from --gpus is refused as well.  Neither prints a JSON line."""
+    r = _bench_cli(["--gpus", "2", "--steps", "20", "--warmup", "5"], {})
+    assert r.returncode == 2 and "refusing" in r.stderr and "{" not in r.stdout
+    r = _bench_cli(["--gpus", "2"], {"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr and "{" not in r.stdout
+    r = _bench_cli(["--gpus", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "{" not in r.stdout

@@ -187,3 +187,43 @@ def test_sharded_solve_with_the_large_nucleus_machinery_survives_the_polish_step
     for g in rec["all_ranks"]:
         assert abs(g["objective"] - ru["objective"]) <= 1e-9 * abs(ru["objective"]), (g, ru["objective"])
     assert ru["certificate"]["relative_gap"] < 1e-9
+
+
+def _bench(args, env_extra, timeout=1500):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MLP_OVERSUBSCRIBE")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    """`python3 bench.py --gpus 2 --steps 20 --warmup 5` with no launcher around it must BE a 2-rank run:
+    bench.py re-executes itself through torch.distributed.run, one process per GPU (both on the one GPU of this box, which
+    MLP_OVERSUBSCRIBE=1 has to allow), and the line says what ran: n_gpus == 2 == ranks_seen, one device index per rank, the
+    transport of the per-pivot exchanges, the size of the process group."""
+    import json
+    r = _bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--no-full-solve", "--no-factor-transport"], {"MLP_OVERSUBSCRIBE": "1"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 20 and rec["warmup"] == 5
+    rk = rec["ranks"]
+    assert rk["ranks_seen"] == 2 and len(rk["devices"]) == 2 and rk["pids_distinct"] and rk["self_launched"]
+    assert rk["process_group"]["size"] == 2
+    assert rk["transport"] and all("none" != t for t in rk["transport"])
+    assert rec["config"]["completed_steps"] == 20 and rec["scaling"] == "strong"
+    assert rec["value"] > 0 and rec.get("value_vs_1gpu") is not None
+    late = rec["windows"]["late_sharded"]
+    assert "error" not in late and late["us_per_pivot"] > 0
+
+
+def test_bench_refuses_more_ranks_than_gpus_without_the_override():
+    """... and on a box with ONE GPU the same command without MLP_OVERSUBSCRIBE=1 is an error (rc != 0, no JSON line), never
+    a 1-GPU run printed under another name."""
+    import minilp_amd as M
+    if M.device_count() >= 2:
+        pytest.skip("needs a box with fewer GPUs than ranks")
+    r = _bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--no-full-solve", "--no-factor-transport"], {}, timeout=300)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "refusing" in r.stderr

@@ -572,6 +572,25 @@ def test_two_phase_instance_pivot_for_pivot(kw):
     check_feasible(lp, sg.values())
 
 
+def test_recompute_inside_the_artificial_phase_leaves_the_reduced_costs_alone():
+    """a budget pause INSIDE the artificial-objective feasibility phase (neither primal nor dual feasible: d = +-1 / 0
+    from try_new, solver.rs:261-270), then mlp_solution_recompute_basic_values, then continue.  The recompute must not overwrite d
+    with the real costs (initial_solve itself never recomputes d on a budget resume): the resumed solve takes the pivots of the
+    uninterrupted one and reaches its optimum."""
+    lp = lpgen.gen_twophase_lp(m=1200, n=1000, k=10, seed=6)
+    ref = lpgen.build_problem(M.Problem, lp).solve(trace=True)
+    n_dual = int(ref.stats()["dual_iters"])
+    assert n_dual > 20
+    s = lpgen.build_problem(M.Problem, lp).solve(budget=n_dual // 2, trace=True)
+    assert s.budget_exhausted and s.state("flags")[:2].tolist() == [0.0, 0.0]     # paused in the artificial phase
+    d_before = s.state("nb_var_obj_coeffs").copy()
+    s.recompute_basic_values()
+    assert np.array_equal(s.state("nb_var_obj_coeffs"), d_before)
+    s.continue_solve(-1)
+    assert [t[:5] for t in s.trace()] == [t[:5] for t in ref.trace()]
+    assert obj_close(s.objective(), ref.objective())
+
+
 def test_two_phase_instance_at_scale_matches_the_oracle_trace_fixture():
     """gen_twophase_lp 10 000 x 10 000 (every 40th row a >= row): 647 dual pivots on the artificial objective,
     recalc_obj_coeffs, then the primal loop with steepest edge — the first ~6 000 pivots against the committed
