@@ -218,6 +218,10 @@ private:
     int sb_kmax = 160;                       // MLP_SMALL_BASIS_K: largest nucleus (at the end of a full record ring) k_small_basis is used for; measured
                                              // crossover with the three launches at k ~ 110-120 (tools/small_basis_curve.py)
     bool sb_now = false;                     // ... decided per batch like str_now (the geometry is baked into the graphs)
+    // small-nucleus primal head (primal_head.inc): FTRAN + Harris test + BTRAN + inverse update + touched columns in ONE workgroup, while the
+    // nucleus stays within ph_kmax slots for the whole batch (the batch is cut short for that); MLP_PRIMAL_HEAD_K overrides the bound (0: off)
+    int ph_kmax = -1;                        // -1: primal_head_kmax(longest column)
+    bool ph_now = false;
     bool touch_done = false;                 // the BASIS stage of the iteration being recorded carried the touched-column list
     bool str_now = false, str_clean = false; // geometry of the batch being run; alpha_r / helper are zero outside touched entries
     DevBuf<int> d_str_list;

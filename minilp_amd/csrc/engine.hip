@@ -113,6 +113,7 @@ Engine::Engine() {
     lazy_dse = !(lz && lz[0] == '0');
     ratio_two = std::getenv("MLP_RATIO_TWO_KERNELS") != nullptr;
     if (const char* hy = std::getenv("MLP_HYPER")) hyper_mode = std::atoi(hy) > 0 ? 1 : 0;  // 1: whenever the kernel applies, 0: never
+    if (const char* phk = std::getenv("MLP_PRIMAL_HEAD_K")) ph_kmax = std::max(0, std::atoi(phk));
     if (const char* sbk = std::getenv("MLP_SMALL_BASIS_K")) sb_kmax = std::max(0, std::min(256, std::atoi(sbk)));
     if (const char* sk = std::getenv("MLP_STR_K")) str_kmax = std::atoi(sk);  // sparse tableau row up to this nucleus size (0: never)
     if (const char* hb = std::getenv("MLP_HYPER_BACKOFF")) hyper_backoff_max = std::max(0, std::min(16, std::atoi(hb)));  // longest stay on the multi-kernel path after bail-outs in a row: 2 << this pivots
@@ -340,6 +341,7 @@ Geom Engine::geom() const {
     g.ratio_two = (ratio_two || (shard_world > 1 && ranks_share_device)) ? 1 : 0;
     g.str = (str_now && !stepping && !fac_on_) ? 1 : 0;
     g.sb = (g.str && sb_now) ? 1 : 0;
+    g.ph = (g.str && ph_now) ? 1 : 0;
     return g;
 }
 
@@ -1331,7 +1333,10 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     const bool vbr = use_vbranch && phase == 0 && pse && lazy && !stepping && shard_world == 1 && !g.head_fused && vbranch_supported(dv, g);
     // small nucleus (first capacity of the inverse), lazy primal iteration: BTRAN, pass over W, v tail and touched-column list are
     // ONE launch (k_small_basis) issued at the BASIS stage; the BTRAN stage is empty.  MLP_SMALL_BASIS=0: the three launches.
-    const bool smallb = phase == 0 && pse && lazy && !stepping && shard_world == 1 && !vbr && !tau_branch && small_basis_supported(dv, g);
+    // ... and for a nucleus of a few dozen columns the whole chain FTRAN -> ratio test -> BTRAN -> inverse update -> touched columns -> partition
+    // change is ONE launch of one workgroup issued at the FTRAN stage (k_primal_head); the RATIO, BTRAN and BASIS stages are empty
+    const bool phead = phase == 0 && pse && lazy && !stepping && shard_world == 1 && !vbr && !tau_branch && primal_head_supported(dv, g);
+    const bool smallb = !phead && phase == 0 && pse && lazy && !stepping && shard_world == 1 && !vbr && !tau_branch && small_basis_supported(dv, g);
     // large nucleus, lazy primal iteration: t_K = alpha_K - F^T y_S rides in the ratio test's launch (blocks behind the ratio blocks);
     // the FTRAN's push combine leaves y_S by row, the BTRAN launch forms rho_K only.  MLP_TK_RIDE=0: t_K in the BTRAN launch.
     const bool tkr = phase == 0 && pse && lazy && !stepping && shard_world == 1 && !vbr && !smallb && !g.head_fused && !dv.pb_det && tk_rides_ratio(dv, g);
@@ -1344,6 +1349,12 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     switch (stage) {
     case STAGE_FTRAN:
         if (with_events) HIPCHECK(hipEventRecord(ev[6], st));
+        if (phead) {
+            launch_primal_head(dv, g, st);
+            touch_done = true;
+            if (with_events) HIPCHECK(hipEventRecord(ev[7], st));
+            break;
+        }
         if (phase == 0 && g.head_fused) {
             launch_ftran_fused(dv, g, 1, st);              // K2 head inside the gather kernel (one launch)
         } else {
@@ -1374,11 +1385,12 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         }
         break;
     case STAGE_RATIO:
+        if (phead) break;
         if (phase == 0) launch_ratio_primal(dv, g, pse, st, tkr ? 1 : (tkr_s ? 2 : 0));  // K5 p1 (+ ||alpha||^2, y_S), p2 (+ K3 head + plan) [| t_K]
         else launch_ratio_dual(dv, g, st);                    // K7 p1, p2 (+ K2 head)
         break;
     case STAGE_BTRAN:
-        if (smallb || rkr) break;
+        if (phead || smallb || rkr) break;
         if (phase == 1 && g.head_fused) {
             launch_btran_fused(dv, g, 0, 1, st);                  // K3 head inside the BTRAN kernel (one launch)
         } else {
@@ -1392,6 +1404,10 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         }
         break;
     case STAGE_BASIS:
+        if (phead) {
+            touch_done = true;  // (the head listed the touched columns)
+            break;
+        }
         if (smallb) {
             if (with_events) arm_kernel_timing(2, ev[2], ev[3]);  // (sampled iteration: the slot of the pass over the nucleus inverse)
             launch_small_basis(dv, g, st, tkr_s ? 0 : 1);
@@ -1429,7 +1445,11 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     case STAGE_ROW:
         if (g.str) {  // small nucleus: the columns that meet supp(rho) only (k_row_touch + k_row_pull)
             if (with_events) HIPCHECK(hipEventRecord(ev[0], st));  // (sampled iteration: the two launches bracketed together)
-            if (phase == 0) launch_row_sparse(dv, g, pse ? 1 : 0, tau_branch ? 0 : 1, touch_done ? 0 : 1, st);
+            if (phead && update_pulls_inside(dv, g)) {  // the update kernel's workgroups pull the touched columns of their own positions
+                if (with_events) HIPCHECK(hipEventRecord(ev[1], st));
+                break;
+            }
+            if (phase == 0) launch_row_sparse(dv, g, pse ? 1 : 0, (tau_branch || phead) ? 0 : 1, touch_done ? 0 : 1, st);  // (the head applied the partition change itself)
             else launch_row_sparse(dv, g, 0, 0, 1, st);
             if (with_events) HIPCHECK(hipEventRecord(ev[1], st));
             break;
@@ -1447,7 +1467,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         if (with_events) HIPCHECK(hipEventRecord(ev[4], st));
         // K8 + zero the work vectors + price the next iteration (dual path without PSE: | partition change)
         if (tau_branch) HIPCHECK(hipStreamWaitEvent(st, evJoin[0], 0));  // the tau push has landed
-        launch_update_pivot(dv, g, phase, dse, pse, st, inl, ((phase == 1 && !pse) || tau_branch) ? 1 : 0);
+        launch_update_pivot(dv, g, phase, dse, pse, st, inl, ((phase == 1 && !pse) || tau_branch) ? 1 : 0, (phead && g.str && update_pulls_inside(dv, g)) ? 1 : 0);
         if (with_events) HIPCHECK(hipEventRecord(ev[5], st));
         break;
     default:
@@ -1785,6 +1805,19 @@ int Engine::run_loop(int phase) {
             }
         }
         const bool graph_batch = graph_now;
+        {   // small-nucleus primal head: the batch must end before the nucleus can outgrow the kernel's slots
+            const int kmax = std::min(ph_kmax >= 0 ? ph_kmax : primal_head_kmax(std::max(max_col_nnz_, 1)), primal_head_kmax(std::max(max_col_nnz_, 1)));
+            bool ph = str_now && phase == 0 && enable_pse && batch_lazy && shard_world == 1 && !stepping && !fac_on_ && kmax > 0 &&
+                      max_row_nnz_ <= HEAD_LIST_CAP && !hview.pb_on && !hview.det_pull && hview.rowinfo != nullptr;
+            if (ph) {
+                const int room = kmax - k_;  // every pivot may add one slot
+                int Bp = std::min(B, room);
+                if (use_multi) Bp -= Bp % graph_iters;
+                if (Bp >= std::min(B, 4)) B = Bp;
+                else ph = false;
+            }
+            ph_now = ph;
+        }
         {
             const bool fac_before = fac_on_;
             ensure_nucleus_cap(k_ + B + 1);  // (may switch to the compact factor: then the batch is planned again)
@@ -3002,7 +3035,7 @@ Engine* Engine::clone() {
     e->h_rptr = h_rptr; e->h_rcol = h_rcol; e->h_rval = h_rval;
     e->h_colnnz = h_colnnz; e->h_single_row = h_single_row; e->h_single_val = h_single_val;
     e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->amax_ = amax_; e->no_head_fusion = no_head_fusion;
-    e->sw_balanced = sw_balanced; e->str_kmax = str_kmax; e->sb_kmax = sb_kmax; e->hyper_mode = hyper_mode; e->hyper_heavy = hyper_heavy; e->hyper_backoff_max = hyper_backoff_max; e->ratio_two = ratio_two; e->ratio_spin_limit = ratio_spin_limit; e->ranks_share_device = false; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->use_pack = use_pack; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
+    e->sw_balanced = sw_balanced; e->str_kmax = str_kmax; e->sb_kmax = sb_kmax; e->ph_kmax = ph_kmax; e->hyper_mode = hyper_mode; e->hyper_heavy = hyper_heavy; e->hyper_backoff_max = hyper_backoff_max; e->ratio_two = ratio_two; e->ratio_spin_limit = ratio_spin_limit; e->ranks_share_device = false; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->use_pack = use_pack; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
     e->h_basic_vars = h_basic_vars; e->h_nb_vars = h_nb_vars; e->h_var_loc = h_var_loc;
     e->h_kslot_of_pos = h_kslot_of_pos; e->h_srow_of_pos = h_srow_of_pos; e->h_kslot_of_row = h_kslot_of_row;
     e->h_pos_of_srow = h_pos_of_srow; e->h_sdiag_of_pos = h_sdiag_of_pos; e->h_nb_fixed = h_nb_fixed;
@@ -3109,6 +3142,9 @@ uint64_t Engine::state(const char* what, double* out, uint64_t cap) {
     else if (w == "small_basis_launches") {  // iterations that ran BTRAN + pass + v tail + touch as one launch (k_small_basis)
         pull_ctl();
         tmp = {(double)h_ctl->sb_count};
+    } else if (w == "primal_head_launches") {
+        pull_ctl();
+        tmp = {(double)h_ctl->ph_count};
     }
     else if (w == "hyper_profile") {  // microseconds per stage of the hypersparse iteration, accumulated since try_new
         pull_ctl();

@@ -107,6 +107,9 @@ struct Ctl {
     double sb_obj0;  // running objective before the primal ratio test added this iteration's step (k_small_basis restores it when its wait stalls:
                      // the iteration is then re-run from the top)
     int sb_count;    // launches of k_small_basis that ran an iteration (state("small_basis_launches"): tests check the path was taken)
+    int ph_count;    // iterations k_primal_head carried through all its stages (state("primal_head_launches"))
+    int rv_n;        // k_primal_head: rows of (rho, v) the previous iteration's head left non-zero, listed in aq_list (the next head zeroes them:
+                     // with the tableau row pulled inside the update kernel nothing else may clear rv while other workgroups still read it)
     unsigned long long hy_prof[24];  // ticks of the 100 MHz wall clock per stage of the hypersparse iteration (diagnostics)
     PivotRec ring[RING];
 };
@@ -338,6 +341,7 @@ struct Geom {
     int str;            // sparse tableau row instead of the sweep over all of A (nucleus of at most MLP_STR_K columns, one GPU)
     int sb;             // nucleus small enough for the one-launch BTRAN + pass + v tail + touch of the lazy primal iteration (k_small_basis; MLP_SMALL_BASIS_K)
     int fac;            // compact factor of the basis instead of the explicit nucleus inverse (factor.inc)
+    int ph;             // small nucleus, lazy primal iteration: FTRAN + Harris test + BTRAN + inverse update + touched columns in ONE workgroup (k_primal_head)
     int ratio_two;      // the two Harris passes as two launches (no in-kernel wait): MLP_RATIO_TWO_KERNELS, ranks sharing a device, after an ITER_STALL
 };
 
@@ -364,6 +368,11 @@ void launch_row_sparse(const DevView& dv, const Geom& g, int mode, int with_stru
 // small nucleus (first capacity), lazy primal iteration: BTRAN + pass over W + v tail + touched-column list in ONE launch
 bool small_basis_supported(const DevView& dv, const Geom& g);
 void launch_small_basis(const DevView& dv, const Geom& g, hipStream_t st, int tk_inside = 1);  // tk_inside = 0: t_K rode in the ratio launch
+// small nucleus (at most primal_head_kmax slots for the whole batch), lazy primal steepest-edge iteration, pushed F products: everything between
+// the pricing decision and the tableau row in ONE launch of one workgroup (primal_head.inc)
+bool primal_head_supported(const DevView& dv, const Geom& g);
+int primal_head_kmax(int longest_column);  // largest nucleus the kernel serves for a model whose longest column has that many entries (0: none)
+void launch_primal_head(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st);                 // K7 p1, p2 (+FTRAN head)
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int with_tau = 1);  // tauK/vK partials + eta update of W
@@ -390,7 +399,8 @@ bool fold_fuses_v(const DevView& dv, int with_v, int with_tau, int fold_only);  
 int stream_coresident_blocks();  // blocks of the default k_stream_w instance the device holds at once (0: unknown)  // large-nucleus streaming pass in strip form (MLP_STREAM_STRIPS=0 disables)
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_dse, int use_pse, hipStream_t st, int inline_comb = 0,
-                         int with_struct = 0);  // K8 + clear + next pricing
+                         int with_struct = 0, int pull_inside = 0);  // K8 + clear + next pricing [pull_inside: + the sparse tableau row, per workgroup]
+bool update_pulls_inside(const DevView& dv, const Geom& g);  // small-nucleus primal head: the touched columns are pulled by the update kernel's own workgroups
 // non-graph helpers
 void launch_set_iter(const DevView& dv, int status, int q, int r, double lnv, int forced, hipStream_t st);
 void launch_reset_ring(const DevView& dv, hipStream_t st);

@@ -588,7 +588,7 @@ __device__ void plan_update(const DevView& v, Ctl* c, int phase) {
     u.kase = -1;
     if (c->it.status != ITER_PIVOT) return;
     if (v.fac_on) {  // compact factor (factor.inc): no partition to maintain; the pivot becomes a rank-1 term (k_fac_append)
-        c->it.inv_alpha = 1.0 / v.alpha_q[c->it.r];
+        c->it.inv_alpha = 1.0 / ld_agent(&v.alpha_q[c->it.r]);
         c->fold = 0;
         u.r = c->it.r;
         return;
@@ -610,7 +610,7 @@ __device__ void plan_update(const DevView& v, Ctl* c, int phase) {
         u.i_r = v.srow_of_pos[r];
         u.inv_diag_r = 1.0 / v.sdiag_of_pos[r];
     }
-    c->it.inv_alpha = 1.0 / v.alpha_q[r];
+    c->it.inv_alpha = 1.0 / ld_agent(&v.alpha_q[r]);  // (L1-bypassing: k_primal_head reads entries that L2 atomics of the same launch produced)
     // (primal iteration: the FTRAN head took the fold decision — with the v branch the fold of this pivot may already be running
     // beside this plan, and its last block clears nlow)
     if (phase != 0 || !v.lrJ) c->fold = (v.lrJ > 0 && c->nlow >= v.lrJ) ? 1 : 0;
@@ -1509,7 +1509,7 @@ __device__ void ratio_primal_finish(const DevView& v, Ctl* c, Cand best) {
         double coeff = 0.0, lnv = 0.0, diff = 0.0, enew = 0.0, pobj = 0.0;
         if (best.idx != NONE_IDX) {
             r = best.idx;
-            coeff = v.alpha_q[r];
+            coeff = ld_agent(&v.alpha_q[r]);
             bool tm;
             leaving_step(v, r, coeff, sign, tm);
             lnv = tm ? v.hiB[r] : v.loB[r];
@@ -3835,7 +3835,7 @@ __global__ void __launch_bounds__(BLK) k_reduce_v(DevView v) {
 // read for the last time here), and (b) prices the NEXT iteration from the values it has just
 // written (K1 when next_phase = 0, K6 when 1), so neither a memset nor a pricing kernel is needed
 // inside the replayed graph.
-__global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int use_dse, int use_pse, int inline_comb, int n_upd) {
+__global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int use_dse, int use_pse, int inline_comb, int n_upd, int pull_inside) {
     Ctl* c = v.ctl;
     if (c->halt) return;
     const IterState* it = &c->it;
@@ -3850,6 +3850,50 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
     const bool flip = status == ITER_FLIP;
     const int r = flip ? -1 : it->r, q = it->q;
     const double pc = it->pivot_coeff;
+    // pull_inside (small-nucleus primal head, one position per thread): the sparse tableau row — alpha_rj = rho . a_j and the PSE helper
+    // v . a_j on the columns the head stamped (solver.rs:685-692, 1126-1132) — is pulled HERE, by the workgroup that updates those
+    // positions, instead of by a launch of its own (k_row_pull, 5.8 us + a kernel boundary for ~3 MB of gathers): each workgroup
+    // compacts the stamped positions of its 256 into LDS, 32 lanes pull each column in storage order (k_row_pull<32, 1>'s sums, bit
+    // for bit), and the update below reads the pair from LDS.  alpha_r / helper are not materialised; (rho, v) is not zeroed here —
+    // other workgroups are still reading it — but by the next head, from the list this iteration's head left (Ctl.rv_n).
+    __shared__ int s_tl[BLK];
+    __shared__ double s_ta[BLK], s_th[BLK];
+    __shared__ int s_tcnt;
+    int my_slot = -1;
+    if (pull_inside) {
+        if (threadIdx.x == 0) s_tcnt = 0;
+        __syncthreads();
+        if (!flip) {
+            const int t = blockIdx.x * BLK + threadIdx.x;
+            if (t < v.n) {
+                const int tn = v.nb_order ? v.nb_order[t] : t;
+                if (tn >= v.nb_lo && tn < v.nb_hi && v.hy_stamp_n[tn] == c->hyper_epoch + 1) {
+                    my_slot = atomicAdd(&s_tcnt, 1);
+                    s_tl[my_slot] = tn;
+                }
+            }
+        }
+        __syncthreads();
+        const int cnt = s_tcnt;
+        const int gl = threadIdx.x & 31;
+        for (int i = threadIdx.x >> 5; i < cnt; i += BLK / 32) {
+            const int2 rg = v.nb_rng[s_tl[i]];
+            double a1 = 0.0, a2 = 0.0;
+            for (int e = rg.x + gl; e < rg.y; e += 32) {
+                const double a = v.csc_val[e];
+                const double2 tt = v.rv[v.csc_row[e]];
+                a1 += a * tt.x;
+                a2 += a * tt.y;
+            }
+            a1 = group_sum<32>(a1);
+            a2 = group_sum<32>(a2);
+            if (gl == 0) {
+                s_ta[i] = a1;
+                s_th[i] = a2;
+            }
+        }
+        __syncthreads();
+    }
     Cand cand = cand_none();
     double cand_d = 0.0;
     // one position per thread on the usual grid; the loop only strides for very large models (launch_update_pivot)
@@ -3886,7 +3930,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
             }
             v.alpha_q[t] = 0.0;
             v.tau[t] = 0.0;
-            v.rv[t] = make_double2(0.0, 0.0);
+            if (!pull_inside) v.rv[t] = make_double2(0.0, 0.0);
             if (phase == 1 && !c->forced) tc = price_dual_one(xb, lo, hi, bt, t, use_dse);
         }
         if (t < v.n) {
@@ -3911,6 +3955,8 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                         if (inline_comb) {
                             ba = 0.0;
                             for (int b = 0; b < v.nbands; ++b) ba += v.band_part[(size_t)b * (size_t)v.n + t].x;
+                        } else if (pull_inside) {
+                            ba = my_slot >= 0 ? s_ta[my_slot] : 0.0;
                         } else {
                             ba = v.alpha_r[q];
                         }
@@ -3918,7 +3964,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                         double err = fabs(fa - ba) / fmax(1.0, fabs(fa));
                         if (err > c->max_pivot_err || err != err) c->max_pivot_err = err;
                     }
-                    if (v.str_on) v.alpha_r[q] = 0.0;
+                    if (v.str_on && !pull_inside) v.alpha_r[q] = 0.0;
                     dd = -it->pivot_obj;
                     v.d[q] = dd;
                     if (use_pse) {
@@ -3949,6 +3995,9 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                     }
                     ar = s1;  // (row_coeffs / the PSE helper are not materialised on this path: nothing reads them — the
                     hp = s2;  // host-paced stepping API, which exposes them, keeps the separate combine kernel)
+                } else if (pull_inside) {
+                    ar = my_slot >= 0 ? s_ta[my_slot] : 0.0;
+                    hp = my_slot >= 0 ? s_th[my_slot] : 0.0;
                 } else {
                     ar = v.alpha_r[tn];
                     if (use_pse) hp = v.helper[tn];
@@ -3960,7 +4009,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                         gm += -2.0 * ar * hp / pc + it->alpha_sq * ar * ar / (pc * pc);
                         v.gamma[tn] = gm;
                     }
-                    if (v.str_on) v.alpha_r[tn] = 0.0;  // sparse tableau row: the vector stays zero outside this iteration's touched entries
+                    if (v.str_on && !pull_inside) v.alpha_r[tn] = 0.0;  // sparse tableau row: the vector stays zero outside this iteration's touched entries
                 }
             }
             if (phase == 0 && tn >= v.nb_lo && tn < v.nb_hi) {
@@ -4005,6 +4054,7 @@ __global__ void k_reset_ring(DevView v) {
     c->forced = 0;
     c->max_pivot_err = 0.0;
     c->hyper_bail = 0;
+    c->rv_n = 0;  // (every batch starts from zeroed work vectors: launch_clear_work)
 }
 // K9: recalc reduced costs (solver.rs:1216-1231): d_c = c_c - a_c . y, then the objective from scratch
 __global__ void __launch_bounds__(BLK) k_gather_basic_obj(DevView v) {
@@ -4455,21 +4505,8 @@ void launch_build_colblk(const int* cptr, const int* crow, int N, int rb, int* c
 // helper N^T v (solver.rs:1126-1132) is needed on the columns with alpha_rj != 0 only, i.e. on the same list.
 //   k_row_touch: one wave per row of supp(rho): its CSR entries -> non-basic positions, each listed once (epoch stamp);
 //   k_row_pull : G lanes per listed column pull alpha_rj (and helper_j) from the CSC in storage order (no float atomics).
-template <bool OWN_RK>
-__device__ __forceinline__ void row_touch_body(const DevView& v, Ctl* c, int block, double own_rk) {
-    const int k = c->k;
-    const int w = (int)((block * BLK + threadIdx.x) >> 6), lane = threadIdx.x & 63;
-    if (w > k) return;
-    int row;
-    if (w < k) {
-        if ((OWN_RK ? own_rk : v.rK[w]) == 0.0) return;  // (k_small_basis: the wave formed its own entry of rho_K)
-        row = v.row_of_kslot[w];
-    } else {  // the leaving singleton's own row (rho there is 1 / its diagonal entry)
-        const int r = c->it.r;
-        if (v.kslot_of_pos[r] >= 0) return;
-        row = v.srow_of_pos[r];
-    }
-    const int ep = c->hyper_epoch + 1;  // (advanced by the update kernel's finaliser)
+// one wave lists the non-basic columns of one row of supp(rho) (each once: epoch stamp of the position)
+__device__ __forceinline__ void row_touch_row(const DevView& v, Ctl* c, int row, int lane, int ep) {
     const int end = v.csr_ptr[row + 1];
     for (int e0 = v.csr_ptr[row]; e0 < end; e0 += 64) {
         const int e = e0 + lane;
@@ -4489,6 +4526,22 @@ __device__ __forceinline__ void row_touch_body(const DevView& v, Ctl* c, int blo
             if (j >= 0) v.str_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = j;
         }
     }
+}
+template <bool OWN_RK>
+__device__ __forceinline__ void row_touch_body(const DevView& v, Ctl* c, int block, double own_rk) {
+    const int k = c->k;
+    const int w = (int)((block * BLK + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (w > k) return;
+    int row;
+    if (w < k) {
+        if ((OWN_RK ? own_rk : v.rK[w]) == 0.0) return;  // (k_small_basis: the wave formed its own entry of rho_K)
+        row = v.row_of_kslot[w];
+    } else {  // the leaving singleton's own row (rho there is 1 / its diagonal entry)
+        const int r = c->it.r;
+        if (v.kslot_of_pos[r] >= 0) return;
+        row = v.srow_of_pos[r];
+    }
+    row_touch_row(v, c, row, lane, c->hyper_epoch + 1);  // (the epoch is advanced by the update kernel's finaliser)
 }
 __global__ void __launch_bounds__(BLK) k_row_touch(DevView v) {
     Ctl* c = v.ctl;
@@ -4724,6 +4777,7 @@ __global__ void __launch_bounds__(BLK) k_row_pull(DevView v, int n_pull) {
     }
 }
 
+#include "primal_head.inc"  // small-nucleus primal iteration: FTRAN + Harris test + BTRAN + inverse update + touched columns in ONE workgroup
 #include "hyper.inc"  // the hypersparse single-workgroup iteration (uses the stage helpers above)
 #include "factor.inc"  // the compact factor of the basis: peel, level-scheduled solves, additive eta terms
 #include "inverse.inc"  // blocked in-place inversion of a dense-filling nucleus (the refactorisation of the explicit inverse)
@@ -4973,6 +5027,21 @@ void launch_small_basis(const DevView& dv, const Geom& g, hipStream_t st, int tk
     LANES_SWITCH(g.lanes, SMALLB(4), SMALLB(16), SMALLB(64));
 #undef SMALLB
 }
+bool primal_head_supported(const DevView& dv, const Geom& g) {
+    const char* e = std::getenv("MLP_PRIMAL_HEAD");  // (read per call, i.e. per captured graph: tests toggle it inside one process)
+    const bool off = e && e[0] == '0';
+    return !off && g.ph && g.str && g.cap > 0 && !g.big && !g.fac && !dv.lrJ && dv.world <= 1 && !dv.pb_on && !dv.det_pull && dv.rowinfo &&
+           dv.hy_stamp_p && dv.str_list;
+}
+int primal_head_kmax(int longest_column) {
+    if (longest_column <= 0 || longest_column > HEAD_CAP) return 0;
+    const int by_list = PH_AQ_CAP / longest_column - 1;  // supp(alpha_q) <= (k + 1) columns' worth of rows
+    return by_list < PH_KMAX ? by_list : PH_KMAX;
+}
+void launch_primal_head(const DevView& dv, const Geom& g, hipStream_t st) {
+    (void)g;
+    LAUNCH_T(2, k_primal_head, dim3(1), dim3(PH_T), 0, st, dv);
+}
 void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st) {
     hipLaunchKernelGGL(k_init_nb_rng, dim3(blocks_for(g.n)), dim3(BLK), 0, st, dv);
 }
@@ -5205,8 +5274,14 @@ void launch_push_tau(const DevView& dv, hipStream_t st) { launch_blocked_push(dv
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st) {
     hipLaunchKernelGGL(k_struct_update, dim3(blocks_for(g.cap)), dim3(BLK), 0, st, dv);
 }
+bool update_pulls_inside(const DevView& dv, const Geom& g) {
+    const char* e = std::getenv("MLP_PULL_INSIDE");
+    if (e && e[0] == '0') return false;
+    const int t = g.m > g.n ? g.m : g.n;
+    return primal_head_supported(dv, g) && blocks_for(t) <= 2048 && dv.hy_stamp_n != nullptr;  // one position per thread
+}
 void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_dse, int use_pse, hipStream_t st, int inline_comb,
-                         int with_struct) {
+                         int with_struct, int pull_inside) {
     int t = g.m > g.n ? g.m : g.n;
     // inline_comb (primal iteration with the banded sweep): the update kernel sums the per-band partials itself
     // with_struct (dual iteration without PSE): the partition change rides in the tail blocks of this launch
@@ -5215,7 +5290,7 @@ void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_ds
     // only beyond 512 * 4 * 256 positions
     const int n_upd = blocks_for(t) <= 2048 ? blocks_for(t) : 2048;
     hipLaunchKernelGGL(k_update_pivot, dim3(n_upd + (with_struct ? blocks_for(g.cap) : 0)), dim3(BLK), 0, st, dv, phase, use_dse, use_pse,
-                       inline_comb, n_upd);
+                       inline_comb, n_upd, pull_inside);
 }
 void launch_set_iter(const DevView& dv, int status, int q, int r, double lnv, int forced, hipStream_t st) {
     hipLaunchKernelGGL(k_set_iter, dim3(1), dim3(1), 0, st, dv, status, q, r, lnv, forced);
