@@ -406,6 +406,8 @@ private:
     uint64_t iters_since_recalc = 0, iters_since_polish = 0;
     bool basic_values_feasible();
     bool reduced_costs_feasible();
+    bool cold_start_ = true;  // the solve started from the slack basis / a loaded basis (try_new, load_basis); add_constraint, fix_var ... clear it:
+                              // warm-start re-solves are short and keep the lazy capture policy
     int graph_iters = 8;  // MLP_GRAPH_ITERS: iterations per graph once a geometry has run for a while (1 = off)
     // graph slots: [0] one iteration per graph, [1] graph_iters iterations per graph (long runs)
     hipGraphExec_t gexec[2][2][2] = {};

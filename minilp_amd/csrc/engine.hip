@@ -1467,7 +1467,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         if (with_events) HIPCHECK(hipEventRecord(ev[4], st));
         // K8 + zero the work vectors + price the next iteration (dual path without PSE: | partition change)
         if (tau_branch) HIPCHECK(hipStreamWaitEvent(st, evJoin[0], 0));  // the tau push has landed
-        launch_update_pivot(dv, g, phase, dse, pse, st, inl, ((phase == 1 && !pse) || tau_branch) ? 1 : 0, (phead && g.str && update_pulls_inside(dv, g)) ? 1 : 0);
+        launch_update_pivot(dv, g, phase, dse, pse, st, inl, ((phase == 1 && !pse) || tau_branch) ? 1 : 0, (phead && g.str && update_pulls_inside(dv, g)) ? (head_applies(dv, g) ? 2 : 1) : 0);
         if (with_events) HIPCHECK(hipEventRecord(ev[5], st));
         break;
     default:
@@ -1791,19 +1791,14 @@ int Engine::run_loop(int phase) {
         // long runs move on to graphs of several iterations and batches of a full record ring: one
         // launch and one host round trip cover more pivots (6 990 -> 7 300 pivots/s on config 4); short
         // warm-start re-solves never pay for capturing the longer graph
-        const bool multi = graph_now && long_run && !fac_on_;
+        // (round 5: a COLD solve — from the slack basis or a loaded basis, not a warm-start re-solve — captures the graph of several iterations
+        // together with the first one-iteration graph: between two graph launches the device idles ~8 us (in-kernel timeline: 33 us of
+        // kernels per pivot, 43 us per pivot on the clock), between two kernels of one graph ~1.4)
+        const bool multi = graph_now && (long_run || cold_start_) && graph_iters > 1 && !fac_on_;
         int B = graph_now ? (multi ? RING : batch) : 1;
         if (pivot_budget > 0 && (int64_t)B > pivot_budget) B = (int)pivot_budget;
         if (hyper_gap > 0 && B > hyper_gap) B = hyper_gap;
-        bool use_multi = multi;
-        if (use_multi) {  // whole graphs only; a short tail falls back to the one-iteration graph
-            B -= B % graph_iters;
-            if (B == 0) {
-                B = (pivot_budget > 0 && pivot_budget < batch) ? (int)pivot_budget : batch;
-                if (hyper_gap > 0 && B > hyper_gap) B = hyper_gap;
-                use_multi = false;
-            }
-        }
+        bool use_multi = multi;  // whole multi-iteration graphs first, the remainder of the batch as one-iteration graphs
         const bool graph_batch = graph_now;
         {   // small-nucleus primal head: the batch must end before the nucleus can outgrow the kernel's slots
             const int kmax = std::min(ph_kmax >= 0 ? ph_kmax : primal_head_kmax(std::max(max_col_nnz_, 1)), primal_head_kmax(std::max(max_col_nnz_, 1)));
@@ -1811,8 +1806,7 @@ int Engine::run_loop(int phase) {
                       max_row_nnz_ <= HEAD_LIST_CAP && !hview.pb_on && !hview.det_pull && hview.rowinfo != nullptr;
             if (ph) {
                 const int room = kmax - k_;  // every pivot may add one slot
-                int Bp = std::min(B, room);
-                if (use_multi) Bp -= Bp % graph_iters;
+                const int Bp = std::min(B, room);
                 if (Bp >= std::min(B, 4)) B = Bp;
                 else ph = false;
             }
@@ -1843,8 +1837,11 @@ int Engine::run_loop(int phase) {
         if (phase == 0) launch_price_primal(dv, geom(), enable_pse ? 1 : 0, st);  // opens the first iteration
         else launch_price_dual(dv, geom(), enable_dse ? 1 : 0, st);
         if (graph_batch) {
-            hipGraphExec_t ge = get_graph(phase, use_multi ? 1 : 0);
-            for (int i = 0; i < B; i += use_multi ? graph_iters : 1) HIPCHECK(hipGraphLaunch(ge, st));
+            const int nfull = use_multi ? B / graph_iters : 0;
+            hipGraphExec_t gm = (use_multi && (nfull > 0 || cold_start_)) ? get_graph(phase, 1) : nullptr;  // (cold solve: captured ahead of its first use)
+            hipGraphExec_t g1 = (B - nfull * graph_iters > 0 || !gm) ? get_graph(phase, 0) : nullptr;
+            for (int i = 0; i < nfull; ++i) HIPCHECK(hipGraphLaunch(gm, st));
+            for (int i = nfull * graph_iters; i < B; ++i) HIPCHECK(hipGraphLaunch(g1, st));
             graph_batches_in_geom += 1;
         } else {
             if (sample)
@@ -2455,6 +2452,7 @@ void Engine::recalc_basic_vals() {
 }
 
 void Engine::fix_var(int var, double val) {  // solver.rs:378-415
+    cold_start_ = false;  // a warm-start re-solve: short, lazy graph capture
     double t0 = now_s();
     ensure_beta();
     if (val < h_lo[var] || val > h_hi[var]) throw LpFail{1};
@@ -2500,6 +2498,7 @@ void Engine::fix_var(int var, double val) {  // solver.rs:378-415
 }
 
 bool Engine::unfix_var(int var) {  // solver.rs:418-438
+    cold_start_ = false;  // a warm-start re-solve: short, lazy graph capture
     if (h_var_loc[var] >= 0) return false;
     int col = -1 - h_var_loc[var];
     if (!h_nb_fixed[col]) return false;
@@ -2604,6 +2603,7 @@ void Engine::append_row_on_device(const Constraint& c, int slack, int row) {
 // solver.rs:549-634.  The new slack is a singleton basic column on the new row, so the nucleus
 // inverse is unchanged unless the new row touches a basic singleton column (then: rebuild).
 void Engine::add_constraint(Constraint c) {
+    cold_start_ = false;  // a warm-start re-solve: short, lazy graph capture
     double t0 = now_s();
     if (!primal_feasible || !dual_feasible) throw MlpError(-1, "add_constraint: model not solved (solver.rs:555-556)");
     if (fac_on_) fac_leave();  // (a new row changes every per-row array of the factor: warm starts run on the explicit inverse)

@@ -108,6 +108,7 @@ struct Ctl {
                      // the iteration is then re-run from the top)
     int sb_count;    // launches of k_small_basis that ran an iteration (state("small_basis_launches"): tests check the path was taken)
     int ph_count;    // iterations k_primal_head carried through all its stages (state("primal_head_launches"))
+    int ph_rng_x, ph_rng_y;  // k_primal_head with `apply`: CSC range of the leaving variable's column, for nb_rng[q] (set by the update kernel)
     int rv_n;        // k_primal_head: rows of (rho, v) the previous iteration's head left non-zero, listed in aq_list (the next head zeroes them:
                      // with the tableau row pulled inside the update kernel nothing else may clear rv while other workgroups still read it)
     unsigned long long hy_prof[24];  // ticks of the 100 MHz wall clock per stage of the hypersparse iteration (diagnostics)
@@ -400,7 +401,8 @@ int stream_coresident_blocks();  // blocks of the default k_stream_w instance th
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_dse, int use_pse, hipStream_t st, int inline_comb = 0,
                          int with_struct = 0, int pull_inside = 0);  // K8 + clear + next pricing [pull_inside: + the sparse tableau row, per workgroup]
-bool update_pulls_inside(const DevView& dv, const Geom& g);  // small-nucleus primal head: the touched columns are pulled by the update kernel's own workgroups
+bool update_pulls_inside(const DevView& dv, const Geom& g);
+bool head_applies(const DevView& dv, const Geom& g);  // the head also applies the basic side of the pivot and position q (update kernel: pull_inside = 2)  // small-nucleus primal head: the touched columns are pulled by the update kernel's own workgroups
 // non-graph helpers
 void launch_set_iter(const DevView& dv, int status, int q, int r, double lnv, int forced, hipStream_t st);
 void launch_reset_ring(const DevView& dv, hipStream_t st);

@@ -3856,20 +3856,26 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
     // compacts the stamped positions of its 256 into LDS, 32 lanes pull each column in storage order (k_row_pull<32, 1>'s sums, bit
     // for bit), and the update below reads the pair from LDS.  alpha_r / helper are not materialised; (rho, v) is not zeroed here —
     // other workgroups are still reading it — but by the next head, from the list this iteration's head left (Ctl.rv_n).
-    __shared__ int s_tl[BLK];
-    __shared__ double s_ta[BLK], s_th[BLK];
+    constexpr int UPT = 4;  // positions per thread a pulling launch may take (launch_update_pivot): 98 workgroups on config 4 — the ticket of the
+                            // pricing reduction is ONE address: 391 arrivals serialise at L2 for ~8 us (in-kernel timeline), 98 for ~2
+    __shared__ int s_tl[BLK * UPT];
+    __shared__ double s_ta[BLK * UPT], s_th[BLK * UPT];
     __shared__ int s_tcnt;
-    int my_slot = -1;
+    int my_slot[UPT] = {-1, -1, -1, -1};
     if (pull_inside) {
         if (threadIdx.x == 0) s_tcnt = 0;
         __syncthreads();
         if (!flip) {
-            const int t = blockIdx.x * BLK + threadIdx.x;
-            if (t < v.n) {
-                const int tn = v.nb_order ? v.nb_order[t] : t;
-                if (tn >= v.nb_lo && tn < v.nb_hi && v.hy_stamp_n[tn] == c->hyper_epoch + 1) {
-                    my_slot = atomicAdd(&s_tcnt, 1);
-                    s_tl[my_slot] = tn;
+            const int ep = c->hyper_epoch + 1;
+#pragma unroll
+            for (int i = 0; i < UPT; ++i) {
+                const int t = blockIdx.x * BLK + threadIdx.x + i * n_upd * BLK;
+                if (t < v.n) {
+                    const int tn = v.nb_order ? v.nb_order[t] : t;
+                    if (tn >= v.nb_lo && tn < v.nb_hi && v.hy_stamp_n[tn] == ep) {
+                        my_slot[i] = atomicAdd(&s_tcnt, 1);
+                        s_tl[my_slot[i]] = tn;
+                    }
                 }
             }
         }
@@ -3896,12 +3902,20 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
     }
     Cand cand = cand_none();
     double cand_d = 0.0;
-    // one position per thread on the usual grid; the loop only strides for very large models (launch_update_pivot)
+    // one position per thread on the usual grid; the loop only strides for very large models and for a pulling launch (launch_update_pivot)
     const int tmax = v.m > v.n ? v.m : v.n;
-    for (int t = blockIdx.x * BLK + threadIdx.x; t < tmax; t += n_upd * BLK) {
+    // pull_inside == 2: the head has applied the basic side (x_B on supp(alpha_q), position r, alpha_q back to zero) and position q's own
+    // entries (d, gamma, flags, nb_vars, x_N) itself: here only the non-basic side remains — the touched columns' d / gamma, the drift
+    // check at q, and the pricing scan
+    const bool head_applied = pull_inside == 2;
+    const int tmax_eff = head_applied ? v.n : tmax;
+    int trip = 0;
+    for (int t = blockIdx.x * BLK + threadIdx.x; t < tmax_eff; t += n_upd * BLK, ++trip) {
         Cand tc = cand_none();
         double tc_d = 0.0;
-        if (t < v.m) {
+        // (a select chain, not an indexed read: the array stays in registers)
+        const int slot_t = !pull_inside ? -1 : (trip == 0 ? my_slot[0] : (trip == 1 ? my_slot[1] : (trip == 2 ? my_slot[2] : (trip == 3 ? my_slot[3] : -1))));
+        if (t < v.m && !head_applied) {
             double a = v.alpha_q[t];
             double xb = v.xB[t], lo = v.loB[t], hi = v.hiB[t], bt = use_dse ? v.beta[t] : 1.0;
             const double tau_t = (use_dse && !flip) ? v.tau[t] : 0.0;  // loaded with the others, not behind `a != 0`
@@ -3939,7 +3953,16 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
             const int tn = v.nb_order ? v.nb_order[t] : t;
             double dd = v.d[tn], gm = use_pse ? v.gamma[tn] : 1.0;
             uint8_t f = v.nbflags[tn];
-            if (tn == q) {
+            if (tn == q && head_applied) {
+                if (!flip && q >= v.nb_lo && q < v.nb_hi) {
+                    // the pivot element computed two ways (FTRAN side / BTRAN side) measures the drift of W
+                    const double ba = slot_t >= 0 ? s_ta[slot_t] : 0.0;
+                    const double fa = 1.0 / it->inv_alpha;
+                    const double err = fabs(fa - ba) / fmax(1.0, fabs(fa));
+                    if (err > c->max_pivot_err || err != err) c->max_pivot_err = err;
+                    v.nb_rng[q] = make_int2(c->ph_rng_x, c->ph_rng_y);
+                }
+            } else if (tn == q) {
                 if (flip) {
                     int ev = it->entering_var;
                     double nv = it->entering_new_val;
@@ -3956,7 +3979,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                             ba = 0.0;
                             for (int b = 0; b < v.nbands; ++b) ba += v.band_part[(size_t)b * (size_t)v.n + t].x;
                         } else if (pull_inside) {
-                            ba = my_slot >= 0 ? s_ta[my_slot] : 0.0;
+                            ba = slot_t >= 0 ? s_ta[slot_t] : 0.0;
                         } else {
                             ba = v.alpha_r[q];
                         }
@@ -3996,8 +4019,8 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                     ar = s1;  // (row_coeffs / the PSE helper are not materialised on this path: nothing reads them — the
                     hp = s2;  // host-paced stepping API, which exposes them, keeps the separate combine kernel)
                 } else if (pull_inside) {
-                    ar = my_slot >= 0 ? s_ta[my_slot] : 0.0;
-                    hp = my_slot >= 0 ? s_th[my_slot] : 0.0;
+                    ar = slot_t >= 0 ? s_ta[slot_t] : 0.0;
+                    hp = slot_t >= 0 ? s_th[slot_t] : 0.0;
                 } else {
                     ar = v.alpha_r[tn];
                     if (use_pse) hp = v.helper[tn];
@@ -4777,8 +4800,8 @@ __global__ void __launch_bounds__(BLK) k_row_pull(DevView v, int n_pull) {
     }
 }
 
-#include "primal_head.inc"  // small-nucleus primal iteration: FTRAN + Harris test + BTRAN + inverse update + touched columns in ONE workgroup
 #include "hyper.inc"  // the hypersparse single-workgroup iteration (uses the stage helpers above)
+#include "primal_head.inc"  // small-nucleus primal iteration: FTRAN + Harris test + BTRAN + inverse update + touched columns in ONE workgroup (uses hyper.inc's DPP reductions)
 #include "factor.inc"  // the compact factor of the basis: peel, level-scheduled solves, additive eta terms
 #include "inverse.inc"  // blocked in-place inversion of a dense-filling nucleus (the refactorisation of the explicit inverse)
 
@@ -5034,13 +5057,13 @@ bool primal_head_supported(const DevView& dv, const Geom& g) {
            dv.hy_stamp_p && dv.str_list;
 }
 int primal_head_kmax(int longest_column) {
-    if (longest_column <= 0 || longest_column > HEAD_CAP) return 0;
+    if (longest_column <= 0 || longest_column > PH_COL_MAX) return 0;  // (every nucleus column sits in the registers of 16 lanes)
     const int by_list = PH_AQ_CAP / longest_column - 1;  // supp(alpha_q) <= (k + 1) columns' worth of rows
     return by_list < PH_KMAX ? by_list : PH_KMAX;
 }
 void launch_primal_head(const DevView& dv, const Geom& g, hipStream_t st) {
-    (void)g;
-    LAUNCH_T(2, k_primal_head, dim3(1), dim3(PH_T), 0, st, dv);
+    // (the touched columns as a LIST only when k_row_pull follows; the update kernel that pulls them itself reads the stamps)
+    LAUNCH_T(2, k_primal_head, dim3(1), dim3(PH_T), 0, st, dv, update_pulls_inside(dv, g) ? 0 : 1, head_applies(dv, g) ? 1 : 0);
 }
 void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st) {
     hipLaunchKernelGGL(k_init_nb_rng, dim3(blocks_for(g.n)), dim3(BLK), 0, st, dv);
@@ -5278,7 +5301,12 @@ bool update_pulls_inside(const DevView& dv, const Geom& g) {
     const char* e = std::getenv("MLP_PULL_INSIDE");
     if (e && e[0] == '0') return false;
     const int t = g.m > g.n ? g.m : g.n;
-    return primal_head_supported(dv, g) && blocks_for(t) <= 2048 && dv.hy_stamp_n != nullptr;  // one position per thread
+    return primal_head_supported(dv, g) && blocks_for(t, BLK * 4) <= 2048 && dv.hy_stamp_n != nullptr;  // at most four positions per thread
+}
+bool head_applies(const DevView& dv, const Geom& g) {  // ... and the head applies the basic side and position q itself (the update kernel: non-basic side only)
+    const char* e = std::getenv("MLP_HEAD_APPLY");
+    if (e && e[0] == '0') return false;
+    return update_pulls_inside(dv, g) && dv.nb_order == nullptr && dv.pk_valid == nullptr;
 }
 void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_dse, int use_pse, hipStream_t st, int inline_comb,
                          int with_struct, int pull_inside) {
@@ -5288,7 +5316,9 @@ void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_ds
     // one position per thread: measured against 4 per thread (a quarter of the blocks and tickets) the longer per-thread
     // chain of band-partial loads costs more than the tickets save (109.0 vs 104.3 us per pivot); the kernel strides
     // only beyond 512 * 4 * 256 positions
-    const int n_upd = blocks_for(t) <= 2048 ? blocks_for(t) : 2048;
+    int n_upd = blocks_for(t) <= 2048 ? blocks_for(t) : 2048;
+    if (pull_inside == 2) n_upd = blocks_for(g.n, BLK * 4);       // non-basic side only, four positions per thread (k_update_pivot: UPT)
+    else if (pull_inside) n_upd = blocks_for(t, BLK * 4);
     hipLaunchKernelGGL(k_update_pivot, dim3(n_upd + (with_struct ? blocks_for(g.cap) : 0)), dim3(BLK), 0, st, dv, phase, use_dse, use_pse,
                        inline_comb, n_upd, pull_inside);
 }

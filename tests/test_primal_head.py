@@ -29,10 +29,18 @@ def _solve(lp, **kw):
     return s, int(s.state("primal_head_launches")[0])
 
 
+FORMS = {"head + k_row_pull + update": {"MLP_PULL_INSIDE": "0"},
+         "head + update that pulls the tableau row": {"MLP_PULL_INSIDE": "1", "MLP_HEAD_APPLY": "0"},
+         "head that applies the basic side + update of the non-basic side": {"MLP_PULL_INSIDE": "1", "MLP_HEAD_APPLY": "1"}}
+
+
+@pytest.mark.parametrize("form", list(FORMS), ids=list(FORMS))
 @pytest.mark.parametrize("fam,args", CASES, ids=str)
-def test_head_takes_the_pivots_of_the_launches_it_replaces_and_of_the_oracle(monkeypatch, fam, args):
+def test_head_takes_the_pivots_of_the_launches_it_replaces_and_of_the_oracle(monkeypatch, fam, args, form):
     monkeypatch.setenv("MLP_HYPER", "0")
     monkeypatch.setenv("MLP_DETERMINISTIC", "0")   # pushed F products, as on models beyond 2^21 non-zeros
+    for k_, v_ in FORMS[form].items():
+        monkeypatch.setenv(k_, v_)
     lp = GEN[fam](*args)
     monkeypatch.setenv("MLP_PRIMAL_HEAD", "1")
     s1, n1 = _solve(lp)

@@ -19,7 +19,8 @@ R = int(sys.argv[3]) if len(sys.argv) > 3 else 7
 lp = lpgen.gen_sparse_lp(100000, 100000, 100, 4)
 prob = lpgen.build_problem(M.Problem, lp)
 FORMS = [("five launches", {"MLP_PRIMAL_HEAD": "0"}), ("head + pull + update", {"MLP_PRIMAL_HEAD": "1", "MLP_PULL_INSIDE": "0"}),
-         ("head + update(pull inside)", {"MLP_PRIMAL_HEAD": "1", "MLP_PULL_INSIDE": "1"})]
+         ("head + update(pull inside)", {"MLP_PRIMAL_HEAD": "1", "MLP_PULL_INSIDE": "1", "MLP_HEAD_APPLY": "0"}),
+         ("head(applies) + update(n side)", {"MLP_PRIMAL_HEAD": "1", "MLP_PULL_INSIDE": "1", "MLP_HEAD_APPLY": "1"})]
 traces = {}
 for name, env in FORMS:
     for k_, v_ in env.items():
