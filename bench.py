@@ -71,7 +71,7 @@ def pmc_traffic(a, which):
     MI355X_MICROARCH.md prescribes and as tools/pmc_calib.sh confirms).  PMC counters cannot be
     collected from inside the timed run, so the figure is the committed per-launch average; null when
     the workload differs from the profiled one."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             doc = json.load(open(os.path.join(ROOT, "profiles", name)))
         except OSError:
@@ -171,13 +171,17 @@ KERNEL_NAMES = {
               "steepest edge (solver.rs:1114).  Nucleus of a few dozen columns: k_small_basis (BTRAN, the pass with the eta update, the v "
               "tail and the touched-column list in one launch); small nucleus: k_fused_w (one read + one write, the eta update rides along); large "
               "nucleus: k_stream_w (read-only).  tau = B^-1 rho (solver.rs:1157) is skipped in primal pivots (lazy dual steepest edge)"),
+    "primal_head": ("k_primal_head (small nucleus: FTRAN + Harris test + BTRAN + v = B^-T alpha_q with the eta update of W + touched columns + "
+                    "partition change + basic side of the pivot in ONE workgroup; a latency chain, not a stream: the byte figure of this entry is "
+                    "the 16 k^2 of the W walk it contains)"),
     "fold": "k_fold_w (fold of the pending rank-1 terms into the nucleus inverse, every 32 pivots: read + write)",
     "dense_ftran": ("dense-rhs FTRAN x_B = B^-1 (b - N x_N) of the polish step (solver.rs:1177-1197): one streaming read of the nucleus "
                     "inverse through k_stream_w's tau side, x_K = W r_K"),
     "sweep_band": ("k_sweep_band (tableau row rho^T N [+ PSE helper]: band-major copy of A, the band of (rho, v) held in "
                    "LDS; per-band partials summed in band order by k_update_pivot)"),
     "sweep": "k_sweep (tableau row rho^T N [+ PSE helper] as a CSC pull over A)",
-    "ftran": "k_ftran_prep + k_ftran_gather (+ F push): alpha_q = B^-1 a_q, the listed columns of the nucleus inverse",
+    "ftran": ("alpha_q = B^-1 a_q, the listed columns of the nucleus inverse: k_ftran_gather_lrh (head inside the gather) + F push in the large-nucleus "
+              "windows; in the driver-timed window the FTRAN is the first stages of k_primal_head and this entry times the whole head"),
 }
 
 
@@ -586,8 +590,14 @@ def main():
         if "update" in kern and ("sweep" in kern or "row_sparse" in kern):
             pricing_us = kern["sweep" if "sweep" in kern else "row_sparse"]["avg_us"] + kern["update"]["avg_us"]
         roofline = None
+        try:
+            head_iters = int(s.state("primal_head_launches")[0])
+        except Exception:
+            head_iters = 0
         if dom:
             which = ("sweep_band" if st.get("banded_sweep") else "sweep") if dom == "sweep" else dom
+            if dom == "fused" and head_iters > 0:
+                which = "primal_head"
             traffic, traffic_src = pmc_traffic(a, dom) if world == 1 else (None, None)  # the PMC figure is the unsharded kernel's
             roofline = dict(bound="hbm", kernel=KERNEL_NAMES[which], achieved=kern[dom]["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=kern[dom]["frac"], traffic=traffic, traffic_measured=("committed:profiles/" + traffic_src) if traffic else None,

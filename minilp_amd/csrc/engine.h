@@ -408,7 +408,7 @@ private:
     bool reduced_costs_feasible();
     bool cold_start_ = true;  // the solve started from the slack basis / a loaded basis (try_new, load_basis); add_constraint, fix_var ... clear it:
                               // warm-start re-solves are short and keep the lazy capture policy
-    int graph_iters = 8;  // MLP_GRAPH_ITERS: iterations per graph once a geometry has run for a while (1 = off)
+    int graph_iters = 10;  // (round 5: 8 -> 10: the driver's 20-pivot window is two graphs) MLP_GRAPH_ITERS: iterations per graph once a geometry has run for a while (1 = off)
     // graph slots: [0] one iteration per graph, [1] graph_iters iterations per graph (long runs)
     hipGraphExec_t gexec[2][2][2] = {};
     hipGraph_t ggraph[2][2][2] = {};

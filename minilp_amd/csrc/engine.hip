@@ -1350,13 +1350,17 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     case STAGE_FTRAN:
         if (with_events) HIPCHECK(hipEventRecord(ev[6], st));
         if (phead) {
+            if (with_events) arm_kernel_timing(2, ev[2], ev[3]);  // (sampled iteration: the head is timed kernel-exactly in the slot of the pass over W, which it contains)
             launch_primal_head(dv, g, st);
+            if (with_events) arm_kernel_timing(2, nullptr, nullptr);
             touch_done = true;
             if (with_events) HIPCHECK(hipEventRecord(ev[7], st));
             break;
         }
         if (phase == 0 && g.head_fused) {
             launch_ftran_fused(dv, g, 1, st);              // K2 head inside the gather kernel (one launch)
+        } else if (phase == 0 && !stepping && max_col_nnz_ <= HEAD_LIST_CAP && ftran_head_rides_gather(dv, g)) {
+            launch_ftran_gather_lrh(dv, g, st, (vbr || tkr) ? 1 : 0);  // delayed-update mode: the head inside the gather too (round 5)
         } else {
             if (phase == 0) launch_ftran_prep(dv, 1, st);  // K2 head: entering column scalars, singleton rows, list
             launch_ftran_gather(dv, g, st, (vbr || tkr) ? 1 : 0);   // K2: alpha_q = B^-1 a_q (dual: the head ran in RATIO); v branch / t_K ride: + y_S by row

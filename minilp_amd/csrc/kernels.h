@@ -352,7 +352,10 @@ void launch_price_primal(const DevView& dv, const Geom& g, int use_pse, hipStrea
 void launch_price_dual(const DevView& dv, const Geom& g, int use_dse, hipStream_t st);    // standalone K6
 void launch_ftran_prep(const DevView& dv, int derive_primal, hipStream_t st);             // FTRAN head (one wave)
 void launch_ftran_gather(const DevView& dv, const Geom& g, hipStream_t st, int ys = 0);               // alpha_q = B^-1 a_q
-void launch_ftran_fused(const DevView& dv, const Geom& g, int derive_primal, hipStream_t st);   // FTRAN head + gather in one launch (Geom.head_fused)
+void launch_ftran_fused(const DevView& dv, const Geom& g, int derive_primal, hipStream_t st);
+// delayed-update mode (large nucleus), primal iteration, one GPU: head + gather (+ blocked push) without the one-wave launch in front
+bool ftran_head_rides_gather(const DevView& dv, const Geom& g);
+void launch_ftran_gather_lrh(const DevView& dv, const Geom& g, hipStream_t st, int ys = 0);   // FTRAN head + gather in one launch (Geom.head_fused)
 void launch_btran_fused(const DevView& dv, const Geom& g, int with_rhs, int derive_dual, hipStream_t st);  // BTRAN head + gather (dual iteration)
 constexpr int HEAD_LIST_CAP = 1024;  // entries an in-kernel stage head can hold (longest column / row of A)
 void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st, int tk_ride = 0);  // K5 p1 (+alpha_sq, y_S), p2 (+BTRAN head, plan) [| t_K blocks]

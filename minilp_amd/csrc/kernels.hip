@@ -2110,6 +2110,137 @@ __device__ void ftran_head_lds(const DevView& v, Ctl* c, int lane, int derive_pr
         if (primary) it->klist_n = cnt;
     }
 }
+// The FTRAN head of the DELAYED-UPDATE mode inside the gather (round 5): k_ftran_prep was a launch of ONE wave in front of
+// k_ftran_gather<4> — 9.0 us of launch floor and a five-deep chain of dependent loads per late pivot (profiles/r04e_late_kernel_stats.csv).
+// Here every block of the gather runs the head for itself into LDS — the entering column is ~100 entries, the row map and the 32
+// pending V rows are L2-resident — and block 0 alone performs the global side effects (pivot scalars, fold decision, entries on
+// singleton rows, the list and the coefficients c_j = V[j] . list for the records and the tails).  Same list order, same sums: the
+// bits of k_ftran_prep + k_ftran_gather<4>.  Primal iteration, blocked push, one GPU.
+__global__ void __launch_bounds__(BLK) k_ftran_gather_lrh(DevView v) {
+    Ctl* c = v.ctl;
+    if (c->halt || c->it.status != ITER_PIVOT) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) c->side_go = 0;
+        return;
+    }
+    KMARK0(c, 0);
+    __shared__ int s_ls[HEAD_CAP];
+    __shared__ double s_la[HEAD_CAP];
+    __shared__ double s_lrc[LR_MAX];
+    __shared__ int s_n;
+    const bool primary = blockIdx.x == 0;
+    const int nlow = c->nlow;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        IterState* it = &c->it;
+        const int q = it->q;
+        const int var = v.nb_vars[q];
+        if (primary && lane == 0) {
+            c->side_go = 1;
+            it->entering_var = var;
+            const double dq = v.d[q];  // solver.rs:741-748
+            it->sign = dq < 0.0;
+            it->entering_cur = v.xN[q];
+            it->entering_other = (dq < 0.0) ? v.var_hi[var] : v.var_lo[var];
+            it->r = -1;
+            it->leaving_var = -1;
+            c->fold = nlow >= v.lrJ ? 1 : 0;  // (decided ahead of everything that reads W0)
+        }
+        const int base = v.csc_ptr[var], end = v.csc_ptr[var + 1];
+        int cnt = 0;
+        const double* Vrow = v.V + (size_t)(lane < nlow ? lane : 0) * v.ld;
+        double lr_acc = 0.0;
+        for (int e0 = base; e0 < end; e0 += 128) {  // (as ftran_prep_wave: two chunks of 64 entries per trip, their loads issued together)
+            int sx[2] = {-1, -1};
+            double ax[2] = {0.0, 0.0};
+            int ix[2];
+            bool vx[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = e0 + 64 * h + lane;
+                vx[h] = e < end;
+                ix[h] = vx[h] ? v.csc_row[e] : 0;
+                ax[h] = vx[h] ? v.csc_val[e] : 0.0;
+            }
+            RowInfo rx[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) rx[h] = v.rowinfo[ix[h]];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (vx[h]) {
+                    sx[h] = rx[h].kslot;
+                    if (sx[h] < 0 && primary) v.alpha_q[rx[h].pos] = ax[h] / rx[h].diag;
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h == 1 && e0 + 64 >= end) break;  // (uniform)
+                const int s = sx[h];
+                const double a = ax[h];
+                const bool isk = vx[h] && s >= 0;
+                const unsigned long long mask = __ballot(isk);
+                if (isk) {
+                    const int off = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (off < HEAD_CAP) {
+                        s_ls[off] = s;
+                        s_la[off] = a;
+                    }
+                    if (primary) {
+                        v.klist_s[off] = s;
+                        v.klist_a[off] = a;
+                    }
+                }
+                cnt += __popcll(mask);
+                if (nlow > 0) lr_dot_listed(mask, s, a, Vrow, lane < nlow, lr_acc);
+            }
+        }
+        if (lane == 0) {
+            s_n = cnt < HEAD_CAP ? cnt : HEAD_CAP;
+            if (primary) it->klist_n = cnt;
+        }
+        if (lane < LR_MAX) s_lrc[lane] = lane < nlow ? lr_acc : 0.0;
+        if (primary && lane < nlow) c->lr_c[lane] = lr_acc;
+    }
+    __syncthreads();
+    const int slot = (blockIdx.x * BLK + threadIdx.x) / 4;
+    const int gl = threadIdx.x & 3;
+    if (slot >= c->k) return;
+    const int n = s_n;
+    double acc = 0.0;
+    const double* wrow = v.W + (size_t)slot * v.ld;
+    for (int j0 = gl; j0 < n; j0 += 16) {  // (k_ftran_gather<4>: the lane's loads of a trip issued together, added in list order)
+        double a[4], w[4];
+        int si[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 4 * u;
+            a[u] = j < n ? s_la[j] : 0.0;
+            si[u] = j < n ? s_ls[j] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = j0 + 4 * u < n ? wrow[si[u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j0 + 4 * u < n) acc += a[u] * w[u];
+    }
+    {
+        double e[LR_MAX / 4], x[LR_MAX / 4];
+#pragma unroll
+        for (int u = 0; u < LR_MAX / 4; ++u) {
+            const int j = gl + 4 * u;
+            e[u] = j < nlow ? s_lrc[j] : 0.0;
+            x[u] = j < nlow ? v.U[(size_t)j * v.ld + slot] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < LR_MAX / 4; ++u)
+            if (gl + 4 * u < nlow) acc += x[u] * e[u];
+    }
+    acc = group_sum<4>(acc);
+    const int p = v.pos_of_kslot[slot];
+    if (gl == 0) {
+        v.aK[slot] = acc;
+        v.alpha_q[p] = acc;
+    }
+}
 template <int G>
 __global__ void __launch_bounds__(BLK) k_ftran_fused(DevView v, int derive_primal) {
     Ctl* c = v.ctl;
@@ -4853,6 +4984,15 @@ void launch_btran_fused(const DevView& dv, const Geom& g, int with_rhs, int deri
     } while (0)
     LANES_SWITCH(g.lanes, BTRANF(4), BTRANF(16), BTRANF(64));
 #undef BTRANF
+}
+bool ftran_head_rides_gather(const DevView& dv, const Geom& g) {  // delayed-update mode: the FTRAN head inside the gather (k_ftran_gather_lrh)
+    const char* e = std::getenv("MLP_LR_HEAD_FUSION");
+    if (e && e[0] == '0') return false;
+    return dv.lrJ > 0 && dv.pb_on && dv.world <= 1 && !g.fac && !dv.det_pull && dv.rowinfo != nullptr;
+}
+void launch_ftran_gather_lrh(const DevView& dv, const Geom& g, hipStream_t st, int ys) {
+    hipLaunchKernelGGL(k_ftran_gather_lrh, dim3(blocks_for((long)g.cap * 4)), dim3(BLK), 0, st, dv);
+    launch_blocked_push(dv, 0, st, ys);
 }
 void launch_ftran_gather(const DevView& dv, const Geom& g, hipStream_t st, int ys) {
     // (delayed-update mode with the blocked push: nothing after the gather needs the lanes of a slot — four lanes per slot)

@@ -113,3 +113,22 @@ def test_stream_strip_geometry_does_not_change_the_pivots(balanced):
     finally:
         for k in env:
             os.environ.pop(k, None)
+
+
+def test_ftran_head_inside_the_gather_is_bit_identical_to_the_one_wave_launch(monkeypatch):
+    """Round 5: in the delayed-update mode the FTRAN head (entering column's scalars, fold decision, singleton entries, list, c_j = V[j] . list)
+    runs inside every block of the gather (k_ftran_gather_lrh) instead of as a one-wave launch in front of it (k_ftran_prep +
+    k_ftran_gather<4>).  Same list order, same sums: with the deterministic blocked push the two solves agree bit for bit — trace,
+    objective, values — and take the oracle's pivots."""
+    for k_, v_ in dict(MLP_LOWRANK="3", MLP_BIGTILE="1", MLP_LDPAD="16", MLP_BANDED="1", MLP_STR_K="0", MLP_PB_DET="1", MLP_HYPER="0").items():
+        monkeypatch.setenv(k_, v_)
+    lp = lpgen.gen_sparse_lp(900, 800, 12, 5)
+    runs = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("MLP_LR_HEAD_FUSION", on)
+        s = lpgen.build_problem(M.Problem, lp).solve(trace=True)
+        runs.append((s.trace(), s.objective(), s.values().tobytes()))
+    so = lpgen.build_problem(O.Problem, lp).solve(trace=True)
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
+    assert [t[:5] for t in runs[0][0]] == [t[:5] for t in so.trace()]
+    assert obj_close(runs[0][1], so.objective())
