@@ -2610,7 +2610,12 @@ void Engine::add_constraint(Constraint c) {
     cold_start_ = false;  // a warm-start re-solve: short, lazy graph capture
     double t0 = now_s();
     if (!primal_feasible || !dual_feasible) throw MlpError(-1, "add_constraint: model not solved (solver.rs:555-556)");
-    if (fac_on_) fac_leave();  // (a new row changes every per-row array of the factor: warm starts run on the explicit inverse)
+    // Round 5: the compact factor SURVIVES a new row.  The new slack is a column singleton on the new row — the first level of the peel,
+    // whatever else the row holds — so the factor of the extended basis is one more refactorisation (a re-peel of the current basis,
+    // ~1 ms: BasisSolver::reset is what the reference does here too, solver.rs:612-613), not a return to the explicit inverse (which
+    // the models this representation exists for cannot even allocate).  The pending rank-1 terms are by position / by row of the OLD
+    // size: the re-peel starts from the current basis and drops them.
+    const bool on_factor = fac_on_;
     ensure_beta();
     if (c.idx.empty()) {
         bool taut = c.op == 0 ? (0.0 == c.rhs) : c.op == 1 ? (0.0 <= c.rhs) : (0.0 >= c.rhs);
@@ -2673,7 +2678,9 @@ void Engine::add_constraint(Constraint c) {
     view_dirty = true;
     sync_view();
     launch_init_nb_rng(hview, geom(), st);
-    if (touches_basic_singleton) rebuild_inverse();  // a singleton column just gained an entry
+    if (on_factor) {
+        if (!fac_refactor()) fac_leave();  // (the extended basis no longer peels within the bump limit: explicit inverse, as before)
+    } else if (touches_basic_singleton) rebuild_inverse();  // a singleton column just gained an entry
 
     if (enable_pse || enable_dse) {  // solver.rs:615-630: last tableau row feeds the edge norms
         calc_row_coeffs(m_ - 1, enable_pse);

@@ -201,7 +201,7 @@ def test_stepped_stages_on_the_compact_factor_satisfy_the_defining_equations(mon
 
 def test_clone_fix_and_unfix_on_the_compact_factor(monkeypatch):
     """Solution::clone re-peels the same basis; fix_var / unfix_var (solver.rs:378-438) run their forced dual pivot and the
-    re-solves on the factor; add_constraint (a new row) goes back to the explicit inverse."""
+    re-solves on the factor; add_constraint (a new row) re-peels the extended basis and stays on the factor (round 5)."""
     monkeypatch.setenv("MLP_FACTOR", "1")
     lp = lpgen.gen_transport_lp(400, 500, 4, 23, tight=0.5)
     so = lpgen.build_problem(O.Problem, lp).solve()
@@ -221,5 +221,35 @@ def test_clone_fix_and_unfix_on_the_compact_factor(monkeypatch):
     k = int(np.argsort(x)[-2])
     sg2 = sg.add_constraint([(j, 1.0), (k, 1.0)], lpgen.LE, 0.7 * (x[j] + x[k]))
     so2 = so.add_constraint([(j, 1.0), (k, 1.0)], lpgen.LE, 0.7 * (x[j] + x[k]))
-    assert sg2.stats()["factor_active"] == 0
+    assert sg2.stats()["factor_active"] == 1   # (round 5: a new row is one more refactorisation, not a return to the explicit inverse)
     assert obj_close(sg2.objective(), so2.objective())
+
+
+def test_cutting_plane_loop_stays_on_the_compact_factor(monkeypatch):
+    """Solution::add_constraint (lib.rs:368 -> solver.rs:549-634) twelve times on a transport instance held as the compact factor:
+    every cut extends the factor by a re-peel of the extended basis (the new slack is a column singleton on the new row: level 1),
+    the dual re-solve runs on it, and objective, feasibility and the re-solve's pivots match the oracle after every cut; the
+    explicit inverse is never built (factor_active stays 1, no mode switch beyond the first)."""
+    monkeypatch.setenv("MLP_FACTOR", "1")
+    lp = lpgen.gen_transport_lp(1500, 2000, 4, 31, tight=0.5)
+    so = lpgen.build_problem(O.Problem, lp).solve(trace=True)
+    sg = lpgen.build_problem(M.Problem, lp).solve(trace=True)
+    assert sg.stats()["factor_active"] == 1 and obj_close(sg.objective(), so.objective())
+    switches0 = sg.stats()["factor_switches"]
+    rng = np.random.default_rng(5)
+    for cut in range(12):
+        x = np.asarray(so.values())
+        nzs = np.flatnonzero(x > 1e-9)
+        pick = rng.choice(nzs, size=min(4, len(nzs)), replace=False)
+        coef = rng.uniform(0.5, 1.5, size=len(pick))
+        rhs = 0.8 * float(coef @ x[pick])
+        terms = [(int(j), float(a)) for j, a in zip(pick, coef)]
+        no, ng = len(so.trace()), len(sg.trace())
+        so = so.add_constraint(terms, lpgen.LE, rhs)
+        sg = sg.add_constraint(terms, lpgen.LE, rhs)
+        assert sg.stats()["factor_active"] == 1, cut
+        assert obj_close(sg.objective(), so.objective()), (cut, sg.objective(), so.objective())
+        assert [t[:5] for t in sg.trace()[ng:]] == [t[:5] for t in so.trace()[no:]], cut
+        xg = np.asarray(sg.values())
+        assert float(np.dot(coef, xg[pick])) <= rhs + 1e-7
+    assert sg.stats()["factor_switches"] == switches0
