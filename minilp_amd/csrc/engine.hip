@@ -978,7 +978,12 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name, const ch
     if (world < 1 || world > MAX_WORLD || rank < 0 || rank >= world)
         throw MlpError(-1, "enable_sharding: bad rank/world (at most " + std::to_string(MAX_WORLD) + " ranks)");
     HIPCHECK(hipStreamSynchronize(st));
-    if (fac_on_ && world > 1) fac_leave();  // (the compact factor is a one-GPU representation)
+    // The compact factor stays a one-GPU representation.  Round 5 tried it under sharding (solves replicated on every rank in fixed-order
+    // sums, the column-block kernels for the rest): pivot for pivot identical to the unsharded run — and 3.9 s per pivot with two ranks on
+    // the one GPU of the test box: k_fac_solve is a persistent kernel with grid barriers, one workgroup per CU, and two of them from two
+    // processes time-slice the device while each one's peers wait in a mailbox spin (40 pivots ran into the spin bound).  On distinct
+    // devices that contention does not exist, but no multi-GPU node was available to verify it, so the switch is not shipped untested.
+    if (fac_on_ && world > 1) fac_leave();
     release_mailboxes();
     std::string tname = transport_name ? transport_name : "";
     if (tname.empty() && std::getenv("MLP_TRANSPORT")) tname = std::getenv("MLP_TRANSPORT");

@@ -22,7 +22,10 @@ def worker(rank, world, port, m, n, k, pivots, out, family="sparse"):
     from minilp_amd import lpgen
     ndev = M.device_count()
     M.set_device(rank if ndev >= world else 0)   # distinct devices whenever the box has them
-    lp = lpgen.gen_cover_lp(m, n, k, 4) if family == "cover" else lpgen.gen_sparse_lp(m, n, k, 4)
+    if family == "transport":   # network with gains (m supplies, n demands, k arcs per demand node): the compact factor's family
+        lp = lpgen.gen_transport_lp(m, n, k, 4, tight=0.5)
+    else:
+        lp = lpgen.gen_cover_lp(m, n, k, 4) if family == "cover" else lpgen.gen_sparse_lp(m, n, k, 4)
     p = lpgen.build_problem(M.Problem, lp)
     blob = None
     if family.startswith("basis="):   # continue from a committed mid-solve basis (config-4 size: tests/golden/cfg4_basis_p*.bin.gz)
@@ -49,7 +52,7 @@ def worker(rank, world, port, m, n, k, pivots, out, family="sparse"):
             ref = p.solve(budget=pivots, trace=True)
         rtr = [t[:5] for t in ref.trace()]
         ok = all(g["trace"] == rtr for g in gathered)
-        print("transport:", transport, "| devices visible:", ndev, flush=True)
+        print("transport:", transport, "| devices visible:", ndev, "| factor active on rank 0:", int(ref.stats()["factor_active"]), flush=True)
         print("sharded world=%d: pivots=%s obj=%s dt=%s | unsharded pivots=%d obj=%.12g | traces identical: %s" % (
             world, [g["n"] for g in gathered], ["%.12g" % g["obj"] for g in gathered], ["%.3f" % g["dt"] for g in gathered],
             len(rtr), ref.objective(), ok), flush=True)
