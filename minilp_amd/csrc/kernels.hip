@@ -5456,7 +5456,12 @@ void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_ds
     // one position per thread: measured against 4 per thread (a quarter of the blocks and tickets) the longer per-thread
     // chain of band-partial loads costs more than the tickets save (109.0 vs 104.3 us per pivot); the kernel strides
     // only beyond 512 * 4 * 256 positions
-    int n_upd = blocks_for(t) <= 2048 ? blocks_for(t) : 2048;
+    // positions per thread: one up to 512 workgroups (measured against 2 and 4 on config 4, mid / late windows: 244.1 / 244.7 / 248.2 and 663.3 /
+    // 664.0 / 667.8 us per pivot), beyond that as many as keep the grid within 512 (the 400 000-column transport instance: 164.6 / 156.2 /
+    // 154.0 us per pivot at 1 / 2 / 4 — 1 563 workgroups queue on the ticket and the launch ramp); MLP_UPDATE_PT forces a value (A/B runs)
+    static const int upd_pt_env = std::getenv("MLP_UPDATE_PT") ? std::max(1, std::min(8, std::atoi(std::getenv("MLP_UPDATE_PT")))) : 0;
+    const int upd_pt = upd_pt_env > 0 ? upd_pt_env : std::max(1, std::min(8, (blocks_for(t) + 511) / 512));
+    int n_upd = blocks_for(t, BLK * upd_pt) <= 2048 ? blocks_for(t, BLK * upd_pt) : 2048;
     if (pull_inside == 2) n_upd = blocks_for(g.n, BLK * 4);       // non-basic side only, four positions per thread (k_update_pivot: UPT)
     else if (pull_inside) n_upd = blocks_for(t, BLK * 4);
     hipLaunchKernelGGL(k_update_pivot, dim3(n_upd + (with_struct ? blocks_for(g.cap) : 0)), dim3(BLK), 0, st, dv, phase, use_dse, use_pse,
