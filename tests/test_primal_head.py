@@ -97,3 +97,29 @@ def test_config4_shape_first_pivots_against_the_oracle():
     assert n >= 20, n
     assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
     assert obj_close(sg.objective(), so.objective())
+
+
+@pytest.mark.parametrize("form", list(FORMS), ids=list(FORMS))
+def test_bound_flips_and_boxed_columns_through_the_head(monkeypatch, form):
+    """Finite upper bounds on a third of the columns (tight enough that the Harris test often ends in a BOUND FLIP, solver.rs:846-851,
+    1031-1042) and a few columns with free lower bounds: the head's no-winner branch (flip applied by the head itself in the applying
+    form: x_B on supp(alpha_q), x_N and the flags of the entering column), entering columns coming from their upper bound
+    (entering_diff_sign, solver.rs:741-748) and the leaving variable's at-max flag — pivot for pivot with the oracle."""
+    monkeypatch.setenv("MLP_HYPER", "0")
+    monkeypatch.setenv("MLP_DETERMINISTIC", "0")
+    for k_, v_ in FORMS[form].items():
+        monkeypatch.setenv(k_, v_)
+    lp = lpgen.gen_sparse_lp(900, 800, 12, 17)
+    rng = np.random.default_rng(3)
+    hi = lp["hi"].copy()
+    boxed = rng.random(len(hi)) < 0.35
+    hi[boxed] = rng.uniform(0.02, 0.6, size=int(boxed.sum()))
+    lp = dict(lp, hi=hi, name=lp["name"] + "_boxed")
+    so = lpgen.build_problem(O.Problem, lp).solve(trace=True)
+    sg, n = _solve(lp)
+    st = sg.stats()
+    assert n > 0 and st["bound_flips"] > 0, (n, st["bound_flips"])
+    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+    assert obj_close(sg.objective(), so.objective())
+    assert np.abs(np.asarray(sg.values()) - np.asarray(so.values())).max() <= X_ATOL
+    print(f"{form}: {len(sg.trace())} pivots, {st['bound_flips']} bound flips, {n} through k_primal_head")

@@ -17,7 +17,15 @@ ENVS = [{}, {"MLP_LOWRANK": "3", "MLP_BIGTILE": "1", "MLP_LDPAD": "16", "MLP_BAN
         {"MLP_LOWRANK": "16", "MLP_BIGTILE": "1", "MLP_LDPAD": "16", "MLP_BANDED": "1"},
         {"MLP_BANDED": "1", "MLP_ORDER_FROM": "0", "MLP_ORDER_EVERY": "5"},
         {"MLP_BANDED": "1", "MLP_ORDER_FROM": "0", "MLP_ORDER_EVERY": "64", "MLP_LOWRANK": "8", "MLP_BIGTILE": "1"},
-        {"MLP_BANDED": "1", "MLP_ORDER_FROM": "3", "MLP_ORDER_EVERY": "11", "MLP_SWEEP_PACKED": "0"}]
+        {"MLP_BANDED": "1", "MLP_ORDER_FROM": "3", "MLP_ORDER_EVERY": "11", "MLP_SWEEP_PACKED": "0"},
+        # round 5: pushed F products forced on small models, so that the small-nucleus primal head (and its three forms) takes pivots
+        {"MLP_DETERMINISTIC": "0", "MLP_HYPER": "0"},
+        {"MLP_DETERMINISTIC": "0", "MLP_HYPER": "0", "MLP_HEAD_APPLY": "0"},
+        {"MLP_DETERMINISTIC": "0", "MLP_HYPER": "0", "MLP_PULL_INSIDE": "0"},
+        {"MLP_DETERMINISTIC": "0", "MLP_PRIMAL_HEAD_K": "5"},
+        {"MLP_DETERMINISTIC": "0", "MLP_HYPER": "0", "MLP_GRAPH_ITERS": "3", "MLP_RATIO_ONE": "0"}]
+if os.environ.get("FUZZ_ENVS") == "head":   # only the round-5 configurations
+    ENVS = ENVS[-5:]
 bad = 0
 t0 = time.time()
 for case in range(n_cases):
@@ -36,7 +44,9 @@ for case in range(n_cases):
     else:
         lp = lpgen.gen_dense_lp(min(m, 150), min(n, 150), seed)
     env = ENVS[case % len(ENVS)]
-    for kk in ("MLP_LOWRANK", "MLP_BIGTILE", "MLP_LDPAD", "MLP_BANDED", "MLP_GRAPH_ITERS", "MLP_NO_GRAPH"):
+    for kk in ("MLP_LOWRANK", "MLP_BIGTILE", "MLP_LDPAD", "MLP_BANDED", "MLP_GRAPH_ITERS", "MLP_NO_GRAPH", "MLP_DETERMINISTIC", "MLP_HYPER",
+               "MLP_HEAD_APPLY", "MLP_PULL_INSIDE", "MLP_PRIMAL_HEAD_K", "MLP_RATIO_ONE", "MLP_STREAM_BALANCED", "MLP_ORDER_FROM", "MLP_ORDER_EVERY",
+               "MLP_SWEEP_PACKED"):
         os.environ.pop(kk, None)
     os.environ.update(env)
     try:
