@@ -176,6 +176,7 @@ public:
     void enable_sharding(int rank, int world, const char* shm_name, const char* transport_name = nullptr, const void* rccl_id = nullptr);
     static void rccl_unique_id(void* out128);
     bool sharded() const { return shard_world > 1; }
+    bool sharding_live() const { return shard_is_live(); }
 
     int num_vars = 0;
     int direction = 0;
@@ -357,6 +358,14 @@ private:
     void release_runtime();
     bool force_big_tiles = false;  // MLP_BIGTILE: use the large-nucleus tiling of the fused W pass at any size (tests)
     int shard_rank = 0, shard_world = 1;
+    // Round 5: DEFERRED sharding.  While the nucleus is small (the sparse-tableau-row regime, a few hundred pivots from the slack basis)
+    // a pivot is 40-60 us of latency-bound launches: two or three per-pivot exchanges over xGMI can only slow it down (measured,
+    // oversubscribed: 3 665 against 19 095 pivots/s).  Until the tableau row becomes a pass over A the ranks therefore run as
+    // bit-identical REPLICAS — the deterministic unsharded iteration on every rank, no exchange — and the column-block sharding goes
+    // live at the first batch that leaves that regime (never back).  MLP_SHARD_DEFER=0: sharded from the first pivot (protocol tests).
+    bool shard_defer_ = true;
+    bool shard_live_ = false;
+    bool shard_is_live() const { return shard_world > 1 && shard_live_; }
     MailRec* d_mail = nullptr;
     void* mail_host = nullptr;
     bool mail_registered = false;

@@ -532,12 +532,13 @@ DevView* Engine::sync_view() {
     v.pad4 = 0;
     v.str_list = d_str_list.p;
     v.aq_list = d_str_list.p ? d_str_list.p + (((size_t)num_vars + 63) & ~(size_t)63) : nullptr;
-    v.rank = shard_rank; v.world = shard_world; v.mail = d_mail;
+    const bool live = shard_is_live();  // (deferred sharding: until it goes live the kernels see one rank that owns every column)
+    v.rank = live ? shard_rank : 0; v.world = live ? shard_world : 1; v.mail = live ? d_mail : nullptr;
     for (int r = 0; r < MAX_WORLD; ++r) v.mail_peer[r] = reinterpret_cast<MailRec*>(peer_box[r]);
-    v.mail_fanout = shard_world > 1 ? mail_fanout : 0;
+    v.mail_fanout = live ? mail_fanout : 0;
     {   // exchange buffers of the row-sharded streaming pass (peer transport, large-nucleus delayed-update mode only)
         const size_t mb = kMailBoxBytesPerRank * (size_t)std::max(shard_world, 1);
-        v.wshard = (shard_world > 1 && mail_fanout > 1 && own_box && v.lrJ > 0 && geom().big && stream_strips_enabled() &&
+        v.wshard = (live && mail_fanout > 1 && own_box && v.lrJ > 0 && geom().big && stream_strips_enabled() &&
                     !no_wshard && (size_t)cap_ <= xb_cap_) ? 1 : 0;
         v.xbuf = own_box ? reinterpret_cast<double*>(static_cast<uint8_t*>(own_box) + mb) : nullptr;
         for (int r = 0; r < MAX_WORLD; ++r)
@@ -547,8 +548,8 @@ DevView* Engine::sync_view() {
     v.sw_nbal = 0; v.sw_pad = 0;
     if (sw_balanced && v.lrJ > 0 && geom().big && stream_strips_enabled())
         v.sw_nbal = sw_balanced > 1 ? sw_balanced : stream_coresident_blocks();
-    v.nb_lo = shard_world > 1 ? (int)((long)num_vars * shard_rank / shard_world) : 0;
-    v.nb_hi = shard_world > 1 ? (int)((long)num_vars * (shard_rank + 1) / shard_world) : num_vars;
+    v.nb_lo = live ? (int)((long)num_vars * shard_rank / shard_world) : 0;
+    v.nb_hi = live ? (int)((long)num_vars * (shard_rank + 1) / shard_world) : num_vars;
     if (std::memcmp(&old, &hview, sizeof(DevView)) != 0) {
         HIPCHECK(hipStreamSynchronize(st));
         drop_graphs();  // kernel arguments (the view, by value) are baked into the captured graphs
@@ -1102,6 +1103,7 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name, const ch
         throw;
     }
     shard_rank = rank; shard_world = world;
+    shard_live_ = true;  // (the handshake below runs through the live view; deferral is decided after it)
     view_dirty = true;
     // Handshake: before any pivot depends on it, every rank posts one record to every box and waits for all of them
     // with a short bound (~2 s).  A transport that maps but does not deliver (no peer-to-peer route, non-coherent
@@ -1125,8 +1127,15 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name, const ch
         // NOT freed here (release_mailboxes() runs at the next enable_sharding call or when the Solution goes away);
         // the view stops pointing at it at once.
         shard_rank = 0; shard_world = 1;
+        shard_live_ = false;
         view_dirty = true;
         throw;
+    }
+    {   // deferred sharding (engine.h): replicas until the tableau row becomes a pass over A; MLP_SHARD_DEFER=0 shards from the first pivot
+        const char* sd = std::getenv("MLP_SHARD_DEFER");
+        shard_defer_ = !(sd && sd[0] == '0');
+        shard_live_ = !(shard_defer_ && world > 1 && !pump_backend_);
+        view_dirty = true;
     }
 }
 
@@ -1341,7 +1350,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     // ... and for a nucleus of a few dozen columns the whole chain FTRAN -> ratio test -> BTRAN -> inverse update -> touched columns -> partition
     // change is ONE launch of one workgroup issued at the FTRAN stage (k_primal_head); the RATIO, BTRAN and BASIS stages are empty
     const bool phead = phase == 0 && pse && lazy && !stepping && shard_world == 1 && !vbr && !tau_branch && primal_head_supported(dv, g);
-    const bool smallb = !phead && phase == 0 && pse && lazy && !stepping && shard_world == 1 && !vbr && !tau_branch && small_basis_supported(dv, g);
+    const bool smallb = !phead && phase == 0 && pse && lazy && !stepping && !shard_is_live() && !vbr && !tau_branch && small_basis_supported(dv, g);
     // large nucleus, lazy primal iteration: t_K = alpha_K - F^T y_S rides in the ratio test's launch (blocks behind the ratio blocks);
     // the FTRAN's push combine leaves y_S by row, the BTRAN launch forms rho_K only.  MLP_TK_RIDE=0: t_K in the BTRAN launch.
     const bool tkr = phase == 0 && pse && lazy && !stepping && shard_world == 1 && !vbr && !smallb && !g.head_fused && !dv.pb_det && tk_rides_ratio(dv, g);
@@ -1775,6 +1784,10 @@ int Engine::run_loop(int phase) {
             // slack basis 55-57 us against 60-62 up to k = 72, 67.0 against 68.8 at k = 104, 78.9 against 77.9 at k = 120, 105
             // against 98 at k = 135 (tools/small_basis_curve.py) — so the form is chosen per batch by the size the nucleus can reach)
             sb_now = want && k_ + RING + 1 <= sb_kmax;
+            if (shard_world > 1 && !shard_live_ && !(shard_defer_ && want && !pump_backend_)) {
+                shard_live_ = true;  // the column-block sharding goes live (every rank takes this decision at the same pivot: k_ is replicated)
+                view_dirty = true;
+            }
             if (str_now) {
                 ensure_hyper();  // the epoch stamps
                 d_str_list.ensure((size_t)num_vars + (size_t)m_ + 192, 0, st);  // touched columns | positions of supp(alpha_q)
@@ -3158,6 +3171,8 @@ uint64_t Engine::state(const char* what, double* out, uint64_t cap) {
     else if (w == "small_basis_launches") {  // iterations that ran BTRAN + pass + v tail + touch as one launch (k_small_basis)
         pull_ctl();
         tmp = {(double)h_ctl->sb_count};
+    } else if (w == "shard_live") {
+        tmp = {(double)(shard_is_live() ? 1 : 0)};
     } else if (w == "primal_head_launches") {
         pull_ctl();
         tmp = {(double)h_ctl->ph_count};

@@ -227,3 +227,18 @@ def test_bench_refuses_more_ranks_than_gpus_without_the_override():
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert "refusing" in r.stderr
+
+
+@pytest.mark.parametrize("world,family,rows,cols", [(2, "sparse", "4000", "3500"), (3, "cover", "3000", "3500")], ids=["2 ranks, primal loop", "3 ranks, dual loop"])
+def test_deferred_sharding_runs_replicas_first_and_goes_live_when_the_tableau_row_becomes_a_pass(world, family, rows, cols):
+    """Round 5 (engine.h: shard_defer_): while the nucleus is small a pivot is 40-60 us of latency-bound launches and per-pivot exchanges
+    only slow it down, so the ranks start as bit-identical REPLICAS (the deterministic unsharded iteration on every rank, no exchange) and
+    the column-block sharding goes live at the first batch that leaves the sparse-tableau-row regime.  The default (MLP_SHARD_DEFER unset
+    = on): after 30 pivots the sharding is not live yet, at the end it is, and the whole run takes the unsharded run's pivots — i.e. the
+    replicas were identical at the switch and the sharded continuation picked up from them."""
+    env = dict(os.environ, MLP_SHARD_DEFER="1", SHARD_TEST_PROBE="30")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_test.py"), str(world), rows, cols, "12", "700", family],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "traces identical: True" in r.stdout
+    assert "sharding live after the probe / at the end: 0 / 1" in r.stdout, r.stdout[-1500:]

@@ -18,6 +18,7 @@ import gzip
 import hashlib
 import json
 import os
+os.environ.setdefault("MLP_SHARD_DEFER", "0")  # protocol tools: sharded from the first pivot unless the caller asks for the default deferral (engine.h)
 import sys
 import time
 

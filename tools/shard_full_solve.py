@@ -5,6 +5,7 @@ final basis into a fresh unsharded engine, which must find it optimal as it stan
   python tools/shard_full_solve.py [world] [rows cols nnz_per_row]"""
 import json
 import os
+os.environ.setdefault("MLP_SHARD_DEFER", "0")  # protocol tools: sharded from the first pivot unless the caller asks for the default deferral (engine.h)
 import sys
 import time
 import types

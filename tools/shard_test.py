@@ -2,6 +2,7 @@
 GPU 0 (the device mailboxes are mapped across processes through HIP IPC either way, so the exchange protocol
 is exercised even on a single-GPU box); gloo for the control plane."""
 import os
+os.environ.setdefault("MLP_SHARD_DEFER", "0")  # protocol tools: sharded from the first pivot unless the caller asks for the default deferral (engine.h)
 import sys
 import time
 
@@ -36,7 +37,16 @@ def worker(rank, world, port, m, n, k, pivots, out, family="sparse"):
     box = md.setup_sharding(s, dist)
     dist.barrier()
     t0 = time.time()
-    s.continue_solve(pivots)
+    probe = int(os.environ.get("SHARD_TEST_PROBE", "0"))   # pivots after which the "sharding is live" flag is read once (deferred sharding)
+    live_probe = None
+    if 0 < probe < pivots:
+        s.continue_solve(probe)
+        live_probe = int(s.state("shard_live")[0])
+        if s.budget_exhausted:
+            s.continue_solve(pivots - probe)
+    else:
+        s.continue_solve(pivots)
+    live_end = int(s.state("shard_live")[0])
     dt = time.time() - t0
     tr = [t[:5] for t in s.trace()]
     transport = s.transport()
@@ -52,6 +62,7 @@ def worker(rank, world, port, m, n, k, pivots, out, family="sparse"):
             ref = p.solve(budget=pivots, trace=True)
         rtr = [t[:5] for t in ref.trace()]
         ok = all(g["trace"] == rtr for g in gathered)
+        print("sharding live after the probe / at the end:", live_probe, "/", live_end, flush=True)
         print("transport:", transport, "| devices visible:", ndev, "| factor active on rank 0:", int(ref.stats()["factor_active"]), flush=True)
         print("sharded world=%d: pivots=%s obj=%s dt=%s | unsharded pivots=%d obj=%.12g | traces identical: %s" % (
             world, [g["n"] for g in gathered], ["%.12g" % g["obj"] for g in gathered], ["%.3f" % g["dt"] for g in gathered],
