@@ -131,7 +131,12 @@ int mlp_solution_recompute_basic_values(mlp_solution* s);
  * it through HIP IPC (the handles travel through the rendezvous object) and write their 64-byte records into it
  * over xGMI; polling is local.  MLP_MAILBOX=host selects the older host-memory mailbox (PCIe) instead.  The call
  * returns when every rank has mapped every mailbox (bounded waits: a missing rank is an error, MLP_EHIP).
- * Primal and dual loops; the Solution mutators are refused.  mlp_solution_transport names the transport in use. */
+ * Primal and dual loops; the Solution mutators are refused.  mlp_solution_transport names the transport in use.
+ * Deferred sharding (default; MLP_SHARD_DEFER=0 turns it off): while the nucleus is small — the sparse-tableau-row regime, a few
+ * hundred pivots from the slack basis, where a pivot is tens of microseconds of latency-bound launches and per-pivot exchanges can
+ * only slow it down — the ranks run as bit-identical REPLICAS (the deterministic unsharded iteration on every rank, no exchange);
+ * the column blocks and the exchanges go live at the first batch that leaves that regime, at the same pivot on every rank, and
+ * stay live.  Nothing changes for the caller: the same calls, the same pivots. */
 int mlp_solution_enable_sharding(mlp_solution* s, int rank, int world, const char* shm_name);
 /* The same with the transport named by the caller: NULL / "" = the default above (or MLP_TRANSPORT), "peer", "host",
  * "rccl" — north_star's literal transport: the mailbox records of every exchange (16-byte pricing candidates, the ratio decision,

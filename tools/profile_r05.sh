@@ -2,7 +2,7 @@
 # Round 5: the GPU suite, rocprofv3 --kernel-trace --stats of the three windows of config 4 (early: pivots 5..37 from the
 # slack basis = the driver-timed window and the batch after it; mid / late: from the committed bases), configs 2 / 3 / 5 wall times,
 # and the full bench line (timed window, mid / late windows, CPU baseline, full solve to the certified optimum, transport solve).
-export TAG=${TAG:-r05a}
+export TAG=${TAG:-r05b}
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 cd $ROOT
 timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/${TAG}_tests.log 2>&1; grep -E "passed|failed" gpurun_out/${TAG}_tests.log | tail -3
