@@ -137,7 +137,7 @@ struct Stats {
     uint64_t hyper_iters = 0, hyper_bails = 0;  // iterations taken by the hypersparse kernel; iterations it handed back
     uint64_t ratio_stalls = 0;   // in-kernel waits of the fused ratio test that timed out (each one retried with two launches)
     uint64_t beta_rebuilds = 0;  // lazy dual steepest edge: exact rebuilds of beta from the basis inverse
-    uint64_t fac_refactors = 0, fac_levels = 0, fac_switches = 0, fac_bump = 0, fac_bump_max = 0;  // compact factor: refactorisations (peels), levels of the last one, mode switches
+    uint64_t fac_refactors = 0, fac_levels = 0, fac_switches = 0, fac_bump = 0, fac_bump_max = 0, fac_sb_factors = 0, fac_sb_fallbacks = 0, fac_sb_rounds = 0;  // compact factor: refactorisations (peels), levels of the last one, mode switches
     // dense-rhs FTRAN x_B = B^-1 (b - N x_N) (recalc_basic_vals): the streaming read of the nucleus inverse, kernel-exact
     double dense_ftran_bytes = 0, dense_ftran_ms = 0;
     uint64_t dense_ftran_launches = 0;
@@ -263,7 +263,16 @@ private:
     DevBuf<double> d_fac_Wb;   // allocated with the first bump
     bool fac_pair_ = true;                   // MLP_FACTOR_PAIR=0: every solve walks the levels on its own (A/B)
     int fac_bump_ = 0;
-    int fac_bump_max_ = FAC_BMAX;            // MLP_FACTOR_BUMP: largest bump the compact factor carries (beyond it: explicit inverse)
+    int fac_bump_max_ = FAC_BMAX;            // MLP_FACTOR_BUMP: largest bump the compact factor carries through its DENSE inverse
+    // sparse factor of the bump (factor_sb.inc): bumps of fac_sb_from_ .. fac_sb_max_ columns are eliminated sparsely (LU with fill in
+    // rounds of independent pivots); one whose rows outgrow their slots falls back to the dense inverse (b <= fac_bump_max_)
+    int fac_sb_max_ = FAC_SB_MAX;            // MLP_FACTOR_SB: 0 = never
+    int fac_sb_from_ = 48;                   // MLP_FACTOR_SB_FROM: smaller bumps keep the dense inverse (one wave-sized product per solve)
+    bool fac_sb_on_ = false;                 // the current factor carries its bump sparsely
+    DevBuf<int> d_fac_sb_int;                // integer scratch + outputs of the factorisation (FacSbWork)
+    DevBuf<double> d_fac_sb_dbl;
+    DevBuf<FacSbRec> d_fac_sb_rec;
+    FacSbWork fac_sb_work(int m) const;
     void fac_alloc();
     void fac_fill_view(DevView& v) const;
     bool fac_refactor(int bump_limit = -1);  // the peel + level lists from the current basis; false when it leaves a bump beyond the limit (-1: MLP_FACTOR_BUMP)

@@ -125,7 +125,12 @@ Engine::Engine() {
     if (const char* ff = std::getenv("MLP_FACTOR_FROM")) fac_auto_cap_ = std::max(256, std::atoi(ff));
     if (const char* fp = std::getenv("MLP_FACTOR_PAIR")) fac_pair_ = fp[0] != '0';
     if (const char* fs = std::getenv("MLP_FACTOR_SKIP")) fac_skip_ = fs[0] != '0';
-    if (const char* fb = std::getenv("MLP_FACTOR_BUMP")) fac_bump_max_ = std::max(0, std::min(FAC_BMAX, std::atoi(fb)));
+    if (const char* fb = std::getenv("MLP_FACTOR_BUMP")) {  // (lowering the bump limit lowers it for both carriers of the bump)
+        fac_bump_max_ = std::max(0, std::min(FAC_BMAX, std::atoi(fb)));
+        fac_sb_max_ = std::min(fac_sb_max_, fac_bump_max_);
+    }
+    if (const char* fb = std::getenv("MLP_FACTOR_SB")) fac_sb_max_ = std::max(0, std::min(FAC_SB_MAX, std::atoi(fb)));
+    if (const char* fb = std::getenv("MLP_FACTOR_SB_FROM")) fac_sb_from_ = std::max(1, std::atoi(fb));
     const char* nhf = std::getenv("MLP_NO_HEAD_FUSION");
     no_head_fusion = nhf && std::atoi(nhf) != 0;
     const char* nws = std::getenv("MLP_NO_WSHARD");
@@ -1991,7 +1996,7 @@ void Engine::fac_alloc() {
     fac_J_ = std::max(1, std::min(fac_J_, fac_solve_grid_blocks()));
     const size_t mm = (size_t)std::max(m_, 1), NN = (size_t)std::max(N_, 1), J = (size_t)fac_J_;
     d_fac_pos_of_var.ensure(NN, 0, st); d_fac_var_of_pos.ensure(mm, 0, st); d_fac_prow.ensure(mm, 0, st);
-    d_fac_items.ensure(mm, 0, st); d_fac_lptr.ensure(FAC_MAX_LEVELS + 2, 0, st); d_fac_meta.ensure(8, 0, st);
+    d_fac_items.ensure(mm, 0, st); d_fac_lptr.ensure(FAC_MAX_LEVELS + 2, 0, st); d_fac_meta.ensure(16, 0, st);
     d_fac_tmp.ensure(8 * mm, 0, st); d_fac_counters.ensure(4, 0, st);
     {   // the work vectors of the solves are zero outside a solve (the levels a solve skips read as zero)
         const double* before = d_fac_x0.p;
@@ -2000,7 +2005,7 @@ void Engine::fac_alloc() {
     }
     d_fac_pval.ensure(mm, 0, st); d_fac_coef.ensure(2 * 64 + 2, 0, st); d_fac_part.ensure((size_t)2 * 64 * 1024, 0, st);
     d_fac_U.ensure(J * mm, 0, st); d_fac_V.ensure(J * mm, 0, st);
-    d_fac_bpos.ensure(FAC_BMAX, 0, st); d_fac_brow.ensure(FAC_BMAX, 0, st);
+    d_fac_bpos.ensure(std::max(FAC_BMAX, FAC_SB_MAX), 0, st); d_fac_brow.ensure(std::max(FAC_BMAX, FAC_SB_MAX), 0, st);
     {   // resolved edge lists: at most the entries of A (incl. the slack identity) on either side
         const size_t nz = h_rcol.size() + 8;
         d_fac_irow.ensure(mm, 0, st); d_fac_ipiv.ensure(mm, 0, st);
@@ -2043,6 +2048,35 @@ void Engine::fac_fill_view(DevView& v) const {
     v.fac_irow = d_fac_irow.p; v.fac_ipiv = d_fac_ipiv.p; v.fac_fptr = d_fac_fptr.p; v.fac_fidx = d_fac_fidx.p; v.fac_fval = d_fac_fval.p;
     v.fac_bptr = d_fac_bptr.p; v.fac_bidx = d_fac_bidx.p; v.fac_bval = d_fac_bval.p;
     v.fac_bpos = d_fac_bpos.p; v.fac_brow = d_fac_brow.p; v.fac_bslot_of_row = d_fac_bslot_of_row.p; v.fac_Wb = d_fac_Wb.p;
+    if (d_fac_sb_rec.p) {
+        const FacSbWork w = fac_sb_work(std::max(m_, 1));
+        v.fac_sb_rec = w.rec; v.fac_sb_lptr = w.lptr; v.fac_sb_oidx = w.oidx; v.fac_sb_oval = w.oval;
+    } else {
+        v.fac_sb_rec = nullptr; v.fac_sb_lptr = nullptr; v.fac_sb_oidx = nullptr; v.fac_sb_oval = nullptr;
+    }
+}
+// the carve-up of the sparse bump factor's buffers (factor_sb.inc)
+FacSbWork Engine::fac_sb_work(int m) const {
+    FacSbWork w;
+    const size_t B = FAC_SB_MAX;
+    int* ip = d_fac_sb_int.p;
+    double* dp = d_fac_sb_dbl.p;
+    auto it = [&](size_t n) { int* r = ip; ip += n; return r; };
+    auto dt = [&](size_t n) { double* r = dp; dp += n; return r; };
+    w.rcol = it(B * FAC_SB_RC); w.rcnt = it(B);
+    w.crow = it(B * FAC_SB_CC); w.ccnt = it(B);
+    w.rstate = it(B); w.cstate = it(B);
+    w.lidx = it(B * FAC_SB_LC); w.lcnt = it(B);
+    w.pivcol = it(B);
+    w.cand_u = it(B); w.cand_cost = it(B); w.won = it(B); w.bid = it(B); w.taken = it(B);
+    w.place = it(B);
+    w.flags = it(8);
+    w.lptr = it(FAC_SB_ROUNDS + 2);
+    w.oidx = it(4 * B * FAC_SB_OVS);
+    w.slot_of_pos = it((size_t)m);  // (last: nothing else moves with the number of rows)
+    w.rval = dt(B * FAC_SB_RC); w.lval = dt(B * FAC_SB_LC); w.piv = dt(B); w.oval = dt(4 * B * FAC_SB_OVS);
+    w.rec = d_fac_sb_rec.p;
+    return w;
 }
 // The refactorisation (BasisSolver::reset, solver.rs:1286-1303 -> lu_factorize, lu.rs:118-304): an iterated column-singleton
 // peel of the CURRENT basis on the device, one level per pair of launches, paced by the host (it reads one counter per level:
@@ -2051,6 +2085,7 @@ void Engine::fac_fill_view(DevView& v) const {
 bool Engine::fac_refactor(int bump_limit) {
     HIPCHECK(hipStreamSynchronize(st));
     if (m_ <= 0) return false;
+    const bool explicit_limit = bump_limit >= 0;
     if (bump_limit < 0) bump_limit = fac_bump_max_;
     fac_alloc();
     sync_view();
@@ -2069,7 +2104,7 @@ bool Engine::fac_refactor(int bump_limit) {
     launch_fac_peel_init(t, cnt, level, row_lev, claim, rcnt, claim_r, st);
     std::vector<int> lptr(1, 0);
     int total = 0;
-    int n_col_steps = 0, n_row_steps = 0;
+    int n_col_steps = 0, n_row_steps = 0, sb_rounds = 0;
     static const bool peel_paced = std::getenv("MLP_FACTOR_PEEL_PACED") != nullptr;  // the round-4 first cut: the host paces the levels
     bool device_peel_done = false;
     if (!peel_paced) {
@@ -2125,7 +2160,10 @@ bool Engine::fac_refactor(int bump_limit) {
     // What the peel leaves is the BUMP (columns on cycles of the basis graph).  A small bump is carried along with its explicit
     // inverse (Gauss-Jordan here, b^2 doubles); a large one means this basis is not the shape the representation is for.
     const int b = m_ - total;
-    if (b > bump_limit) return false;
+    // (an explicit limit — the automatic selection's 32 — is meant as given; the default is what either carrier of the bump takes)
+    const bool sb_try = b > 0 && b >= fac_sb_from_ && b <= fac_sb_max_;
+    if (b > (explicit_limit ? bump_limit : std::max(bump_limit, fac_sb_max_))) return false;
+    bool sb_now = false;
     if (b > 0 || fac_bump_ > 0) {
         std::vector<int> hlev(mm), hrow(mm), bslot(mm, -1), bpos, brow;
         HIPCHECK(hipMemcpyAsync(hlev.data(), level, sizeof(int) * mm, hipMemcpyDeviceToHost, st));
@@ -2141,13 +2179,40 @@ bool Engine::fac_refactor(int bump_limit) {
         if ((int)bpos.size() != b || (int)brow.size() != b) throw MlpError(-2, "singular basis matrix: the bump of the peel is not square (solver.rs:1301)");
         HIPCHECK(hipMemcpyAsync(d_fac_bslot_of_row.p, bslot.data(), sizeof(int) * mm, hipMemcpyHostToDevice, st));
         if (b > 0) {
+            HIPCHECK(hipMemcpyAsync(d_fac_bpos.p, bpos.data(), sizeof(int) * (size_t)b, hipMemcpyHostToDevice, st));
+            HIPCHECK(hipMemcpyAsync(d_fac_brow.p, brow.data(), sizeof(int) * (size_t)b, hipMemcpyHostToDevice, st));
+        }
+        if (sb_try) {
+            // the bump as a sparse LU with fill (factor_sb.inc): one launch of one workgroup, two flags back
+            const size_t B = FAC_SB_MAX;
+            const size_t ni = mm + B * (FAC_SB_RC + FAC_SB_CC + FAC_SB_LC) + 13 * B + 8 + FAC_SB_ROUNDS + 2 + 4 * B * FAC_SB_OVS + 64;
+            const size_t nd = B * (FAC_SB_RC + FAC_SB_LC) + B + 4 * B * FAC_SB_OVS + 64;
+            const int* ib = d_fac_sb_int.p; const double* db = d_fac_sb_dbl.p; const FacSbRec* rb = d_fac_sb_rec.p;
+            d_fac_sb_int.ensure(ni, 0, st); d_fac_sb_dbl.ensure(nd, 0, st); d_fac_sb_rec.ensure(4 * B, 0, st);
+            if (ib != d_fac_sb_int.p || db != d_fac_sb_dbl.p || rb != d_fac_sb_rec.p) view_dirty = true;
+            const FacSbWork w = fac_sb_work(m_);
+            t.fac_sb_rec = w.rec; t.fac_sb_lptr = w.lptr; t.fac_sb_oidx = w.oidx; t.fac_sb_oval = w.oval;
+            launch_fac_sb_factor(t, level, w, b, st);
+            int hf[4] = {0, 0, 0, 0};
+            HIPCHECK(hipMemcpyAsync(hf, w.flags, sizeof(hf), hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipStreamSynchronize(st));
+            if (!hf[0] && !hf[1] && hf[3] == 0) {
+                sb_now = true;
+                sb_rounds = hf[2];
+                stats.fac_sb_factors += 1;
+                stats.fac_sb_rounds = (uint64_t)hf[2];
+            } else {
+                stats.fac_sb_fallbacks += 1;  // rows outgrew their slots (or the elimination stalled): this bump is not sparse enough
+                if (b > bump_limit) return false;
+            }
+        }
+        if (b > 0 && !sb_now && b > std::min(bump_limit, FAC_BMAX)) return false;  // (the dense inverse holds FAC_BMAX columns)
+        if (b > 0 && !sb_now) {
             d_fac_Wb.ensure((size_t)FAC_BMAX * FAC_BMAX, 0, st);
             d_fac_WbT.ensure((size_t)FAC_BMAX * FAC_BMAX, 0, st);
             t.fac_Wb = d_fac_Wb.p;
             t.fac_WbT = d_fac_WbT.p;
             if (hview.fac_Wb != d_fac_Wb.p || hview.fac_WbT != d_fac_WbT.p) view_dirty = true;
-            HIPCHECK(hipMemcpyAsync(d_fac_bpos.p, bpos.data(), sizeof(int) * (size_t)b, hipMemcpyHostToDevice, st));
-            HIPCHECK(hipMemcpyAsync(d_fac_brow.p, brow.data(), sizeof(int) * (size_t)b, hipMemcpyHostToDevice, st));
             // work arrays of the inversion, kept across refactorisations (grown in steps of 64 rows)
             const size_t brows = (size_t)((b + 63) / 64) * 64;
             d_fac_Kd.ensure(brows * FAC_BMAX, 0, st);
@@ -2191,7 +2256,8 @@ bool Engine::fac_refactor(int bump_limit) {
         t.fac_segs = d_fac_segs.p;
         view_dirty = true;
     }
-    const int meta[8] = {nlev, total, b, nlev, n_col_steps, n_row_steps, 0, 0};
+    fac_sb_on_ = sb_now;
+    const int meta[16] = {nlev, total, b, nlev, n_col_steps, n_row_steps, 0, 0, sb_now ? 1 : 0, sb_rounds, 0, 0, 0, 0, 0, 0};
     HIPCHECK(hipMemcpyAsync(d_fac_meta.p, meta, sizeof(meta), hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)std::max(nlev, 1), st));  // (cnt is free again: the per-level fill cursors)
     launch_fac_peel_fill(t, level, cnt, st);
@@ -3116,7 +3182,7 @@ Engine* Engine::clone() {
     HIPCHECK(hipStreamSynchronize(s2));
     std::memcpy(e->h_ctl, h_ctl, sizeof(Ctl));
     e->values_dirty = true;
-    e->fac_mode = fac_mode; e->fac_J_ = fac_J_; e->fac_auto_cap_ = fac_auto_cap_; e->fac_bump_max_ = fac_bump_max_; e->fac_pair_ = fac_pair_; e->fac_skip_ = fac_skip_;
+    e->fac_mode = fac_mode; e->fac_J_ = fac_J_; e->fac_auto_cap_ = fac_auto_cap_; e->fac_bump_max_ = fac_bump_max_; e->fac_sb_max_ = fac_sb_max_; e->fac_sb_from_ = fac_sb_from_; e->fac_pair_ = fac_pair_; e->fac_skip_ = fac_skip_;
     if (fac_on_ && !e->fac_enter())  // (a fresh peel of the same basis: the same operator, no pending terms)
         throw MlpError(-3, "clone: the basis of a solution on the compact factor must peel");
     return owner.release();
@@ -3206,6 +3272,10 @@ uint64_t Engine::state(const char* what, double* out, uint64_t cap) {
                 tmp.push_back((double)(lp[sg[3 * q + 2] + 1] - lp[sg[3 * q + 1]]));
             }
         }
+    }
+    else if (w == "factor_sb") {  // sparse factor of the bump: in use now, factorisations, fallbacks to the dense inverse, rounds of the last one
+        tmp.push_back(fac_on_ && fac_sb_on_ ? 1.0 : 0.0); tmp.push_back((double)stats.fac_sb_factors);
+        tmp.push_back((double)stats.fac_sb_fallbacks); tmp.push_back((double)stats.fac_sb_rounds);
     }
     else if (w == "hyper_bail_reasons") {
         for (int i = 0; i < 10; ++i) tmp.push_back((double)stats.hyper_bail_reason[i]);

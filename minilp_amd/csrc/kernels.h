@@ -155,6 +155,38 @@ struct alignas(16) FacTailRec {
     int pad[3];
 };
 static_assert(sizeof(FacTailRec) == 128, "16 + 6 x 16 + 16 bytes");
+// SPARSE FACTOR OF THE BUMP (round 5, factor_sb.inc; lu.rs:118-304 with the pivot rule of 194-233): the bump K the two-sided peel
+// leaves is eliminated right-looking in ROUNDS of mutually independent pivots (threshold 0.1, lowest Markowitz count first); fill is
+// stored, rows that would outgrow their slots send the bump back to the dense inverse.  One item of a round, ready to execute in
+// pull form: out = (rhs - sum val[e] * x[idx[e]]) / piv  (edges beyond the inline ones at ovf in fac_sb_oidx / fac_sb_oval).
+constexpr int FAC_SB_MAX = 4096;   // bump columns the sparse factor carries (four solve vectors of that length live in LDS)
+constexpr int FAC_SB_RC = 32;      // entries of an active row, fill included
+constexpr int FAC_SB_CC = 64;      // rows ever listed for a column (stale ones included)
+constexpr int FAC_SB_LC = 64;      // multipliers of a row
+constexpr int FAC_SB_INL = 8;      // edges inside a record
+constexpr int FAC_SB_OVS = 64;     // overflow edges per item (>= the longest list)
+constexpr int FAC_SB_ROUNDS = 1022;
+struct alignas(16) FacSbRec {
+    int out, rhs, n, ovf;
+    double piv, pad;
+    int idx[FAC_SB_INL];
+    double val[FAC_SB_INL];
+};
+static_assert(sizeof(FacSbRec) == 128, "32 + 32 + 64 bytes");
+struct FacSbWork {  // scratch and outputs of the factorisation (all by bump slot)
+    int* slot_of_pos;                         // m: bump slot of a position (valid at bump positions only)
+    int* rcol; double* rval; int* rcnt;       // b x RC | b: the active matrix by rows
+    int* crow; int* ccnt;                     // b x CC | b: rows listed per column (never shrinks: inactive rows are skipped)
+    int* rstate; int* cstate;                 // b: 0 active, else the round (1-based) that pivoted the row / column
+    int* lidx; double* lval; int* lcnt;       // b x LC | b: multipliers of a row (pivot row slot, factor) in elimination order
+    int* pivcol; double* piv;                 // by row slot
+    int* cand_u; int* cand_cost; int* won; int* bid; int* taken;  // selection of a round
+    int* place;                               // by row slot: place in round order
+    int* flags;                               // [0] overflow, [1] singular / stuck, [2] rounds, [3] columns left
+    FacSbRec* rec;                            // 4 x FAC_SB_MAX: L | U | U^T | L^T records in round order
+    int* lptr;                                // FAC_SB_ROUNDS + 2
+    int* oidx; double* oval;                  // 4 x FAC_SB_MAX x FAC_SB_OVS overflow edges
+};
 struct DevView {
     int m, n;  // constraints (= basic positions), non-basic positions (= num_vars)
     int ld;    // leading dimension (= capacity) of W
@@ -319,6 +351,8 @@ struct DevView {
     int* fac_brow;           // FAC_BMAX: row of a bump slot
     int* fac_bslot_of_row;   // m: bump slot of a row, -1 for a pivot row of the peel
     double* fac_Wb;          // FAC_BMAX x FAC_BMAX, row-major: Wb[s][u] = (K^-1)[position slot s, row slot u]
+    // sparse factor of the bump (fac_meta[8] = 1: in use, fac_meta[9] = rounds): records L | U | U^T | L^T, FAC_SB_MAX each, in round order
+    const FacSbRec* fac_sb_rec; const int* fac_sb_lptr; const int* fac_sb_oidx; const double* fac_sb_oval;
 };
 constexpr int FAC_BMAX = 1024;
 
@@ -438,6 +472,7 @@ void launch_fac_bump_transpose(const double* in, double* outT, int b, hipStream_
 void launch_fac_tail_prog(const DevView& dv, FacTailRec* pf, FacTailRec* pb, int nlev, hipStream_t st);
 void launch_fac_plan(const DevView& dv, int* ltslot, int* segs, hipStream_t st);  // small levels, their LDS slots, the segments of a solve's walk (device-side)  // the tail's items as records (both directions)
 void launch_fac_reach_all(const DevView& dv, hipStream_t st);  // reach_of_pos of every position (levels in descending order, one launch); level of the bump
+void launch_fac_sb_factor(const DevView& dv, const int* level, const FacSbWork& w, int b, hipStream_t st);  // sparse factor of the bump (one workgroup)
 void launch_fac_bump_build(const DevView& dv, double* Kd, int b, hipStream_t st);  // K = B0[bump rows, bump columns], dense, row-major with pitch FAC_BMAX
 void launch_str_reset(const DevView& dv, hipStream_t st);  // sparse tableau row: new stamp epoch, empty lists
 void launch_checksum_w(const DevView& dv, unsigned long long* out, hipStream_t st);  // order-independent checksum of W[0:k, 0:k] and the slot maps (tests)

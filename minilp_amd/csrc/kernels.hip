@@ -4934,6 +4934,7 @@ __global__ void __launch_bounds__(BLK) k_row_pull(DevView v, int n_pull) {
 #include "hyper.inc"  // the hypersparse single-workgroup iteration (uses the stage helpers above)
 #include "primal_head.inc"  // small-nucleus primal iteration: FTRAN + Harris test + BTRAN + inverse update + touched columns in ONE workgroup (uses hyper.inc's DPP reductions)
 #include "factor.inc"  // the compact factor of the basis: peel, level-scheduled solves, additive eta terms
+#include "factor_sb.inc"  // ... sparse factor (LU with fill, rounds of independent pivots) of the bump the peel leaves
 #include "inverse.inc"  // blocked in-place inversion of a dense-filling nucleus (the refactorisation of the explicit inverse)
 
 // ===================================================================================== launchers

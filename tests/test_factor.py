@@ -5,6 +5,8 @@ factor without fill: lu.rs:118-304 / ordering.rs:4-21 carried to the fixed point
 (solver.rs:1274-1284).  Gates: the oracle's pivot sequence on the non-degenerate families (the operator is the same
 whichever representation applies it), objective / values at the optimum, the defining equations of every solve against the
 matrix itself, and the switches between the two representations."""
+import sys
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -22,6 +24,10 @@ def _pair(lp, **kw):
     so = lpgen.build_problem(O.Problem, lp).solve(trace=True)
     sg = lpgen.build_problem(M.Problem, lp).solve(trace=True, **kw)
     return so, sg
+
+
+def _sb(s):
+    return dict(zip(("in_use", "factorisations", "fallbacks", "rounds"), s.state("factor_sb").astype(int).tolist()))
 
 
 @pytest.mark.parametrize("args,tight", [((300, 300, 3, 7), 1.0), ((800, 1000, 4, 11), 0.5), ((2500, 2500, 4, 3), 0.4), ((4000, 5000, 5, 9), 0.4)], ids=str)
@@ -138,8 +144,14 @@ def test_auto_selection_keeps_the_explicit_inverse_for_a_nucleus_that_does_not_p
     assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
 
 
+_NORMWISE = False
+
+
 def _backward_error(resid, *abs_terms):
     den = sum(abs_terms)
+    if _NORMWISE:  # (a basis with cycles: entries that are zero in exact arithmetic come out as rounding noise, and the componentwise
+        # measure divides noise by noise there; the normwise one does not)
+        return float(np.abs(resid).max() / max(float(den.max()), 1e-300))
     den = np.where(den > 0, den, 1.0)
     return float((np.abs(resid) / den).max())
 
@@ -150,12 +162,36 @@ def test_stepped_stages_on_the_compact_factor_satisfy_the_defining_equations(mon
     nothing of the engine on the reference side (the same check tests/test_late_regime.py makes on the explicit inverse)."""
     monkeypatch.setenv("MLP_FACTOR", "1")
     monkeypatch.setenv("MLP_FACTOR_J", "8")
-    lp = lpgen.gen_transport_lp(900, 900, 4, 17, tight=0.45)
+    _stepped_check(lpgen.gen_transport_lp(900, 900, 4, 17, tight=0.45), 300)    # 300 pivots in: pending terms, several levels
+
+
+@pytest.mark.parametrize("carrier", ["sparse_lu", "dense_inverse"])
+def test_stepped_stages_through_the_bump_satisfy_the_defining_equations(monkeypatch, carrier):
+    """The same check late in config 3's solve on the compact factor, where the peel leaves a bump of ~30 columns — carried as a sparse
+    LU with fill (factor_sb.inc) or through its dense inverse: every FTRAN / BTRAN / tau solve of 20 stepped pivots against the
+    matrix itself."""
+    monkeypatch.setenv("MLP_FACTOR", "1")
+    monkeypatch.setenv("MLP_FACTOR_J", "8")
+    monkeypatch.setenv("MLP_FACTOR_SB_FROM", "2")
+    if carrier == "dense_inverse":
+        monkeypatch.setenv("MLP_FACTOR_SB", "0")
+    monkeypatch.setattr(sys.modules[__name__], "_NORMWISE", True)
+    s = _stepped_check(lpgen.gen_mixed_lp(6000, 10000, 4, 3), 3700)
+    sb = _sb(s)
+    print("sparse bump", sb, "bump", s.stats()["factor_bump"])
+    assert s.stats()["factor_bump"] >= 2
+    if carrier == "sparse_lu":
+        assert sb["factorisations"] >= 1 and sb["fallbacks"] == 0 and sb["in_use"] == 1
+    else:
+        assert sb["factorisations"] == 0
+
+
+def _stepped_check(lp, budget):
     m, n = lp["m"], lp["n"]
     Acsc = sp.csr_matrix((lp["data"], lp["indices"], lp["indptr"]), shape=(m, n)).tocsc()
     Aext = sp.hstack([Acsc, sp.identity(m, format="csc")], format="csc")
     Aabs = abs(Aext)
-    s = lpgen.build_problem(M.Problem, lp).solve(budget=300)    # 300 pivots in: pending terms, several levels
+    s = lpgen.build_problem(M.Problem, lp).solve(budget=budget)
     assert s.stats()["factor_active"] == 1
     st, info = s.engine_open()
     assert st == A.ITER_PIVOT and info["phase"] == 1
@@ -190,13 +226,14 @@ def test_stepped_stages_on_the_compact_factor_satisfy_the_defining_equations(mon
                     btran=_backward_error(B.T @ rho - e_r, Babs.T @ np.abs(rho), e_r),
                     tau=_backward_error(B @ tau - rho, Babs @ np.abs(tau), np.abs(rho)))
         N, Nabs = Aext[:, nb], Aabs[:, nb]
-        errs["row"] = float((np.abs(alpha_r - N.T @ rho) / np.maximum(Nabs.T @ np.abs(rho), 1e-300)).max())
+        errs["row"] = _backward_error(alpha_r - N.T @ rho, np.maximum(Nabs.T @ np.abs(rho), 1e-300))
         for kname, e in errs.items():
             worst[kname] = max(worst.get(kname, 0.0), e)
             assert e < 1e-9, (kname, e, done)
         if st == A.ITER_FEASIBLE:
             break
     print("stepped pivots on the compact factor; worst componentwise backward errors:", {k: f"{e:.1e}" for k, e in worst.items()})
+    return s
 
 
 def test_clone_fix_and_unfix_on_the_compact_factor(monkeypatch):
@@ -253,3 +290,52 @@ def test_cutting_plane_loop_stays_on_the_compact_factor(monkeypatch):
         xg = np.asarray(sg.values())
         assert float(np.dot(coef, xg[pick])) <= rhs + 1e-7
     assert sg.stats()["factor_switches"] == switches0
+
+
+def test_config3_on_the_compact_factor_with_the_bump_as_a_sparse_lu(monkeypatch):
+    """Config 3 (6 000 x 10 000, four entries per row) solved on the compact factor from the slack basis on, the bump the two-sided
+    peel leaves (2 ... 32 columns on cycles of the basis graph) carried as a SPARSE LU WITH FILL (factor_sb.inc: rounds of
+    independent pivots, threshold 0.1, lowest Markowitz count) instead of its dense inverse (MLP_FACTOR_SB_FROM lowered from 48):
+    the oracle's pivots and optimum; then the same solve with the dense inverse: the same pivots again."""
+    lp = lpgen.gen_mixed_lp(6000, 10000, 4, 3)
+    monkeypatch.setenv("MLP_FACTOR", "1")
+    monkeypatch.setenv("MLP_FACTOR_SB_FROM", "2")
+    so, sg = _pair(lp)
+    st, sb = sg.stats(), _sb(sg)
+    print("pivots", st["iterations"], "refactorisations", st["factor_refactors"], "largest bump", st["factor_bump_max"], "sparse bump", sb)
+    assert st["factor_active"] == 1 and st["factor_bump_max"] >= 10
+    assert sb["factorisations"] >= 10 and sb["fallbacks"] == 0
+    assert obj_close(sg.objective(), so.objective())
+    check_feasible(lp, sg.values())  # (another optimal vertex than the oracle's: see below)
+    assert sg.stats()["max_pivot_err"] < 1e-9
+    # the pivot sequence: config 3 is degenerate — at pivot 663 the dual ratio test sees a floating-point tie and the GPU engine (every
+    # path of it: explicit inverse, hypersparse kernel, compact factor) continues along another vertex path than the oracle, 3 955
+    # pivots against 3 954 to the same optimum — so the sequence is compared up to there with the oracle and, whole, with the
+    # engine's own default path and with the dense carrier of the bump
+    to, tg = [t[:5] for t in so.trace()], [t[:5] for t in sg.trace()]
+    div = next((i for i, (a, b) in enumerate(zip(tg, to)) if a != b), min(len(tg), len(to)))
+    assert div >= 600, div
+    monkeypatch.setenv("MLP_FACTOR_SB", "0")
+    sd = lpgen.build_problem(M.Problem, lp).solve(trace=True)
+    assert _sb(sd)["factorisations"] == 0 and sd.stats()["factor_bump_max"] == st["factor_bump_max"]
+    assert [t[:5] for t in sd.trace()] == tg
+    monkeypatch.setenv("MLP_FACTOR", "0")
+    s0 = lpgen.build_problem(M.Problem, lp).solve(trace=True)
+    assert s0.stats()["factor_active"] == 0
+    assert [t[:5] for t in s0.trace()] == tg
+
+
+def test_a_bump_that_fills_falls_back_to_the_dense_inverse(monkeypatch):
+    """Config-4 family (twelve entries per row, a nucleus that is all cycles): the sparse elimination of its bump outgrows the row
+    slots (measured fill), every such refactorisation carries the bump through the dense inverse instead — same pivots as the oracle."""
+    monkeypatch.setenv("MLP_FACTOR", "1")
+    monkeypatch.setenv("MLP_FACTOR_J", "7")
+    monkeypatch.setenv("MLP_FACTOR_SB_FROM", "2")
+    lp = lpgen.gen_sparse_lp(400, 300, 12, 7)
+    so, sg = _pair(lp)
+    st, sb = sg.stats(), _sb(sg)
+    print("pivots", st["iterations"], "largest bump", st["factor_bump_max"], "sparse bump", sb)
+    assert st["factor_active"] == 1 and st["factor_bump_max"] >= 20
+    assert sb["fallbacks"] >= 1
+    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+    assert obj_close(sg.objective(), so.objective())
