@@ -241,7 +241,9 @@ private:
     int fac_mode = -1;                       // MLP_FACTOR: 1 from the start (falls back to the explicit inverse when the peel leaves a bump),
                                              // 0 never, -1 auto: tried when the nucleus would need more than fac_auto_cap_ slots
     bool fac_on_ = false;
-    int fac_J_ = 32;                         // MLP_FACTOR_J: pivots between refactorisations (rank-1 terms kept)
+    int fac_J_ = 64;                         // rank-1 terms the factor has room for (MLP_FACTOR_J: room = period = that value)
+    int fac_period_ = 32;                    // pivots between refactorisations: 32, or 64 while a refactorisation is expensive (many levels, a bump)
+    bool fac_period_auto_ = true;
     int fac_nlev_ = 0;
     int fac_auto_cap_ = 8192;                // MLP_FACTOR_FROM
     uint64_t fac_tried_at_ = 0;              // lifetime pivot count of the last attempt that found a bump

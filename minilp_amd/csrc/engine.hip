@@ -121,7 +121,10 @@ Engine::Engine() {
     if (const char* rs = std::getenv("MLP_RATIO_SPIN_LIMIT")) ratio_spin_limit = std::atoll(rs);
     if (const char* sb = std::getenv("MLP_STREAM_BALANCED")) sw_balanced = std::atoi(sb);
     if (const char* fm = std::getenv("MLP_FACTOR")) fac_mode = std::atoi(fm) > 0 ? 1 : 0;
-    if (const char* fj = std::getenv("MLP_FACTOR_J")) fac_J_ = std::max(1, std::min(64, std::atoi(fj)));
+    if (const char* fj = std::getenv("MLP_FACTOR_J")) {  // a fixed period; default: 32, and 64 while a refactorisation is expensive (fac_refactor)
+        fac_J_ = fac_period_ = std::max(1, std::min(64, std::atoi(fj)));
+        fac_period_auto_ = false;
+    }
     if (const char* ff = std::getenv("MLP_FACTOR_FROM")) fac_auto_cap_ = std::max(256, std::atoi(ff));
     if (const char* fp = std::getenv("MLP_FACTOR_PAIR")) fac_pair_ = fp[0] != '0';
     if (const char* fs = std::getenv("MLP_FACTOR_SKIP")) fac_skip_ = fs[0] != '0';
@@ -1847,13 +1850,13 @@ int Engine::run_loop(int phase) {
         if (fac_on_) {
             // compact factor: every basis change of the batch appends a rank-1 term; refactor (re-peel the current basis)
             // when fewer than a batch of them fit — the reference's rule is eta nnz >= LU nnz (solver.rs:1096-1103)
-            int room = fac_J_ - h_ctl->nlow;
-            if (room < std::min(fac_J_, std::max(1, std::min(B, 8)))) {
+            int room = fac_period_ - h_ctl->nlow;
+            if (room < std::min(fac_period_, std::max(1, std::min(B, 8)))) {
                 if (!fac_refactor()) {  // the basis no longer peels: back to the explicit inverse
                     fac_leave();
                     continue;
                 }
-                room = fac_J_;
+                room = fac_period_;
             }
             if (B > room) B = room;
         }
@@ -1994,6 +1997,7 @@ void Engine::fac_alloc() {
     // workgroup j of k_fac_solve reduces the coefficient of pending term j: never more terms than workgroups (a partitioned device —
     // CPX mode, ~32 CUs — with MLP_FACTOR_J=64 would silently drop the terms beyond the grid: ADVICE r4)
     fac_J_ = std::max(1, std::min(fac_J_, fac_solve_grid_blocks()));
+    fac_period_ = std::min(fac_period_, fac_J_);
     const size_t mm = (size_t)std::max(m_, 1), NN = (size_t)std::max(N_, 1), J = (size_t)fac_J_;
     d_fac_pos_of_var.ensure(NN, 0, st); d_fac_var_of_pos.ensure(mm, 0, st); d_fac_prow.ensure(mm, 0, st);
     d_fac_items.ensure(mm, 0, st); d_fac_lptr.ensure(FAC_MAX_LEVELS + 2, 0, st); d_fac_meta.ensure(16, 0, st);
@@ -2072,9 +2076,9 @@ FacSbWork Engine::fac_sb_work(int m) const {
     w.place = it(B);
     w.flags = it(8);
     w.lptr = it(FAC_SB_ROUNDS + 2);
-    w.oidx = it(4 * B * FAC_SB_OVS);
+    w.oidx = it(FAC_SB_KINDS * B * FAC_SB_OVS);
     w.slot_of_pos = it((size_t)m);  // (last: nothing else moves with the number of rows)
-    w.rval = dt(B * FAC_SB_RC); w.lval = dt(B * FAC_SB_LC); w.piv = dt(B); w.oval = dt(4 * B * FAC_SB_OVS);
+    w.rval = dt(B * FAC_SB_RC); w.lval = dt(B * FAC_SB_LC); w.piv = dt(B); w.oval = dt(FAC_SB_KINDS * B * FAC_SB_OVS);
     w.rec = d_fac_sb_rec.p;
     return w;
 }
@@ -2185,10 +2189,10 @@ bool Engine::fac_refactor(int bump_limit) {
         if (sb_try) {
             // the bump as a sparse LU with fill (factor_sb.inc): one launch of one workgroup, two flags back
             const size_t B = FAC_SB_MAX;
-            const size_t ni = mm + B * (FAC_SB_RC + FAC_SB_CC + FAC_SB_LC) + 13 * B + 8 + FAC_SB_ROUNDS + 2 + 4 * B * FAC_SB_OVS + 64;
-            const size_t nd = B * (FAC_SB_RC + FAC_SB_LC) + B + 4 * B * FAC_SB_OVS + 64;
+            const size_t ni = mm + B * (FAC_SB_RC + FAC_SB_CC + FAC_SB_LC) + 13 * B + 8 + FAC_SB_ROUNDS + 2 + FAC_SB_KINDS * B * FAC_SB_OVS + 64;
+            const size_t nd = B * (FAC_SB_RC + FAC_SB_LC) + B + FAC_SB_KINDS * B * FAC_SB_OVS + 64;
             const int* ib = d_fac_sb_int.p; const double* db = d_fac_sb_dbl.p; const FacSbRec* rb = d_fac_sb_rec.p;
-            d_fac_sb_int.ensure(ni, 0, st); d_fac_sb_dbl.ensure(nd, 0, st); d_fac_sb_rec.ensure(4 * B, 0, st);
+            d_fac_sb_int.ensure(ni, 0, st); d_fac_sb_dbl.ensure(nd, 0, st); d_fac_sb_rec.ensure(FAC_SB_KINDS * B, 0, st);
             if (ib != d_fac_sb_int.p || db != d_fac_sb_dbl.p || rb != d_fac_sb_rec.p) view_dirty = true;
             const FacSbWork w = fac_sb_work(m_);
             t.fac_sb_rec = w.rec; t.fac_sb_lptr = w.lptr; t.fac_sb_oidx = w.oidx; t.fac_sb_oval = w.oval;
@@ -2279,6 +2283,11 @@ bool Engine::fac_refactor(int bump_limit) {
     HIPCHECK(hipStreamSynchronize(st));  // (lptr / meta were staged from local memory)
     h_ctl->nlow = 0;
     fac_nlev_ = nlev;
+    // The refactor period (the reference's rule is eta nnz >= LU nnz, solver.rs:1096-1103).  A pending term costs every dense-rhs solve
+    // one more dot product over m; a refactorisation costs the peel (two grid barriers per level) and the factorisation of the bump.
+    // Measured: the transport family (20 levels, no bump) 28.4 s with 32 terms, 31.5 s with 64; the config-3 family at 100 000 rows
+    // (120-140 levels, bump 1 300-2 200) 25.0 s with 32, 22.9 s with 64.
+    if (fac_period_auto_) fac_period_ = std::min(fac_J_, (nlev >= 64 || b >= 64) ? 64 : 32);
     stats.fac_refactors += 1;
     stats.fac_levels = (uint64_t)nlev;
     stats.reinversions += 1;
@@ -2288,7 +2297,7 @@ bool Engine::fac_refactor(int bump_limit) {
 void Engine::fac_make_room(int need) {
     if (!fac_on_) return;
     pull_ctl();
-    if (fac_J_ - h_ctl->nlow >= need) return;
+    if (fac_period_ - h_ctl->nlow >= need) return;
     if (!fac_refactor()) fac_leave();
 }
 bool Engine::fac_enter(int bump_limit) {
@@ -3182,7 +3191,7 @@ Engine* Engine::clone() {
     HIPCHECK(hipStreamSynchronize(s2));
     std::memcpy(e->h_ctl, h_ctl, sizeof(Ctl));
     e->values_dirty = true;
-    e->fac_mode = fac_mode; e->fac_J_ = fac_J_; e->fac_auto_cap_ = fac_auto_cap_; e->fac_bump_max_ = fac_bump_max_; e->fac_sb_max_ = fac_sb_max_; e->fac_sb_from_ = fac_sb_from_; e->fac_pair_ = fac_pair_; e->fac_skip_ = fac_skip_;
+    e->fac_mode = fac_mode; e->fac_J_ = fac_J_; e->fac_period_ = fac_period_; e->fac_period_auto_ = fac_period_auto_; e->fac_auto_cap_ = fac_auto_cap_; e->fac_bump_max_ = fac_bump_max_; e->fac_sb_max_ = fac_sb_max_; e->fac_sb_from_ = fac_sb_from_; e->fac_pair_ = fac_pair_; e->fac_skip_ = fac_skip_;
     if (fac_on_ && !e->fac_enter())  // (a fresh peel of the same basis: the same operator, no pending terms)
         throw MlpError(-3, "clone: the basis of a solution on the compact factor must peel");
     return owner.release();

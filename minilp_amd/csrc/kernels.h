@@ -166,6 +166,7 @@ constexpr int FAC_SB_LC = 64;      // multipliers of a row
 constexpr int FAC_SB_INL = 8;      // edges inside a record
 constexpr int FAC_SB_OVS = 64;     // overflow edges per item (>= the longest list)
 constexpr int FAC_SB_ROUNDS = 1022;
+constexpr int FAC_SB_KINDS = 6;     // record arrays: L, U, U^T, L^T, FTRAN right-hand side, BTRAN right-hand side
 struct alignas(16) FacSbRec {
     int out, rhs, n, ovf;
     double piv, pad;
@@ -183,9 +184,9 @@ struct FacSbWork {  // scratch and outputs of the factorisation (all by bump slo
     int* cand_u; int* cand_cost; int* won; int* bid; int* taken;  // selection of a round
     int* place;                               // by row slot: place in round order
     int* flags;                               // [0] overflow, [1] singular / stuck, [2] rounds, [3] columns left
-    FacSbRec* rec;                            // 4 x FAC_SB_MAX: L | U | U^T | L^T records in round order
+    FacSbRec* rec;                            // 6 x FAC_SB_MAX: L | U | U^T | L^T records in round order, the right-hand sides of the two solves by slot
     int* lptr;                                // FAC_SB_ROUNDS + 2
-    int* oidx; double* oval;                  // 4 x FAC_SB_MAX x FAC_SB_OVS overflow edges
+    int* oidx; double* oval;                  // 6 x FAC_SB_MAX x FAC_SB_OVS overflow edges
 };
 struct DevView {
     int m, n;  // constraints (= basic positions), non-basic positions (= num_vars)

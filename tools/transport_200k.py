@@ -13,6 +13,8 @@ that is k = 130 000: 135 GB of inverse and 16 k^2 bytes of traffic per pivot.
   factor : minilp_amd on the compact factor (auto-selected when the nucleus passes MLP_FACTOR_FROM slots)
   dense  : minilp_amd with MLP_FACTOR=0 (explicit inverse only), for at most --dense-pivots pivots past the point where the
            other run switched (it would need hours, or end in MLP_ENOMEM)
+  factor_dense_bump : the compact factor with MLP_FACTOR_SB=0 (the bump through its dense inverse, at most 1 024 columns: the tree
+           before round 5), for at most --dense-pivots pivots
 Objectives of finished runs must agree to 1e-9 relative."""
 import json
 import os
@@ -52,7 +54,8 @@ try:
         e = dict(pivots=piv, us_per_pivot=round(dt * 1e6 / max(1, piv - done), 1), objective=s.objective())
         if path != "oracle":
             e.update(nucleus=int(st["nucleus_size"]), capacity=int(st["nucleus_capacity"]), factor=int(st["factor_active"]), levels=int(st["factor_levels"]),
-                     refactorisations=int(st["factor_refactors"]), bump=int(st["factor_bump"]), switches=int(st["factor_switches"]))
+                     refactorisations=int(st["factor_refactors"]), bump=int(st["factor_bump"]), bump_max=int(st["factor_bump_max"]), switches=int(st["factor_switches"]),
+                     sparse_bump=dict(zip(("in_use", "factorisations", "fallbacks", "rounds"), s.state("factor_sb").astype(int).tolist())))
         rec["chunks"].append(e)
         print(json.dumps(e), file=sys.stderr, flush=True)
         done = piv
@@ -85,7 +88,9 @@ def main():
         env = dict(os.environ)
         if path == "dense":
             env["MLP_FACTOR"] = "0"
-        limit = dense_pivots if path == "dense" else 0
+        if path == "factor_dense_bump":  # the compact factor as it was before round 5's sparse LU of the bump: dense inverse, 1 024 columns at most
+            env["MLP_FACTOR_SB"] = "0"
+        limit = dense_pivots if path in ("dense", "factor_dense_bump") else 0
         t0 = time.time()
         r = subprocess.run([sys.executable, "-c", CODE, str(S), str(D), str(deg), str(tight), path, str(limit), family, opt("--chunk", "20000")], env=env, capture_output=True, text=True)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
