@@ -2349,25 +2349,30 @@ void Engine::launch_stage_fac(int phase, int stage, bool with_events) {
     const Geom g = geom();
     const int pse = enable_pse ? 1 : 0, dse = enable_dse ? 1 : 0;
     const int inl = (dv.banded && phase == 0 && !stepping) ? 1 : 0;
+    // A dual iteration without primal steepest edge, run whole (not stepped): the three single-purpose launches around the solves —
+    // the leaving row's scalars, the plan after the FTRAN, the new rank-1 term — ride inside the solves (16.8 us of 170 per pivot on the
+    // 200 000-row transport instance, profiles/r05c_transport_first60k_kernel_stats.csv); bit-identical (MLP_FACTOR_FUSE=0: A/B, tests)
+    static const bool fuse_env = !(std::getenv("MLP_FACTOR_FUSE") && std::getenv("MLP_FACTOR_FUSE")[0] == '0');
+    const bool fused = fuse_env && phase == 1 && !pse && dse && fac_pair_ && !stepping;
     switch (stage) {
     case STAGE_FTRAN:
         if (with_events) HIPCHECK(hipEventRecord(ev[6], st));
         if (phase == 0) launch_ftran_prep(dv, 1, st);            // entering column's scalars; the column becomes the right-hand side
         // alpha_q = B^-1 a_q; in a dual iteration rho is known already, so tau = B^-1 rho (solver.rs:1157) shares the walk over the levels
-        if (phase == 1 && dse && fac_pair_) launch_fac_solve2(dv, g, 0, 0, 0, 1, 1, st);
+        if (phase == 1 && dse && fac_pair_) launch_fac_solve2(dv, g, 0, 0, 0, 1, 1, st, fused ? 6 : 0);
         else launch_fac_solve(dv, g, 0, 0, 0, nullptr, 0, st);
         if (with_events) HIPCHECK(hipEventRecord(ev[7], st));
-        if (phase == 1) launch_post_ftran(dv, g, pse, st);       // ||alpha_q||^2 + 1, plan (1 / alpha_q[r])
+        if (phase == 1 && !fused) launch_post_ftran(dv, g, pse, st);       // ||alpha_q||^2 + 1, plan (1 / alpha_q[r])
         break;
     case STAGE_RATIO:
         if (phase == 0) launch_ratio_primal(dv, g, pse, st);
         else launch_ratio_dual(dv, g, st);                       // (its finaliser scatters the entering column for the FTRAN)
         break;
     case STAGE_BTRAN:
-        if (phase == 1) launch_btran_prep(dv, 1, 0, st);         // leaving row's scalars
+        if (phase == 1 && !fused) launch_btran_prep(dv, 1, 0, st);         // leaving row's scalars
         // rho = B^-T e_r, ||rho||^2; in a primal iteration alpha_q is known already, so v = B^-T alpha_q (solver.rs:1114) shares the walk
         if (phase == 0 && pse && fac_pair_) launch_fac_solve2(dv, g, 1, 0, 0, 1, 1, st);
-        else launch_fac_solve(dv, g, 1, 0, 0, nullptr, 0, st);
+        else launch_fac_solve(dv, g, 1, 0, 0, nullptr, 0, st, fused ? 1 : 0);
         break;
     case STAGE_BASIS:
         if (pse && !(phase == 0 && fac_pair_)) launch_fac_solve(dv, g, 1, 1, 1, nullptr, 0, st);   // v = B^-T alpha_q      (solver.rs:1114)
@@ -2380,7 +2385,7 @@ void Engine::launch_stage_fac(int phase, int stage, bool with_events) {
     case STAGE_APPLY:
         if (phase == 1 && pse) launch_sweep(dv, g, 2, 0, st);
         if (with_events) HIPCHECK(hipEventRecord(ev[4], st));
-        launch_fac_append(dv, st);
+        if (!fused) launch_fac_append(dv, st);
         launch_update_pivot(dv, g, phase, dse, pse, st, inl, 0);
         if (with_events) HIPCHECK(hipEventRecord(ev[5], st));
         break;

@@ -97,6 +97,7 @@ struct Ctl {
                      // (aq_n and str_n are adjacent: the host clears the pair with one 8-byte memset)
     // compact factor (factor.inc): level ranges a solve has to walk, produced by the solve / head that precedes it (a right-hand side
     // that is zero on every level beyond L leaves those levels at zero: they are skipped)
+    double fac_inv[64];  // compact factor: 1 / alpha_q[r] of pending term j — fac_U holds (alpha_q - e_r) unscaled, readers form U_j = -(...) * fac_inv[j]
     int fac_aq_hi;     // FTRAN of the entering column: highest level among the pivot positions of its rows
     int fac_rho_hi;    // FTRAN of rho (tau = B^-1 rho): highest level among the rows of supp(rho)        (atomicMax by the BTRAN's epilogue)
     int fac_aq_lo;     // BTRAN of alpha_q (v = B^-T alpha_q): lowest level among supp(alpha_q)           (atomicMin by the FTRAN's epilogue)
@@ -454,8 +455,10 @@ void launch_build_nucleus(const DevView& dv, const Geom& g, double* Kd, int k, h
 // compact factor (factor.inc)
 // one level-scheduled solve: dir 0 FTRAN (src 0 entering column | 1 rho | 2 src_ptr by row; dst 0 alpha_q | 1 tau),
 // dir 1 BTRAN (src 0 e_r | 1 alpha_q | 2 src_ptr by position; dst 0 rho + ||rho||^2 | 1 v); always: whatever the iteration status
-void launch_fac_solve(const DevView& dv, const Geom& g, int dir, int src, int dst, const double* src_ptr, int always, hipStream_t st);
-void launch_fac_solve2(const DevView& dv, const Geom& g, int dir, int srcA, int dstA, int srcB, int dstB, hipStream_t st);  // two right-hand sides, one walk over the levels
+// fuse (dual iteration without primal steepest edge, not stepping): 1 = the leaving row's scalars (k_btran_prep) in the head of the BTRAN,
+// 2 = the plan (k_post_ftran) and 4 = the new rank-1 term (k_fac_append) in the epilogue of the FTRAN
+void launch_fac_solve(const DevView& dv, const Geom& g, int dir, int src, int dst, const double* src_ptr, int always, hipStream_t st, int fuse = 0);
+void launch_fac_solve2(const DevView& dv, const Geom& g, int dir, int srcA, int dstA, int srcB, int dstB, hipStream_t st, int fuse = 0);  // two right-hand sides, one walk over the levels
 int fac_solve_grid_blocks();  // workgroups of k_fac_solve's grid: workgroup j reduces the coefficient of pending term j, so fac_J must not exceed it
 void launch_fac_append(const DevView& dv, hipStream_t st);     // U_nlow, V_nlow from alpha_q / rho of this pivot; nlow += 1
 void launch_fac_gather_cb(const DevView& dv, hipStream_t st);  // alpha_q[p] = c[basic_vars[p]]
