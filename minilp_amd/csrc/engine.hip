@@ -2273,7 +2273,19 @@ bool Engine::fac_refactor(int bump_limit) {
     launch_fac_edges(t, 1, d_fac_fptr.p, d_fac_bptr.p, level, st);
     launch_fac_plan(t, d_fac_ltslot.p, d_fac_segs.p, st);
     launch_fac_tail_prog(t, d_fac_tprog.p, d_fac_tprog.p + mm, nlev, st);  // the items of the small levels as records, both directions
-    launch_fac_reach_all(t, st);  // the level ranges of the solves (factor.inc): reach of every position, levels in descending order; level of the bump
+    {   // the level ranges of the solves (factor.inc): reach of every position, levels in descending order; level of the bump.  Runs of
+        // small levels by one workgroup, a level of more than 4 096 positions by the grid
+        int hi = nlev - 1;
+        for (int lev = nlev - 1; lev >= 0; --lev) {
+            const int sz = lptr[lev + 1] - lptr[lev];
+            if (sz > 4096) {
+                launch_fac_reach_all(t, hi, lev + 1, st);
+                launch_fac_reach_level(t, lev, sz, st);
+                hi = lev - 1;
+            }
+        }
+        launch_fac_reach_all(t, hi, 0, st);
+    }
     {   // level statistics produced before this refactorisation describe the old levels: conservative values until the next producer
         const int stat[4] = {INT_MAX, INT_MAX, 0, INT_MAX};  // fac_aq_hi, fac_rho_hi, fac_aq_lo, fac_aq_reach
         HIPCHECK(hipMemcpyAsync(&d_ctl.p->fac_aq_hi, stat, sizeof(stat), hipMemcpyHostToDevice, st));

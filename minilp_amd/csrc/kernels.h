@@ -475,7 +475,8 @@ void launch_fac_bump_invert(const DevView& dv, double* K, double* W, double* out
 void launch_fac_bump_transpose(const double* in, double* outT, int b, hipStream_t st);  // K^-1 of the bump, one launch
 void launch_fac_tail_prog(const DevView& dv, FacTailRec* pf, FacTailRec* pb, int nlev, hipStream_t st);
 void launch_fac_plan(const DevView& dv, int* ltslot, int* segs, hipStream_t st);  // small levels, their LDS slots, the segments of a solve's walk (device-side)  // the tail's items as records (both directions)
-void launch_fac_reach_all(const DevView& dv, hipStream_t st);  // reach_of_pos of every position (levels in descending order, one launch); level of the bump
+void launch_fac_reach_all(const DevView& dv, int lev_hi, int lev_lo, hipStream_t st);
+void launch_fac_reach_level(const DevView& dv, int lev, int size, hipStream_t st);  // one large level by the grid  // reach_of_pos of every position (levels in descending order, one launch); level of the bump
 void launch_fac_sb_factor(const DevView& dv, const int* level, const FacSbWork& w, int b, hipStream_t st);  // sparse factor of the bump (one workgroup)
 void launch_fac_bump_build(const DevView& dv, double* Kd, int b, hipStream_t st);  // K = B0[bump rows, bump columns], dense, row-major with pitch FAC_BMAX
 void launch_str_reset(const DevView& dv, hipStream_t st);  // sparse tableau row: new stamp epoch, empty lists

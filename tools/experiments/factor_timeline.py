@@ -7,7 +7,8 @@ import numpy as np
 import minilp_amd as M
 from minilp_amd import lpgen
 S, D, piv = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-lp = lpgen.gen_mixed_lp(S, D, 4, 3)
+fam = sys.argv[4] if len(sys.argv) > 4 else "mixed"
+lp = lpgen.gen_mixed_lp(S, D, 4, 3) if fam == "mixed" else lpgen.gen_transport_lp(S, D, 4, tight=0.4)
 s = lpgen.build_problem(M.Problem, lp).solve(budget=piv)
 for rep in range(4):
     s.continue_solve(5)
