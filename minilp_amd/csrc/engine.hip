@@ -2007,7 +2007,7 @@ void Engine::fac_alloc() {
         d_fac_x0.ensure(2 * mm, 0, st);
         if (d_fac_x0.p != before) HIPCHECK(hipMemsetAsync(d_fac_x0.p, 0, sizeof(double) * d_fac_x0.cap, st));
     }
-    d_fac_pval.ensure(mm, 0, st); d_fac_coef.ensure(2 * 64 + 2, 0, st); d_fac_part.ensure((size_t)2 * 64 * 1024, 0, st);
+    d_fac_pval.ensure(mm, 0, st); d_fac_coef.ensure(2 * 64 + 2, 0, st); d_fac_part.ensure((size_t)3 * 64 * 1024, 0, st);
     d_fac_U.ensure(J * mm, 0, st); d_fac_V.ensure(J * mm, 0, st);
     d_fac_bpos.ensure(std::max(FAC_BMAX, FAC_SB_MAX), 0, st); d_fac_brow.ensure(std::max(FAC_BMAX, FAC_SB_MAX), 0, st);
     {   // resolved edge lists: at most the entries of A (incl. the slack identity) on either side

@@ -97,6 +97,8 @@ struct Ctl {
                      // (aq_n and str_n are adjacent: the host clears the pair with one 8-byte memset)
     // compact factor (factor.inc): level ranges a solve has to walk, produced by the solve / head that precedes it (a right-hand side
     // that is zero on every level beyond L leaves those levels at zero: they are skipped)
+    int fac_rho_part_n;  // compact factor: the BTRAN that produced rho also left the per-workgroup partial sums of V_j . rho for this many
+    int fac_rho_part_ok; // pending terms (region 2 of fac_part); consumed (and cleared) by the FTRAN that solves tau = B^-1 rho
     double fac_inv[64];  // compact factor: 1 / alpha_q[r] of pending term j — fac_U holds (alpha_q - e_r) unscaled, readers form U_j = -(...) * fac_inv[j]
     int fac_aq_hi;     // FTRAN of the entering column: highest level among the pivot positions of its rows
     int fac_rho_hi;    // FTRAN of rho (tau = B^-1 rho): highest level among the rows of supp(rho)        (atomicMax by the BTRAN's epilogue)
