@@ -356,6 +356,17 @@ def factor_transport(a):
             out["objective_matches_oracle"] = bool(abs(orc["objective"] - out["objective"]) <= 1e-9 * abs(orc["objective"]))
     except (OSError, KeyError, ValueError):
         pass
+    try:  # (committed, not re-run here: the oracle alone needs two minutes on it) the bump of the factor as a sparse LU with fill, DESIGN 2.8
+        ev = json.load(open(os.path.join(ROOT, "profiles", "r05_mixed100k_sparse_bump_evidence.json")))
+        f, d, o = (ev["runs"].get(k_, {}) for k_ in ("factor", "factor_dense_bump", "oracle"))
+        out["sparse_bump_committed"] = dict(
+            source="profiles/r05_mixed100k_sparse_bump_evidence.json", family="config-3 generator at 100000 x 160000",
+            gpu_wall_s=f.get("wall_s"), pivots=f.get("pivots"), largest_bump=max((c_.get("bump_max", 0) for c_ in f.get("chunks", [])), default=None),
+            oracle_wall_s=o.get("wall_s"), gpu_over_oracle=(o.get("wall_s") / f["wall_s"]) if f.get("wall_s") and o.get("wall_s") else None,
+            dense_bump_carrier=dict(finished=d.get("finished"), pivots=d.get("pivots"), wall_s=d.get("wall_s"),
+                                    last_us_per_pivot=(d.get("chunks") or [{}])[-1].get("us_per_pivot")))
+    except (OSError, KeyError, ValueError, TypeError):
+        pass
     return out
 
 
@@ -440,6 +451,10 @@ def compact_line(out):
     if out.get("factor_transport"):
         ft_ = out["factor_transport"]
         line["factor_transport"] = {k_: (r(v_, 2) if isinstance(v_, float) else v_) for k_, v_ in ft_.items() if k_ not in ("chunks", "note")}
+        sbc = line["factor_transport"].get("sparse_bump_committed")
+        if isinstance(sbc, dict):  # (the detail file keeps the whole record)
+            line["factor_transport"]["sparse_bump_committed"] = {k_: (r(v_, 2) if isinstance(v_, float) else v_) for k_, v_ in sbc.items()
+                                                                 if k_ in ("source", "gpu_wall_s", "oracle_wall_s", "gpu_over_oracle", "largest_bump")}
     return line
 
 
