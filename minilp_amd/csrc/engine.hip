@@ -541,7 +541,8 @@ DevView* Engine::sync_view() {
     v.str_list = d_str_list.p;
     v.aq_list = d_str_list.p ? d_str_list.p + (((size_t)num_vars + 63) & ~(size_t)63) : nullptr;
     const bool live = shard_is_live();  // (deferred sharding: until it goes live the kernels see one rank that owns every column)
-    v.rank = live ? shard_rank : 0; v.world = live ? shard_world : 1; v.mail = live ? d_mail : nullptr;
+    // (a world of ONE — the rccl transport's self-test on a one-GPU box — keeps its mailbox: the handshake and the pump kernels go through it)
+    v.rank = live ? shard_rank : 0; v.world = live ? shard_world : 1; v.mail = (live || shard_world == 1) ? d_mail : nullptr;
     for (int r = 0; r < MAX_WORLD; ++r) v.mail_peer[r] = reinterpret_cast<MailRec*>(peer_box[r]);
     v.mail_fanout = live ? mail_fanout : 0;
     {   // exchange buffers of the row-sharded streaming pass (peer transport, large-nucleus delayed-update mode only)
