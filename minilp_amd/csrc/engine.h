@@ -262,6 +262,7 @@ private:
     DevBuf<FacTailRec> d_fac_tprog;  // the tail of the solves as records: FTRAN | BTRAN, FAC_TAIL_CAP each
     DevBuf<int> d_fac_lev3;   // 3 m: level of a position | level of a row's pivot position | reach of a position
     bool fac_skip_ = true;    // MLP_FACTOR_SKIP=0: every solve walks every level (A/B)
+    bool fac_flow_ = true;    // MLP_FACTOR_FLOW=0: a grid barrier after every level of the grid's segments (the form before the data-flow walk)
     DevBuf<double> d_fac_Wb;   // allocated with the first bump
     bool fac_pair_ = true;                   // MLP_FACTOR_PAIR=0: every solve walks the levels on its own (A/B)
     int fac_bump_ = 0;

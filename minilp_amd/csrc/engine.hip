@@ -128,6 +128,7 @@ Engine::Engine() {
     if (const char* ff = std::getenv("MLP_FACTOR_FROM")) fac_auto_cap_ = std::max(256, std::atoi(ff));
     if (const char* fp = std::getenv("MLP_FACTOR_PAIR")) fac_pair_ = fp[0] != '0';
     if (const char* fs = std::getenv("MLP_FACTOR_SKIP")) fac_skip_ = fs[0] != '0';
+    if (const char* fs = std::getenv("MLP_FACTOR_FLOW")) fac_flow_ = fs[0] != '0';
     if (const char* fb = std::getenv("MLP_FACTOR_BUMP")) {  // (lowering the bump limit lowers it for both carriers of the bump)
         fac_bump_max_ = std::max(0, std::min(FAC_BMAX, std::atoi(fb)));
         fac_sb_max_ = std::min(fac_sb_max_, fac_bump_max_);
@@ -2044,7 +2045,7 @@ void Engine::fac_fill_view(DevView& v) const {
     v.fac_bar = d_fac_bar.p;
     v.fac_lev_of_pos = d_fac_lev3.p; v.fac_lev_of_row = d_fac_lev3.p ? d_fac_lev3.p + (size_t)std::max(m_, 1) : nullptr;
     v.fac_reach_of_pos = d_fac_lev3.p ? d_fac_lev3.p + 2 * (size_t)std::max(m_, 1) : nullptr;
-    v.fac_skip = fac_skip_ ? 1 : 0; v.fac_pad1 = 0;
+    v.fac_skip = fac_skip_ ? 1 : 0; v.fac_flow = fac_flow_ ? 1 : 0;
     v.fac_idx_of_pos = d_fac_lev3.p ? d_fac_lev3.p + 3 * (size_t)std::max(m_, 1) : nullptr;
     v.fac_idx_of_row = d_fac_lev3.p ? d_fac_lev3.p + 4 * (size_t)std::max(m_, 1) : nullptr;
     v.fac_tprog_f = d_fac_tprog.p; v.fac_tprog_b = d_fac_tprog.p ? d_fac_tprog.p + (size_t)std::max(m_, 1) : nullptr;
@@ -3209,7 +3210,7 @@ Engine* Engine::clone() {
     HIPCHECK(hipStreamSynchronize(s2));
     std::memcpy(e->h_ctl, h_ctl, sizeof(Ctl));
     e->values_dirty = true;
-    e->fac_mode = fac_mode; e->fac_J_ = fac_J_; e->fac_period_ = fac_period_; e->fac_period_auto_ = fac_period_auto_; e->fac_auto_cap_ = fac_auto_cap_; e->fac_bump_max_ = fac_bump_max_; e->fac_sb_max_ = fac_sb_max_; e->fac_sb_from_ = fac_sb_from_; e->fac_pair_ = fac_pair_; e->fac_skip_ = fac_skip_;
+    e->fac_mode = fac_mode; e->fac_J_ = fac_J_; e->fac_period_ = fac_period_; e->fac_period_auto_ = fac_period_auto_; e->fac_auto_cap_ = fac_auto_cap_; e->fac_bump_max_ = fac_bump_max_; e->fac_sb_max_ = fac_sb_max_; e->fac_sb_from_ = fac_sb_from_; e->fac_pair_ = fac_pair_; e->fac_skip_ = fac_skip_; e->fac_flow_ = fac_flow_;
     if (fac_on_ && !e->fac_enter())  // (a fresh peel of the same basis: the same operator, no pending terms)
         throw MlpError(-3, "clone: the basis of a solution on the compact factor must peel");
     return owner.release();

@@ -329,7 +329,7 @@ struct DevView {
     int* fac_lev_of_pos;     // m: level of a position (-1: bump)
     int* fac_lev_of_row;     // m: level of the position that pivots on a row (-1: bump row)
     int* fac_reach_of_pos;   // m: highest level any BTRAN dependent of the position reaches
-    int fac_skip, fac_pad1;  // MLP_FACTOR_SKIP: walk only the levels a right-hand side can reach
+    int fac_skip, fac_flow;  // MLP_FACTOR_SKIP: walk only the levels a right-hand side can reach; MLP_FACTOR_FLOW: the walk is ordered by data, not by grid barriers
     // the single-workgroup tail of the solves (factor.inc): place of a position / of a row's pivot position in fac_items (-1: bump),
     // and the tail's items as fixed-size records in walking order (one per direction)
     int* fac_idx_of_pos; int* fac_idx_of_row;
