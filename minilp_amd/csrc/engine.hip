@@ -2368,6 +2368,7 @@ void Engine::launch_stage_fac(int phase, int stage, bool with_events) {
     // 200 000-row transport instance, profiles/r05c_transport_first60k_kernel_stats.csv); bit-identical (MLP_FACTOR_FUSE=0: A/B, tests)
     static const bool fuse_env = !(std::getenv("MLP_FACTOR_FUSE") && std::getenv("MLP_FACTOR_FUSE")[0] == '0');
     const bool fused = fuse_env && phase == 1 && !pse && dse && fac_pair_ && !stepping;
+    static const bool rho_part_env = !(std::getenv("MLP_FACTOR_RHO_PART") && std::getenv("MLP_FACTOR_RHO_PART")[0] == '0');
     switch (stage) {
     case STAGE_FTRAN:
         if (with_events) HIPCHECK(hipEventRecord(ev[6], st));
@@ -2385,8 +2386,8 @@ void Engine::launch_stage_fac(int phase, int stage, bool with_events) {
     case STAGE_BTRAN:
         if (phase == 1 && !fused) launch_btran_prep(dv, 1, 0, st);         // leaving row's scalars
         // rho = B^-T e_r, ||rho||^2; in a primal iteration alpha_q is known already, so v = B^-T alpha_q (solver.rs:1114) shares the walk
-        if (phase == 0 && pse && fac_pair_) launch_fac_solve2(dv, g, 1, 0, 0, 1, 1, st);
-        else launch_fac_solve(dv, g, 1, 0, 0, nullptr, 0, st, fused ? 1 : 0);
+        if (phase == 0 && pse && fac_pair_) launch_fac_solve2(dv, g, 1, 0, 0, 1, 1, st, rho_part_env ? 0 : 8);
+        else launch_fac_solve(dv, g, 1, 0, 0, nullptr, 0, st, (fused ? 1 : 0) | (rho_part_env ? 0 : 8));
         break;
     case STAGE_BASIS:
         if (pse && !(phase == 0 && fac_pair_)) launch_fac_solve(dv, g, 1, 1, 1, nullptr, 0, st);   // v = B^-T alpha_q      (solver.rs:1114)

@@ -458,7 +458,8 @@ void launch_build_nucleus(const DevView& dv, const Geom& g, double* Kd, int k, h
 // one level-scheduled solve: dir 0 FTRAN (src 0 entering column | 1 rho | 2 src_ptr by row; dst 0 alpha_q | 1 tau),
 // dir 1 BTRAN (src 0 e_r | 1 alpha_q | 2 src_ptr by position; dst 0 rho + ||rho||^2 | 1 v); always: whatever the iteration status
 // fuse (dual iteration without primal steepest edge, not stepping): 1 = the leaving row's scalars (k_btran_prep) in the head of the BTRAN,
-// 2 = the plan (k_post_ftran) and 4 = the new rank-1 term (k_fac_append) in the epilogue of the FTRAN
+// 2 = the plan (k_post_ftran) and 4 = the new rank-1 term (k_fac_append) in the epilogue of the FTRAN; 8 = the BTRAN does NOT leave the
+// partial sums of V_j . rho behind (MLP_FACTOR_RHO_PART=0: A/B, tests)
 void launch_fac_solve(const DevView& dv, const Geom& g, int dir, int src, int dst, const double* src_ptr, int always, hipStream_t st, int fuse = 0);
 void launch_fac_solve2(const DevView& dv, const Geom& g, int dir, int srcA, int dstA, int srcB, int dstB, hipStream_t st, int fuse = 0);  // two right-hand sides, one walk over the levels
 int fac_solve_grid_blocks();  // workgroups of k_fac_solve's grid: workgroup j reduces the coefficient of pending term j, so fac_J must not exceed it

@@ -338,3 +338,57 @@ def test_a_bump_that_fills_falls_back_to_the_dense_inverse(monkeypatch):
     assert sb["fallbacks"] >= 1
     assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
     assert obj_close(sg.objective(), so.objective())
+
+
+@pytest.mark.parametrize("knob", ["MLP_FACTOR_FUSE", "MLP_FACTOR_RHO_PART"])
+def test_fused_launches_and_left_behind_partial_sums_change_no_bit(knob):
+    """The dual iteration on the compact factor with its three single-purpose launches riding inside the solves (U_j stored unscaled with
+    its factor beside it) and with the BTRAN leaving the partial sums of V_j . rho for the FTRAN of tau — against the forms they replace
+    (knob = 0, read once per process: each form runs in a process of its own): the same pivots, and x, the objective and the dual
+    steepest-edge weights BIT for bit.  Transport instance (several levels, 32 pending terms) and config 3 (a bump as a sparse LU)."""
+    import subprocess, sys, os, json
+    code = r'''
+import sys, json, hashlib
+import numpy as np
+import minilp_amd as M
+from minilp_amd import lpgen
+out = {}
+for name, lp in (("transport", lpgen.gen_transport_lp(800, 1000, 4, 11, tight=0.5)), ("config3", lpgen.gen_mixed_lp(6000, 10000, 4, 3))):
+    s = lpgen.build_problem(M.Problem, lp).solve(trace=True)
+    assert s.stats()["factor_active"] == 1
+    h = hashlib.sha1()
+    h.update(np.asarray(s.values(), dtype=np.float64).tobytes())
+    h.update(np.asarray(s.state("dual_edge_sq_norms"), dtype=np.float64).tobytes())
+    h.update(np.float64(s.objective()).tobytes())
+    h.update(repr([t[:5] for t in s.trace()]).encode())
+    out[name] = [h.hexdigest(), int(s.stats()["iterations"])]
+print("RESULT " + json.dumps(out))
+'''
+    res = []
+    for val in ("1", "0"):
+        env = dict(os.environ, MLP_FACTOR="1", MLP_FACTOR_SB_FROM="2")
+        env[knob] = val
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+        assert r.returncode == 0 and line, (r.returncode, r.stderr[-800:])
+        res.append(json.loads(line[-1][7:]))
+    print(knob, res)
+    assert res[0] == res[1]
+    assert res[0]["transport"][1] > 100 and res[0]["config3"][1] > 3000
+
+
+def test_data_flow_walk_takes_the_same_pivots(monkeypatch):
+    """MLP_FACTOR_FLOW=1 (the grid's segments ordered by data: sentinel + bounded waits instead of a grid barrier per level; measured, not
+    the default): the oracle's pivots on a transport instance with a dozen levels, the optimum of config 3 with its bump."""
+    monkeypatch.setenv("MLP_FACTOR", "1")
+    monkeypatch.setenv("MLP_FACTOR_FLOW", "1")
+    lp = lpgen.gen_transport_lp(2500, 2500, 4, 3, tight=0.4)
+    so, sg = _pair(lp)
+    assert sg.stats()["factor_active"] == 1 and sg.stats()["factor_levels"] >= 2
+    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+    assert obj_close(sg.objective(), so.objective())
+    lp3 = lpgen.gen_mixed_lp(6000, 10000, 4, 3)
+    monkeypatch.setenv("MLP_FACTOR_SB_FROM", "2")
+    so3, sg3 = _pair(lp3)
+    assert obj_close(sg3.objective(), so3.objective())
+    check_feasible(lp3, sg3.values())
