@@ -1826,7 +1826,10 @@ int Engine::run_loop(int phase) {
         // (round 5: a COLD solve — from the slack basis or a loaded basis, not a warm-start re-solve — captures the graph of several iterations
         // together with the first one-iteration graph: between two graph launches the device idles ~8 us (in-kernel timeline: 33 us of
         // kernels per pivot, 43 us per pivot on the clock), between two kernels of one graph ~1.4)
-        const bool multi = graph_now && (long_run || cold_start_) && graph_iters > 1 && !fac_on_;
+        // (second session of round 5: the compact factor too — a batch between two refactorisations is 32 or 64 pivots, three to six graphs
+        // of ten iterations instead of one graph launch, and ~8 us of idle device, per pivot; MLP_FACTOR_MULTI=0: A/B)
+        static const bool fac_multi = !(std::getenv("MLP_FACTOR_MULTI") && std::getenv("MLP_FACTOR_MULTI")[0] == '0');
+        const bool multi = graph_now && (long_run || cold_start_) && graph_iters > 1 && (!fac_on_ || fac_multi);
         int B = graph_now ? (multi ? RING : batch) : 1;
         if (pivot_budget > 0 && (int64_t)B > pivot_budget) B = (int)pivot_budget;
         if (hyper_gap > 0 && B > hyper_gap) B = hyper_gap;
