@@ -241,3 +241,57 @@ def gen_transport_lp(S, D, deg, seed=7, tight=1.0):
     rhs = np.concatenate((s, d))
     return dict(name=f"transport_{S}x{D}_deg{deg}_s{seed}_t{tight}", direction=MINIMIZE, m=S + D, n=n, obj=c, lo=np.zeros(n),
                 hi=np.full(n, np.inf), indptr=indptr, indices=indices, data=data, ops=ops, rhs=rhs)
+
+
+def gen_staircase_lp(T, R, P, caps, k=3, seed=5):
+    """Multi-period production / inventory model (a STAIRCASE: the classical structure whose bases triangularise around small bumps):
+    period t has R product-balance rows  sum_j a_ij x_tj + s_(t-1)i - s_ti = d_ti  (P activities, k products each; inventories s link
+    period t to t + 1: columns with two entries) and `caps` capacity rows  sum_j b_cj x_tj <= cap_tc  (every activity uses two
+    resources).  Minimise production + holding cost; built around a known feasible point; continuous random data (comparable pivot
+    sequences).  m = T (R + caps) rows, n = T (P + R) columns."""
+    m, n = T * (R + caps), T * (P + R)
+    u = lambda tag, cnt: uniform01(_stream(seed, tag), cnt)
+    pick = lambda tag, cnt, mod: (splitmix64(_stream(seed, tag), cnt) % np.uint64(mod)).astype(np.int64)
+    rows, cols, vals = [], [], []
+    prod_rows = pick(31, T * P * k, R).reshape(T, P, k)
+    prod_vals = np.round(0.5 + 2.0 * u(32, T * P * k), 3).reshape(T, P, k)
+    cap_rows = pick(33, T * P * 2, caps).reshape(T, P, 2)
+    cap_vals = np.round(0.2 + 1.0 * u(34, T * P * 2), 3).reshape(T, P, 2)
+    for t in range(T):
+        r0, c0 = t * (R + caps), t * (P + R)
+        for e in range(k):   # activities on the balance rows (duplicates of a row within an activity are merged below)
+            rows.append(r0 + prod_rows[t, :, e]); cols.append(c0 + np.arange(P)); vals.append(prod_vals[t, :, e])
+        for e in range(2):
+            rows.append(r0 + R + cap_rows[t, :, e]); cols.append(c0 + np.arange(P)); vals.append(cap_vals[t, :, e])
+        rows.append(r0 + np.arange(R)); cols.append(c0 + P + np.arange(R)); vals.append(-np.ones(R))        # - s_t
+        if t + 1 < T:
+            rows.append(r0 + (R + caps) + np.arange(R)); cols.append(c0 + P + np.arange(R)); vals.append(np.ones(R))  # + s_t in period t + 1
+    import scipy.sparse as sp
+    A = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(m, n))
+    A.sum_duplicates()
+    A.sort_indices()
+    x0 = np.zeros(n)
+    act = u(35, T * P) < 0.35
+    lvl = np.round(3.0 * u(36, T * P), 3) * act
+    inv = np.round(2.0 * u(37, T * R), 3) * (u(38, T * R) < 0.3)
+    for t in range(T):
+        c0 = t * (P + R)
+        x0[c0:c0 + P] = lvl[t * P:(t + 1) * P]
+        x0[c0 + P:c0 + P + R] = inv[t * R:(t + 1) * R]
+    lhs = A @ x0
+    ops = np.empty(m, np.int32)
+    rhs = np.empty(m)
+    slack = np.round(1.0 + 4.0 * u(39, m), 3)
+    for t in range(T):
+        r0 = t * (R + caps)
+        ops[r0:r0 + R] = EQ
+        rhs[r0:r0 + R] = lhs[r0:r0 + R]
+        ops[r0 + R:r0 + R + caps] = LE
+        rhs[r0 + R:r0 + R + caps] = lhs[r0 + R:r0 + R + caps] + slack[r0 + R:r0 + R + caps]
+    cost = np.empty(n)
+    for t in range(T):
+        c0 = t * (P + R)
+        cost[c0:c0 + P] = np.round(1.0 + 3.0 * u(40 + (t % 7), P), 3) * (1.0 + 0.3 * np.sin(0.37 * t))
+        cost[c0 + P:c0 + P + R] = np.round(0.05 + 0.2 * u(50 + (t % 5), R), 3)
+    return dict(name=f"staircase_T{T}_R{R}_P{P}_c{caps}_s{seed}", m=m, n=n, direction=MINIMIZE, obj=cost, lo=np.zeros(n), hi=np.full(n, np.inf),
+                indptr=A.indptr.astype(np.int64), indices=A.indices.astype(np.int64), data=A.data.astype(np.float64), ops=ops, rhs=rhs)

@@ -392,3 +392,21 @@ def test_data_flow_walk_takes_the_same_pivots(monkeypatch):
     so3, sg3 = _pair(lp3)
     assert obj_close(sg3.objective(), so3.objective())
     check_feasible(lp3, sg3.values())
+
+
+def test_staircase_family_hands_a_filling_bump_over(monkeypatch):
+    """Multi-period production / inventory model (lpgen.gen_staircase_lp, 5 000 rows): with the compact factor forced its bump grows to a
+    quarter of the rows and the elimination of it fills in a dense tail (rows of 60-80 entries: tools/experiments/bump_lu.py staircase).
+    The sparse LU carries the bump while its rows fit their slots (dozens of factorisations), then raises its flag; beyond 1 024
+    columns there is no dense carrier either, so the solve goes back to the explicit nucleus inverse — and reaches the oracle's optimum.
+    (On the default path this family is where the explicit inverse shines: 1.0 s against 7.8 s for the oracle, whose LU fills.)"""
+    monkeypatch.setenv("MLP_FACTOR", "1")
+    lp = lpgen.gen_staircase_lp(40, 100, 150, 25)
+    so = lpgen.build_problem(O.Problem, lp).solve()
+    sg = lpgen.build_problem(M.Problem, lp).solve()
+    st, sb = sg.stats(), _sb(sg)
+    print("pivots", st["iterations"], "largest bump", st["factor_bump_max"], "switches", st["factor_switches"], "sparse bump", sb)
+    assert sb["factorisations"] >= 10 and sb["fallbacks"] >= 1
+    assert st["factor_switches"] >= 2 and st["factor_active"] == 0 and st["factor_bump_max"] > 1024
+    assert obj_close(sg.objective(), so.objective())
+    check_feasible(lp, sg.values())

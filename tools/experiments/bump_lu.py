@@ -88,7 +88,8 @@ def markowitz_rounds(K):
 
 fam, a, b, k, chunk = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 skip = int(sys.argv[6]) if len(sys.argv) > 6 else 0
-lp = lpgen.gen_mixed_lp(a, b, k, 3)
+# (staircase: T periods, b = R products, k = P activities per period, R // 4 capacity rows)
+lp = lpgen.gen_staircase_lp(a, b, k, max(1, b // 4)) if fam == "staircase" else lpgen.gen_mixed_lp(a, b, k, 3)
 m, n = lp["m"], lp["n"]
 A = sp.csr_matrix((lp["data"], lp["indices"], lp["indptr"]), shape=(m, n)).tocsc()
 Aext = sp.hstack([A, sp.identity(m, format="csc")], format="csc")
