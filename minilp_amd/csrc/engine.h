@@ -137,7 +137,7 @@ struct Stats {
     uint64_t hyper_iters = 0, hyper_bails = 0;  // iterations taken by the hypersparse kernel; iterations it handed back
     uint64_t ratio_stalls = 0;   // in-kernel waits of the fused ratio test that timed out (each one retried with two launches)
     uint64_t beta_rebuilds = 0;  // lazy dual steepest edge: exact rebuilds of beta from the basis inverse
-    uint64_t fac_refactors = 0, fac_levels = 0, fac_switches = 0, fac_bump = 0, fac_bump_max = 0, fac_sb_factors = 0, fac_sb_fallbacks = 0, fac_sb_rounds = 0;  // compact factor: refactorisations (peels), levels of the last one, mode switches
+    uint64_t fac_refactors = 0, fac_levels = 0, fac_switches = 0, fac_bump = 0, fac_bump_max = 0, fac_sb_factors = 0, fac_sb_fallbacks = 0, fac_sb_rounds = 0, fac_sb_tail = 0;  // compact factor: refactorisations (peels), levels of the last one, mode switches
     // dense-rhs FTRAN x_B = B^-1 (b - N x_N) (recalc_basic_vals): the streaming read of the nucleus inverse, kernel-exact
     double dense_ftran_bytes = 0, dense_ftran_ms = 0;
     uint64_t dense_ftran_launches = 0;

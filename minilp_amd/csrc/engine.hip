@@ -2060,8 +2060,10 @@ void Engine::fac_fill_view(DevView& v) const {
     if (d_fac_sb_rec.p) {
         const FacSbWork w = fac_sb_work(std::max(m_, 1));
         v.fac_sb_rec = w.rec; v.fac_sb_lptr = w.lptr; v.fac_sb_oidx = w.oidx; v.fac_sb_oval = w.oval;
+        v.fac_sb_trow = w.trow; v.fac_sb_tcol = w.tcol; v.fac_sb_tinv = w.tinv; v.fac_sb_tinvT = w.tinvT;
     } else {
         v.fac_sb_rec = nullptr; v.fac_sb_lptr = nullptr; v.fac_sb_oidx = nullptr; v.fac_sb_oval = nullptr;
+        v.fac_sb_trow = nullptr; v.fac_sb_tcol = nullptr; v.fac_sb_tinv = nullptr; v.fac_sb_tinvT = nullptr;
     }
 }
 // the carve-up of the sparse bump factor's buffers (factor_sb.inc)
@@ -2082,6 +2084,9 @@ FacSbWork Engine::fac_sb_work(int m) const {
     w.flags = it(8);
     w.lptr = it(FAC_SB_ROUNDS + 2);
     w.oidx = it(FAC_SB_KINDS * B * FAC_SB_OVS);
+    w.trow = it(FAC_SB_DT); w.tcol = it(FAC_SB_DT); w.tidx = it(B);
+    w.tK = dt((size_t)FAC_SB_DT * FAC_SB_DT); w.tW = dt((size_t)FAC_SB_DT * FAC_SB_DT);
+    w.tinv = dt((size_t)FAC_SB_DT * FAC_SB_DT); w.tinvT = dt((size_t)FAC_SB_DT * FAC_SB_DT);
     w.slot_of_pos = it((size_t)m);  // (last: nothing else moves with the number of rows)
     w.rval = dt(B * FAC_SB_RC); w.lval = dt(B * FAC_SB_LC); w.piv = dt(B); w.oval = dt(FAC_SB_KINDS * B * FAC_SB_OVS);
     w.rec = d_fac_sb_rec.p;
@@ -2113,7 +2118,7 @@ bool Engine::fac_refactor(int bump_limit) {
     launch_fac_peel_init(t, cnt, level, row_lev, claim, rcnt, claim_r, st);
     std::vector<int> lptr(1, 0);
     int total = 0;
-    int n_col_steps = 0, n_row_steps = 0, sb_rounds = 0;
+    int n_col_steps = 0, n_row_steps = 0, sb_rounds = 0, sb_tail = 0;
     static const bool peel_paced = std::getenv("MLP_FACTOR_PEEL_PACED") != nullptr;  // the round-4 first cut: the host paces the levels
     bool device_peel_done = false;
     if (!peel_paced) {
@@ -2194,22 +2199,25 @@ bool Engine::fac_refactor(int bump_limit) {
         if (sb_try) {
             // the bump as a sparse LU with fill (factor_sb.inc): one launch of one workgroup, two flags back
             const size_t B = FAC_SB_MAX;
-            const size_t ni = mm + B * (FAC_SB_RC + FAC_SB_CC + FAC_SB_LC) + 13 * B + 8 + FAC_SB_ROUNDS + 2 + FAC_SB_KINDS * B * FAC_SB_OVS + 64;
-            const size_t nd = B * (FAC_SB_RC + FAC_SB_LC) + B + FAC_SB_KINDS * B * FAC_SB_OVS + 64;
+            const size_t ni = mm + B * (FAC_SB_RC + FAC_SB_CC + FAC_SB_LC) + 14 * B + 2 * FAC_SB_DT + 8 + FAC_SB_ROUNDS + 2 + FAC_SB_KINDS * B * FAC_SB_OVS + 64;
+            const size_t nd = B * (FAC_SB_RC + FAC_SB_LC) + B + FAC_SB_KINDS * B * FAC_SB_OVS + 4 * (size_t)FAC_SB_DT * FAC_SB_DT + 64;
             const int* ib = d_fac_sb_int.p; const double* db = d_fac_sb_dbl.p; const FacSbRec* rb = d_fac_sb_rec.p;
             d_fac_sb_int.ensure(ni, 0, st); d_fac_sb_dbl.ensure(nd, 0, st); d_fac_sb_rec.ensure(FAC_SB_KINDS * B, 0, st);
             if (ib != d_fac_sb_int.p || db != d_fac_sb_dbl.p || rb != d_fac_sb_rec.p) view_dirty = true;
             const FacSbWork w = fac_sb_work(m_);
             t.fac_sb_rec = w.rec; t.fac_sb_lptr = w.lptr; t.fac_sb_oidx = w.oidx; t.fac_sb_oval = w.oval;
+            t.fac_sb_trow = w.trow; t.fac_sb_tcol = w.tcol; t.fac_sb_tinv = w.tinv; t.fac_sb_tinvT = w.tinvT;
             launch_fac_sb_factor(t, level, w, b, st);
-            int hf[4] = {0, 0, 0, 0};
+            int hf[6] = {0, 0, 0, 0, 0, 0};
             HIPCHECK(hipMemcpyAsync(hf, w.flags, sizeof(hf), hipMemcpyDeviceToHost, st));
             HIPCHECK(hipStreamSynchronize(st));
             if (!hf[0] && !hf[1] && hf[3] == 0) {
                 sb_now = true;
                 sb_rounds = hf[2];
+                sb_tail = hf[4];
                 stats.fac_sb_factors += 1;
                 stats.fac_sb_rounds = (uint64_t)hf[2];
+                stats.fac_sb_tail = (uint64_t)hf[4];
             } else {
                 stats.fac_sb_fallbacks += 1;  // rows outgrew their slots (or the elimination stalled): this bump is not sparse enough
                 if (b > bump_limit) return false;
@@ -2266,7 +2274,7 @@ bool Engine::fac_refactor(int bump_limit) {
         view_dirty = true;
     }
     fac_sb_on_ = sb_now;
-    const int meta[16] = {nlev, total, b, nlev, n_col_steps, n_row_steps, 0, 0, sb_now ? 1 : 0, sb_rounds, 0, 0, 0, 0, 0, 0};
+    const int meta[16] = {nlev, total, b, nlev, n_col_steps, n_row_steps, 0, 0, sb_now ? 1 : 0, sb_rounds, sb_now ? sb_tail : 0, 0, 0, 0, 0, 0};
     HIPCHECK(hipMemcpyAsync(d_fac_meta.p, meta, sizeof(meta), hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)std::max(nlev, 1), st));  // (cnt is free again: the per-level fill cursors)
     launch_fac_peel_fill(t, level, cnt, st);
@@ -3307,7 +3315,7 @@ uint64_t Engine::state(const char* what, double* out, uint64_t cap) {
     }
     else if (w == "factor_sb") {  // sparse factor of the bump: in use now, factorisations, fallbacks to the dense inverse, rounds of the last one
         tmp.push_back(fac_on_ && fac_sb_on_ ? 1.0 : 0.0); tmp.push_back((double)stats.fac_sb_factors);
-        tmp.push_back((double)stats.fac_sb_fallbacks); tmp.push_back((double)stats.fac_sb_rounds);
+        tmp.push_back((double)stats.fac_sb_fallbacks); tmp.push_back((double)stats.fac_sb_rounds); tmp.push_back((double)stats.fac_sb_tail);
     }
     else if (w == "hyper_bail_reasons") {
         for (int i = 0; i < 10; ++i) tmp.push_back((double)stats.hyper_bail_reason[i]);

@@ -169,6 +169,7 @@ constexpr int FAC_SB_LC = 64;      // multipliers of a row
 constexpr int FAC_SB_INL = 8;      // edges inside a record
 constexpr int FAC_SB_OVS = 64;     // overflow edges per item (>= the longest list)
 constexpr int FAC_SB_ROUNDS = 1022;
+constexpr int FAC_SB_DT = 128;      // dense tail: once this few columns are left the elimination stops and the rest is inverted densely
 constexpr int FAC_SB_KINDS = 6;     // record arrays: L, U, U^T, L^T, FTRAN right-hand side, BTRAN right-hand side
 struct alignas(16) FacSbRec {
     int out, rhs, n, ovf;
@@ -190,6 +191,9 @@ struct FacSbWork {  // scratch and outputs of the factorisation (all by bump slo
     FacSbRec* rec;                            // 6 x FAC_SB_MAX: L | U | U^T | L^T records in round order, the right-hand sides of the two solves by slot
     int* lptr;                                // FAC_SB_ROUNDS + 2
     int* oidx; double* oval;                  // 6 x FAC_SB_MAX x FAC_SB_OVS overflow edges
+    // dense tail (the last <= FAC_SB_DT rows x columns, by ascending slot): their slots, the work copy, K_t^-1 and its transpose
+    int* trow; int* tcol; int* tidx;          // DT | DT | b (tail index of a column slot)
+    double* tK; double* tW; double* tinv; double* tinvT;  // DT x DT each: [a][c] work arrays, tinv[c][a] = (K_t^-1)[column c, row a], tinvT[a][c]
 };
 struct DevView {
     int m, n;  // constraints (= basic positions), non-basic positions (= num_vars)
@@ -357,6 +361,8 @@ struct DevView {
     double* fac_Wb;          // FAC_BMAX x FAC_BMAX, row-major: Wb[s][u] = (K^-1)[position slot s, row slot u]
     // sparse factor of the bump (fac_meta[8] = 1: in use, fac_meta[9] = rounds): records L | U | U^T | L^T, FAC_SB_MAX each, in round order
     const FacSbRec* fac_sb_rec; const int* fac_sb_lptr; const int* fac_sb_oidx; const double* fac_sb_oval;
+    // ... its dense tail (fac_meta[10] rows x columns, the last level of the rounds): slots and the inverse in both layouts
+    const int* fac_sb_trow; const int* fac_sb_tcol; const double* fac_sb_tinv; const double* fac_sb_tinvT;
 };
 constexpr int FAC_BMAX = 1024;
 
