@@ -26,6 +26,10 @@ ENVS = [{}, {"MLP_LOWRANK": "3", "MLP_BIGTILE": "1", "MLP_LDPAD": "16", "MLP_BAN
         {"MLP_DETERMINISTIC": "0", "MLP_HYPER": "0", "MLP_GRAPH_ITERS": "3", "MLP_RATIO_ONE": "0"}]
 if os.environ.get("FUZZ_ENVS") == "head":   # only the round-5 configurations
     ENVS = ENVS[-5:]
+if os.environ.get("FUZZ_ENVS") == "factor":   # round 5, second session: the compact factor forced, the carriers of its bump, the data-flow walk
+    ENVS = [{"MLP_FACTOR": "1"}, {"MLP_FACTOR": "1", "MLP_FACTOR_SB_FROM": "2"}, {"MLP_FACTOR": "1", "MLP_FACTOR_SB_FROM": "2", "MLP_FACTOR_J": "5"},
+            {"MLP_FACTOR": "1", "MLP_FACTOR_FLOW": "1", "MLP_FACTOR_SB_FROM": "2"}, {"MLP_FACTOR": "1", "MLP_FACTOR_BUMP": "16"},
+            {"MLP_FACTOR": "1", "MLP_FACTOR_SB": "0"}, {"MLP_FACTOR": "1", "MLP_FACTOR_SB_FROM": "2", "MLP_FACTOR_J": "64", "MLP_NO_GRAPH": "1"}]
 bad = 0
 t0 = time.time()
 for case in range(n_cases):
@@ -46,7 +50,7 @@ for case in range(n_cases):
     env = ENVS[case % len(ENVS)]
     for kk in ("MLP_LOWRANK", "MLP_BIGTILE", "MLP_LDPAD", "MLP_BANDED", "MLP_GRAPH_ITERS", "MLP_NO_GRAPH", "MLP_DETERMINISTIC", "MLP_HYPER",
                "MLP_HEAD_APPLY", "MLP_PULL_INSIDE", "MLP_PRIMAL_HEAD_K", "MLP_RATIO_ONE", "MLP_STREAM_BALANCED", "MLP_ORDER_FROM", "MLP_ORDER_EVERY",
-               "MLP_SWEEP_PACKED"):
+               "MLP_SWEEP_PACKED", "MLP_FACTOR", "MLP_FACTOR_SB_FROM", "MLP_FACTOR_J", "MLP_FACTOR_FLOW", "MLP_FACTOR_BUMP", "MLP_FACTOR_SB"):
         os.environ.pop(kk, None)
     os.environ.update(env)
     try:
