@@ -163,7 +163,7 @@ static_assert(sizeof(FacTailRec) == 128, "16 + 6 x 16 + 16 bytes");
 // stored, rows that would outgrow their slots send the bump back to the dense inverse.  One item of a round, ready to execute in
 // pull form: out = (rhs - sum val[e] * x[idx[e]]) / piv  (edges beyond the inline ones at ovf in fac_sb_oidx / fac_sb_oval).
 constexpr int FAC_SB_MAX = 4096;   // bump columns the sparse factor carries (four solve vectors of that length live in LDS)
-constexpr int FAC_SB_RC = 32;      // entries of an active row, fill included
+constexpr int FAC_SB_RC = 64;      // entries of an active row, fill included
 constexpr int FAC_SB_CC = 64;      // rows ever listed for a column (stale ones included)
 constexpr int FAC_SB_LC = 64;      // multipliers of a row
 constexpr int FAC_SB_INL = 8;      // edges inside a record
