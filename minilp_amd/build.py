@@ -26,17 +26,28 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _deps(src):
+    """Files an object depends on: its source, every header, and (kernels.hip only) the .inc files it includes."""
+    inc = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h") or (src == "kernels.hip" and f.endswith(".inc"))]
+    return [os.path.join(CSRC, src), os.path.join(HERE, "..", "include", "minilp_hip.h")] + inc
+
+
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return SO
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in _deps(src)):
+            continue  # (per-object: a change to engine.hip does not recompile the kernels)
         cmd = [hipcc()] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
-        objs.append(obj)
+        jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in jobs:  # the translation units compile side by side
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -137,7 +137,7 @@ struct Stats {
     uint64_t hyper_iters = 0, hyper_bails = 0;  // iterations taken by the hypersparse kernel; iterations it handed back
     uint64_t ratio_stalls = 0;   // in-kernel waits of the fused ratio test that timed out (each one retried with two launches)
     uint64_t beta_rebuilds = 0;  // lazy dual steepest edge: exact rebuilds of beta from the basis inverse
-    uint64_t fac_refactors = 0, fac_levels = 0, fac_switches = 0, fac_bump = 0, fac_bump_max = 0, fac_sb_factors = 0, fac_sb_fallbacks = 0, fac_sb_rounds = 0, fac_sb_tail = 0;  // compact factor: refactorisations (peels), levels of the last one, mode switches
+    uint64_t fac_refactors = 0, fac_levels = 0, fac_switches = 0, fac_bump = 0, fac_bump_max = 0, fac_sb_factors = 0, fac_sb_fallbacks = 0, fac_sb_rounds = 0, fac_sb_tail = 0, fac_sb_skipped = 0;  // compact factor: refactorisations (peels), levels of the last one, mode switches
     // dense-rhs FTRAN x_B = B^-1 (b - N x_N) (recalc_basic_vals): the streaming read of the nucleus inverse, kernel-exact
     double dense_ftran_bytes = 0, dense_ftran_ms = 0;
     uint64_t dense_ftran_launches = 0;
@@ -272,6 +272,7 @@ private:
     // rounds of independent pivots); one whose rows outgrow their slots falls back to the dense inverse (b <= fac_bump_max_)
     int fac_sb_max_ = FAC_SB_MAX;            // MLP_FACTOR_SB: 0 = never
     int fac_sb_from_ = 48;                   // MLP_FACTOR_SB_FROM: smaller bumps keep the dense inverse (one wave-sized product per solve)
+    int fac_sb_fail_b_ = 0, fac_sb_fail_skip_ = 0;  // size of the last bump that failed the sparse elimination / refactorisations left before it is tried again
     bool fac_sb_on_ = false;                 // the current factor carries its bump sparsely
     DevBuf<int> d_fac_sb_int;                // integer scratch + outputs of the factorisation (FacSbWork)
     DevBuf<double> d_fac_sb_dbl;
@@ -402,6 +403,9 @@ private:
     void pump_until_idle();                // call after enqueueing kernels that contain exchanges, before synchronising the stream
     void pump_round(bool done_local, bool* all_done);
     void shm_barrier();
+    bool fac_allowed_under_sharding() const;  // the compact factor shards on distinct devices only (enable_sharding)
+    void golive_check();                   // deferred sharding: the ranks compare fingerprints of their replicated state before the switch
+    uint64_t golive_seq_ = 0, golive_checks_ = 0;
   public:
     std::string transport = "none";        // human-readable name of the exchange transport
   private:

@@ -130,8 +130,9 @@ Engine::Engine() {
     if (const char* fs = std::getenv("MLP_FACTOR_SKIP")) fac_skip_ = fs[0] != '0';
     if (const char* fs = std::getenv("MLP_FACTOR_FLOW")) fac_flow_ = fs[0] != '0';
     if (const char* fb = std::getenv("MLP_FACTOR_BUMP")) {  // (lowering the bump limit lowers it for both carriers of the bump)
-        fac_bump_max_ = std::max(0, std::min(FAC_BMAX, std::atoi(fb)));
-        fac_sb_max_ = std::min(fac_sb_max_, fac_bump_max_);
+        const int want = std::atoi(fb);
+        fac_bump_max_ = std::max(0, std::min(FAC_BMAX, want));
+        if (want < FAC_BMAX) fac_sb_max_ = std::min(fac_sb_max_, fac_bump_max_);  // (a value at or above the dense carrier's capacity leaves the sparse carrier's limit alone)
     }
     if (const char* fb = std::getenv("MLP_FACTOR_SB")) fac_sb_max_ = std::max(0, std::min(FAC_SB_MAX, std::atoi(fb)));
     if (const char* fb = std::getenv("MLP_FACTOR_SB_FROM")) fac_sb_from_ = std::max(1, std::atoi(fb));
@@ -631,7 +632,7 @@ void Engine::ensure_nucleus_cap(int need) {
     // every column (no bump: the LU of this basis has no fill) the solve continues on the compact factor.  A basis that does
     // not peel (config 4: a random sparse nucleus fills to dense) keeps the explicit inverse; the attempt is repeated only
     // after the nucleus has doubled again.
-    if (fac_mode < 0 && need > fac_auto_cap_ && shard_world == 1 && !stepping && d_ctl.p && k_ > 0 &&
+    if (fac_mode < 0 && need > fac_auto_cap_ && fac_allowed_under_sharding() && !stepping && d_ctl.p && k_ > 0 &&
         (!fac_tried_ || cap_ >= 2 * (int)fac_tried_at_)) {
         fac_tried_ = true;
         fac_tried_at_ = (uint64_t)std::max(cap_, 1);
@@ -753,7 +754,10 @@ struct Rendezvous {  // 128 bytes
     uint64_t ready;  // 1: handle valid, 2: every peer handle opened by this rank
     int32_t device, pid;
     hipIpcMemHandle_t handle;  // 64 bytes
-    uint8_t pad[128 - 8 - 8 - sizeof(hipIpcMemHandle_t)];
+    // go-live check of the deferred sharding (Engine::golive_check): this rank's fingerprint of the replicated state, published under
+    // fp_seq (the number of the check), acknowledged under fp_ack once every peer's fingerprint has been compared
+    uint64_t fp_seq, fp_ack;
+    uint64_t fp[4];  // pivots taken, nucleus size, hash of (basic_vars, nb_vars), bits of the objective
 };
 static_assert(sizeof(Rendezvous) == 128, "rendezvous record layout");
 constexpr size_t kHostBoxBytesPerRank = sizeof(MailRec) * 2 * MAIL_KINDS;  // 768
@@ -902,6 +906,59 @@ void Engine::shm_barrier() {  // all ranks of the solve, through the counter at 
         __builtin_ia32_pause();
     }
 }
+// Deferred sharding goes live on the assumption that every rank is the same replica: same pivots taken, same basis, same nucleus.
+// Nothing exchanged so far could have shown a divergence (replicas run without exchanges), and a sharded phase entered on
+// inconsistent state would run on silently — every rank keeping only its own block of d / gamma from then on.  So the switch is
+// guarded: every rank publishes a fingerprint of its replicated host-side state through the rendezvous object, waits (bounded) for
+// its peers', and the solve fails loudly on EVERY rank if any two differ (or if a peer never arrives: it went live at another pivot).
+void Engine::golive_check() {
+    if (shard_world <= 1 || !mail_host) return;
+    Rendezvous* rv = reinterpret_cast<Rendezvous*>(static_cast<uint8_t*>(mail_host) + kHostBoxBytesPerRank * (size_t)shard_world);
+    uint64_t h = 1469598103934665603ull;  // FNV-1a over the two index sets
+    auto mix = [&h](const std::vector<int>& a) {
+        for (int x : a) {
+            h ^= (uint64_t)(uint32_t)x;
+            h *= 1099511628211ull;
+        }
+    };
+    mix(h_basic_vars);
+    mix(h_nb_vars);
+    const double obj = cur_obj_val();
+    uint64_t ob = 0;
+    std::memcpy(&ob, &obj, sizeof(ob));
+    uint64_t fp[4] = {(uint64_t)lifetime_pivots, (uint64_t)(int64_t)k_, h, ob};
+    {   // test hook: MLP_TEST_GOLIVE_SKEW=<rank> makes that rank publish a perturbed fingerprint (tests/test_dist_gpu.py)
+        const char* sk = std::getenv("MLP_TEST_GOLIVE_SKEW");
+        if (sk && std::atoi(sk) == shard_rank) fp[2] ^= 1ull;
+    }
+    Rendezvous* mine = rv + shard_rank;
+    const uint64_t seq = ++golive_seq_;
+    for (int j = 0; j < 4; ++j) mine->fp[j] = fp[j];
+    __atomic_store_n(&mine->fp_seq, seq, __ATOMIC_RELEASE);
+    std::string bad;
+    for (int r = 0; r < shard_world; ++r) {
+        if (r == shard_rank) continue;
+        if (!wait_flag(&rv[r].fp_seq, seq, 120.0)) {
+            bad = "rank " + std::to_string(r) + " did not reach the go-live point of the deferred sharding within 120 s (it diverged or stopped)";
+            break;
+        }
+        for (int j = 0; j < 4 && bad.empty(); ++j)
+            if (rv[r].fp[j] != fp[j]) {
+                static const char* what[4] = {"pivots taken", "nucleus size", "basis (hash of basic_vars / nb_vars)", "objective bits"};
+                bad = std::string("ranks ") + std::to_string(shard_rank) + " and " + std::to_string(r) + " are not the same replica at the go-live point of the "
+                      "deferred sharding: " + what[j] + " differ (" + std::to_string(fp[j]) + " vs " + std::to_string(rv[r].fp[j]) + ")";
+            }
+        if (!bad.empty()) break;
+    }
+    // acknowledge whatever the outcome, so that no peer overwrites a fingerprint another rank is still reading (a later check of the
+    // same rendezvous object) and a failing rank does not leave the others waiting for its acknowledgement
+    __atomic_store_n(&mine->fp_ack, seq, __ATOMIC_RELEASE);
+    if (!bad.empty()) throw MlpError(-3, "enable_sharding / go-live: " + bad);
+    for (int r = 0; r < shard_world; ++r)
+        if (r != shard_rank && !wait_flag(&rv[r].fp_ack, seq, 120.0))
+            throw MlpError(-3, "enable_sharding / go-live: rank " + std::to_string(r) + " did not acknowledge the fingerprint check within 120 s");
+    golive_checks_ += 1;
+}
 void Engine::pump_round(bool done_local, bool* all_done) {
     const int world = shard_world, rank = shard_rank;
     const size_t blk = (size_t)MAIL_PUMP_RECS * sizeof(MailRec);
@@ -989,12 +1046,13 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name, const ch
     if (world < 1 || world > MAX_WORLD || rank < 0 || rank >= world)
         throw MlpError(-1, "enable_sharding: bad rank/world (at most " + std::to_string(MAX_WORLD) + " ranks)");
     HIPCHECK(hipStreamSynchronize(st));
-    // The compact factor stays a one-GPU representation.  Round 5 tried it under sharding (solves replicated on every rank in fixed-order
-    // sums, the column-block kernels for the rest): pivot for pivot identical to the unsharded run — and 3.9 s per pivot with two ranks on
-    // the one GPU of the test box: k_fac_solve is a persistent kernel with grid barriers, one workgroup per CU, and two of them from two
-    // processes time-slice the device while each one's peers wait in a mailbox spin (40 pivots ran into the spin bound).  On distinct
-    // devices that contention does not exist, but no multi-GPU node was available to verify it, so the switch is not shipped untested.
-    if (fac_on_ && world > 1) fac_leave();
+    // The compact factor under sharding: the solves run replicated on every rank (fixed-order sums), the column-block kernels do the rest —
+    // pivot for pivot identical to the unsharded run (round 5).  It is PATHOLOGICAL only when ranks share a device: k_fac_solve is a
+    // persistent kernel with grid barriers, one workgroup per CU, and two of them from two processes time-slice the device while each
+    // one's peers wait in a mailbox spin (3.9 s per pivot with two ranks on one GPU).  The gate therefore follows `ranks_share_device`,
+    // which is known only once the transport is up: see the end of this function (MLP_FACTOR_SHARED_DEVICE=1 keeps the factor even then:
+    // the oversubscribed correctness test).
+    const bool had_factor = fac_on_;
     release_mailboxes();
     std::string tname = transport_name ? transport_name : "";
     if (tname.empty() && std::getenv("MLP_TRANSPORT")) tname = std::getenv("MLP_TRANSPORT");
@@ -1140,6 +1198,10 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name, const ch
         shard_live_ = false;
         view_dirty = true;
         throw;
+    }
+    if (had_factor && fac_on_ && world > 1 && !fac_allowed_under_sharding()) {
+        fac_leave();  // (ranks sharing a device, or a transport that cannot tell: back to the explicit inverse)
+        view_dirty = true;
     }
     {   // deferred sharding (engine.h): replicas until the tableau row becomes a pass over A; MLP_SHARD_DEFER=0 shards from the first pivot
         const char* sd = std::getenv("MLP_SHARD_DEFER");
@@ -1795,7 +1857,10 @@ int Engine::run_loop(int phase) {
             // against 98 at k = 135 (tools/small_basis_curve.py) — so the form is chosen per batch by the size the nucleus can reach)
             sb_now = want && k_ + RING + 1 <= sb_kmax;
             if (shard_world > 1 && !shard_live_ && !(shard_defer_ && want && !pump_backend_)) {
-                shard_live_ = true;  // the column-block sharding goes live (every rank takes this decision at the same pivot: k_ is replicated)
+                // the column-block sharding goes live (every rank takes this decision at the same pivot: k_ is replicated) — after the
+                // ranks have shown each other that they ARE the same replica (golive_check throws on every rank otherwise)
+                if (shard_defer_) golive_check();
+                shard_live_ = true;
                 view_dirty = true;
             }
             if (str_now) {
@@ -2175,7 +2240,15 @@ bool Engine::fac_refactor(int bump_limit) {
     // inverse (Gauss-Jordan here, b^2 doubles); a large one means this basis is not the shape the representation is for.
     const int b = m_ - total;
     // (an explicit limit — the automatic selection's 32 — is meant as given; the default is what either carrier of the bump takes)
-    const bool sb_try = b > 0 && b >= fac_sb_from_ && b <= fac_sb_max_;
+    // (a bump that failed the sparse elimination — a row outgrew its slots, or the rounds stalled — is not tried again while it stays that
+    // large: every retry is a single-workgroup launch of up to ~1 000 rounds plus a flag read-back, at every refactorisation)
+    if (fac_sb_fail_b_ > 0 && (b < fac_sb_fail_b_ - fac_sb_fail_b_ / 8 || fac_sb_fail_skip_ <= 0)) fac_sb_fail_b_ = 0;
+    const bool sb_blocked = fac_sb_fail_b_ > 0;
+    if (sb_blocked) {
+        fac_sb_fail_skip_ -= 1;
+        stats.fac_sb_skipped += 1;
+    }
+    const bool sb_try = b > 0 && b >= fac_sb_from_ && b <= fac_sb_max_ && !sb_blocked;
     if (b > (explicit_limit ? bump_limit : std::max(bump_limit, fac_sb_max_))) return false;
     bool sb_now = false;
     if (b > 0 || fac_bump_ > 0) {
@@ -2220,6 +2293,8 @@ bool Engine::fac_refactor(int bump_limit) {
                 stats.fac_sb_tail = (uint64_t)hf[4];
             } else {
                 stats.fac_sb_fallbacks += 1;  // rows outgrew their slots (or the elimination stalled): this bump is not sparse enough
+                fac_sb_fail_b_ = b;           // remembered: no retry until the bump has shrunk by an eighth, or 16 refactorisations have passed
+                fac_sb_fail_skip_ = 16;
                 if (b > bump_limit) return false;
             }
         }
@@ -2327,7 +2402,7 @@ void Engine::fac_make_room(int need) {
 }
 bool Engine::fac_enter(int bump_limit) {
     if (fac_on_) return true;
-    if (shard_world > 1 || m_ <= 0 || !d_ctl.p) return false;
+    if (!fac_allowed_under_sharding() || m_ <= 0 || !d_ctl.p) return false;
     ensure_beta();      // (the exact rebuild of the dual edge weights reads the explicit inverse: do it while there is one)
     flush_lowrank();
     if (!fac_refactor(bump_limit)) return false;
@@ -2345,6 +2420,10 @@ bool Engine::fac_enter(int bump_limit) {
     stats.fac_switches += 1;
     sync_view();
     return true;
+}
+bool Engine::fac_allowed_under_sharding() const {
+    static const bool forced = std::getenv("MLP_FACTOR_SHARED_DEVICE") && std::getenv("MLP_FACTOR_SHARED_DEVICE")[0] == '1';
+    return shard_world <= 1 || !ranks_share_device || forced;
 }
 void Engine::fac_leave() {
     if (!fac_on_) return;
@@ -2827,7 +2906,7 @@ void Engine::rebuild_inverse() {
         fac_on_ = false;  // the basis no longer peels: fall through to the explicit inverse
         view_dirty = true;
         stats.fac_switches += 1;
-    } else if (fac_mode == 1 && shard_world == 1 && !stepping) {
+    } else if (fac_mode == 1 && fac_allowed_under_sharding() && !stepping) {
         if (fac_enter(32)) return;  // (automatic selection: only a basis that peels almost completely — a bump that grows would flip back)
     }
     HIPCHECK(hipMemsetAsync(&d_ctl.p->nlow, 0, 2 * sizeof(int), st));  // a fresh inverse has no pending terms
@@ -3223,6 +3302,7 @@ Engine* Engine::clone() {
     std::memcpy(e->h_ctl, h_ctl, sizeof(Ctl));
     e->values_dirty = true;
     e->fac_mode = fac_mode; e->fac_J_ = fac_J_; e->fac_period_ = fac_period_; e->fac_period_auto_ = fac_period_auto_; e->fac_auto_cap_ = fac_auto_cap_; e->fac_bump_max_ = fac_bump_max_; e->fac_sb_max_ = fac_sb_max_; e->fac_sb_from_ = fac_sb_from_; e->fac_pair_ = fac_pair_; e->fac_skip_ = fac_skip_; e->fac_flow_ = fac_flow_;
+    e->cold_start_ = false;  // a clone continues a solve (branch-and-bound: clone + fix_var): warm-start policy, no eager capture of the long graph
     if (fac_on_ && !e->fac_enter())  // (a fresh peel of the same basis: the same operator, no pending terms)
         throw MlpError(-3, "clone: the basis of a solution on the compact factor must peel");
     return owner.release();
@@ -3277,6 +3357,8 @@ uint64_t Engine::state(const char* what, double* out, uint64_t cap) {
     else if (w == "small_basis_launches") {  // iterations that ran BTRAN + pass + v tail + touch as one launch (k_small_basis)
         pull_ctl();
         tmp = {(double)h_ctl->sb_count};
+    } else if (w == "golive_checks") {  // fingerprint comparisons passed at the go-live point of the deferred sharding
+        tmp = {(double)golive_checks_};
     } else if (w == "shard_live") {
         tmp = {(double)(shard_is_live() ? 1 : 0)};
     } else if (w == "primal_head_launches") {
@@ -3316,6 +3398,7 @@ uint64_t Engine::state(const char* what, double* out, uint64_t cap) {
     else if (w == "factor_sb") {  // sparse factor of the bump: in use now, factorisations, fallbacks to the dense inverse, rounds of the last one
         tmp.push_back(fac_on_ && fac_sb_on_ ? 1.0 : 0.0); tmp.push_back((double)stats.fac_sb_factors);
         tmp.push_back((double)stats.fac_sb_fallbacks); tmp.push_back((double)stats.fac_sb_rounds); tmp.push_back((double)stats.fac_sb_tail);
+        tmp.push_back((double)stats.fac_sb_skipped); tmp.push_back((double)fac_sb_fail_b_);  // refactorisations that skipped the sparse attempt, size of the bump that failed last
     }
     else if (w == "hyper_bail_reasons") {
         for (int i = 0; i < 10; ++i) tmp.push_back((double)stats.hyper_bail_reason[i]);

@@ -27,7 +27,7 @@ def _pair(lp, **kw):
 
 
 def _sb(s):
-    return dict(zip(("in_use", "factorisations", "fallbacks", "rounds", "tail"), s.state("factor_sb").astype(int).tolist()))
+    return dict(zip(("in_use", "factorisations", "fallbacks", "rounds", "tail", "skipped", "failed_bump"), s.state("factor_sb").astype(int).tolist()))
 
 
 @pytest.mark.parametrize("args,tight", [((300, 300, 3, 7), 1.0), ((800, 1000, 4, 11), 0.5), ((2500, 2500, 4, 3), 0.4), ((4000, 5000, 5, 9), 0.4)], ids=str)

@@ -47,10 +47,11 @@ def worker(rank, world, port, m, n, k, pivots, out, family="sparse"):
     else:
         s.continue_solve(pivots)
     live_end = int(s.state("shard_live")[0])
+    golive = int(s.state("golive_checks")[0])   # fingerprint comparisons passed at the go-live point of the deferred sharding
     dt = time.time() - t0
     tr = [t[:5] for t in s.trace()]
     transport = s.transport()
-    res = dict(rank=rank, n=len(tr), obj=s.objective(), dt=dt, trace=tr, done=not s.budget_exhausted)
+    res = dict(rank=rank, n=len(tr), obj=s.objective(), dt=dt, trace=tr, done=not s.budget_exhausted, factor=int(s.stats()["factor_active"]))
     gathered = [None] * world
     dist.all_gather_object(gathered, res)
     if rank == 0:
@@ -63,7 +64,9 @@ def worker(rank, world, port, m, n, k, pivots, out, family="sparse"):
         rtr = [t[:5] for t in ref.trace()]
         ok = all(g["trace"] == rtr for g in gathered)
         print("sharding live after the probe / at the end:", live_probe, "/", live_end, flush=True)
+        print("go-live fingerprint checks passed on rank 0:", golive, flush=True)
         print("transport:", transport, "| devices visible:", ndev, "| factor active on rank 0:", int(ref.stats()["factor_active"]), flush=True)
+        print("compact factor active on the sharded ranks:", [g["factor"] for g in gathered], flush=True)
         print("sharded world=%d: pivots=%s obj=%s dt=%s | unsharded pivots=%d obj=%.12g | traces identical: %s" % (
             world, [g["n"] for g in gathered], ["%.12g" % g["obj"] for g in gathered], ["%.3f" % g["dt"] for g in gathered],
             len(rtr), ref.objective(), ok), flush=True)
