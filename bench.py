@@ -447,7 +447,7 @@ def compact_line(out):
         line["parity"] = dict(oracle_identical_through_pivot=out["parity"]["oracle_identical_through_pivot"], beyond="defining equations vs A at k = 9 999 / 20 493 + live duality certificate")
     for key in ("ranks", "value_vs_1gpu", "pricing_speedup_vs_1gpu", "late_sharded", "unsharded_same_run"):
         if out.get(key) is not None:
-            line[key] = out[key] if isinstance(out[key], dict) else r(out[key], 3)
+            line[key] = ({k_: r(v_, 1) for k_, v_ in out[key].items()} if key == "late_sharded" else out[key]) if isinstance(out[key], dict) else r(out[key], 3)
     if out.get("factor_transport"):
         ft_ = out["factor_transport"]
         line["factor_transport"] = {k_: (r(v_, 2) if isinstance(v_, float) else v_) for k_, v_ in ft_.items() if k_ not in ("chunks", "note")}

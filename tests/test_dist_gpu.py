@@ -247,7 +247,7 @@ def test_bench_gpus_2_starts_two_ranks_by_itself():
     assert rec["value"] > 0
     late = rec["windows"]["late_sharded"]
     assert "error" not in late and late["us_per_pivot"] > 0
-    assert rec["late_sharded"]["us_per_pivot"] == late["us_per_pivot"] and rec["late_sharded"]["k"] == 20493
+    assert abs(rec["late_sharded"]["us_per_pivot"] - late["us_per_pivot"]) <= 0.11 and rec["late_sharded"]["k"] == 20493
     assert rec.get("pricing_speedup_vs_1gpu") is not None
 
 
