@@ -351,6 +351,17 @@ private:
     void restart_sampling() { batches_run = 0; }
   private:
     void ensure_banded();
+    // pulled F product of the large-nucleus primal iteration (fpull.inc): row-major packed copy of the nucleus columns, rebuilt at the
+    // start of every solve / continue call and every fpk_every_ pivots (entering columns are appended in between); alpha_K by variable
+    DevBuf<int> d_fpk_cnt, d_fpk_var;
+    DevBuf<double> d_fpk_val, d_fpk_x;
+    DevBuf<unsigned char> d_fpk_in;
+    bool fpull_on_ = true;       // MLP_FPULL=0: the blocked push + k_ratio_primal_fused (A/B, tests)
+    bool fpk_valid_ = false;
+    uint64_t fpk_built_at_ = 0, fpk_builds_ = 0;
+    int fpk_every_ = 1024;
+    bool fpk_wanted() const;
+    void fpk_rebuild();
     DevBuf<int> d_colblk;        // blocked F push (large nucleus): row-block offsets per column
     DevBuf<double> d_push_part;  // ... and its PB_CHUNKS x m partial sums
     bool colblk_dirty = true;

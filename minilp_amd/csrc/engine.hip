@@ -136,6 +136,8 @@ Engine::Engine() {
     }
     if (const char* fb = std::getenv("MLP_FACTOR_SB")) fac_sb_max_ = std::max(0, std::min(FAC_SB_MAX, std::atoi(fb)));
     if (const char* fb = std::getenv("MLP_FACTOR_SB_FROM")) fac_sb_from_ = std::max(1, std::atoi(fb));
+    if (const char* fp = std::getenv("MLP_FPULL")) fpull_on_ = fp[0] != '0';
+    if (const char* fe = std::getenv("MLP_FPULL_EVERY")) fpk_every_ = std::max(1, std::atoi(fe));
     const char* nhf = std::getenv("MLP_NO_HEAD_FUSION");
     no_head_fusion = nhf && std::atoi(nhf) != 0;
     const char* nws = std::getenv("MLP_NO_WSHARD");
@@ -352,6 +354,7 @@ Geom Engine::geom() const {
     g.str = (str_now && !stepping && !fac_on_) ? 1 : 0;
     g.sb = (g.str && sb_now) ? 1 : 0;
     g.ph = (g.str && ph_now) ? 1 : 0;
+    g.fp = hview.fpk_on ? 1 : 0;
     return g;
 }
 
@@ -444,6 +447,36 @@ void Engine::ensure_colblk() {
     colblk_dirty = false;
 }
 
+// Pulled F product (fpull.inc): wanted wherever the blocked push in its float-atomic form serves the unsharded delayed-update mode
+bool Engine::fpk_wanted() const {
+    const int lr = fac_on_ ? 0 : (lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 32 : 0));
+    return fpull_on_ && shard_world == 1 && !fac_on_ && !stepping && lr > 0 && enable_pse && d_rowinfo.p != nullptr;
+}
+// (Re)build the row-major packed copy of the nucleus columns from the CSR of A and the device's CURRENT maps, on the device, in one
+// pass (~30 us on config 4: 10^7 entries read once); alpha_K by variable starts from zero.  Called between batches: at the first batch
+// of every run_loop, and every fpk_every_ pivots to drop the entries of columns that have left the basis since.
+void Engine::fpk_rebuild() {
+    const size_t nnz = h_rcol.size();
+    d_fpk_cnt.ensure((size_t)m_ + 8, 0, st);
+    d_fpk_var.ensure(nnz + 8, 0, st);
+    d_fpk_val.ensure(nnz + 8, 0, st);
+    d_fpk_in.ensure((size_t)N_ + 8, 0, st);
+    d_fpk_x.ensure((size_t)N_ + 8, 0, st);
+    DevView t = *sync_view();
+    t.fpk_cnt = d_fpk_cnt.p; t.fpk_var = d_fpk_var.p; t.fpk_val = d_fpk_val.p; t.fpk_in = d_fpk_in.p; t.fpk_x = d_fpk_x.p;
+    HIPCHECK(hipMemsetAsync(d_fpk_in.p, 0, (size_t)N_, st));
+    HIPCHECK(hipMemsetAsync(d_fpk_x.p, 0, sizeof(double) * (size_t)N_, st));
+    launch_fpk_build(t, st);
+    fpk_valid_ = true;
+    fpk_built_at_ = lifetime_pivots;
+    fpk_builds_ += 1;
+    if (!hview.fpk_on || hview.fpk_cnt != d_fpk_cnt.p || hview.fpk_var != d_fpk_var.p || hview.fpk_val != d_fpk_val.p ||
+        hview.fpk_in != d_fpk_in.p || hview.fpk_x != d_fpk_x.p) {
+        view_dirty = true;
+        sync_view();
+    }
+}
+
 DevView* Engine::sync_view() {
     if (!view_dirty) return &hview;
     DevView old = hview;
@@ -488,6 +521,15 @@ DevView* Engine::sync_view() {
     v.colblk = v.pb_on ? d_colblk.p : nullptr;
     v.push_part = v.pb_on ? d_push_part.p : nullptr;
     v.pb_rb = (m_ + PB_ROWS - 1) / PB_ROWS;
+    {   // pulled F product (fpull.inc): on while a valid packed copy exists for the mode it serves; the pointers stay in the view either way
+        // (the update kernel keeps alpha_K-by-variable zero at the leaving variable whichever path ran the pivot)
+        // (a view without it does not append the entering columns: the copy is stale from then on)
+        if (!(fpk_wanted() && v.pb_on && !v.pb_det)) fpk_valid_ = false;
+        const bool fp = fpk_valid_ && d_fpk_cnt.p != nullptr;
+        v.fpk_cnt = d_fpk_cnt.p; v.fpk_var = d_fpk_var.p; v.fpk_val = d_fpk_val.p; v.fpk_in = d_fpk_in.p;
+        v.fpk_x = fp ? d_fpk_x.p : nullptr;
+        v.fpk_on = fp ? 1 : 0; v.pad5 = 0;
+    }
     v.det_pull = (!v.pb_on && (det_mode == 1 || shard_det || force_det_push_ || (det_mode < 0 && h_rcol.size() <= ((size_t)1 << 21)))) ? 1 : 0;
     if (v.det_pull) {  // (a pooled block is not zero: cleared whenever the allocation changes; the pull clears what it consumes)
         const unsigned char* before = d_fmark.p;
@@ -606,6 +648,7 @@ void Engine::upload_matrix() {
     d_lo.upload(h_lo, st); d_hi.upload(h_hi, st); d_obj.upload(h_obj, st);
     colblk_dirty = true;
     banded_dirty = true;
+    fpk_valid_ = false;  // (the packed copy of the nucleus columns is a copy of matrix entries)
     view_dirty = true;
 }
 
@@ -690,7 +733,8 @@ void Engine::ensure_nucleus_cap(int need) {
 }
 
 void Engine::ensure_red() {
-    size_t need = std::max<size_t>(1024, (size_t)(std::max(m_, num_vars) + 255) / 256 + 8);
+    // (k_fpull_p1 reduces over one block per 32 items of m rows + cap slots, cap <= m)
+    size_t need = std::max<size_t>(1024, std::max((size_t)(std::max(m_, num_vars) + 255) / 256, ((size_t)m_ * 2 + 2048) / 32) + 8);
     d_red_key.ensure(need, 0, st); d_red_key2.ensure(need, 0, st); d_red_idx.ensure(need, 0, st);
     view_dirty = true;
 }
@@ -1429,6 +1473,9 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     const bool tkr_s = smallb && tk_rides_ratio_small(dv, g);  // small nucleus: t_K rides in the ratio launch too (y_S on the fly)
     // ... and rho_K rides behind the v tail of the pass (k_post_fused): the BTRAN stage is then empty.  MLP_RK_RIDE=0: its own launch.
     const bool rkr = tkr && rk_rides_post(dv, g);
+    // ... and the F product of the FTRAN is PULLED inside the ratio test's launch (fpull.inc): no blocked push, no combine; the gather also
+    // leaves alpha_K by variable and pushes the few columns that entered the basis since the packed copy was built.  MLP_FPULL=0: the push.
+    const bool fpl = tkr && g.fp && max_col_nnz_ <= HEAD_LIST_CAP && ftran_head_rides_gather(dv, g) && fpull_supported(dv, g);
     if (stage == STAGE_BASIS) touch_done = false;
     // The pricing decision (q for primal, r for dual) is already in Ctl: it was taken by the
     // previous iteration's update kernel, or by the standalone pricing kernel at batch start.
@@ -1446,12 +1493,12 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         if (phase == 0 && g.head_fused) {
             launch_ftran_fused(dv, g, 1, st);              // K2 head inside the gather kernel (one launch)
         } else if (phase == 0 && !stepping && max_col_nnz_ <= HEAD_LIST_CAP && ftran_head_rides_gather(dv, g)) {
-            launch_ftran_gather_lrh(dv, g, st, (vbr || tkr) ? 1 : 0);  // delayed-update mode: the head inside the gather too (round 5)
+            launch_ftran_gather_lrh(dv, g, st, (vbr || tkr) ? 1 : 0, fpl ? 1 : 0);  // delayed-update mode: the head inside the gather too (round 5)
         } else {
             if (phase == 0) launch_ftran_prep(dv, 1, st);  // K2 head: entering column scalars, singleton rows, list
             launch_ftran_gather(dv, g, st, (vbr || tkr) ? 1 : 0);   // K2: alpha_q = B^-1 a_q (dual: the head ran in RATIO); v branch / t_K ride: + y_S by row
         }
-        if (with_events) HIPCHECK(hipEventRecord(ev[7], st));
+        if (with_events && !fpl) HIPCHECK(hipEventRecord(ev[7], st));  // (fpl: the F product of this FTRAN runs inside the ratio test's launch — stamped there)
         if (phase == 1) {
             launch_post_ftran(dv, g, pse, st);         // alpha_sq, y_S, partition plan
             if (pse) launch_btran_rhs(dv, g, st);      // tK
@@ -1476,7 +1523,10 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         break;
     case STAGE_RATIO:
         if (phead) break;
-        if (phase == 0) launch_ratio_primal(dv, g, pse, st, tkr ? 1 : (tkr_s ? 2 : 0));  // K5 p1 (+ ||alpha||^2, y_S), p2 (+ K3 head + plan) [| t_K]
+        if (fpl) {
+            launch_fpull_ratio(dv, g, st);  // pull of -F alpha_K (+ y_S), K5 p1, p2 (+ K3 head + plan) | t_K
+            if (with_events) HIPCHECK(hipEventRecord(ev[7], st));  // (sampled iteration: the FTRAN bracket closes behind the launch that completes alpha_q)
+        } else if (phase == 0) launch_ratio_primal(dv, g, pse, st, tkr ? 1 : (tkr_s ? 2 : 0));  // K5 p1 (+ ||alpha||^2, y_S), p2 (+ K3 head + plan) [| t_K]
         else launch_ratio_dual(dv, g, st);                    // K7 p1, p2 (+ K2 head)
         break;
     case STAGE_BTRAN:
@@ -1777,6 +1827,7 @@ int Engine::run_loop(int phase) {
     if (fac_on_) pull_ctl();        // (the count of pending rank-1 terms)
     str_clean = false;  // (whatever ran since the last loop may have written alpha_r / helper densely)
     batch_lazy = lazy_now(phase);
+    bool fpk_fresh = false;  // (this loop has built its packed copy of the nucleus columns)
     for (;;) {
         if (pivot_budget == 0) {
             budget_exhausted = true;
@@ -1796,6 +1847,12 @@ int Engine::run_loop(int phase) {
         if (hview.nb_order && use_pack && pack_built != (hview.pk_ptr != nullptr)) {  // the packed copy came or went
             view_dirty = true;
             sync_view();
+        }
+        // pulled F product (fpull.inc): the packed copy of the nucleus columns is rebuilt at the first batch of this loop and every
+        // fpk_every_ pivots (the entries of columns that have left the basis since are dead weight in the rows: dropped by the rebuild)
+        if (phase == 0 && fpk_wanted() && hview.pb_on && !hview.pb_det && (!fpk_fresh || !fpk_valid_ || lifetime_pivots - fpk_built_at_ >= (uint64_t)fpk_every_)) {
+            fpk_rebuild();
+            fpk_fresh = true;
         }
         // pivots the multi-kernel path still has to take before the hypersparse kernel is tried again (after a bail-out)
         int hyper_gap = 0;
@@ -2804,6 +2861,7 @@ void Engine::append_row_on_device(const Constraint& c, int slack, int row) {
     }
     colblk_dirty = true;
     banded_dirty = true;
+    fpk_valid_ = false;  // (the packed copy of the nucleus columns is a copy of matrix entries)
     view_dirty = true;
 }
 
@@ -3248,7 +3306,7 @@ Engine* Engine::clone() {
     e->h_obj = h_obj; e->h_lo = h_lo; e->h_hi = h_hi; e->h_rhs = h_rhs;
     e->h_rptr = h_rptr; e->h_rcol = h_rcol; e->h_rval = h_rval;
     e->h_colnnz = h_colnnz; e->h_single_row = h_single_row; e->h_single_val = h_single_val;
-    e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->amax_ = amax_; e->no_head_fusion = no_head_fusion;
+    e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->amax_ = amax_; e->no_head_fusion = no_head_fusion; e->fpull_on_ = fpull_on_;
     e->sw_balanced = sw_balanced; e->str_kmax = str_kmax; e->sb_kmax = sb_kmax; e->ph_kmax = ph_kmax; e->hyper_mode = hyper_mode; e->hyper_heavy = hyper_heavy; e->hyper_backoff_max = hyper_backoff_max; e->ratio_two = ratio_two; e->ratio_spin_limit = ratio_spin_limit; e->ranks_share_device = false; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->use_pack = use_pack; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
     e->h_basic_vars = h_basic_vars; e->h_nb_vars = h_nb_vars; e->h_var_loc = h_var_loc;
     e->h_kslot_of_pos = h_kslot_of_pos; e->h_srow_of_pos = h_srow_of_pos; e->h_kslot_of_row = h_kslot_of_row;
@@ -3357,6 +3415,8 @@ uint64_t Engine::state(const char* what, double* out, uint64_t cap) {
     else if (w == "small_basis_launches") {  // iterations that ran BTRAN + pass + v tail + touch as one launch (k_small_basis)
         pull_ctl();
         tmp = {(double)h_ctl->sb_count};
+    } else if (w == "fpull") {  // pulled F product: [in use now, builds of the packed copy, pivot count at the last build]
+        tmp = {(double)(hview.fpk_on ? 1 : 0), (double)fpk_builds_, (double)fpk_built_at_, (double)(fpull_supported(hview, geom()) ? 1 : 0)};
     } else if (w == "golive_checks") {  // fingerprint comparisons passed at the go-live point of the deferred sharding
         tmp = {(double)golive_checks_};
     } else if (w == "shard_live") {

@@ -310,6 +310,19 @@ struct DevView {
     int* str_list;   // n
     int* aq_list;    // m: positions of supp(alpha_q) (listed by the FTRAN when str_on and the F products are pushed)
     int str_on, pad4;
+    // PULLED F product of the large-nucleus primal iteration (round 6, fpull.inc): a ROW-major packed copy of the nucleus columns of A.
+    // Row i owns the slots csr_ptr[i] .. csr_ptr[i + 1] of fpk_var / fpk_val (a row of the copy is a subset of the row of A) and holds
+    // fpk_cnt[i] entries (variable, value): the columns that were nucleus basics when the copy was built, in CSR order, then one entry
+    // per column that entered the basis since, in pivot order (appended by the pivot's partition-change blocks).  alpha_S[i] =
+    // (a_q[i] - sum_e fpk_val[e] * fpk_x[fpk_var[e]]) / diag_i is then ONE gather pass per singleton row (fixed summation order, no
+    // atomics, no partial sums).  fpk_x = alpha_K scattered BY VARIABLE (zero for every variable that is not a nucleus basic: a column
+    // that has LEFT the basis contributes exact zeros until the next build drops its entries).
+    int* fpk_cnt;            // m: entries of row i in use
+    int* fpk_var;            // nnz: variable (column of A)
+    double* fpk_val;         // nnz: coefficient
+    unsigned char* fpk_in;   // N: the variable's column is part of the packed copy
+    double* fpk_x;           // N: alpha_K by variable
+    int fpk_on, pad5;
     // ---- compact factor of the basis (csrc/factor.inc) -------------------------------------
     // fac_on: B^-1 is NOT held as singleton split + dense nucleus inverse but as a frozen PEELED TRIANGULAR FACTOR of the
     // basis B0 of the last refactorisation — an iterated column-singleton peel orders (pivot row, position) pairs into levels
@@ -388,6 +401,7 @@ struct Geom {
     int fac;            // compact factor of the basis instead of the explicit nucleus inverse (factor.inc)
     int ph;             // small nucleus, lazy primal iteration: FTRAN + Harris test + BTRAN + inverse update + touched columns in ONE workgroup (k_primal_head)
     int ratio_two;      // the two Harris passes as two launches (no in-kernel wait): MLP_RATIO_TWO_KERNELS, ranks sharing a device, after an ITER_STALL
+    int fp;             // large nucleus, lazy primal iteration: the F product of the FTRAN is PULLED inside the ratio test's launch (fpull.inc)
 };
 
 // ---- launch wrappers (all asynchronous on `st`; the DevView is passed to the kernels by value) ----
@@ -399,7 +413,11 @@ void launch_ftran_gather(const DevView& dv, const Geom& g, hipStream_t st, int y
 void launch_ftran_fused(const DevView& dv, const Geom& g, int derive_primal, hipStream_t st);
 // delayed-update mode (large nucleus), primal iteration, one GPU: head + gather (+ blocked push) without the one-wave launch in front
 bool ftran_head_rides_gather(const DevView& dv, const Geom& g);
-void launch_ftran_gather_lrh(const DevView& dv, const Geom& g, hipStream_t st, int ys = 0);   // FTRAN head + gather in one launch (Geom.head_fused)
+void launch_ftran_gather_lrh(const DevView& dv, const Geom& g, hipStream_t st, int ys = 0, int fpk = 0);   // FTRAN head + gather in one launch; fpk: no blocked push (fpull.inc)
+// pulled F product + both Harris passes + BTRAN head + plan | t_K in ONE launch (fpull.inc); the packed copy is built by the two passes below
+bool fpull_supported(const DevView& dv, const Geom& g);
+void launch_fpull_ratio(const DevView& dv, const Geom& g, hipStream_t st);
+void launch_fpk_build(const DevView& dv, hipStream_t st);   // the packed copy from the CSR of A and the current maps (fpk_in cleared beforehand)
 void launch_btran_fused(const DevView& dv, const Geom& g, int with_rhs, int derive_dual, hipStream_t st);  // BTRAN head + gather (dual iteration)
 constexpr int HEAD_LIST_CAP = 1024;  // entries an in-kernel stage head can hold (longest column / row of A)
 void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st, int tk_ride = 0);  // K5 p1 (+alpha_sq, y_S), p2 (+BTRAN head, plan) [| t_K blocks]

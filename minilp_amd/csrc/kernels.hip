@@ -2116,7 +2116,7 @@ __device__ void ftran_head_lds(const DevView& v, Ctl* c, int lane, int derive_pr
 // pending V rows are L2-resident — and block 0 alone performs the global side effects (pivot scalars, fold decision, entries on
 // singleton rows, the list and the coefficients c_j = V[j] . list for the records and the tails).  Same list order, same sums: the
 // bits of k_ftran_prep + k_ftran_gather<4>.  Primal iteration, blocked push, one GPU.
-__global__ void __launch_bounds__(BLK) k_ftran_gather_lrh(DevView v) {
+__global__ void __launch_bounds__(BLK) k_ftran_gather_lrh(DevView v, int fpk) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) {
         if (blockIdx.x == 0 && threadIdx.x == 0) c->side_go = 0;
@@ -2207,6 +2207,9 @@ __global__ void __launch_bounds__(BLK) k_ftran_gather_lrh(DevView v) {
     const int n = s_n;
     double acc = 0.0;
     const double* wrow = v.W + (size_t)slot * v.ld;
+    // (fpull.inc: the slot's variable — a chain of two loads that overlaps the gather)
+    const int p = v.pos_of_kslot[slot];
+    const int fvar = fpk ? v.basic_vars[p] : 0;
     for (int j0 = gl; j0 < n; j0 += 16) {  // (k_ftran_gather<4>: the lane's loads of a trip issued together, added in list order)
         double a[4], w[4];
         int si[4];
@@ -2235,10 +2238,10 @@ __global__ void __launch_bounds__(BLK) k_ftran_gather_lrh(DevView v) {
             if (gl + 4 * u < nlow) acc += x[u] * e[u];
     }
     acc = group_sum<4>(acc);
-    const int p = v.pos_of_kslot[slot];
     if (gl == 0) {
         v.aK[slot] = acc;
         v.alpha_q[p] = acc;
+        if (fpk) v.fpk_x[fvar] = acc;  // alpha_K by variable: what the pull of the F product gathers
     }
 }
 template <int G>
@@ -2442,9 +2445,11 @@ __device__ __forceinline__ void lowrank_append(const DevView& v, Ctl* c, const S
     }
     if (s == 0) c->nlow = jn + 1;
 }
+__device__ __forceinline__ void fpk_append_wave(const DevView& v, const Ctl* c, int lane);  // (fpull.inc)
 __device__ __forceinline__ void struct_update_body(const DevView& v, Ctl* c, int s) {
     const StructUpdate u = c->up;
     if (u.kase < 0) return;
+    if (v.fpk_on && s < 64) fpk_append_wave(v, c, s);  // the entering column joins the packed copy of the pulled F product (threads 0..63: one wave)
     if (v.lrJ) lowrank_append(v, c, u, s);
     if (u.kase == 0) return;
     const int kold = u.kold;
@@ -4065,6 +4070,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                 v.basic_vars[r] = ev;
                 v.var_loc[ev] = r;
                 v.var_loc[it->leaving_var] = -1 - q;
+                if (v.fpk_x) v.fpk_x[it->leaving_var] = 0.0;  // (fpull.inc: alpha_K by variable is zero outside the nucleus basics)
             } else if (a != 0.0) {
                 xb -= it->entering_diff * a;
                 v.xB[t] = xb;
@@ -4931,6 +4937,7 @@ __global__ void __launch_bounds__(BLK) k_row_pull(DevView v, int n_pull) {
     }
 }
 
+#include "fpull.inc"  // large-nucleus primal iteration: the F product of the FTRAN pulled inside the ratio test's launch
 #include "hyper.inc"  // the hypersparse single-workgroup iteration (uses the stage helpers above)
 #include "primal_head.inc"  // small-nucleus primal iteration: FTRAN + Harris test + BTRAN + inverse update + touched columns in ONE workgroup (uses hyper.inc's DPP reductions)
 #include "factor.inc"  // the compact factor of the basis: peel, level-scheduled solves, additive eta terms
@@ -4991,9 +4998,9 @@ bool ftran_head_rides_gather(const DevView& dv, const Geom& g) {  // delayed-upd
     if (e && e[0] == '0') return false;
     return dv.lrJ > 0 && dv.pb_on && dv.world <= 1 && !g.fac && !dv.det_pull && dv.rowinfo != nullptr;
 }
-void launch_ftran_gather_lrh(const DevView& dv, const Geom& g, hipStream_t st, int ys) {
-    hipLaunchKernelGGL(k_ftran_gather_lrh, dim3(blocks_for((long)g.cap * 4)), dim3(BLK), 0, st, dv);
-    launch_blocked_push(dv, 0, st, ys);
+void launch_ftran_gather_lrh(const DevView& dv, const Geom& g, hipStream_t st, int ys, int fpk) {
+    hipLaunchKernelGGL(k_ftran_gather_lrh, dim3(blocks_for((long)g.cap * 4)), dim3(BLK), 0, st, dv, fpk);
+    if (!fpk) launch_blocked_push(dv, 0, st, ys);  // (fpk: the product is pulled inside the ratio test's launch, fpull.inc)
 }
 void launch_ftran_gather(const DevView& dv, const Geom& g, hipStream_t st, int ys) {
     // (delayed-update mode with the blocked push: nothing after the gather needs the lanes of a slot — four lanes per slot)
@@ -5007,8 +5014,8 @@ void launch_ftran_gather(const DevView& dv, const Geom& g, hipStream_t st, int y
 // Blocks of `fn` (BLK threads, no dynamic LDS) that the CURRENT device holds at once, halved as a margin for kernels of
 // other queues sharing the CUs; cached per device (mlp_set_device may move a process to another GPU or partition).
 static int coresident_half(const void* fn, int slot) {
-    static int cache[2][64];
-    static bool known[2][64];
+    static int cache[3][64];
+    static bool known[3][64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
     if (!known[slot][dev]) {
@@ -5046,6 +5053,21 @@ bool tk_rides_ratio_small(const DevView& dv, const Geom& g) {
     const int nb = grid_for(g.m);
     const int max_coresident = coresident_half(reinterpret_cast<const void*>(k_ratio_primal_fused), 0);
     return nb <= max_coresident && (long)nb * BLK * 4 >= (long)g.m;
+}
+// Pulled F product (fpull.inc): two launches, neither with an in-kernel wait.  The first reduces over one block per 32 items (m rows + cap
+// slots): the partials travel through red_key / red_key2, which Engine::ensure_red sizes for it.
+bool fpull_supported(const DevView& dv, const Geom& g) {
+    return dv.world <= 1 && dv.fpk_on && dv.fpk_cnt && dv.rowinfo && dv.lrJ > 0;
+}
+void launch_fpull_ratio(const DevView& dv, const Geom& g, hipStream_t st) {
+    const long items = (long)g.m + (long)g.cap;
+    const int n1 = blocks_for(items * FP_G);
+    hipLaunchKernelGGL(k_fpull_p1, dim3(n1), dim3(BLK), 0, st, dv);
+    const int nb = grid_for(g.m);
+    const int lanes = g.lanes <= 4 ? 4 : (g.lanes <= 16 ? 16 : 64);
+    LANES_SWITCH(lanes, hipLaunchKernelGGL(k_fpull_p2<4>, dim3(nb + blocks_for((long)g.cap * 4)), dim3(BLK), 0, st, dv, nb, n1),
+                 hipLaunchKernelGGL(k_fpull_p2<16>, dim3(nb + blocks_for((long)g.cap * 16)), dim3(BLK), 0, st, dv, nb, n1),
+                 hipLaunchKernelGGL(k_fpull_p2<64>, dim3(nb + blocks_for((long)g.cap * 64)), dim3(BLK), 0, st, dv, nb, n1));
 }
 void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st, int tk_ride) {
     if (tk_ride) {  // (the caller asked tk_rides_ratio / tk_rides_ratio_small first); 2: small nucleus, y_S on the fly

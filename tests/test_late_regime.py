@@ -93,6 +93,7 @@ def test_t_K_riding_in_the_ratio_launch_changes_no_bit(cfg4, monkeypatch):
     quotients, the same sums in the same order: 96 pivots from the mid basis must agree bit for bit."""
     lp, prob = cfg4
     monkeypatch.setenv("MLP_RK_RIDE", "0")  # (rho_K riding behind the v tail needs the t_K ride and is not bit-neutral on folding pivots: next test)
+    monkeypatch.setenv("MLP_FPULL", "0")    # (round 6: with the t_K ride the F product is PULLED — another summation order; its own tests are below)
     runs = []
     for on in ("1", "0"):
         monkeypatch.setenv("MLP_TK_RIDE", on)
@@ -120,6 +121,51 @@ def test_rho_K_riding_behind_the_v_tail_takes_the_same_pivots(cfg4, monkeypatch)
     assert abs(runs[0][1] - runs[1][1]) <= 1e-11 * abs(runs[0][1])
     assert np.abs(runs[0][2] - runs[1][2]).max() <= 1e-9
     assert runs[0][3] < 1e-9 and runs[1][3] < 1e-9
+
+
+@pytest.mark.parametrize("path,pivots", [(MID, 1100), (LATE, 160)], ids=["mid, across a rebuild of the packed copy", "late"])
+def test_pulled_F_product_takes_the_pushed_form_s_pivots(cfg4, monkeypatch, path, pivots):
+    """Round 6 (csrc/fpull.inc): in the large-nucleus lazy primal iteration the singleton part of the FTRAN, alpha_S = D^-1 (a_q - F alpha_K)
+    (solver.rs:671-677 -> 1305-1319), is PULLED per singleton row from a row-major packed copy of the nucleus columns inside the launch
+    that runs Harris pass 1, instead of pushed through LDS atomics (k_push_stage1 + k_push_combine) in front of k_ratio_primal_fused
+    (MLP_FPULL=0).  Other summation orders, the same numbers to rounding: both forms must take the same pivots from the committed
+    basis — over a stretch that appends > 1 000 entering columns to the copy and crosses its periodic rebuild (every 1 024 pivots) —
+    end at the same objective, and keep x_B consistent with x_B = B^-1 (b - N x_N) recomputed from scratch (a wrong alpha_q in ANY
+    pivot shows there: the cooperative-push bug found while building this did, at 1e-9 against 1e-11)."""
+    lp, prob = cfg4
+    runs = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("MLP_FPULL", on)
+        s = _load(prob, path, trace=True)
+        s.continue_solve(pivots)
+        fp = s.state("fpull")
+        assert int(fp[0]) == int(on) and int(fp[3]) == int(on)          # the path under test is the one that ran
+        if on == "1":
+            assert int(fp[1]) >= (2 if pivots > 1024 else 1)             # builds of the packed copy: load, and the periodic one
+        x1 = s.values().copy()
+        s.recompute_basic_values()
+        gap = float(np.abs(x1 - s.values()).max())
+        runs.append(([t[:5] for t in s.trace()], s.objective(), x1, s.stats()["max_pivot_err"], gap))
+    assert runs[0][0] == runs[1][0]
+    assert abs(runs[0][1] - runs[1][1]) <= 1e-11 * abs(runs[0][1])
+    assert np.abs(runs[0][2] - runs[1][2]).max() <= 1e-8
+    assert runs[0][3] < 1e-9 and runs[1][3] < 1e-9
+    assert runs[0][4] <= max(1e-7, 20.0 * runs[1][4]), (runs[0][4], runs[1][4])   # maintained x_B vs recomputed: the pulled form no worse
+
+
+def test_pulled_F_product_makes_the_late_pivot_reproducible_bit_for_bit(cfg4):
+    """The pushed form's LDS float atomics made alpha_S — hence every later number — reproducible only to rounding (the pivot count of a
+    config-4 solve varied by ~1 % from run to run).  The pull has a fixed summation order: two runs of 200 pivots from the late basis
+    with the default machinery must agree in every bit of the trace (pivot elements, objectives), of x and of the objective."""
+    lp, prob = cfg4
+    runs = []
+    for _ in range(2):
+        s = _load(prob, LATE, trace=True)
+        s.continue_solve(200)
+        assert int(s.state("fpull")[0]) == 1
+        runs.append((s.trace(), s.objective(), s.values().tobytes()))
+    assert runs[0][0] == runs[1][0]
+    assert runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
 
 
 def test_the_v_branch_of_the_late_pivot_takes_the_same_pivots(cfg4, monkeypatch):

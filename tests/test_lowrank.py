@@ -47,6 +47,27 @@ def test_lowrank_mode_matches_oracle_pivot_for_pivot(lowrank, fam, kw):
     assert sg.reinvert() < 1e-8  # fold + compare with a from-scratch inverse
 
 
+@pytest.mark.parametrize("fam,kw", CASES[:2] + [("sparse", dict(m=1500, n=1400, k=12, seed=9))], ids=lambda v: str(v))
+def test_pulled_F_product_matches_oracle_pivot_for_pivot(fam, kw, monkeypatch):
+    """Round 6 (csrc/fpull.inc): the F product of the primal FTRAN pulled per singleton row from the packed copy of the nucleus columns,
+    entering columns appended to it pivot by pivot, Harris pass 1 in the same launch — the path of the large-nucleus regime (from
+    capacity 8 192 on), forced here on small instances (delayed-update mode, blocked-push geometry, the grid forms of the ratio test) so
+    that the ORACLE is the other side: the whole solve pivot for pivot, through every partition case.  The solve starts from the slack
+    basis: the packed copy is built empty and every nucleus column of the solve gets into it through the append."""
+    for k, v in dict(MLP_LOWRANK="3", MLP_STR_K="0", MLP_BIGTILE="1", MLP_LDPAD="16", MLP_BANDED="1", MLP_RATIO_ONE="0", MLP_HYPER="0").items():
+        monkeypatch.setenv(k, v)
+    lp = GEN[fam](**kw)
+    so = lpgen.build_problem(O.Problem, lp).solve(trace=True)
+    sg = lpgen.build_problem(M.Problem, lp).solve(trace=True)
+    fp = sg.state("fpull")
+    assert int(fp[0]) == 1 and int(fp[3]) == 1 and int(fp[1]) >= 1, fp      # the pulled form was the one in use
+    assert obj_close(sg.objective(), so.objective())
+    assert np.abs(so.values() - sg.values()).max() <= X_ATOL
+    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+    assert sum(sg.stats()["kase"]) == sg.stats()["basis_changes"]
+    assert sg.reinvert() < 1e-8
+
+
 def test_lowrank_mode_dual_and_warm_start(lowrank):
     lp = lpgen.gen_mixed_lp(300, 400, 8, 4)   # dual simplex, every partition case incl. singleton swaps
     so = lpgen.build_problem(O.Problem, lp).solve()
