@@ -5065,9 +5065,10 @@ void launch_fpull_ratio(const DevView& dv, const Geom& g, hipStream_t st) {
     hipLaunchKernelGGL(k_fpull_p1, dim3(n1), dim3(BLK), 0, st, dv);
     const int nb = grid_for(g.m);
     const int lanes = g.lanes <= 4 ? 4 : (g.lanes <= 16 ? 16 : 64);
-    LANES_SWITCH(lanes, hipLaunchKernelGGL(k_fpull_p2<4>, dim3(nb + blocks_for((long)g.cap * 4)), dim3(BLK), 0, st, dv, nb, n1),
-                 hipLaunchKernelGGL(k_fpull_p2<16>, dim3(nb + blocks_for((long)g.cap * 16)), dim3(BLK), 0, st, dv, nb, n1),
-                 hipLaunchKernelGGL(k_fpull_p2<64>, dim3(nb + blocks_for((long)g.cap * 64)), dim3(BLK), 0, st, dv, nb, n1));
+    // (grid: nb ratio blocks | the t_K blocks | one block that appends the entering column to the packed copy)
+    LANES_SWITCH(lanes, hipLaunchKernelGGL(k_fpull_p2<4>, dim3(nb + blocks_for((long)g.cap * 4) + 1), dim3(BLK), 0, st, dv, nb, n1),
+                 hipLaunchKernelGGL(k_fpull_p2<16>, dim3(nb + blocks_for((long)g.cap * 16) + 1), dim3(BLK), 0, st, dv, nb, n1),
+                 hipLaunchKernelGGL(k_fpull_p2<64>, dim3(nb + blocks_for((long)g.cap * 64) + 1), dim3(BLK), 0, st, dv, nb, n1));
 }
 void launch_ratio_primal(const DevView& dv, const Geom& g, int use_pse, hipStream_t st, int tk_ride) {
     if (tk_ride) {  // (the caller asked tk_rides_ratio / tk_rides_ratio_small first); 2: small nucleus, y_S on the fly
