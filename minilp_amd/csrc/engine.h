@@ -210,7 +210,6 @@ private:
     double amax_ = 0.0;                       // max |A_ij| (incl. the slack identity): scale bound of the deterministic blocked push
     bool force_det_push_ = false;             // set around recalc_basic_vals: the blocked push in its deterministic form
     bool pb_det_default = false;              // unsharded solves: deterministic blocked push by default (set from the measured A/B)
-    bool no_head_fusion = false;             // MLP_NO_HEAD_FUSION: keep the stage heads as launches of their own
     bool ratio_two = false;                  // MLP_RATIO_TWO_KERNELS, or latched by an ITER_STALL: two launches for the two Harris passes
     long long ratio_spin_limit = 20000000LL; // MLP_RATIO_SPIN_LIMIT: polls before a fused ratio test gives up (0: the first launch stalls; tests)
     bool ranks_share_device = false;
@@ -229,7 +228,7 @@ private:
     // hypersparse single-workgroup iteration (hyper.inc)
     int hyper_mode = -1;                     // MLP_HYPER: 1 on wherever the kernel applies, 0 off, -1 auto (<= 16 non-zeros per row on average)
     long hyper_heavy = 0;                    // MLP_HYPER_HEAVY: eta-update entries one workgroup takes on (0: the kernel's default)
-    int hyper_backoff_max = 8;   // MLP_HYPER_BACKOFF: after bail-outs in a row the multi-kernel path keeps going for up to 2 << this pivots
+    int hyper_backoff_max = 8;   // after bail-outs in a row the multi-kernel path keeps going for up to 2 << this pivots (swept 2..8 on config 3)
     uint64_t hyper_off_until = 0;            // lifetime pivot count until which the multi-kernel path runs (after bail-outs)
     int hyper_bail_streak = 0;
     DevBuf<int> d_hy_stamp;                  // n + m epoch stamps (alpha_r list / singleton part of the alpha_q list) + the kernel's derived maps
@@ -261,11 +260,10 @@ private:
     DevBuf<double> d_fac_WbT;               // transpose of the bump inverse
     DevBuf<FacTailRec> d_fac_tprog;  // the tail of the solves as records: FTRAN | BTRAN, FAC_TAIL_CAP each
     DevBuf<int> d_fac_lev3;   // 3 m: level of a position | level of a row's pivot position | reach of a position
-    bool fac_skip_ = true;    // MLP_FACTOR_SKIP=0: every solve walks every level (A/B)
-    bool fac_flow_ = false;   // MLP_FACTOR_FLOW=1: the grid's segments ordered by data (sentinel + bounded waits) instead of a barrier per level — built,
-                              // measured, not the default: transport 15.6 s against 14.3 s, config-3 family at 100 000 rows 19.9 against 20.8 s
+    bool fac_skip_ = true;    // every solve walks only the levels its right-hand side can reach
+    bool fac_flow_ = false;   // (unused: the data-flow walk of round 5 was removed)
     DevBuf<double> d_fac_Wb;   // allocated with the first bump
-    bool fac_pair_ = true;                   // MLP_FACTOR_PAIR=0: every solve walks the levels on its own (A/B)
+    bool fac_pair_ = true;                   // the two solves of a stage share one walk over the levels
     int fac_bump_ = 0;
     int fac_bump_max_ = FAC_BMAX;            // MLP_FACTOR_BUMP: largest bump the compact factor carries through its DENSE inverse
     // sparse factor of the bump (factor_sb.inc): bumps of fac_sb_from_ .. fac_sb_max_ columns are eliminated sparsely (LU with fill in
@@ -334,7 +332,7 @@ private:
     bool use_pack = true;           // MLP_SWEEP_PACKED=0: the sweep always takes the indirect path through the full copy
     bool pack_built = false;
     size_t band_total_ = 0;         // entries of the band-major copy (incl. pad entries)
-    bool use_order = true;          // MLP_SWEEP_LOCALITY=0: plain position order
+    bool use_order = true;          // banded sweep in the locality order (positions sorted by the variable they hold)
     uint64_t order_built_at = 0;    // lifetime pivot count at the last rebuild
     uint64_t lifetime_pivots = 0;   // (stats can be reset by the caller)
     uint64_t order_every = 2048;
@@ -365,7 +363,6 @@ private:
     DevBuf<int> d_colblk;        // blocked F push (large nucleus): row-block offsets per column
     DevBuf<double> d_push_part;  // ... and its PB_CHUNKS x m partial sums
     bool colblk_dirty = true;
-    bool pb_disable = false;     // MLP_NO_BLOCKED_PUSH
     void ensure_colblk();
     DevBuf<double> d_sdiag_of_pos, d_W, d_U, d_V, d_Ut;
     int ld_pad = 16;    // MLP_LDPAD: extra doubles per row of a large W (row pitch = cap + pad): breaks the power-of-two stride
@@ -377,7 +374,6 @@ private:
     DevBuf<int2> d_nb_rng;
     int sweep_variant = 0;
     int sw_balanced = 1;  // MLP_STREAM_BALANCED=0: fixed 128-row strips in the streaming pass (A/B runs); N > 1: that many blocks
-    int lanes_force = 0;  // MLP_LANES: lanes per column / slot in the gather kernels (4, 16, 64)
     int rt_device = 0;
     void acquire_runtime();  // streams, events, pinned Ctl mirror: recycled across Solutions
     void release_runtime();
@@ -437,7 +433,7 @@ private:
     bool values_dirty = true;
 
     // --- iteration graphs: [phase][pse]
-    bool use_graph = true, use_branches = false, use_vbranch = false;
+    bool use_graph = true;
     int batch = 32;  // (round 4: 16 -> 32: one host round trip per 32 replayed iterations; the driver's 20-pivot window is then ONE batch)
     long final_refresh_pivots = 50000;  // MLP_FINAL_REFRESH: re-examine optimality on recomputed reduced costs after this many pivots (0 = never)
     uint64_t iters_since_recalc = 0, iters_since_polish = 0;

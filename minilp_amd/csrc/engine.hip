@@ -73,25 +73,12 @@ Engine::Engine() {
     std::memset(&hview, 0, sizeof(hview));
     const char* ng = std::getenv("MLP_NO_GRAPH");
     use_graph = !(ng && ng[0] == '1');
-    const char* br = std::getenv("MLP_BRANCH");
-    // side branch of the graph for the tau push of the large-nucleus regime: measured (round 2) 902.6 vs 901.6 us per
-    // pivot at k = 20 500 and 367.7 vs 358.6 us at k = 10 000 — the two kernels do not overlap usefully with the sweep and
-    // the fork / join costs a little; off unless MLP_BRANCH=1
-    use_branches = br && br[0] == '1';
-    // v branch of the late primal iteration (launch_stage): measured in round 4 at k = 20 500 — 708.9 / 711.9 us per pivot
-    // with the branch against 683.3 / 686.6 without (k = 10 000: 271.3 against 264.1).  The streaming pass saturates HBM,
-    // so the latency-bound ratio test and BTRAN beside it see loaded-memory latencies and the pass itself loses bandwidth to
-    // them: the overlap costs more than the 42 us it hides.  Off unless MLP_VBRANCH=1.
-    const char* vb = std::getenv("MLP_VBRANCH");
-    use_vbranch = vb && vb[0] == '1';
     const char* rt = std::getenv("MLP_REFRESH_TOL");
     if (rt) refresh_tol = std::atof(rt);
     const char* lr = std::getenv("MLP_LOWRANK");
     if (lr) lr_force = std::max(0, std::min(LR_MAX, std::atoi(lr)));
     const char* lp = std::getenv("MLP_LDPAD");
     if (lp) ld_pad = std::max(0, std::min(4096, std::atoi(lp))) & ~1;
-    const char* sv = std::getenv("MLP_SWEEP");
-    if (sv) sweep_variant = std::atoi(sv);
     const char* bt = std::getenv("MLP_BIGTILE");
     force_big_tiles = bt && std::atoi(bt) != 0;
     const char* dm = std::getenv("MLP_DETERMINISTIC");
@@ -100,15 +87,9 @@ Engine::Engine() {
     if (bd) banded_mode = std::atoi(bd) != 0 ? 1 : 0;
     const char* fr = std::getenv("MLP_FINAL_REFRESH");
     if (fr) final_refresh_pivots = std::atol(fr);
-    const char* nbp = std::getenv("MLP_NO_BLOCKED_PUSH");
-    pb_disable = nbp && std::atoi(nbp) != 0;
-    const char* ln = std::getenv("MLP_LANES");
-    if (ln) lanes_force = std::atoi(ln);
     if (const char* sp = std::getenv("MLP_SWEEP_PACKED")) use_pack = sp[0] != '0';
     if (const char* of = std::getenv("MLP_ORDER_FROM")) order_from = (uint64_t)std::atoll(of);    // (tests: locality order from pivot 0,
     if (const char* oe = std::getenv("MLP_ORDER_EVERY")) order_every = (uint64_t)std::atoll(oe);  //  rebuilt every few pivots)
-    const char* sl = std::getenv("MLP_SWEEP_LOCALITY");
-    use_order = !(sl && sl[0] == '0');
     const char* lz = std::getenv("MLP_LAZY_DSE");
     lazy_dse = !(lz && lz[0] == '0');
     ratio_two = std::getenv("MLP_RATIO_TWO_KERNELS") != nullptr;
@@ -116,7 +97,6 @@ Engine::Engine() {
     if (const char* phk = std::getenv("MLP_PRIMAL_HEAD_K")) ph_kmax = std::max(0, std::atoi(phk));
     if (const char* sbk = std::getenv("MLP_SMALL_BASIS_K")) sb_kmax = std::max(0, std::min(256, std::atoi(sbk)));
     if (const char* sk = std::getenv("MLP_STR_K")) str_kmax = std::atoi(sk);  // sparse tableau row up to this nucleus size (0: never)
-    if (const char* hb = std::getenv("MLP_HYPER_BACKOFF")) hyper_backoff_max = std::max(0, std::min(16, std::atoi(hb)));  // longest stay on the multi-kernel path after bail-outs in a row: 2 << this pivots
     if (const char* hh = std::getenv("MLP_HYPER_HEAVY")) hyper_heavy = std::atol(hh);        // work bound per iteration (tests force bail-outs)
     if (const char* rs = std::getenv("MLP_RATIO_SPIN_LIMIT")) ratio_spin_limit = std::atoll(rs);
     if (const char* sb = std::getenv("MLP_STREAM_BALANCED")) sw_balanced = std::atoi(sb);
@@ -126,9 +106,6 @@ Engine::Engine() {
         fac_period_auto_ = false;
     }
     if (const char* ff = std::getenv("MLP_FACTOR_FROM")) fac_auto_cap_ = std::max(256, std::atoi(ff));
-    if (const char* fp = std::getenv("MLP_FACTOR_PAIR")) fac_pair_ = fp[0] != '0';
-    if (const char* fs = std::getenv("MLP_FACTOR_SKIP")) fac_skip_ = fs[0] != '0';
-    if (const char* fs = std::getenv("MLP_FACTOR_FLOW")) fac_flow_ = fs[0] != '0';
     if (const char* fb = std::getenv("MLP_FACTOR_BUMP")) {  // (lowering the bump limit lowers it for both carriers of the bump)
         const int want = std::atoi(fb);
         fac_bump_max_ = std::max(0, std::min(FAC_BMAX, want));
@@ -137,9 +114,6 @@ Engine::Engine() {
     if (const char* fb = std::getenv("MLP_FACTOR_SB")) fac_sb_max_ = std::max(0, std::min(FAC_SB_MAX, std::atoi(fb)));
     if (const char* fb = std::getenv("MLP_FACTOR_SB_FROM")) fac_sb_from_ = std::max(1, std::atoi(fb));
     if (const char* fp = std::getenv("MLP_FPULL")) fpull_on_ = fp[0] != '0';
-    if (const char* fe = std::getenv("MLP_FPULL_EVERY")) fpk_every_ = std::max(1, std::atoi(fe));
-    const char* nhf = std::getenv("MLP_NO_HEAD_FUSION");
-    no_head_fusion = nhf && std::atoi(nhf) != 0;
     const char* nws = std::getenv("MLP_NO_WSHARD");
     no_wshard = nws && std::atoi(nws) != 0;
     const char* bs = std::getenv("MLP_BATCH");
@@ -342,11 +316,10 @@ Geom Engine::geom() const {
     g.cap = cap_;
     double avg = num_vars > 0 ? (double)(h_rcol.size() - (size_t)m_) / (double)num_vars : 1.0;  // structural columns
     g.lanes = avg >= 40.0 ? 64 : (avg >= 6.0 ? 16 : 4);
-    if (lanes_force > 0) g.lanes = lanes_force;  // MLP_LANES (A/B runs)
     g.sweep_variant = sweep_variant;
     g.big = (cap_ > 4096 || force_big_tiles) ? 1 : 0;
     const int lr = lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 32 : 0);  // as in sync_view
-    g.head_fused = (!no_head_fusion && !fac_on_ && lr == 0 && max_col_nnz_ <= HEAD_LIST_CAP && max_row_nnz_ <= HEAD_LIST_CAP) ? 1 : 0;
+    g.head_fused = (!fac_on_ && lr == 0 && max_col_nnz_ <= HEAD_LIST_CAP && max_row_nnz_ <= HEAD_LIST_CAP) ? 1 : 0;
     g.fac = fac_on_ ? 1 : 0;
     // in-kernel wait between the two Harris passes: never while the ranks of a sharded solve share a device (their grids
     // compete for the same CUs), never again after a wait has timed out once
@@ -498,9 +471,7 @@ DevView* Engine::sync_view() {
     // block's entering columns: an expansive coupled recurrence) until the reduced costs are off by 1e-1 relative and the
     // solve makes 5x less progress per pivot (found in round 3: DESIGN.md §6, profiles/r03g_sharded_long_run.log).  So a
     // sharded solve takes the deterministic pull (k_pull_F: fixed summation order), as small models do anyway.
-    // MLP_SHARD_ATOMICS=1 restores the atomic forms (experiments).
-    static const bool shard_atomics = std::getenv("MLP_SHARD_ATOMICS") != nullptr;
-    const bool shard_det = shard_world > 1 && !shard_atomics;
+    const bool shard_det = shard_world > 1;
     // Round 4: the blocked push has a DETERMINISTIC form (k_push_stage1_det: fixed-point limbs, integer LDS atomics — exact,
     // hence independent of the order in which they land), so a sharded solve no longer needs the pull for a nucleus beyond a
     // few hundred columns: it takes the blocked push from capacity 512 on (below that the marked pull touches few rows and
@@ -513,7 +484,7 @@ DevView* Engine::sync_view() {
     // (small models take the pull sharded or not — MLP_DETERMINISTIC auto — so that their sharded and unsharded runs stay bit-identical)
     const bool pb_size = cap_ > 4096 || force_big_tiles ||
                          (shard_det && pb_det && cap_ >= 512 && det_mode != 1 && h_rcol.size() > ((size_t)1 << 21));
-    v.pb_on = (pb_size && !pb_disable && (!shard_det || pb_det)) ? 1 : 0;
+    v.pb_on = (pb_size && (!shard_det || pb_det)) ? 1 : 0;
     v.pb_det = (v.pb_on && pb_det) ? 1 : 0;
     v.pb_hbits = hbits;
     v.pb_amax = amax_;
@@ -788,7 +759,7 @@ void Engine::push_maps() {
 
 // ------------------------------------------------------------------ column-block sharding
 // Rendezvous: a POSIX shared-memory object created (zeroed) by the launcher, mapped by every rank:
-//   [0, 768 * world)                 host-transport mailbox (MLP_MAILBOX=host), registered with HIP
+//   [0, 768 * world)                 host-transport mailbox (MLP_TRANSPORT=host), registered with HIP
 //   [768 * world, 896 * world)       one 128-byte rendezvous record per rank: HIP IPC handle of its device box
 // Peer transport (default): every rank allocates its box in its OWN HBM (uncached, falling back to fine-grained),
 // publishes the IPC handle, opens the peers' handles (peer access is enabled lazily by hipIpcOpenMemHandle), and
@@ -1108,8 +1079,7 @@ void Engine::enable_sharding(int rank, int world, const char* shm_name, const ch
         view_dirty = true;
         return;
     }
-    const char* mb = std::getenv("MLP_MAILBOX");
-    const bool host_transport = !pump && (tname == "host" || (tname.empty() && mb && std::string(mb) == "host"));
+    const bool host_transport = !pump && tname == "host";
     const size_t host_bytes = kHostBoxBytesPerRank * (size_t)world;
     const size_t bytes = host_bytes + sizeof(Rendezvous) * (size_t)world;
     int fd = shm_open(shm_name, O_RDWR, 0600);
@@ -1451,25 +1421,19 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     // banded sweep, primal iteration: k_update_pivot sums the per-band partials itself (no combine launch);
     // the host-paced stepping API keeps the separate combine so that row_coeffs is readable after STAGE_ROW
     const int inl = (dv.banded && phase == 0 && !stepping && !g.str) ? 1 : 0;
-    const bool tau_branch = use_branches && dv.pb_on && phase == 0 && !stepping && shard_world == 1 && !lazy_now(phase);
     if (dv.fac_on) {  // compact factor of the basis (factor.inc): the same stages over level-scheduled solves
         launch_stage_fac(phase, stage, with_events);
         return;
     }
-    // v branch (round 4): in the lazy primal iteration of the delayed-update mode the pass over the nucleus inverse computes
-    // v = B^-T alpha_q only — it needs alpha_q, not the leaving row — so it leaves the chain FTRAN -> ratio test -> BTRAN -> pass
-    // and runs on the side stream beside the ratio test and the BTRAN (t_K, the fold of a folding pivot, the streaming pass);
-    // the BTRAN waits for the fold (W0 must be whole), the tails of the pass wait for the stream.  Off by default (MLP_VBRANCH=1).
-    const bool vbr = use_vbranch && phase == 0 && pse && lazy && !stepping && shard_world == 1 && !g.head_fused && vbranch_supported(dv, g);
     // small nucleus (first capacity of the inverse), lazy primal iteration: BTRAN, pass over W, v tail and touched-column list are
     // ONE launch (k_small_basis) issued at the BASIS stage; the BTRAN stage is empty.  MLP_SMALL_BASIS=0: the three launches.
     // ... and for a nucleus of a few dozen columns the whole chain FTRAN -> ratio test -> BTRAN -> inverse update -> touched columns -> partition
     // change is ONE launch of one workgroup issued at the FTRAN stage (k_primal_head); the RATIO, BTRAN and BASIS stages are empty
-    const bool phead = phase == 0 && pse && lazy && !stepping && shard_world == 1 && !vbr && !tau_branch && primal_head_supported(dv, g);
-    const bool smallb = !phead && phase == 0 && pse && lazy && !stepping && !shard_is_live() && !vbr && !tau_branch && small_basis_supported(dv, g);
+    const bool phead = phase == 0 && pse && lazy && !stepping && shard_world == 1 && primal_head_supported(dv, g);
+    const bool smallb = !phead && phase == 0 && pse && lazy && !stepping && !shard_is_live() && small_basis_supported(dv, g);
     // large nucleus, lazy primal iteration: t_K = alpha_K - F^T y_S rides in the ratio test's launch (blocks behind the ratio blocks);
     // the FTRAN's push combine leaves y_S by row, the BTRAN launch forms rho_K only.  MLP_TK_RIDE=0: t_K in the BTRAN launch.
-    const bool tkr = phase == 0 && pse && lazy && !stepping && shard_world == 1 && !vbr && !smallb && !g.head_fused && !dv.pb_det && tk_rides_ratio(dv, g);
+    const bool tkr = phase == 0 && pse && lazy && !stepping && shard_world == 1 && !smallb && !g.head_fused && !dv.pb_det && tk_rides_ratio(dv, g);
     const bool tkr_s = smallb && tk_rides_ratio_small(dv, g);  // small nucleus: t_K rides in the ratio launch too (y_S on the fly)
     // ... and rho_K rides behind the v tail of the pass (k_post_fused): the BTRAN stage is then empty.  MLP_RK_RIDE=0: its own launch.
     const bool rkr = tkr && rk_rides_post(dv, g);
@@ -1493,32 +1457,15 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         if (phase == 0 && g.head_fused) {
             launch_ftran_fused(dv, g, 1, st);              // K2 head inside the gather kernel (one launch)
         } else if (phase == 0 && !stepping && max_col_nnz_ <= HEAD_LIST_CAP && ftran_head_rides_gather(dv, g)) {
-            launch_ftran_gather_lrh(dv, g, st, (vbr || tkr) ? 1 : 0, fpl ? 1 : 0);  // delayed-update mode: the head inside the gather too (round 5)
+            launch_ftran_gather_lrh(dv, g, st, tkr ? 1 : 0, fpl ? 1 : 0);  // delayed-update mode: the head inside the gather too (round 5)
         } else {
             if (phase == 0) launch_ftran_prep(dv, 1, st);  // K2 head: entering column scalars, singleton rows, list
-            launch_ftran_gather(dv, g, st, (vbr || tkr) ? 1 : 0);   // K2: alpha_q = B^-1 a_q (dual: the head ran in RATIO); v branch / t_K ride: + y_S by row
+            launch_ftran_gather(dv, g, st, tkr ? 1 : 0);   // K2: alpha_q = B^-1 a_q (dual: the head ran in RATIO); t_K ride: + y_S by row
         }
         if (with_events && !fpl) HIPCHECK(hipEventRecord(ev[7], st));  // (fpl: the F product of this FTRAN runs inside the ratio test's launch — stamped there)
         if (phase == 1) {
             launch_post_ftran(dv, g, pse, st);         // alpha_sq, y_S, partition plan
             if (pse) launch_btran_rhs(dv, g, st);      // tK
-        }
-        if (vbr) {
-            HIPCHECK(hipEventRecord(evFork[1], st));
-            HIPCHECK(hipStreamWaitEvent(st2, evFork[1], 0));
-            launch_pse_tk(dv, g, st2);                  // tK = alpha_K - F^T y_S (y_S on the fly)
-            if (with_events) {  // sampled iteration: the pass and the fold are timed kernel-exactly (beside the ratio test, as they run)
-                arm_kernel_timing(2, ev[2], ev[3]);
-                arm_kernel_timing(3, ev[10], ev[11]);
-            }
-            launch_fused_w_side(dv, g, 1, st2);         // the fold of a folding pivot (also the v partials of that pivot)
-            HIPCHECK(hipEventRecord(evFork[2], st2));  // W0 is whole again
-            launch_fused_w_side(dv, g, 2, st2);         // vK partials: one read of W0
-            if (with_events) {
-                arm_kernel_timing(2, nullptr, nullptr);
-                arm_kernel_timing(3, nullptr, nullptr);
-            }
-            HIPCHECK(hipEventRecord(evJoin[1], st2));
         }
         break;
     case STAGE_RATIO:
@@ -1535,12 +1482,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
             launch_btran_fused(dv, g, 0, 1, st);                  // K3 head inside the BTRAN kernel (one launch)
         } else {
             if (phase == 1) launch_btran_prep(dv, 1, 0, st);      // K3 head (device-driven by it.r)
-            if (vbr) {
-                HIPCHECK(hipStreamWaitEvent(st, evFork[2], 0));   // a folding pivot: rho is a row of the folded W0
-                launch_btran(dv, g, 0, st, 1);                    // K3: rho, rK, ||rho||^2 (tK was built on the side stream)
-            } else {
-                launch_btran(dv, g, (phase == 0 && !tkr) ? pse : 0, st);    // K3: rho, rK, ||rho||^2  |  tK = alpha_K - F^T y_S (unless it rode in the ratio launch)
-            }
+            launch_btran(dv, g, (phase == 0 && !tkr) ? pse : 0, st);    // K3: rho, rK, ||rho||^2  |  tK = alpha_K - F^T y_S (unless it rode in the ratio launch)
         }
         break;
     case STAGE_BASIS:
@@ -1555,32 +1497,17 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
             touch_done = true;
             break;
         }
-        if (vbr) {
-            HIPCHECK(hipStreamWaitEvent(st, evJoin[1], 0));   // the v partials have landed
-        } else {
-            if (with_events) {  // sampled iteration: the pass over the nucleus inverse and the fold are timed kernel-exactly
-                arm_kernel_timing(2, ev[2], ev[3]);
-                arm_kernel_timing(3, ev[10], ev[11]);
-            }
-            launch_fused_w(dv, g, pse, st, wtau);                 // tauK / vK partials + eta update of W
-            if (with_events) {
-                arm_kernel_timing(2, nullptr, nullptr);
-                arm_kernel_timing(3, nullptr, nullptr);
-            }
+        if (with_events) {  // sampled iteration: the pass over the nucleus inverse and the fold are timed kernel-exactly
+            arm_kernel_timing(2, ev[2], ev[3]);
+            arm_kernel_timing(3, ev[10], ev[11]);
         }
-        if (tau_branch) {
-            // large-nucleus regime: the blocked push of -F tau_K (two kernels, ~40 us of serial chains) is needed by the
-            // update kernel only; it runs on a side branch of the graph next to the tableau-row sweep.  The partition
-            // change then rides in the update kernel instead of the sweep (the push reads the OLD slot maps).
-            launch_post_fused(dv, g, pse, st, 0, 1, wtau);
-            HIPCHECK(hipEventRecord(evFork[0], st));
-            HIPCHECK(hipStreamWaitEvent(st2, evFork[0], 0));
-            launch_push_tau(dv, st2);
-            HIPCHECK(hipEventRecord(evJoin[0], st2));
-        } else {
-            // tau by position (F push)  |  v reduce + scatter  |  (sparse tableau row, primal: its touched-column list)
-            touch_done = launch_post_fused(dv, g, pse, st, 0, 0, wtau, (g.str && phase == 0) ? 1 : 0, rkr ? 1 : 0) != 0;
+        launch_fused_w(dv, g, pse, st, wtau);                 // tauK / vK partials + eta update of W
+        if (with_events) {
+            arm_kernel_timing(2, nullptr, nullptr);
+            arm_kernel_timing(3, nullptr, nullptr);
         }
+        // tau by position (F push)  |  v reduce + scatter  |  (sparse tableau row, primal: its touched-column list)
+        touch_done = launch_post_fused(dv, g, pse, st, 0, 0, wtau, (g.str && phase == 0) ? 1 : 0, rkr ? 1 : 0) != 0;
         break;
     case STAGE_ROW:
         if (g.str) {  // small nucleus: the columns that meet supp(rho) only (k_row_touch + k_row_pull)
@@ -1589,13 +1516,13 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
                 if (with_events) HIPCHECK(hipEventRecord(ev[1], st));
                 break;
             }
-            if (phase == 0) launch_row_sparse(dv, g, pse ? 1 : 0, (tau_branch || phead) ? 0 : 1, touch_done ? 0 : 1, st);  // (the head applied the partition change itself)
+            if (phase == 0) launch_row_sparse(dv, g, pse ? 1 : 0, phead ? 0 : 1, touch_done ? 0 : 1, st);  // (the head applied the partition change itself)
             else launch_row_sparse(dv, g, 0, 0, 1, st);
             if (with_events) HIPCHECK(hipEventRecord(ev[1], st));
             break;
         }
         if (with_events) arm_kernel_timing(1, ev[0], ev[1]);  // sampled iteration: the sweep kernel is timed kernel-exactly
-        if (phase == 0) launch_sweep(dv, g, pse ? 1 : 0, tau_branch ? 0 : 1, st, inl);  // K4 (+ PSE helper in the same pass)  |  partition change
+        if (phase == 0) launch_sweep(dv, g, pse ? 1 : 0, 1, st, inl);  // K4 (+ PSE helper in the same pass)  |  partition change
         else launch_sweep(dv, g, 0, 0, st);                    // K4: alpha_r = rho^T N
         if (with_events) arm_kernel_timing(1, nullptr, nullptr);
         break;
@@ -1606,8 +1533,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         }
         if (with_events) HIPCHECK(hipEventRecord(ev[4], st));
         // K8 + zero the work vectors + price the next iteration (dual path without PSE: | partition change)
-        if (tau_branch) HIPCHECK(hipStreamWaitEvent(st, evJoin[0], 0));  // the tau push has landed
-        launch_update_pivot(dv, g, phase, dse, pse, st, inl, ((phase == 1 && !pse) || tau_branch) ? 1 : 0, (phead && g.str && update_pulls_inside(dv, g)) ? (head_applies(dv, g) ? 2 : 1) : 0);
+        launch_update_pivot(dv, g, phase, dse, pse, st, inl, (phase == 1 && !pse) ? 1 : 0, (phead && g.str && update_pulls_inside(dv, g)) ? (head_applies(dv, g) ? 2 : 1) : 0);
         if (with_events) HIPCHECK(hipEventRecord(ev[5], st));
         break;
     default:
@@ -1949,8 +1875,8 @@ int Engine::run_loop(int phase) {
         // together with the first one-iteration graph: between two graph launches the device idles ~8 us (in-kernel timeline: 33 us of
         // kernels per pivot, 43 us per pivot on the clock), between two kernels of one graph ~1.4)
         // (second session of round 5: the compact factor too — a batch between two refactorisations is 32 or 64 pivots, three to six graphs
-        // of ten iterations instead of one graph launch, and ~8 us of idle device, per pivot; MLP_FACTOR_MULTI=0: A/B)
-        static const bool fac_multi = !(std::getenv("MLP_FACTOR_MULTI") && std::getenv("MLP_FACTOR_MULTI")[0] == '0');
+        // of ten iterations instead of one graph launch, and ~8 us of idle device, per pivot)
+        const bool fac_multi = true;
         const bool multi = graph_now && (long_run || cold_start_) && graph_iters > 1 && (!fac_on_ || fac_multi);
         int B = graph_now ? (multi ? RING : batch) : 1;
         if (pivot_budget > 0 && (int64_t)B > pivot_budget) B = (int)pivot_budget;
@@ -2241,7 +2167,7 @@ bool Engine::fac_refactor(int bump_limit) {
     std::vector<int> lptr(1, 0);
     int total = 0;
     int n_col_steps = 0, n_row_steps = 0, sb_rounds = 0, sb_tail = 0;
-    static const bool peel_paced = std::getenv("MLP_FACTOR_PEEL_PACED") != nullptr;  // the round-4 first cut: the host paces the levels
+    const bool peel_paced = false;  // (the host-paced peel of round 4 remains below as the fallback when a grid barrier of the device peel gives up)
     bool device_peel_done = false;
     if (!peel_paced) {
         // one launch for the whole peel (grid barriers between the phases), one read-back of the level counts
@@ -2371,7 +2297,7 @@ bool Engine::fac_refactor(int bump_limit) {
             int* flag = d_fac_gjrow.p + 2 * 64;
             HIPCHECK(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
             launch_fac_bump_build(t, d_fac_Kd.p, b, st);
-            static const bool gj_launches = std::getenv("MLP_FACTOR_GJ_LAUNCHES") != nullptr;  // A/B: the launch-per-column Gauss-Jordan
+            const bool gj_launches = false;  // (the launch-per-column Gauss-Jordan below is the fallback when a grid barrier of the one-launch form gives up)
             int hflag[2] = {0, 0};
             if (!gj_launches) {
                 launch_fac_bump_invert(t, d_fac_Kd.p, d_fac_Wtmp.p, d_fac_Wb.p, d_fac_WbT.p, b, flag, d_fac_gjval.p, d_fac_gjrow.p, st);
@@ -3306,7 +3232,7 @@ Engine* Engine::clone() {
     e->h_obj = h_obj; e->h_lo = h_lo; e->h_hi = h_hi; e->h_rhs = h_rhs;
     e->h_rptr = h_rptr; e->h_rcol = h_rcol; e->h_rval = h_rval;
     e->h_colnnz = h_colnnz; e->h_single_row = h_single_row; e->h_single_val = h_single_val;
-    e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->amax_ = amax_; e->no_head_fusion = no_head_fusion; e->fpull_on_ = fpull_on_;
+    e->max_col_nnz_ = max_col_nnz_; e->max_row_nnz_ = max_row_nnz_; e->amax_ = amax_; e->fpull_on_ = fpull_on_;
     e->sw_balanced = sw_balanced; e->str_kmax = str_kmax; e->sb_kmax = sb_kmax; e->ph_kmax = ph_kmax; e->hyper_mode = hyper_mode; e->hyper_heavy = hyper_heavy; e->hyper_backoff_max = hyper_backoff_max; e->ratio_two = ratio_two; e->ratio_spin_limit = ratio_spin_limit; e->ranks_share_device = false; e->lazy_dse = lazy_dse; e->beta_stale = beta_stale; e->use_order = use_order; e->use_pack = use_pack; e->order_force = order_force; e->lifetime_pivots = lifetime_pivots;
     e->h_basic_vars = h_basic_vars; e->h_nb_vars = h_nb_vars; e->h_var_loc = h_var_loc;
     e->h_kslot_of_pos = h_kslot_of_pos; e->h_srow_of_pos = h_srow_of_pos; e->h_kslot_of_row = h_kslot_of_row;
@@ -3320,7 +3246,7 @@ Engine* Engine::clone() {
     e->banded_mode = banded_mode; e->det_mode = det_mode;
     e->final_refresh_pivots = final_refresh_pivots; e->iters_since_recalc = iters_since_recalc;
     e->iters_since_polish = iters_since_polish;
-    e->ld_pad = ld_pad; e->lr_force = lr_force; e->force_big_tiles = force_big_tiles; e->pb_disable = pb_disable;
+    e->ld_pad = ld_pad; e->lr_force = lr_force; e->force_big_tiles = force_big_tiles;
     hipStream_t s2 = e->st;
     {   // the matrix is copied device to device (the host keeps no CSC)
         const size_t nz = h_rcol.size();

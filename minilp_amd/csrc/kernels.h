@@ -346,7 +346,7 @@ struct DevView {
     int* fac_lev_of_pos;     // m: level of a position (-1: bump)
     int* fac_lev_of_row;     // m: level of the position that pivots on a row (-1: bump row)
     int* fac_reach_of_pos;   // m: highest level any BTRAN dependent of the position reaches
-    int fac_skip, fac_flow;  // MLP_FACTOR_SKIP: walk only the levels a right-hand side can reach; MLP_FACTOR_FLOW: the walk is ordered by data, not by grid barriers
+    int fac_skip, fac_flow;  // fac_skip: walk only the levels a right-hand side can reach (always on); fac_flow: unused (the data-flow walk of round 5 was removed)
     // the single-workgroup tail of the solves (factor.inc): place of a position / of a row's pivot position in fac_items (-1: bump),
     // and the tail's items as fixed-size records in walking order (one per direction)
     int* fac_idx_of_pos; int* fac_idx_of_row;
@@ -388,12 +388,12 @@ constexpr int BAND_ROWS = 8192;  // rows per band of the banded sweep: 128 KB of
 constexpr int BAND_THREADS = 1024;
 constexpr int PB_ROWS = 4096;   // rows per LDS block of the blocked F push (32 KB of doubles)
 constexpr int PB_CHUNKS = 48;   // capacity of the partial-sum buffer of the blocked F push (column chunks = slot ranges)
-constexpr int PB_CHUNKS_DEFAULT = 24;  // chunks used (MLP_PB_CHUNKS overrides)
+constexpr int PB_CHUNKS_DEFAULT = 24;  // chunks used
 
 struct Geom {
     int m, n, cap;
     int lanes;  // lanes per CSC column in the pull kernels (4, 16 or 64; from the average column length)
-    int sweep_variant;  // tuning knob (MLP_SWEEP): 0 default
+    int sweep_variant;  // 0 (the lane / gather-chain variants of round 1 are gone as a choice)
     int big;            // fused W pass: 64-row x 1024-column blocks, non-temporal (cap > 4096, or forced by MLP_BIGTILE)
     int head_fused;     // stage heads run inside the consuming kernel (delayed-update mode off, every column / row fits the LDS list)
     int str;            // sparse tableau row instead of the sweep over all of A (nucleus of at most MLP_STR_K columns, one GPU)
@@ -426,7 +426,6 @@ bool tk_rides_ratio_small(const DevView& dv, const Geom& g);  // the same for a 
 void launch_post_ftran(const DevView& dv, const Geom& g, int use_pse, hipStream_t st);    // dual path: alpha_sq, y_S, plan
 void launch_btran_prep(const DevView& dv, int derive_dual, int plan_after, hipStream_t st);  // BTRAN head (one wave)
 void launch_btran(const DevView& dv, const Geom& g, int with_rhs, hipStream_t st, int after_fold = 0);  // rho, rK, rho_sq [| tK]
-void launch_pse_tk(const DevView& dv, const Geom& g, hipStream_t st);  // v branch: tK = alpha_K - F^T y_S straight from alpha_q (y_S formed on the fly)
 void launch_btran_rhs(const DevView& dv, const Geom& g, hipStream_t st);                  // tK alone
 void launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, hipStream_t st, int inline_combine = 0);  // K4 [| partition change]
 // sparse tableau row: touched-column list, then the pull of alpha_r / helper on the listed columns (| partition change)
@@ -442,14 +441,9 @@ void launch_primal_head(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st);                 // K7 p1, p2 (+FTRAN head)
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int with_tau = 1);  // tauK/vK partials + eta update of W
-// v branch (delayed-update mode, lazy primal iteration): the same pass in two parts on the side stream — part 1 the fold of a
-// folding pivot (its last block clears nlow), part 2 the streaming pass; both gated by Ctl.side_go
-void launch_fused_w_side(const DevView& dv, const Geom& g, int part, hipStream_t st);
-bool vbranch_supported(const DevView& dv, const Geom& g);  // the strip-tiled pass with the default fold kernel is the one that has a side form
 int launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic = 0, int skip_push = 0, int with_tau = 1, int touch = 0, int rk_ride = 0);
 bool rk_rides_post(const DevView& dv, const Geom& g);  // (strip-tiled tail of the large-nucleus pass: the form that carries the rho_K blocks)
 void launch_exact_beta(const DevView& dv, hipStream_t st);  // beta_p = ||e_p^T B^-1||^2 for every basic position (lazy dual steepest edge)
-void launch_push_tau(const DevView& dv, hipStream_t st);  // blocked push of -F tau_K alone (runs on a side branch of the graph)  // tau push | v reduce+scatter (classic: partials of k_fused_w's tiling)
 // hypersparse iteration (hyper.inc): up to max_iters dual iterations (no primal steepest edge) in ONE launch of one workgroup
 void launch_hyper_dual(const DevView& dv, int use_dse, int max_iters, long heavy, hipStream_t st);  // heavy <= 0: default work bound
 void launch_mail_handshake(const DevView& dv, int* out, hipStream_t st);  // transport self-test at enable_sharding
@@ -462,7 +456,7 @@ void launch_mail_deliver(const DevView& dv, const void* stage, hipStream_t st);
 void arm_kernel_timing(int slot, hipEvent_t t0, hipEvent_t t1);
 bool stream_strips_enabled();
 bool fold_fuses_v(const DevView& dv, int with_v, int with_tau, int fold_only);  // a folding pivot's fold also produces the v partials (its streaming pass is skipped)
-int stream_coresident_blocks();  // blocks of the default k_stream_w instance the device holds at once (0: unknown)  // large-nucleus streaming pass in strip form (MLP_STREAM_STRIPS=0 disables)
+int stream_coresident_blocks();  // blocks of the default k_stream_w instance the device holds at once (0: unknown)
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_dse, int use_pse, hipStream_t st, int inline_comb = 0,
                          int with_struct = 0, int pull_inside = 0);  // K8 + clear + next pricing [pull_inside: + the sparse tableau row, per workgroup]

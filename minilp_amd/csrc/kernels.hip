@@ -1143,7 +1143,7 @@ __global__ void __launch_bounds__(BLK) k_push_stage1(DevView v, int which) {
 // bit-identical replicas without the pull over every singleton row (k_pull_F: nnz(A) work per call), and unsharded runs of
 // the large-nucleus regime become reproducible bit for bit.
 constexpr int PBD_TILE = 256;  // slot descriptors per round
-constexpr int PBD_CHUNKS_DEFAULT = 16;  // slot chunks of the deterministic form (MLP_PB_CHUNKS overrides)
+constexpr int PBD_CHUNKS_DEFAULT = 16;  // slot chunks of the deterministic form
 constexpr size_t PBD_LDS = sizeof(unsigned long long) * 2 * PB_ROWS + sizeof(double) * PBD_TILE + sizeof(int) * 2 * PBD_TILE;
 __global__ void __launch_bounds__(BLK) k_push_stage1_det(DevView v, int which) {
     Ctl* c = v.ctl;
@@ -1255,56 +1255,6 @@ __global__ void __launch_bounds__(BLK) k_push_stage1_det(DevView v, int which) {
     __syncthreads();
     for (int t = tid; t < nrows; t += BLK) dst[t] = (double)(long long)accH[t] * iS1 + (double)(long long)accL[t] * iSL;
 }
-// The same product through the band-major copy of A (when the banded sweep keeps one): block (band b, chunk c) walks the
-// nucleus slots of its chunk and reads each column's segment inside the band — one 8-byte load for the (begin, end) pair,
-// a contiguous run of ~8 entries — instead of 25 row blocks each re-reading every column's offsets and ~4 entries out of
-// a 128-byte line (PMC: 196 MB of HBM traffic per launch for 27 MB of algorithmic bytes at k = 20 500).  8 192 rows of
-// accumulators (64 KB of LDS) per workgroup, 13 x 19 workgroups on config 4.
-constexpr int PBB_THREADS = 512, PBB_TILE = 512;
-__global__ void __launch_bounds__(PBB_THREADS) k_push_band(DevView v, int which, int chunks) {
-    Ctl* c = v.ctl;
-    if (c->halt || c->it.status != ITER_PIVOT) return;
-    extern __shared__ double s_pb[];
-    double* acc = s_pb;                                    // BAND_ROWS
-    double* s_x = s_pb + BAND_ROWS;                        // PBB_TILE
-    int* s_beg = reinterpret_cast<int*>(s_x + PBB_TILE);   // PBB_TILE
-    int* s_len = s_beg + PBB_TILE;                         // PBB_TILE
-    const int b = (int)blockIdx.x / chunks, cc = (int)blockIdx.x % chunks, tid = threadIdx.x;
-    const int row0 = b * BAND_ROWS;
-    const int nrows = min(BAND_ROWS, v.m - row0);
-    for (int t = tid; t < nrows; t += PBB_THREADS) acc[t] = 0.0;
-    const int k = c->k;
-    const int per = (k + chunks - 1) / chunks;
-    const int s_lo = cc * per, s_hi = min(k, s_lo + per);
-    const double* xK = which ? v.tauK : v.aK;
-    const int* bp = v.bptr + (size_t)b * (size_t)(v.m + v.n + 1);
-    const int lane = tid & 7, grp = tid >> 3;  // 8 lanes per slot, 64 slots side by side
-    for (int tile0 = s_lo; tile0 < s_hi; tile0 += PBB_TILE) {
-        const int nt = min(PBB_TILE, s_hi - tile0);
-        __syncthreads();
-        for (int t = tid; t < nt; t += PBB_THREADS) {  // phase A: one thread per slot fetches its descriptor
-            const int slot = tile0 + t;
-            const double x = xK[slot];
-            const int var = v.basic_vars[v.pos_of_kslot[slot]];
-            const int beg = bp[var], end = bp[var + 1];
-            s_x[t] = x;
-            s_beg[t] = beg;
-            s_len[t] = (x != 0.0) ? end - beg : 0;
-        }
-        __syncthreads();
-        for (int t = grp; t < nt; t += PBB_THREADS / 8) {  // phase B: 8 lanes walk the slot's segment
-            const int len = s_len[t], beg = s_beg[t];
-            const double x = s_x[t];
-            for (int o = lane; o < len; o += 8) {
-                const double a = v.bval[beg + o];
-                if (a != 0.0) unsafeAtomicAdd(&acc[v.brow[beg + o]], a * x);  // (pad entries carry 0)
-            }
-        }
-    }
-    __syncthreads();
-    double* dst = v.push_part + (size_t)cc * v.m + row0;
-    for (int t = tid; t < nrows; t += PBB_THREADS) dst[t] = acc[t];
-}
 __global__ void __launch_bounds__(BLK) k_push_combine(DevView v, int which, int nchunks, int ys = 0) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
@@ -1410,8 +1360,7 @@ __global__ void __launch_bounds__(BLK) k_pull_F_scan(DevView v) {
     }
 }
 static void launch_pull_F(const DevView& dv, const Geom& g, int which, hipStream_t st) {
-    static const bool scan_off = std::getenv("MLP_PULL_SCAN") && std::getenv("MLP_PULL_SCAN")[0] == '0';
-    if (!which && dv.fmark && g.lanes > 16 && !scan_off && dv.m >= 16384) {
+    if (!which && dv.fmark && g.lanes > 16 && dv.m >= 16384) {
         hipLaunchKernelGGL(k_pull_F_scan, dim3(512), dim3(BLK), 0, st, dv);
         return;
     }
@@ -1420,28 +1369,11 @@ static void launch_pull_F(const DevView& dv, const Geom& g, int which, hipStream
     else hipLaunchKernelGGL(k_pull_F<64>, dim3(blocks_for((long)dv.m * 64)), dim3(BLK), 0, st, dv, which);
 }
 static void launch_blocked_push(const DevView& dv, int which, hipStream_t st, int ys = 0) {
-    // Measured (round 2, k = 20 500): the band form runs in 34.6 + 9.5 us against 34.8 + 6.4 us for the row-block form
-    // over the CSC — neither is bound by its traffic (the row-block form moves 196 MB for 27 MB of algorithmic bytes, PMC)
-    // but by the serial descriptor / entry chains of its slot tiles.  The row-block form stays the default;
-    // MLP_PUSH_BAND=1 selects the band form for experiments.
-    static const bool band_push = std::getenv("MLP_PUSH_BAND") != nullptr;
-    if (dv.banded && band_push && !dv.pb_det && !ys) {
-        static bool attr_set = false;
-        const size_t lds = sizeof(double) * (BAND_ROWS + PBB_TILE) + sizeof(int) * 2 * PBB_TILE;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_push_band), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
-        int chunks = 256 / dv.nbands;  // about one workgroup per CU (two fit by LDS)
-        if (chunks < 1) chunks = 1;
-        if (chunks > PB_CHUNKS) chunks = PB_CHUNKS;  // push_part holds PB_CHUNKS x m partial sums
-        hipLaunchKernelGGL(k_push_band, dim3(dv.nbands * chunks), dim3(PBB_THREADS), lds, st, dv, which, chunks);
-        hipLaunchKernelGGL(k_push_combine, dim3((dv.m + BLK - 1) / BLK), dim3(BLK), 0, st, dv, which, chunks);
-        return;
-    }
+    // (a band form of this push — LDS blocks of the band-major copy — was measured in round 2: 34.6 + 9.5 us against 34.8 + 6.4 us,
+    // neither bound by its traffic; removed.  Round 6: in the lazy primal iteration the product is PULLED instead: fpull.inc)
     // slot chunks: as many as keep (row blocks x chunks) within one round of workgroups (3 per CU by LDS), at most PB_CHUNKS
-    static const int want = std::getenv("MLP_PB_CHUNKS") ? std::atoi(std::getenv("MLP_PB_CHUNKS")) : 0;
-    int chunks = want > 0 ? want : PB_CHUNKS_DEFAULT;
+    const int want = 0;
+    int chunks = PB_CHUNKS_DEFAULT;  // (24 measured best: 727 / 731 / 732 / 746 us per pivot at k = 20 500 for 24 / 30 / 36 / 48)
     if (chunks > PB_CHUNKS) chunks = PB_CHUNKS;
     if (dv.pb_det) {  // fixed-point limbs: order-independent
         static bool det_attr = false;
@@ -2023,27 +1955,6 @@ __global__ void __launch_bounds__(BLK) k_btran(DevView v, int n_gather, int afte
 
 
 // v branch of the late primal iteration: tK = alpha_K - F^T y_S (solver.rs:1114) on its own, as soon as the FTRAN has landed.
-// y_S[i] = alpha_q[pos] / diag of the singleton covering row i was left in rv.y by the combine of the F push (the same quotient
-// the ratio test forms, so tK is bit-identical to k_btran's), which frees this kernel — and the streaming pass behind it —
-// from the ratio test: v = B^-T alpha_q does not depend on the leaving row.
-template <int G>
-__global__ void __launch_bounds__(BLK) k_pse_tk(DevView v) {
-    Ctl* c = v.ctl;
-    if (!c->side_go) return;
-    const int k = c->k;
-    const int slot = (int)((blockIdx.x * BLK + threadIdx.x) / G);
-    const int gl = threadIdx.x & (G - 1);
-    if (slot >= k) return;
-    const int p = v.pos_of_kslot[slot];
-    const int var = v.basic_vars[p];
-    const int end = v.csc_ptr[var + 1];
-    double acc = 0.0;
-    // (rv.y holds y_S on the singleton rows — the F push's combine left it there — and zeros on the nucleus rows)
-    for (int e = v.csc_ptr[var] + gl; e < end; e += G) acc += v.csc_val[e] * v.rv[v.csc_row[e]].y;
-    acc = group_sum<G>(acc);
-    if (gl == 0) v.tK[slot] = v.alpha_q[p] - acc;
-}
-
 // ------------------------------------------------------------------- stage heads inside the consuming kernel
 // A stage head (one wave: a five-deep chain of dependent loads that turns the pivot column / row into a short list)
 // used to be its own launch in front of the kernel that consumes the list: k_ftran_prep -> k_ftran_gather in the primal
@@ -3268,140 +3179,6 @@ __global__ void __launch_bounds__(BLK) k_fused_lr(DevView v, int fold_only) {
         }
     }
 }
-// Fold kernel of the large-nucleus tiling (16 rows x 1024 columns per block, at most 16 pending terms).
-// Register budget decides its speed: the fold needs the block's V entries (they do not depend on the
-// row) and a tile of W in registers at once, and it must keep enough waves per SIMD to overlap its load,
-// FMA and store phases.  Each thread therefore owns 2 columns at a time (the block walks its 1024
-// columns in two halves): 32 V values + a 4-row tile = ~110 VGPRs, 4 waves per SIMD.
-template <bool WITH_V, bool NT>
-__global__ void __launch_bounds__(BLK) k_fused_lr16(DevView v, int fold_only) {
-    constexpr int TRB = 16, JM = 16;
-    Ctl* c = v.ctl;
-    // mode (parameter `fold_only`): 0 = a folding pivot folds AND produces the tau / v partials (16 x 1024 tiling);
-    // 1 = host-requested fold outside the pivot loop; 2 = a folding pivot only folds, k_stream_w then reads the folded W0
-    const int mode = fold_only;
-    if (mode != 1 && (c->halt || c->it.status != ITER_PIVOT)) return;
-    const int k = c->k, ld = v.ld;
-    const int nlow = c->nlow;
-    if (!(mode == 1 || c->fold)) return;
-    fold_only = mode != 0;
-    const int tid = threadIdx.x;
-    __shared__ double s_tau[TRB][BLK / 64];
-    __shared__ double s_u[LR_MAX][TRB];
-    // 1-D grid striding over the (stripe, chunk) tiles of the current k (see k_fused_w, TILED)
-    const int nchunks_k = (k + FW_TC - 1) / FW_TC;
-    const int ntiles = ((k + TRB - 1) / TRB) * nchunks_k;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int stripe = tile / nchunks_k, chunk = tile % nchunks_k;
-    const int row0 = stripe * TRB;
-    const int col0 = chunk * FW_TC;
-    __syncthreads();  // the previous tile's readers of s_u / s_tau are done
-    for (int i = tid; i < LR_MAX * TRB; i += BLK) {
-        int j = i / TRB, a = i % TRB;
-        int row = row0 + a;
-        s_u[j][a] = (j < nlow && row < k) ? v.U[(size_t)j * ld + row] : 0.0;
-    }
-    if (tid < TRB * (BLK / 64)) (&s_tau[0][0])[tid] = 0.0;
-    __syncthreads();
-    const int wv = tid >> 6, l = tid & 63;
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-        const int c0 = col0 + half * (FW_TC / 2) + 2 * tid;
-        if (col0 + half * (FW_TC / 2) >= k) break;
-        const bool pair = c0 + 1 < k, one = c0 < k;
-        double rk0 = 0.0, rk1 = 0.0;
-        if (!fold_only) {
-            if (one) rk0 = v.rK[c0];
-            if (pair) rk1 = v.rK[c0 + 1];
-        }
-        double vacc0 = 0.0, vacc1 = 0.0;
-        // all 16 rows of the tile stay in registers while the pending terms are applied in groups of
-        // 16 (two groups when the period is 32), each group's V entries loaded once
-        double w[TRB][2];
-#pragma unroll
-        for (int a = 0; a < TRB; ++a) {
-            const int row = row0 + a;
-            w[a][0] = w[a][1] = 0.0;
-            if (row >= k) continue;
-            const double* wp = v.W + (size_t)row * ld;
-            if (pair) {
-                double2 t = fw_load2<NT>(wp + c0);
-                w[a][0] = t.x;
-                w[a][1] = t.y;
-            } else if (one) {
-                w[a][0] = wp[c0];
-            }
-        }
-#pragma unroll 1
-        for (int jg = 0; jg < nlow; jg += JM) {
-            double vj[JM][2];
-#pragma unroll
-            for (int j = 0; j < JM; ++j) {
-                vj[j][0] = vj[j][1] = 0.0;
-                if (jg + j < nlow) {
-                    const double* Vj = v.V + (size_t)(jg + j) * ld;
-                    if (pair) {
-                        double2 t = *reinterpret_cast<const double2*>(Vj + c0);
-                        vj[j][0] = t.x;
-                        vj[j][1] = t.y;
-                    } else if (one) {
-                        vj[j][0] = Vj[c0];
-                    }
-                }
-            }
-            // explicit FMA: the build runs with -ffp-contract=off (the update formulas mirror the
-            // reference's separate multiply and add), but a fold is already a re-association of the
-            // pending updates; one rounding per term is both cheaper and more accurate
-#pragma unroll
-            for (int j = 0; j < JM; ++j) {
-#pragma unroll
-                for (int a = 0; a < TRB; ++a) {
-                    const double u = s_u[jg + j][a];
-                    w[a][0] = __builtin_fma(u, vj[j][0], w[a][0]);
-                    w[a][1] = __builtin_fma(u, vj[j][1], w[a][1]);
-                }
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < TRB; ++a) {
-            const int row = row0 + a;
-            if (row >= k) continue;
-            double* wp = v.W + (size_t)row * ld;
-            if (pair) fw_store2<NT>(wp + c0, w[a][0], w[a][1]);
-            else if (one) wp[c0] = w[a][0];
-        }
-        if (!fold_only) {
-#pragma unroll
-            for (int a = 0; a < TRB; ++a) {
-                const int row = row0 + a;
-                double tacc = w[a][0] * rk0 + w[a][1] * rk1;
-                if (WITH_V && row < k) {
-                    const double t = v.tK[row];
-                    vacc0 += w[a][0] * t;
-                    vacc1 += w[a][1] * t;
-                }
-                const double sacc = wave_sum(tacc);
-                if (l == 0) s_tau[a][wv] += sacc;  // this wave's own cell: no race
-            }
-        }
-        if (!fold_only && WITH_V) {
-            double* pv = v.part_v + (size_t)stripe * ld;
-            if (one) pv[c0] = vacc0;
-            if (pair) pv[c0 + 1] = vacc1;
-        }
-    }
-    if (fold_only) continue;
-    __syncthreads();
-    if (tid < TRB) {
-        int row = row0 + tid;
-        if (row < k) {
-            double sacc = s_tau[tid][0];
-            for (int i = 1; i < BLK / 64; ++i) sacc += s_tau[tid][i];
-            v.part_tau[(size_t)chunk * ld + row] = sacc;
-        }
-    }
-    }
-}
 
 // Streaming pass of the large-nucleus delayed-update mode (every pivot): tau_K = W0 rho_K and v_K = W0^T t_K partials
 // in ONE read of W0, nothing written back.  Shape found with tools/stream_bench.hip (MI355X, k = 20 480: 546 us =
@@ -3414,14 +3191,13 @@ __global__ void __launch_bounds__(BLK) k_fused_lr16(DevView v, int fold_only) {
 //     and re-read 8 k^2 / 16 bytes of partials per pivot: 100 us of k_post_fused at k = 20 000);
 //   * the 8 row sums of a step go through an LDS transpose (two alternating buffers, one barrier per step).
 // The last LR_MAX blocks compute the low-rank dots g_j = V[j].rho_K, h_j = U[j].t_K for k_post_fused.  On a folding
-// pivot k_fused_lr16 (mode 2) has already applied the pending terms to W0, so the dots are skipped and the pass
+// pivot the fold kernel (mode 2) has already applied the pending terms to W0, so the dots are skipped and the pass
 // reads the folded matrix.
 constexpr int SW_MAX_BLOCKS = 8192;
-// grid of the fold (tiles are strided over by its blocks): MLP_FOLD_BLOCKS for A/B runs (tools/rw_bench.hip: a bare in-place
+// grid of the fold (tiles are strided over by its blocks; tools/rw_bench.hip: a bare in-place
 // read + write pass over the same matrix runs in 1 140 us with 4 096 blocks against 1 237 / 1 265 with 2 048 / 8 192)
 static int fold_max_blocks() {
-    static const int v = std::getenv("MLP_FOLD_BLOCKS") ? std::max(256, std::atoi(std::getenv("MLP_FOLD_BLOCKS"))) : SW_MAX_BLOCKS;
-    return v;
+    return SW_MAX_BLOCKS;  // (1 024 ... 8 192 measured alike in situ)
 }
 // rows per strip of the streaming pass: fixed (template value) or balanced over the co-resident blocks (DevView.sw_nbal)
 __device__ __forceinline__ int sw_strip_rows(const DevView& v, int k, int ch, int rs, int rb_fixed) {
@@ -3434,12 +3210,11 @@ __device__ __forceinline__ int sw_strip_rows(const DevView& v, int k, int ch, in
     return max(rb, 32);  // (part_v holds cap / 8 rows of partials)
 }
 template <bool WITH_V, int SW_CH, int SW_RB, int SW_RS>
-__global__ void __launch_bounds__(BLK, 4) k_stream_w(DevView v, int with_tau, int skip_on_fold = 0, int side = 0) {  // 4 waves per SIMD: keep the double buffer within 128 VGPRs
+__global__ void __launch_bounds__(BLK, 4) k_stream_w(DevView v, int with_tau, int skip_on_fold = 0) {  // 4 waves per SIMD: keep the double buffer within 128 VGPRs
     static_assert(SW_CH == 2 * BLK || SW_CH == 4 * BLK, "one or two column pairs per thread");
     constexpr int NP = SW_CH / (2 * BLK);
     Ctl* c = v.ctl;
-    // (side: v branch — the ratio test runs beside this pass and may rewrite `status`; the pass is then merely unused)
-    if (side ? !c->side_go : (c->halt || c->it.status != ITER_PIVOT)) return;
+    if (c->halt || c->it.status != ITER_PIVOT) return;
     if (skip_on_fold && c->fold) return;  // the fold of this pivot produced the v partials itself (k_fold_w, fuse_v)
     KMARK0(c, 21);
     const int k = c->k, ld = v.ld;
@@ -3553,7 +3328,7 @@ __global__ void __launch_bounds__(BLK, 4) k_stream_w(DevView v, int with_tau, in
 }
 
 // Fold of the pending rank-1 terms into W0 for the large-nucleus mode:  W0[r][c] += sum_j U[j][r] V[j][c], j < nlow
-// (one explicit FMA per term, in term order, like k_fused_lr16).  One read and one write of W0, 2 JM flops per
+// (one explicit FMA per term, in term order).  One read and one write of W0, 2 JM flops per
 // element: memory-bound as long as the FMAs hide behind the stream, so the kernel is shaped like k_stream_w:
 //   * a block owns FD_CH = 256 columns x FD_RB rows; a thread owns ONE column and keeps the JM values V[j][col] in
 //     registers for the whole strip (a pair of columns would need 2 JM registers and halve the occupancy);
@@ -3565,91 +3340,6 @@ constexpr int FD_CH = 256, FD_RB = 256, FD_RS = 8;
 // The hot loop is branch-free: rows and columns beyond the edge are CLAMPED (the loads are unconditional, their
 // results masked or never stored).  With `cond ? load : 0` forms the loop breaks into ~20 basic blocks and the
 // register allocator spills the V values (measured: 1.8 KB of scratch per lane).
-template <int JM>
-__global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : 3)) k_fold_w(DevView v, int mode, int fuse_v) {
-    // fuse_v (a folding pivot of the lazy primal iteration, unsharded): the tile that has just been folded also yields its
-    // part of v_K = W0^T t_K — the streaming pass of that pivot (one more read of the whole inverse) is skipped; the
-    // partials land in part_v by this kernel's strips of FD_RB rows (k_post_fused reads them with that geometry).
-    Ctl* c = v.ctl;
-    if (mode != 1 && (c->halt || c->it.status != ITER_PIVOT)) return;
-    if (!(mode == 1 || c->fold)) return;
-    const int k = c->k, ld = v.ld;
-    const int nlow = min(c->nlow, JM);
-    if (nlow <= 0 || k <= 0) return;
-    const int tid = threadIdx.x;
-    __shared__ __attribute__((aligned(16))) double s_u[2][FD_RS][JM];
-    __shared__ double s_t[2][FD_RS];
-    const int nch = (k + FD_CH - 1) / FD_CH, nstr = (k + FD_RB - 1) / FD_RB;
-    const int sa = tid / JM, sj = tid % JM;  // staging: thread -> (row of the step, term)
-    const bool stager = sa < FD_RS;
-    const int sjc = min(sj, nlow - 1);
-    double* __restrict__ Wp = v.W;
-    const double* __restrict__ Up = v.U;
-    const double* __restrict__ Vp = v.V;
-    for (int tile = blockIdx.x; tile < nstr * nch; tile += gridDim.x) {
-        const int strip = tile / nch, chunk = tile % nch;
-        const int rbeg = strip * FD_RB, rend = min(k, rbeg + FD_RB);
-        const int col = chunk * FD_CH + tid;
-        const bool active = col < k;
-        const int colc = active ? col : k - 1;
-        double vj[JM];
-#pragma unroll
-        for (int j = 0; j < JM; ++j) {
-            const double x = Vp[(size_t)min(j, nlow - 1) * ld + colc];
-            vj[j] = (active && j < nlow) ? x : 0.0;
-        }
-        double* wcol = Wp + colc;
-        double w[FD_RS], wn[FD_RS];
-        double vacc = 0.0;
-        __syncthreads();  // the previous tile's readers of s_u are done
-        {
-            const int row = min(rbeg + (stager ? sa : 0), rend - 1);
-            const double x = Up[(size_t)sjc * ld + row];
-            if (stager) s_u[0][sa][sj] = (sj < nlow && rbeg + sa < rend) ? x : 0.0;
-            if (fuse_v && stager && sj == 0) s_t[0][sa] = (rbeg + sa < rend) ? v.tK[row] : 0.0;
-        }
-#pragma unroll
-        for (int a = 0; a < FD_RS; ++a) w[a] = __builtin_nontemporal_load(wcol + (size_t)min(rbeg + a, rend - 1) * ld);
-        int buf = 0;
-        for (int r0 = rbeg; r0 < rend; r0 += FD_RS, buf ^= 1) {
-            __syncthreads();  // s_u[buf] is staged; s_u[buf ^ 1] is free (its readers passed this barrier)
-            if (r0 + FD_RS < rend) {  // uniform branch: the last step has no successor
-                const int rn = r0 + FD_RS;
-                const int row = min(rn + (stager ? sa : 0), rend - 1);
-                const double x = Up[(size_t)sjc * ld + row];
-                if (stager) s_u[buf ^ 1][sa][sj] = (sj < nlow && rn + sa < rend) ? x : 0.0;
-                if (fuse_v && stager && sj == 0) s_t[buf ^ 1][sa] = (rn + sa < rend) ? v.tK[row] : 0.0;
-#pragma unroll
-                for (int a = 0; a < FD_RS; ++a) wn[a] = __builtin_nontemporal_load(wcol + (size_t)min(rn + a, rend - 1) * ld);
-            }
-#pragma unroll
-            for (int a = 0; a < FD_RS; ++a) {
-                double acc = w[a];
-#pragma unroll
-                for (int j = 0; j < JM; j += 2) {
-                    const double2 u = *reinterpret_cast<const double2*>(&s_u[buf][a][j]);
-                    acc = __builtin_fma(u.x, vj[j], acc);
-                    acc = __builtin_fma(u.y, vj[j + 1], acc);
-                }
-                w[a] = acc;
-                if (fuse_v) vacc = __builtin_fma(acc, s_t[buf][a], vacc);  // (rows beyond the strip carry t = 0)
-            }
-            if (active) {
-                if (r0 + FD_RS <= rend) {
-#pragma unroll
-                    for (int a = 0; a < FD_RS; ++a) __builtin_nontemporal_store(w[a], wcol + (size_t)(r0 + a) * ld);
-                } else {
-#pragma unroll
-                    for (int a = 0; a < FD_RS; ++a)
-                        if (r0 + a < rend) __builtin_nontemporal_store(w[a], wcol + (size_t)(r0 + a) * ld);
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < FD_RS; ++a) w[a] = wn[a];
-        }
-        if (fuse_v && active) v.part_v[(size_t)strip * ld + col] = vacc;
-    }
-}
 // The same fold with the U side read through the SCALAR unit (round 3).  k_fold_w stages the FD_RS x JM values U[j][row]
 // of a step in LDS and every thread reads them back as broadcasts: 16 ds_read_b128 per element row — at 420 M elements per
 // fold that is ~105 M LDS wave-instructions, which bound the kernel (1.43 ms = 4.7 TB/s at k = 20 500 where a read + write
@@ -3657,17 +3347,14 @@ __global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : 3)) k_fold_w(DevView v, i
 // scalar registers: lowrank_append keeps a slot-major copy Ut[slot][j], a row's JM values are one contiguous 256-byte
 // block, loaded with s_load (constant address space: nothing in this kernel writes Ut or t_K) and used as the scalar operand
 // of the FMAs.  No LDS, no barriers.  Measured at k = 20 500 (rocprofv3): 1 338 us against 1 426 us, 695 vs 707 us per pivot
-// of the late window (MLP_FOLD_SCALAR=0 keeps the LDS form for the A/B).  What bounds it now is the scalar-load latency per
+// of the late window (the LDS form was kept for the A/B until round 6).  What bounds it now is the scalar-load latency per
 // row (one batch, one wait: s_load returns out of order, there is no partial wait), hidden only by the 3 waves per SIMD.
 typedef const __attribute__((address_space(4))) double const_f64;
 typedef double sreg8 __attribute__((ext_vector_type(8)));  // 16 consecutive SGPRs
 template <int JM>
 __global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : JM <= 32 ? 3 : 2)) k_fold_w2(DevView v, int mode, int fuse_v) {
     Ctl* c = v.ctl;
-    // mode 3: the fold of a folding pivot on the v branch — it runs beside the ratio test, which may turn the pivot into a bound
-    // flip while the fold is under way: the fold goes through whatever the ratio test decides (W0 + the pending terms is the same
-    // inverse either way) and its last block clears the list itself
-    if (mode == 3 ? !c->side_go : (mode != 1 && (c->halt || c->it.status != ITER_PIVOT))) return;
+    if (mode != 1 && (c->halt || c->it.status != ITER_PIVOT)) return;
     if (!(mode == 1 || c->fold)) return;
     const int k = c->k, ld = v.ld;
     const int nlow = min(c->nlow, JM);
@@ -3751,10 +3438,6 @@ __global__ void __launch_bounds__(BLK, (JM <= 16 ? 4 : JM <= 32 ? 3 : 2)) k_fold
             for (int a = 0; a < FD_RS; ++a) w[a] = wn[a];
         }
         if (fuse_v && active) v.part_v[(size_t)strip * ld + col] = vacc;
-    }
-    if (mode == 3 && last_block_arrives(&v.ticket[2], gridDim.x) && tid == 0) {
-        v.ticket[2] = 0;
-        c->nlow = 0;  // (lowrank_append of a pivot sets it to 1; a bound flip leaves the folded inverse with an empty list)
     }
 }
 // (Measured and rejected in round 3: the same update on the matrix cores — v_mfma_f64_16x16x4_f64, operands one f64 per lane
@@ -4994,8 +4677,6 @@ void launch_btran_fused(const DevView& dv, const Geom& g, int with_rhs, int deri
 #undef BTRANF
 }
 bool ftran_head_rides_gather(const DevView& dv, const Geom& g) {  // delayed-update mode: the FTRAN head inside the gather (k_ftran_gather_lrh)
-    const char* e = std::getenv("MLP_LR_HEAD_FUSION");
-    if (e && e[0] == '0') return false;
     return dv.lrJ > 0 && dv.pb_on && dv.world <= 1 && !g.fac && !dv.det_pull && dv.rowinfo != nullptr;
 }
 void launch_ftran_gather_lrh(const DevView& dv, const Geom& g, hipStream_t st, int ys, int fpk) {
@@ -5102,12 +4783,6 @@ void launch_post_ftran(const DevView& dv, const Geom& g, int use_pse, hipStream_
 void launch_btran_prep(const DevView& dv, int derive_dual, int plan_after, hipStream_t st) {
     hipLaunchKernelGGL(k_btran_prep, dim3(1), dim3(64), 0, st, dv, derive_dual, plan_after);
 }
-void launch_pse_tk(const DevView& dv, const Geom& g, hipStream_t st) {
-    LANES_SWITCH(g.lanes,
-                 hipLaunchKernelGGL(k_pse_tk<4>, dim3(blocks_for((long)g.cap * 4)), dim3(BLK), 0, st, dv),
-                 hipLaunchKernelGGL(k_pse_tk<16>, dim3(blocks_for((long)g.cap * 16)), dim3(BLK), 0, st, dv),
-                 hipLaunchKernelGGL(k_pse_tk<64>, dim3(blocks_for((long)g.cap * 64)), dim3(BLK), 0, st, dv));
-}
 void launch_btran(const DevView& dv, const Geom& g, int with_rhs, hipStream_t st, int after_fold) {
     int n_gather = blocks_for(dv.lrJ ? (long)g.cap * 4 : (long)g.cap);  // delayed-update mode: 4 lanes per slot
     if (n_gather > (dv.lrJ ? 1024 : 512)) n_gather = dv.lrJ ? 1024 : 512;  // (the reduction buffers hold >= 1024 partials)
@@ -5141,9 +4816,8 @@ static void launch_sweep_banded(const DevView& dv, const Geom& g, int mode, int 
     // column order of the pass
     // Measured (round 2): variable order does NOT pay — late window 77.5 us against 73.4 us in position order, early window
     // 112.4 against 103.9 us per pivot: the 16-byte partial stores scattered by position cost what the sequential read
-    // saves.  Position order stays the default; MLP_SWEEP_ORDER=var selects the other for experiments.
-    static const bool want_var = std::getenv("MLP_SWEEP_ORDER") && std::string(std::getenv("MLP_SWEEP_ORDER")) == "var";
-    const bool vord = dv.world <= 1 && want_var && dv.nb_order == nullptr;  // (the two orders exclude each other)
+    // saves. Position order it is.
+    const bool vord = false;  // (variable order of the pass: measured slower — 112.4 against 103.9 us per pivot — and removed as a choice)
     // One workgroup per CU (LDS-bound): all blocks of the launch must fit the 256 CUs at once, or a second,
     // almost empty round of workgroups doubles the kernel time (260 workgroups: 43 us, 247: 36 us).  In the
     // primal iteration the per-band partials are summed by k_update_pivot itself (inline_combine) and the
@@ -5253,13 +4927,11 @@ constexpr int FW_RL = 1;  // measured: 4 row tiles per block slow the stream dow
 static inline int fw_rows(const Geom& g) { return g.big ? 16 * FW_RL : 8; }
 // 1-D grid of the tiled large-nucleus passes: enough blocks to fill the chip a few times over
 constexpr int FW_TILE_BLOCKS = 4096;
-// MLP_STREAM_STRIPS=0 keeps the older 16 x 1024 tiling of the large-nucleus streaming pass (A/B measurements)
-// strip geometry of k_stream_w (columns x rows per block, rows per step); MLP_SW_VARIANT selects one for A/B runs
+// strip geometry of k_stream_w (columns x rows per block, rows per step)
 struct SwGeom { int ch, rb, rs; };
 static constexpr SwGeom kSwGeoms[] = {{512, 512, 8}, {1024, 256, 4}, {1024, 128, 4}, {512, 256, 8}, {1024, 64, 4}, {512, 128, 4}};
 static int stream_variant() {
-    static const int vv = std::getenv("MLP_SW_VARIANT") ? std::atoi(std::getenv("MLP_SW_VARIANT")) : 2;
-    return (vv >= 0 && vv < (int)(sizeof(kSwGeoms) / sizeof(kSwGeoms[0]))) ? vv : 2;
+    return 2;  // 1 024 columns x 128 rows, 4 rows per step (the other shapes were A/B runs of round 2: tools/stream_bench.hip)
 }
 static int sw_ch() { return kSwGeoms[stream_variant()].ch; }
 static int sw_rb() { return kSwGeoms[stream_variant()].rb; }
@@ -5279,18 +4951,15 @@ int stream_coresident_blocks() {
     return (stream_variant() == 2) ? n : 0;
 }
 bool stream_strips_enabled() {
-    static const bool on = !(std::getenv("MLP_STREAM_STRIPS") && std::atoi(std::getenv("MLP_STREAM_STRIPS")) == 0);
-    return on;
+    return true;
 }
 // A folding pivot of the lazy primal iteration (v only, no tau), unsharded: the fold kernel produces the v partials of the
 // freshly folded inverse itself and the streaming pass of that pivot is skipped (one read of the inverse less in every
-// lrJ pivots: 0.49 ms of 1.92 ms at k = 20 500).  MLP_FOLD_FUSE=0 restores fold-then-stream.
+// lrJ pivots: 0.49 ms of 1.92 ms at k = 20 500).
 bool fold_fuses_v(const DevView& dv, int with_v, int with_tau, int fold_only) {
-    static const bool off = std::getenv("MLP_FOLD_FUSE") && std::getenv("MLP_FOLD_FUSE")[0] == '0';
-    return !off && with_v && !with_tau && !fold_only && !dv.wshard && dv.lrJ > 0 && stream_strips_enabled();
+    return with_v && !with_tau && !fold_only && !dv.wshard && dv.lrJ > 0 && stream_strips_enabled();
 }
-// part / side: the v branch launches the fold (part 1) and the streaming pass (part 2) separately on the side stream
-static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fold_only, hipStream_t st, int with_tau = 1, int part = 0, int side = 0) {
+static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fold_only, hipStream_t st, int with_tau = 1) {
     const int rows = fw_rows(g);
     int nstripes = (g.cap + rows - 1) / rows, nchunks = (g.cap + FW_TC - 1) / FW_TC;
     dim3 b(BLK);
@@ -5303,79 +4972,28 @@ static void launch_fused_lr(const DevView& dv, const Geom& g, int with_v, int fo
         }
         if (with_v) hipLaunchKernelGGL((k_fused_lr<8, true, false>), gf, b, 0, st, dv, fold_only);
         else hipLaunchKernelGGL((k_fused_lr<8, false, false>), gf, b, 0, st, dv, fold_only);
-    } else {
-        const long tiles_cap = (long)nstripes * nchunks;
-        const int nb = (int)(tiles_cap < FW_TILE_BLOCKS ? tiles_cap : FW_TILE_BLOCKS);
-        if (FW_RL == 1 && stream_strips()) {
-            // a folding pivot folds first (mode 2: no partials), then EVERY pivot streams W0 once (k_stream_w)
-            static const bool old_fold = std::getenv("MLP_OLD_FOLD") != nullptr;  // A/B: the 16 x 1024 fold kernel
-            const int fuse = fold_fuses_v(dv, with_v, with_tau, fold_only) && !old_fold ? 1 : 0;
-            if (part == 2) {
-                // (the fold of this pivot was launched on its own)
-            } else if (old_fold) {
-                hipLaunchKernelGGL((k_fused_lr16<false, true>), dim3(nb), b, 0, st, dv, fold_only ? 1 : 2);
-            } else {
-                const long ftiles = (long)((g.cap + FD_RB - 1) / FD_RB) * ((g.cap + FD_CH - 1) / FD_CH);
-                const int nf = (int)(ftiles < fold_max_blocks() ? ftiles : fold_max_blocks());
-                const char* fs = std::getenv("MLP_FOLD_SCALAR");  // A/B: "0" = the form with U staged in LDS (read per launch: tests toggle it)
-                const bool scalar_u = !(fs && fs[0] == '0');
-                if (scalar_u) {
-                    if (dv.lrJ <= 16) LAUNCH_T(3, k_fold_w2<16>, dim3(nf), b, 0, st, dv, fold_only ? 1 : (side ? 3 : 2), fuse);
-                    else LAUNCH_T(3, k_fold_w2<LR_MAX>, dim3(nf), b, 0, st, dv, fold_only ? 1 : (side ? 3 : 2), fuse);
-                } else {
-                    if (dv.lrJ <= 16) LAUNCH_T(3, k_fold_w<16>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, fuse);
-                    else LAUNCH_T(3, k_fold_w<LR_MAX>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, fuse);
-                }
-            }
-            if (!fold_only && part != 1) {
-                long tiles = (long)((g.cap + sw_rb() - 1) / sw_rb()) * ((g.cap + sw_ch() - 1) / sw_ch());
-                if (dv.sw_nbal > tiles) tiles = dv.sw_nbal;  // balanced strips: one tile per co-resident block
-                const int nt = (int)(tiles < SW_MAX_BLOCKS ? tiles : SW_MAX_BLOCKS);
-#define SW_LAUNCH(CH, RB, RS)                                                                                     \
-    do {                                                                                                          \
-        if (with_v) LAUNCH_T(2, (k_stream_w<true, CH, RB, RS>), dim3(nt + LR_MAX), b, 0, st, dv, with_tau, fuse, side); \
-        else if (with_tau) LAUNCH_T(2, (k_stream_w<false, CH, RB, RS>), dim3(nt + LR_MAX), b, 0, st, dv, 1, 0, 0);  \
-    } while (0)
-                switch (stream_variant()) {
-                case 0: SW_LAUNCH(512, 512, 8); break;
-                case 1: SW_LAUNCH(1024, 256, 4); break;
-                case 3: SW_LAUNCH(512, 256, 8); break;
-                case 4: SW_LAUNCH(1024, 64, 4); break;
-                case 5: SW_LAUNCH(512, 128, 4); break;
-                default: SW_LAUNCH(1024, 128, 4); break;
-                }
-#undef SW_LAUNCH
-            }
-            return;
-        }
-        if (!fold_only) {  // cap-sized 2-D grid: measured 146 us against 154 us tiled at k = 10 000
-            dim3 gr(nstripes < LR_MAX ? LR_MAX : nstripes, nchunks + 1);
-            if (with_v) hipLaunchKernelGGL((k_fused_w<16, true, true, false, true, true, FW_RL>), gr, b, 0, st, dv);
-            else hipLaunchKernelGGL((k_fused_w<16, true, false, false, true, true, FW_RL>), gr, b, 0, st, dv);
-        }
-        if (FW_RL == 1) {  // register-resident V
-            if (with_v) hipLaunchKernelGGL((k_fused_lr16<true, true>), dim3(nb), b, 0, st, dv, fold_only);
-            else hipLaunchKernelGGL((k_fused_lr16<false, true>), dim3(nb), b, 0, st, dv, fold_only);
-        } else {
-            dim3 gf(nstripes, nchunks);
-            if (with_v) hipLaunchKernelGGL((k_fused_lr<16, true, true, FW_RL>), gf, b, 0, st, dv, fold_only);
-            else hipLaunchKernelGGL((k_fused_lr<16, false, true, FW_RL>), gf, b, 0, st, dv, fold_only);
-        }
+        return;
+    }
+    // large tiles: a folding pivot folds first (k_fold_w2: U through the scalar unit; with `fuse` it also yields that pivot's v
+    // partials and the streaming pass below exits at once), then every pivot streams W0 once (k_stream_w: 1 024 columns x 128 rows,
+    // 4 rows per step, one balanced tile per co-resident block)
+    const int fuse = fold_fuses_v(dv, with_v, with_tau, fold_only) ? 1 : 0;
+    const long ftiles = (long)((g.cap + FD_RB - 1) / FD_RB) * ((g.cap + FD_CH - 1) / FD_CH);
+    const int nf = (int)(ftiles < fold_max_blocks() ? ftiles : fold_max_blocks());
+    if (dv.lrJ <= 16) LAUNCH_T(3, k_fold_w2<16>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, fuse);
+    else LAUNCH_T(3, k_fold_w2<LR_MAX>, dim3(nf), b, 0, st, dv, fold_only ? 1 : 2, fuse);
+    if (!fold_only) {
+        long tiles = (long)((g.cap + sw_rb() - 1) / sw_rb()) * ((g.cap + sw_ch() - 1) / sw_ch());
+        if (dv.sw_nbal > tiles) tiles = dv.sw_nbal;  // balanced strips: one tile per co-resident block
+        const int nt = (int)(tiles < SW_MAX_BLOCKS ? tiles : SW_MAX_BLOCKS);
+        if (with_v) LAUNCH_T(2, (k_stream_w<true, 1024, 128, 4>), dim3(nt + LR_MAX), b, 0, st, dv, with_tau, fuse);
+        else if (with_tau) LAUNCH_T(2, (k_stream_w<false, 1024, 128, 4>), dim3(nt + LR_MAX), b, 0, st, dv, 1, 0);
     }
 }
 void launch_fold_lowrank(const DevView& dv, const Geom& g, hipStream_t st) {
     if (!dv.lrJ || g.cap <= 0) return;
     launch_fused_lr(dv, g, 0, 1, st);
     hipLaunchKernelGGL(k_reset_nlow, dim3(1), dim3(1), 0, st, dv);
-}
-bool vbranch_supported(const DevView& dv, const Geom& g) {
-    static const bool other_fold = std::getenv("MLP_OLD_FOLD") != nullptr ||
-                                   (std::getenv("MLP_FOLD_SCALAR") && std::getenv("MLP_FOLD_SCALAR")[0] == '0');
-    return dv.lrJ > 0 && g.cap > 0 && fw_rows(g) != 8 && FW_RL == 1 && stream_strips() && !other_fold && !dv.wshard && dv.world <= 1 &&
-           dv.pb_on && !dv.pb_det;
-}
-void launch_fused_w_side(const DevView& dv, const Geom& g, int part, hipStream_t st) {
-    launch_fused_lr(dv, g, 1, 0, st, 0, part, 1);
 }
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int with_tau) {
     if (g.cap <= 0) return;  // a model without kept rows has no nucleus: nothing to stream (and no valid grid)
@@ -5457,12 +5075,11 @@ int launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t 
     else if (dv.det_pull && with_tau) launch_pull_F(dv, g, 1, st);
     return (touch_asked && !touch) ? 1 : 0;
 }
-void launch_push_tau(const DevView& dv, hipStream_t st) { launch_blocked_push(dv, 1, st); }  // the tau push alone (side branch)
 void launch_structure_update(const DevView& dv, const Geom& g, hipStream_t st) {
     hipLaunchKernelGGL(k_struct_update, dim3(blocks_for(g.cap)), dim3(BLK), 0, st, dv);
 }
 bool update_pulls_inside(const DevView& dv, const Geom& g) {
-    const char* e = std::getenv("MLP_PULL_INSIDE");
+    const char* e = std::getenv("MLP_PULL_INSIDE");  // (tests: the three forms of the small-nucleus iteration must agree, tests/test_primal_head.py)
     if (e && e[0] == '0') return false;
     const int t = g.m > g.n ? g.m : g.n;
     return primal_head_supported(dv, g) && blocks_for(t, BLK * 4) <= 2048 && dv.hy_stamp_n != nullptr;  // at most four positions per thread
@@ -5482,9 +5099,8 @@ void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_ds
     // only beyond 512 * 4 * 256 positions
     // positions per thread: one up to 512 workgroups (measured against 2 and 4 on config 4, mid / late windows: 244.1 / 244.7 / 248.2 and 663.3 /
     // 664.0 / 667.8 us per pivot), beyond that as many as keep the grid within 512 (the 400 000-column transport instance: 164.6 / 156.2 /
-    // 154.0 us per pivot at 1 / 2 / 4 — 1 563 workgroups queue on the ticket and the launch ramp); MLP_UPDATE_PT forces a value (A/B runs)
-    static const int upd_pt_env = std::getenv("MLP_UPDATE_PT") ? std::max(1, std::min(8, std::atoi(std::getenv("MLP_UPDATE_PT")))) : 0;
-    const int upd_pt = upd_pt_env > 0 ? upd_pt_env : std::max(1, std::min(8, (blocks_for(t) + 511) / 512));
+    // 154.0 us per pivot at 1 / 2 / 4 — 1 563 workgroups queue on the ticket and the launch ramp)
+    const int upd_pt = std::max(1, std::min(8, (blocks_for(t) + 511) / 512));
     int n_upd = blocks_for(t, BLK * upd_pt) <= 2048 ? blocks_for(t, BLK * upd_pt) : 2048;
     if (pull_inside == 2) n_upd = blocks_for(g.n, BLK * 4);       // non-basic side only, four positions per thread (k_update_pivot: UPT)
     else if (pull_inside) n_upd = blocks_for(t, BLK * 4);

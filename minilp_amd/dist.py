@@ -3,7 +3,7 @@
 Control plane only (no arithmetic).  The pivot kernels exchange their per-pivot candidates through mailboxes
 that live in each GPU's own HBM and are written by the peers over xGMI (HIP IPC peer mappings); the IPC handles
 travel through a small POSIX shared-memory rendezvous object created and zeroed by rank 0, whose first part
-doubles as the host-memory mailbox of the fallback transport (MLP_MAILBOX=host).  `torch.distributed` (RCCL on
+doubles as the host-memory mailbox of the fallback transport (MLP_TRANSPORT=host).  `torch.distributed` (RCCL on
 GPUs, gloo in the CPU tests) carries the object's name, the barriers and the timing reductions.
 """
 import os
@@ -49,7 +49,7 @@ def remove_mailbox(name):
 def _try_enable(solution, dist, rank, world, transport=None):
     """One collective attempt: rank 0 creates the rendezvous object, every rank enables sharding; returns
     (box name, list of per-rank error strings).  transport None: the engine's default (device mailboxes written by the peers,
-    or what MLP_TRANSPORT / MLP_MAILBOX say); "rccl": rank 0 also makes the ncclUniqueId that travels with the box name."""
+    or what MLP_TRANSPORT says); "rccl": rank 0 also makes the ncclUniqueId that travels with the box name."""
     uid = None
     if transport == "rccl" and rank == 0:
         import minilp_amd as _M
@@ -88,8 +88,8 @@ def setup_sharding(solution, dist=None):
         return None
     rank, world = dist.get_rank(), dist.get_world_size()
     forced = os.environ.get("MLP_TRANSPORT")  # "peer" / "host" / "rccl" / "pump": no fallback chain, that transport or an error
-    name, bad = _try_enable(solution, dist, rank, world, forced if forced in ("rccl", "pump") else None)
-    if bad and not forced and os.environ.get("MLP_MAILBOX") != "host":
+    name, bad = _try_enable(solution, dist, rank, world, forced if forced in ("rccl", "pump", "host") else None)
+    if bad and not forced:
         # fallback chain: peer stores -> RCCL all-gather pump (ranks on distinct devices) -> host-memory mailbox
         if rank == 0:
             remove_mailbox(name)
@@ -99,8 +99,7 @@ def setup_sharding(solution, dist=None):
             if rank == 0:
                 remove_mailbox(name)
                 print("[minilp_amd.dist] RCCL transport unavailable (" + "; ".join(bad) + "): falling back to the host-memory mailbox", flush=True)
-            os.environ["MLP_MAILBOX"] = "host"   # read by the engine at enable_sharding
-            name, bad = _try_enable(solution, dist, rank, world)
+            name, bad = _try_enable(solution, dist, rank, world, "host")
     if bad:
         if rank == 0:
             remove_mailbox(name)

@@ -21,7 +21,7 @@ def test_sharded_pricing_matches_unsharded_pivot_for_pivot(world, pivots):
     assert "traces identical: True" in r.stdout
 
 
-@pytest.mark.parametrize("world,extra", [(2, {}), (3, {}), (2, {"MLP_NO_WSHARD": "1"}), (2, {"MLP_MAILBOX": "host"})],
+@pytest.mark.parametrize("world,extra", [(2, {}), (3, {}), (2, {"MLP_NO_WSHARD": "1"}), (2, {"MLP_TRANSPORT": "host"})],
                          ids=["2 ranks, row-sharded W stream", "3 ranks, row-sharded W stream", "2 ranks, replicated stream", "2 ranks, host mailbox"])
 def test_sharded_pricing_with_the_large_nucleus_machinery(world, extra):
     """Same gate with the delayed-update mode, the strip-shaped streaming pass, the padded pitch of W and the blocked
@@ -47,8 +47,8 @@ def test_sharded_dual_loop_matches_unsharded_pivot_for_pivot(world):
 
 
 def test_host_mailbox_transport_still_works():
-    """MLP_MAILBOX=host: the older transport (one mailbox in host memory, polled across PCIe) behind the same protocol."""
-    env = dict(os.environ, MLP_MAILBOX="host")
+    """MLP_TRANSPORT=host: the older transport (one mailbox in host memory, polled across PCIe) behind the same protocol."""
+    env = dict(os.environ, MLP_TRANSPORT="host")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_test.py"), "2", "3000", "3000", "12", "300"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -380,23 +380,6 @@ print("RESULT " + json.dumps(out))
     assert res[0]["transport"][1] > 100 and res[0]["config3"][1] > 3000
 
 
-def test_data_flow_walk_takes_the_same_pivots(monkeypatch):
-    """MLP_FACTOR_FLOW=1 (the grid's segments ordered by data: sentinel + bounded waits instead of a grid barrier per level; measured, not
-    the default): the oracle's pivots on a transport instance with a dozen levels, the optimum of config 3 with its bump."""
-    monkeypatch.setenv("MLP_FACTOR", "1")
-    monkeypatch.setenv("MLP_FACTOR_FLOW", "1")
-    lp = lpgen.gen_transport_lp(2500, 2500, 4, 3, tight=0.4)
-    so, sg = _pair(lp)
-    assert sg.stats()["factor_active"] == 1 and sg.stats()["factor_levels"] >= 2
-    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
-    assert obj_close(sg.objective(), so.objective())
-    lp3 = lpgen.gen_mixed_lp(6000, 10000, 4, 3)
-    monkeypatch.setenv("MLP_FACTOR_SB_FROM", "2")
-    so3, sg3 = _pair(lp3)
-    assert obj_close(sg3.objective(), so3.objective())
-    check_feasible(lp3, sg3.values())
-
-
 def test_staircase_family_hands_a_filling_bump_over(monkeypatch):
     """Multi-period production / inventory model (lpgen.gen_staircase_lp, 5 000 rows): with the compact factor forced its bump grows to a
     quarter of the rows and the elimination of it fills in a dense tail (rows of 60-80 entries: tools/experiments/bump_lu.py staircase).

@@ -71,22 +71,6 @@ def test_default_machinery_from_saved_basis_keeps_the_invariants(cfg4, path, k0,
           f"max |W - W_fresh| {drift:.2e} (max |W| {scale:.2e}), cases {st['kase']}")
 
 
-def test_both_forms_of_the_fold_kernel_give_the_same_inverse(cfg4, monkeypatch):
-    """The fold W0 += sum_j U_j V_j^T reads U through the scalar unit by default (k_fold_w2); MLP_FOLD_SCALAR=0 keeps the
-    form that stages U in LDS (k_fold_w).  Both add the terms of an element in the same order with explicit FMAs: 96
-    pivots from the mid basis (three folds, the fused v partials of each driving the next pricing decisions) must give
-    the same trace and bit-identical values."""
-    lp, prob = cfg4
-    runs = []
-    for form in ("1", "0"):
-        monkeypatch.setenv("MLP_FOLD_SCALAR", form)
-        s = _load(prob, MID, trace=True)
-        s.continue_solve(96)
-        runs.append((s.trace(), s.objective(), s.values().tobytes()))
-    assert runs[0][0] == runs[1][0]
-    assert runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
-
-
 def test_t_K_riding_in_the_ratio_launch_changes_no_bit(cfg4, monkeypatch):
     """Large nucleus, lazy primal iteration: t_K = alpha_K - F^T y_S is formed by blocks that ride behind the ratio blocks of
     k_ratio_primal_fused (y_S left by row by the F push's combine) instead of in the BTRAN launch (MLP_TK_RIDE=0).  The same
@@ -166,23 +150,6 @@ def test_pulled_F_product_makes_the_late_pivot_reproducible_bit_for_bit(cfg4):
         runs.append((s.trace(), s.objective(), s.values().tobytes()))
     assert runs[0][0] == runs[1][0]
     assert runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
-
-
-def test_the_v_branch_of_the_late_pivot_takes_the_same_pivots(cfg4, monkeypatch):
-    """MLP_VBRANCH=1 runs the pass v_K = W^T t_K on a side stream beside the ratio test and the BTRAN (off by default: it is
-    slower, engine.hip).  On a folding pivot the branch takes v from the fold's own partials, so from the first fold on the
-    two orders differ at rounding level (pivot element 1.1118724973741045 against ...028 at pivot 33) — nothing more: 96
-    pivots from the mid basis (three folds) must choose the same (entering, leaving) pairs and end at the same point."""
-    lp, prob = cfg4
-    runs = []
-    for on in ("0", "1"):
-        monkeypatch.setenv("MLP_VBRANCH", on)
-        s = _load(prob, MID, trace=True)
-        s.continue_solve(96)
-        runs.append((s.trace(), s.objective(), s.values()))
-    assert [t[:5] for t in runs[0][0]] == [t[:5] for t in runs[1][0]]
-    assert abs(runs[0][1] - runs[1][1]) <= 1e-11 * abs(runs[0][1])
-    assert np.abs(runs[0][2] - runs[1][2]).max() <= 1e-9
 
 
 def _backward_error(resid, *abs_terms):
