@@ -171,7 +171,7 @@ public:
     std::vector<uint8_t> save_basis(int mode);
     void load_basis(const uint8_t* blob, size_t len);  // call after try_new on the same problem
     // column-block pricing across ranks.  transport: nullptr / "" = MLP_TRANSPORT or the default (device mailboxes written by the peers,
-    // MLP_MAILBOX=host for the host mailbox); "rccl" = records delivered by ncclAllGather (rccl_id: the 128-byte ncclUniqueId of
+    // MLP_TRANSPORT=host for the host mailbox); "rccl" = records delivered by ncclAllGather (rccl_id: the 128-byte ncclUniqueId of
     // rank 0); "pump" = the same pump protocol with peer copies in place of the collective (ranks sharing one GPU: tests)
     void enable_sharding(int rank, int world, const char* shm_name, const char* transport_name = nullptr, const void* rccl_id = nullptr);
     static void rccl_unique_id(void* out128);

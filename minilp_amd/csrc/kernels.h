@@ -289,7 +289,7 @@ struct DevView {
     // Mailboxes of the per-pivot exchanges, one box of [MAIL_KINDS][2 parities][world] records per rank.  `mail` is
     // the box this rank POLLS.  Peer transport (default): the box lives in this GPU's own HBM (uncached /
     // fine-grained), every peer maps it through a HIP IPC handle and writes its slot into it over xGMI, so a post
-    // is `mail_fanout` = world remote stores and a wait polls local memory.  Host transport (MLP_MAILBOX=host):
+    // is `mail_fanout` = world remote stores and a wait polls local memory.  Host transport (MLP_TRANSPORT=host):
     // one box in host memory shared by all ranks (mail_fanout = 1, every poll crosses PCIe).
     MailRec* mail;                   // null when world == 1
     MailRec* mail_peer[MAX_WORLD];   // mail_peer[r]: rank r's box as mapped into this process (mail_peer[rank] == mail)
