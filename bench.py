@@ -71,7 +71,7 @@ def pmc_traffic(a, which):
     MI355X_MICROARCH.md prescribes and as tools/pmc_calib.sh confirms).  PMC counters cannot be
     collected from inside the timed run, so the figure is the committed per-launch average; null when
     the workload differs from the profiled one."""
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             doc = json.load(open(os.path.join(ROOT, "profiles", name)))
         except OSError:
@@ -180,8 +180,9 @@ KERNEL_NAMES = {
     "sweep_band": ("k_sweep_band (tableau row rho^T N [+ PSE helper]: band-major copy of A, the band of (rho, v) held in "
                    "LDS; per-band partials summed in band order by k_update_pivot)"),
     "sweep": "k_sweep (tableau row rho^T N [+ PSE helper] as a CSC pull over A)",
-    "ftran": ("alpha_q = B^-1 a_q, the listed columns of the nucleus inverse: k_ftran_gather_lrh (head inside the gather) + F push in the large-nucleus "
-              "windows; in the driver-timed window the FTRAN is the first stages of k_primal_head and this entry times the whole head"),
+    "ftran": ("alpha_q = B^-1 a_q: the listed columns of the nucleus inverse (k_ftran_gather_lrh, head inside the gather) + the F product of the "
+              "singleton rows — round 6: PULLED per row from the packed copy of the nucleus columns (k_fpull_p1, which also runs Harris pass 1) — in "
+              "the large-nucleus windows; in the driver-timed window the FTRAN is the first stages of k_primal_head and this entry times the whole head"),
 }
 
 

@@ -1471,8 +1471,9 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     case STAGE_RATIO:
         if (phead) break;
         if (fpl) {
-            launch_fpull_ratio(dv, g, st);  // pull of -F alpha_K (+ y_S), K5 p1, p2 (+ K3 head + plan) | t_K
-            if (with_events) HIPCHECK(hipEventRecord(ev[7], st));  // (sampled iteration: the FTRAN bracket closes behind the launch that completes alpha_q)
+            // pull of -F alpha_K (+ y_S) with K5 p1 | K5 p2 (+ K3 head + plan) | t_K; sampled iteration: the FTRAN bracket closes behind the
+            // first of the two launches, which completes alpha_q
+            launch_fpull_ratio(dv, g, st, with_events ? ev[7] : nullptr);
         } else if (phase == 0) launch_ratio_primal(dv, g, pse, st, tkr ? 1 : (tkr_s ? 2 : 0));  // K5 p1 (+ ||alpha||^2, y_S), p2 (+ K3 head + plan) [| t_K]
         else launch_ratio_dual(dv, g, st);                    // K7 p1, p2 (+ K2 head)
         break;

@@ -416,7 +416,7 @@ bool ftran_head_rides_gather(const DevView& dv, const Geom& g);
 void launch_ftran_gather_lrh(const DevView& dv, const Geom& g, hipStream_t st, int ys = 0, int fpk = 0);   // FTRAN head + gather in one launch; fpk: no blocked push (fpull.inc)
 // pulled F product + both Harris passes + BTRAN head + plan | t_K in ONE launch (fpull.inc); the packed copy is built by the two passes below
 bool fpull_supported(const DevView& dv, const Geom& g);
-void launch_fpull_ratio(const DevView& dv, const Geom& g, hipStream_t st);
+void launch_fpull_ratio(const DevView& dv, const Geom& g, hipStream_t st, hipEvent_t ftran_done = nullptr);
 void launch_fpk_build(const DevView& dv, hipStream_t st);   // the packed copy from the CSR of A and the current maps (fpk_in cleared beforehand)
 void launch_btran_fused(const DevView& dv, const Geom& g, int with_rhs, int derive_dual, hipStream_t st);  // BTRAN head + gather (dual iteration)
 constexpr int HEAD_LIST_CAP = 1024;  // entries an in-kernel stage head can hold (longest column / row of A)

@@ -4740,10 +4740,11 @@ bool tk_rides_ratio_small(const DevView& dv, const Geom& g) {
 bool fpull_supported(const DevView& dv, const Geom& g) {
     return dv.world <= 1 && dv.fpk_on && dv.fpk_cnt && dv.rowinfo && dv.lrJ > 0;
 }
-void launch_fpull_ratio(const DevView& dv, const Geom& g, hipStream_t st) {
+void launch_fpull_ratio(const DevView& dv, const Geom& g, hipStream_t st, hipEvent_t ftran_done) {
     const long items = (long)g.m + (long)g.cap;
     const int n1 = blocks_for(items * FP_G);
     hipLaunchKernelGGL(k_fpull_p1, dim3(n1), dim3(BLK), 0, st, dv);
+    if (ftran_done) (void)hipEventRecord(ftran_done, st);  // (sampled iteration: alpha_q is complete here — the FTRAN bracket closes)
     const int nb = grid_for(g.m);
     const int lanes = g.lanes <= 4 ? 4 : (g.lanes <= 16 ? 16 : 64);
     // (grid: nb ratio blocks | the t_K blocks | one block that appends the entering column to the packed copy)
