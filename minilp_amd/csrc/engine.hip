@@ -423,7 +423,9 @@ void Engine::ensure_colblk() {
 // Pulled F product (fpull.inc): wanted wherever the blocked push in its float-atomic form serves the unsharded delayed-update mode
 bool Engine::fpk_wanted() const {
     const int lr = fac_on_ ? 0 : (lr_force >= 0 ? lr_force : (cap_ >= 8192 ? 32 : 0));
-    return fpull_on_ && shard_world == 1 && !fac_on_ && !stepping && lr > 0 && enable_pse && d_rowinfo.p != nullptr;
+    // (sharded solves too: the pull is replicated on every rank like the rest of the FTRAN, and — a fixed summation order — it keeps the ranks
+    // bit-identical replicas without the fixed-point limbs of the deterministic push)
+    return fpull_on_ && !fac_on_ && !stepping && lr > 0 && enable_pse && d_rowinfo.p != nullptr;
 }
 // (Re)build the row-major packed copy of the nucleus columns from the CSR of A and the device's CURRENT maps, on the device, in one
 // pass (~30 us on config 4: 10^7 entries read once); alpha_K by variable starts from zero.  Called between batches: at the first batch
@@ -495,7 +497,7 @@ DevView* Engine::sync_view() {
     {   // pulled F product (fpull.inc): on while a valid packed copy exists for the mode it serves; the pointers stay in the view either way
         // (the update kernel keeps alpha_K-by-variable zero at the leaving variable whichever path ran the pivot)
         // (a view without it does not append the entering columns: the copy is stale from then on)
-        if (!(fpk_wanted() && v.pb_on && !v.pb_det)) fpk_valid_ = false;
+        if (!(fpk_wanted() && v.pb_on && (!v.pb_det || shard_world > 1))) fpk_valid_ = false;
         const bool fp = fpk_valid_ && d_fpk_cnt.p != nullptr;
         v.fpk_cnt = d_fpk_cnt.p; v.fpk_var = d_fpk_var.p; v.fpk_val = d_fpk_val.p; v.fpk_in = d_fpk_in.p;
         v.fpk_x = fp ? d_fpk_x.p : nullptr;
@@ -1439,7 +1441,10 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
     const bool rkr = tkr && rk_rides_post(dv, g);
     // ... and the F product of the FTRAN is PULLED inside the ratio test's launch (fpull.inc): no blocked push, no combine; the gather also
     // leaves alpha_K by variable and pushes the few columns that entered the basis since the packed copy was built.  MLP_FPULL=0: the push.
-    const bool fpl = tkr && g.fp && max_col_nnz_ <= HEAD_LIST_CAP && ftran_head_rides_gather(dv, g) && fpull_supported(dv, g);
+    // A sharded solve takes it too (every rank pulls the whole product, as it pushed it before: the FTRAN is replicated): the gather with the
+    // head inside, the two launches of the pull; t_K rides in the second one, rho_K keeps its BTRAN launch (the v tail waits for the exchange).
+    const bool fpl_base = g.fp && phase == 0 && pse && lazy && !stepping && !smallb && !g.head_fused && max_col_nnz_ <= HEAD_LIST_CAP && fpull_supported(dv, g);
+    const bool fpl = fpl_base && ((tkr && ftran_head_rides_gather(dv, g)) || (shard_world > 1 && dv.lrJ > 0 && dv.pb_on && !dv.det_pull && dv.rowinfo != nullptr));
     if (stage == STAGE_BASIS) touch_done = false;
     // The pricing decision (q for primal, r for dual) is already in Ctl: it was taken by the
     // previous iteration's update kernel, or by the standalone pricing kernel at batch start.
@@ -1456,7 +1461,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         }
         if (phase == 0 && g.head_fused) {
             launch_ftran_fused(dv, g, 1, st);              // K2 head inside the gather kernel (one launch)
-        } else if (phase == 0 && !stepping && max_col_nnz_ <= HEAD_LIST_CAP && ftran_head_rides_gather(dv, g)) {
+        } else if (phase == 0 && !stepping && max_col_nnz_ <= HEAD_LIST_CAP && (fpl || ftran_head_rides_gather(dv, g))) {
             launch_ftran_gather_lrh(dv, g, st, tkr ? 1 : 0, fpl ? 1 : 0);  // delayed-update mode: the head inside the gather too (round 5)
         } else {
             if (phase == 0) launch_ftran_prep(dv, 1, st);  // K2 head: entering column scalars, singleton rows, list
@@ -1483,7 +1488,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
             launch_btran_fused(dv, g, 0, 1, st);                  // K3 head inside the BTRAN kernel (one launch)
         } else {
             if (phase == 1) launch_btran_prep(dv, 1, 0, st);      // K3 head (device-driven by it.r)
-            launch_btran(dv, g, (phase == 0 && !tkr) ? pse : 0, st);    // K3: rho, rK, ||rho||^2  |  tK = alpha_K - F^T y_S (unless it rode in the ratio launch)
+            launch_btran(dv, g, (phase == 0 && !tkr && !fpl) ? pse : 0, st);    // K3: rho, rK, ||rho||^2  |  tK = alpha_K - F^T y_S (unless it rode in the ratio launch)
         }
         break;
     case STAGE_BASIS:
@@ -1777,7 +1782,7 @@ int Engine::run_loop(int phase) {
         }
         // pulled F product (fpull.inc): the packed copy of the nucleus columns is rebuilt at the first batch of this loop and every
         // fpk_every_ pivots (the entries of columns that have left the basis since are dead weight in the rows: dropped by the rebuild)
-        if (phase == 0 && fpk_wanted() && hview.pb_on && !hview.pb_det && (!fpk_fresh || !fpk_valid_ || lifetime_pivots - fpk_built_at_ >= (uint64_t)fpk_every_)) {
+        if (phase == 0 && fpk_wanted() && hview.pb_on && (!hview.pb_det || shard_world > 1) && (!fpk_fresh || !fpk_valid_ || lifetime_pivots - fpk_built_at_ >= (uint64_t)fpk_every_)) {
             fpk_rebuild();
             fpk_fresh = true;
         }

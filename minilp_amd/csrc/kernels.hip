@@ -4740,7 +4740,7 @@ bool tk_rides_ratio_small(const DevView& dv, const Geom& g) {
 // Pulled F product (fpull.inc): two launches, neither with an in-kernel wait.  The first reduces over one block per 32 items (m rows + cap
 // slots): the partials travel through red_key / red_key2, which Engine::ensure_red sizes for it.
 bool fpull_supported(const DevView& dv, const Geom& g) {
-    return dv.world <= 1 && dv.fpk_on && dv.fpk_cnt && dv.rowinfo && dv.lrJ > 0;
+    return dv.fpk_on && dv.fpk_cnt && dv.rowinfo && dv.lrJ > 0;
 }
 void launch_fpull_ratio(const DevView& dv, const Geom& g, hipStream_t st, hipEvent_t ftran_done) {
     const long items = (long)g.m + (long)g.cap;
