@@ -352,7 +352,7 @@ private:
     // pulled F product of the large-nucleus primal iteration (fpull.inc): row-major packed copy of the nucleus columns, rebuilt at the
     // start of every solve / continue call and every fpk_every_ pivots (entering columns are appended in between); alpha_K by variable
     DevBuf<int> d_fpk_cnt, d_fpk_var;
-    DevBuf<double> d_fpk_val, d_fpk_x;
+    DevBuf<double> d_fpk_val, d_fpk_x, d_fpk_part;
     DevBuf<unsigned char> d_fpk_in;
     bool fpull_on_ = true;       // MLP_FPULL=0: the blocked push + k_ratio_primal_fused (A/B, tests)
     bool fpk_valid_ = false;

@@ -437,6 +437,7 @@ void Engine::fpk_rebuild() {
     d_fpk_val.ensure(nnz + 8, 0, st);
     d_fpk_in.ensure((size_t)N_ + 8, 0, st);
     d_fpk_x.ensure((size_t)N_ + 8, 0, st);
+    d_fpk_part.ensure(2 * (((size_t)m_ * 2 + 2048) / 32 + 8), 0, st);  // (one pair per block of k_fpull_p1: 32 items of m rows + cap <= m slots each)
     DevView t = *sync_view();
     t.fpk_cnt = d_fpk_cnt.p; t.fpk_var = d_fpk_var.p; t.fpk_val = d_fpk_val.p; t.fpk_in = d_fpk_in.p; t.fpk_x = d_fpk_x.p;
     HIPCHECK(hipMemsetAsync(d_fpk_in.p, 0, (size_t)N_, st));
@@ -446,7 +447,7 @@ void Engine::fpk_rebuild() {
     fpk_built_at_ = lifetime_pivots;
     fpk_builds_ += 1;
     if (!hview.fpk_on || hview.fpk_cnt != d_fpk_cnt.p || hview.fpk_var != d_fpk_var.p || hview.fpk_val != d_fpk_val.p ||
-        hview.fpk_in != d_fpk_in.p || hview.fpk_x != d_fpk_x.p) {
+        hview.fpk_in != d_fpk_in.p || hview.fpk_x != d_fpk_x.p || hview.fpk_part != d_fpk_part.p) {
         view_dirty = true;
         sync_view();
     }
@@ -500,7 +501,7 @@ DevView* Engine::sync_view() {
         if (!(fpk_wanted() && v.pb_on && (!v.pb_det || shard_world > 1))) fpk_valid_ = false;
         const bool fp = fpk_valid_ && d_fpk_cnt.p != nullptr;
         v.fpk_cnt = d_fpk_cnt.p; v.fpk_var = d_fpk_var.p; v.fpk_val = d_fpk_val.p; v.fpk_in = d_fpk_in.p;
-        v.fpk_x = fp ? d_fpk_x.p : nullptr;
+        v.fpk_x = fp ? d_fpk_x.p : nullptr; v.fpk_part = d_fpk_part.p;
         v.fpk_on = fp ? 1 : 0; v.pad5 = 0;
     }
     v.det_pull = (!v.pb_on && (det_mode == 1 || shard_det || force_det_push_ || (det_mode < 0 && h_rcol.size() <= ((size_t)1 << 21)))) ? 1 : 0;

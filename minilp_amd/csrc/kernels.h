@@ -322,6 +322,8 @@ struct DevView {
     double* fpk_val;         // nnz: coefficient
     unsigned char* fpk_in;   // N: the variable's column is part of the packed copy
     double* fpk_x;           // N: alpha_K by variable
+    double* fpk_part;        // 2 per block of k_fpull_p1: its part of Harris pass 1 (minimum) and of ||alpha_q||^2 — a buffer of their own: the
+                             // blocks of k_fpull_p2 fold them while earlier blocks of the same launch already post pass-2 candidates in red_key
     int fpk_on, pad5;
     // ---- compact factor of the basis (csrc/factor.inc) -------------------------------------
     // fac_on: B^-1 is NOT held as singleton split + dense nucleus inverse but as a frozen PEELED TRIANGULAR FACTOR of the

@@ -9,7 +9,7 @@ inverse.  Rank 0 then runs the UNSHARDED solve through the same checkpoints.
 mode "default"   : row-sharded streaming pass (v_K is summed over the ranks' partials, i.e. in another order than
                    unsharded): the ranks must be BIT-IDENTICAL replicas of the basic side at every checkpoint, and the
                    objective must keep the unsharded run's pace.
-mode "replicated": MLP_NO_WSHARD=1 and the deterministic blocked push on both sides: the sharded arithmetic then equals
+mode "replicated": MLP_NO_WSHARD=1, the pulled F product and rho_K in a BTRAN launch on both sides: the sharded arithmetic then equals
                    the unsharded run's operation for operation, so the UNION of the ranks' d / gamma blocks and x_B must
                    equal the unsharded vectors bit for bit as well.
 
@@ -52,7 +52,9 @@ def worker(rank, world, port, pivots, step, mode, out):
     os.environ["MASTER_PORT"] = str(port)
     if mode == "replicated":
         os.environ["MLP_NO_WSHARD"] = "1"
-        os.environ["MLP_PB_DET"] = "1"
+        # (round 6: the F product of the FTRAN is PULLED on both sides — a fixed summation order, the same on every rank and in the unsharded
+        # run; a sharded solve forms rho_K in a BTRAN launch of its own, so the unsharded side is told to do the same)
+        os.environ["MLP_RK_RIDE"] = "0"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import minilp_amd as M
     from minilp_amd import dist as md, lpgen
