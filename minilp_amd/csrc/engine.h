@@ -235,7 +235,7 @@ private:
     DevBuf<double> d_hy_score;               // m dual pricing scores (derived by the kernel at every launch)
     size_t hy_stamp_len = 0;
     bool hyper_capable(int phase) const;
-    // ---- compact factor of the basis (csrc/factor.inc): B^-1 = (peeled triangular factor of the
+    // ---- compact factor of the basis (csrc/factor.inc, HISTORY.md §2.6): B^-1 = (peeled triangular factor of the
     // basis at the last refactorisation)^-1 + at most fac_J_ additive rank-1 terms, instead of the explicit nucleus inverse
     int fac_mode = -1;                       // MLP_FACTOR: 1 from the start (falls back to the explicit inverse when the peel leaves a bump),
                                              // 0 never, -1 auto: tried when the nucleus would need more than fac_auto_cap_ slots

@@ -45,7 +45,7 @@ struct IterState {
     double inv_alpha;  // 1 / alpha_q[r], the FTRAN-side pivot used by the inverse update
 };
 
-struct StructUpdate {  // how the (P_K, R_K) partition changes at this pivot
+struct StructUpdate {  // HISTORY.md §3.3: how the (P_K, R_K) partition changes at this pivot
     int kase;  // 0 nuc->nuc, 1 sing->nuc (grow), 2 nuc->sing (shrink), 3 sing->sing, 4 sing->sing same row, -1 none
     int r;     // leaving position
     int sr;    // row slot of r (cases 0, 2), -1 otherwise
@@ -76,7 +76,7 @@ struct Ctl {
     int halt;    // set when an iteration ends the loop (optimal / unbounded / ...): later replays no-op
     int ring_n;  // records written since the host last reset it
     int forced;  // dual iteration with a host-forced row (fix_var): skip dual pricing
-    // delayed-update mode: W = W0 + sum_{j<nlow} U[j] V[j]^T
+    // delayed-update mode (HISTORY.md §2.1): W = W0 + sum_{j<nlow} U[j] V[j]^T
     int nlow;   // number of pending rank-1 terms
     int fold;   // this pivot's fused pass folds the pending terms into W0 (primal: set by the FTRAN head, dual: by the plan)
     double lr_c[LR_MAX], lr_e[LR_MAX], lr_g[LR_MAX], lr_h[LR_MAX];  // V[j].a_list, U[j].b_list, V[j].rho_K, U[j].t_K
@@ -218,7 +218,7 @@ struct DevView {
     const unsigned short* pk_row;
     const double* pk_val;
     unsigned char* pk_valid;       // n
-    // basis inverse: singleton split + dense nucleus inverse W
+    // basis inverse: singleton split + dense nucleus inverse W (HISTORY.md §3.2)
     int* kslot_of_pos;     // m: row slot of W for a nucleus position, -1 for a singleton position
     int* srow_of_pos;      // m: the row of the single entry of a singleton basic column
     double* sdiag_of_pos;  // m: its value
@@ -325,7 +325,7 @@ struct DevView {
     double* fpk_part;        // 2 per block of k_fpull_p1: its part of Harris pass 1 (minimum) and of ||alpha_q||^2 — a buffer of their own: the
                              // blocks of k_fpull_p2 fold them while earlier blocks of the same launch already post pass-2 candidates in red_key
     int fpk_on, pad5;
-    // ---- compact factor of the basis (csrc/factor.inc) -------------------------------------
+    // ---- compact factor of the basis (csrc/factor.inc, HISTORY.md §2.6) -------------------------------------
     // fac_on: B^-1 is NOT held as singleton split + dense nucleus inverse but as a frozen PEELED TRIANGULAR FACTOR of the
     // basis B0 of the last refactorisation — an iterated column-singleton peel orders (pivot row, position) pairs into levels
     // such that B0 is upper triangular in that order; nothing is stored beyond A itself and the order (lu.rs:118-304 without

@@ -581,7 +581,7 @@ void launch_mail_handshake(const DevView& dv, int* out, hipStream_t st) {
     hipLaunchKernelGGL(k_mail_handshake, dim3(1), dim3(64), 0, st, dv, out);
 }
 
-// Partition-change plan, run by ONE thread once q, r and the final alpha_q are
+// Partition-change plan (HISTORY.md §3.3), run by ONE thread once q, r and the final alpha_q are
 // known.  The host never needs (q, r): this is what makes the iteration graph-replayable.
 __device__ void plan_update(const DevView& v, Ctl* c, int phase) {
     StructUpdate& u = c->up;
@@ -947,7 +947,7 @@ __global__ void __launch_bounds__(BLK) k_price_dual(DevView v, int use_dse) {
 
 // ------------------------------------------------------------------- K2: FTRAN of one column
 // alpha_q = B^-1 a_q  (solver.rs:671-677 -> 1305-1319 -> lu.rs:79-106).  B^-1 is held as a
-// singleton split + dense nucleus inverse W, so the solve is:
+// singleton split + dense nucleus inverse W (HISTORY.md §3.2), so the solve is:
 //   head   : singleton rows of a_q land directly; entries on nucleus rows become a short list
 //   gather : aK = W[:, list] * coeffs  (only the touched columns of W are read)
 //            + push of -F*aK into the singleton positions (CSC columns of the nucleus basics)
@@ -3061,7 +3061,7 @@ __global__ void __launch_bounds__(BLK) k_fused_w(DevView v) {
     if (TILED) __syncthreads();  // s_tau is reused by the next tile
     }
 }
-// Delayed-update mode: W = W0 + sum_j U[j] V[j]^T with at most J pending rank-1
+// Delayed-update mode (HISTORY.md §2.1): W = W0 + sum_j U[j] V[j]^T with at most J pending rank-1
 // terms.  A normal pivot only READS W0 here (tau/v partials; the low-rank part of the two products is
 // added in k_post_fused from the dots g_j = V[j].rho_K, h_j = U[j].t_K computed by the extra block
 // row of this launch); every J-th pivot FOLDS: w = w0 + sum_j U[j][row] V[j][col] is formed in

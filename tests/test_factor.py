@@ -1,4 +1,4 @@
-"""GPU: the COMPACT FACTOR of the basis (minilp_amd/csrc/factor.inc) — the second
+"""GPU: the COMPACT FACTOR of the basis (minilp_amd/csrc/factor.inc, HISTORY.md §2.6) — the second
 representation of B^-1 next to the explicit nucleus inverse: an iterated column-singleton peel of the basis (a triangular
 factor without fill: lu.rs:118-304 / ordering.rs:4-21 carried to the fixed point), level-scheduled pulls for FTRAN / BTRAN
 (lu.rs:79-106, 432-463) and the eta transformations since the last refactorisation as additive rank-1 terms

@@ -1,5 +1,5 @@
 """GPU: the delayed-update mode of the nucleus inverse (W = W0 + sum_j U_j V_j^T, folded every J
-pivots).  It is switched on automatically from capacity 8192; here it is forced on
+pivots; HISTORY.md §2.1).  It is switched on automatically from capacity 8192; here it is forced on
 small instances (MLP_LOWRANK=J is read when a Solution is created) and must reproduce the oracle's
 pivot sequence exactly like the in-place mode, through every partition case."""
 import os

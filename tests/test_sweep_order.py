@@ -1,4 +1,4 @@
-"""GPU: locality order of the banded tableau-row sweep and its packed non-basic copy.  On config 4
+"""GPU: locality order of the banded tableau-row sweep and its packed non-basic copy (HISTORY.md §7.0).  On config 4
 they switch on after 4 096 pivots and are rebuilt every 2 048; here they are forced on from the first pivot and rebuilt
 every few pivots on small instances (MLP_BANDED=1, MLP_ORDER_FROM=0, MLP_ORDER_EVERY=7): the pass visits the positions in
 a different order and reads a different copy of A, but every tableau row, hence every pivot, must stay the oracle's —

@@ -1,5 +1,5 @@
 // stream_bench.hip — micro-benchmark of the read-only pass over the dense nucleus inverse W
-// (tau = W rho, v = W^T t; the streaming pass of the delayed-update mode).
+// (tau = W rho, v = W^T t; the streaming pass of the delayed-update mode, HISTORY.md §2.1).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/stream_bench.hip -o tools/stream_bench
 // Run  : tools/stream_bench [k] [ld] [reps]     (prints GB/s of 8 k^2 algorithmic bytes per variant)
 #include <hip/hip_runtime.h>
