@@ -224,6 +224,8 @@ private:
     bool ph_now = false;
     bool touch_done = false;                 // the BASIS stage of the iteration being recorded carried the touched-column list
     bool str_now = false, str_clean = false; // geometry of the batch being run; alpha_r / helper are zero outside touched entries
+    DevBuf<int> d_ar_list;   // non-basic positions with alpha_r != 0 (dual iteration, CSC-pull tableau row): the dual Harris test walks the list
+    bool ar_built_ = false;  // the ROW stage of the iteration being launched listed them
     DevBuf<int> d_str_list;
     // hypersparse single-workgroup iteration (hyper.inc)
     int hyper_mode = -1;                     // MLP_HYPER: 1 on wherever the kernel applies, 0 off, -1 auto (<= 16 non-zeros per row on average)

@@ -557,6 +557,10 @@ DevView* Engine::sync_view() {
     fac_fill_view(v);
     v.pad4 = 0;
     v.str_list = d_str_list.p;
+    {   // list of alpha_r's non-zeros for the dual Harris test (one GPU; the CSC-pull tableau row builds it, kernels.hip ratio_dual_list)
+        if (shard_world == 1) d_ar_list.ensure((size_t)num_vars + 64, 0, st);
+        v.ar_list = shard_world == 1 ? d_ar_list.p : nullptr;
+    }
     v.aq_list = d_str_list.p ? d_str_list.p + (((size_t)num_vars + 63) & ~(size_t)63) : nullptr;
     const bool live = shard_is_live();  // (deferred sharding: until it goes live the kernels see one rank that owns every column)
     // (a world of ONE — the rccl transport's self-test on a one-GPU box — keeps its mailbox: the handshake and the pump kernels go through it)
@@ -1481,7 +1485,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
             // first of the two launches, which completes alpha_q
             launch_fpull_ratio(dv, g, st, with_events ? ev[7] : nullptr);
         } else if (phase == 0) launch_ratio_primal(dv, g, pse, st, tkr ? 1 : (tkr_s ? 2 : 0));  // K5 p1 (+ ||alpha||^2, y_S), p2 (+ K3 head + plan) [| t_K]
-        else launch_ratio_dual(dv, g, st);                    // K7 p1, p2 (+ K2 head)
+        else launch_ratio_dual(dv, g, st, ar_built_ ? 1 : 0);  // K7 p1, p2 (+ K2 head); over the listed non-zeros of alpha_r when the tableau row listed them
         break;
     case STAGE_BTRAN:
         if (phead || smallb || rkr) break;
@@ -1517,6 +1521,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         touch_done = launch_post_fused(dv, g, pse, st, 0, 0, wtau, (g.str && phase == 0) ? 1 : 0, rkr ? 1 : 0) != 0;
         break;
     case STAGE_ROW:
+        ar_built_ = false;
         if (g.str) {  // small nucleus: the columns that meet supp(rho) only (k_row_touch + k_row_pull)
             if (with_events) HIPCHECK(hipEventRecord(ev[0], st));  // (sampled iteration: the two launches bracketed together)
             if (phead && update_pulls_inside(dv, g)) {  // the update kernel's workgroups pull the touched columns of their own positions
@@ -1530,7 +1535,7 @@ void Engine::launch_stage(int phase, int stage, bool with_events) {
         }
         if (with_events) arm_kernel_timing(1, ev[0], ev[1]);  // sampled iteration: the sweep kernel is timed kernel-exactly
         if (phase == 0) launch_sweep(dv, g, pse ? 1 : 0, 1, st, inl);  // K4 (+ PSE helper in the same pass)  |  partition change
-        else launch_sweep(dv, g, 0, 0, st);                    // K4: alpha_r = rho^T N
+        else ar_built_ = launch_sweep(dv, g, 0, 0, st, 0, 1);  // K4: alpha_r = rho^T N (+ the list of its non-zeros: CSC-pull form)
         if (with_events) arm_kernel_timing(1, nullptr, nullptr);
         break;
     case STAGE_APPLY:
@@ -2461,7 +2466,7 @@ void Engine::launch_stage_fac(int phase, int stage, bool with_events) {
         break;
     case STAGE_RATIO:
         if (phase == 0) launch_ratio_primal(dv, g, pse, st);
-        else launch_ratio_dual(dv, g, st);                       // (its finaliser scatters the entering column for the FTRAN)
+        else launch_ratio_dual(dv, g, st, ar_built_ ? 1 : 0);    // (its finaliser scatters the entering column for the FTRAN)
         break;
     case STAGE_BTRAN:
         if (phase == 1 && !fused) launch_btran_prep(dv, 1, 0, st);         // leaving row's scalars
@@ -2475,7 +2480,7 @@ void Engine::launch_stage_fac(int phase, int stage, bool with_events) {
         break;
     case STAGE_ROW:
         if (phase == 0) launch_sweep(dv, g, pse ? 1 : 0, 0, st, inl);
-        else launch_sweep(dv, g, 0, 0, st);
+        else ar_built_ = launch_sweep(dv, g, 0, 0, st, 0, 1);
         break;
     case STAGE_APPLY:
         if (phase == 1 && pse) launch_sweep(dv, g, 2, 0, st);
@@ -3348,6 +3353,10 @@ uint64_t Engine::state(const char* what, double* out, uint64_t cap) {
     else if (w == "small_basis_launches") {  // iterations that ran BTRAN + pass + v tail + touch as one launch (k_small_basis)
         pull_ctl();
         tmp = {(double)h_ctl->sb_count};
+    } else if (w == "dual_list_tests") {  // dual Harris tests that ran over the listed non-zeros of alpha_r (kernels.hip ratio_dual_list)
+        int n_ = 0;
+        HIPCHECK(hipMemcpy(&n_, &d_ctl.p->ar_used, sizeof(int), hipMemcpyDeviceToHost));
+        tmp = {(double)n_};
     } else if (w == "fpull") {  // pulled F product: [in use now, builds of the packed copy, pivot count at the last build]
         tmp = {(double)(hview.fpk_on ? 1 : 0), (double)fpk_builds_, (double)fpk_built_at_, (double)(fpull_supported(hview, geom()) ? 1 : 0)};
     } else if (w == "golive_checks") {  // fingerprint comparisons passed at the go-live point of the deferred sharding

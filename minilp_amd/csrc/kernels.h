@@ -112,6 +112,8 @@ struct Ctl {
     int sb_count;    // launches of k_small_basis that ran an iteration (state("small_basis_launches"): tests check the path was taken)
     int ph_count;    // iterations k_primal_head carried through all its stages (state("primal_head_launches"))
     int ph_rng_x, ph_rng_y;  // k_primal_head with `apply`: CSC range of the leaving variable's column, for nb_rng[q] (set by the update kernel)
+    int ar_used;     // dual Harris tests that ran over the listed non-zeros of alpha_r since the Solution was created (state("dual_list_tests"))
+    int ar_n;        // entries of DevView.ar_list this iteration (zeroed by the dual ratio test's finaliser and at every batch start)
     int rv_n;        // k_primal_head: rows of (rho, v) the previous iteration's head left non-zero, listed in aq_list (the next head zeroes them:
                      // with the tableau row pulled inside the update kernel nothing else may clear rv while other workgroups still read it)
     unsigned long long hy_prof[24];  // ticks of the 100 MHz wall clock per stage of the hypersparse iteration (diagnostics)
@@ -307,6 +309,9 @@ struct DevView {
     // over the columns that meet a row of supp(rho) only, listed in str_list through the epoch stamps hy_stamp_n, instead of
     // a pass over all of A.  alpha_r / helper are then kept ZERO outside the touched entries (the update kernel zeroes what it
     // used).
+    int* ar_list;    // n or null: non-basic positions with alpha_r != 0, listed by the CSC-pull tableau row of a dual iteration (k_sweep MODE 0);
+                     // Ctl.ar_n entries.  The dual Harris test runs over the list in ONE block when it is short (solver.rs:962-1002 walks the
+                     // non-zeros of row_coeffs only) instead of two grid-wide passes over all n positions
     int* str_list;   // n
     int* aq_list;    // m: positions of supp(alpha_q) (listed by the FTRAN when str_on and the F products are pushed)
     int str_on, pad4;
@@ -429,7 +434,7 @@ void launch_post_ftran(const DevView& dv, const Geom& g, int use_pse, hipStream_
 void launch_btran_prep(const DevView& dv, int derive_dual, int plan_after, hipStream_t st);  // BTRAN head (one wave)
 void launch_btran(const DevView& dv, const Geom& g, int with_rhs, hipStream_t st, int after_fold = 0);  // rho, rK, rho_sq [| tK]
 void launch_btran_rhs(const DevView& dv, const Geom& g, hipStream_t st);                  // tK alone
-void launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, hipStream_t st, int inline_combine = 0);  // K4 [| partition change]
+bool launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, hipStream_t st, int inline_combine = 0, int list = 0);  // K4 [| partition change]; true: mode 0 and the non-zeros of alpha_r were listed (DevView.ar_list)
 // sparse tableau row: touched-column list, then the pull of alpha_r / helper on the listed columns (| partition change)
 void launch_row_sparse(const DevView& dv, const Geom& g, int mode, int with_struct, int touch, hipStream_t st);
 // small nucleus (first capacity), lazy primal iteration: BTRAN + pass over W + v tail + touched-column list in ONE launch
@@ -441,7 +446,7 @@ bool primal_head_supported(const DevView& dv, const Geom& g);
 int primal_head_kmax(int longest_column);  // largest nucleus the kernel serves for a model whose longest column has that many entries (0: none)
 void launch_primal_head(const DevView& dv, const Geom& g, hipStream_t st);
 void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st);
-void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st);                 // K7 p1, p2 (+FTRAN head)
+void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st, int list_ok = 0); // K7 p1, p2 (+FTRAN head); list_ok: the tableau row of this iteration listed its non-zeros
 void launch_fused_w(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int with_tau = 1);  // tauK/vK partials + eta update of W
 int launch_post_fused(const DevView& dv, const Geom& g, int with_v, hipStream_t st, int classic = 0, int skip_push = 0, int with_tau = 1, int touch = 0, int rk_ride = 0);
 bool rk_rides_post(const DevView& dv, const Geom& g);  // (strip-tiled tail of the large-nucleus pass: the form that carries the rho_K blocks)

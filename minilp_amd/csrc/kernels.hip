@@ -2442,7 +2442,7 @@ __global__ void __launch_bounds__(BLK) k_struct_update(DevView v) {
 // in the 256 MB Infinity Cache and the kernel is bound by the L2 request rate of the 10^7 gathers.
 // Non-temporal loads on the A stream were tried: 82 us vs 57 us (worse).
 template <int G, int U, int MODE>  // MODE 0: alpha_r, 1: alpha_r + helper, 2: helper
-__global__ void __launch_bounds__(BLK) k_sweep(DevView v, int n_sweep) {
+__global__ void __launch_bounds__(BLK) k_sweep(DevView v, int n_sweep, int build_list) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
     if ((int)blockIdx.x >= n_sweep) {
@@ -2483,6 +2483,17 @@ __global__ void __launch_bounds__(BLK) k_sweep(DevView v, int n_sweep) {
     if (gl == 0) {
         if (MODE != 2) v.alpha_r[col] = a1;
         if (MODE != 0) v.helper[col] = a2;
+    }
+    if (MODE == 0 && build_list && v.ar_list) {  // (dual iteration: the Harris test that follows consumes and resets the list) the non-zeros of the tableau row as a list (wave-aggregated counter; the order of the list is free)
+        const bool nz = gl == 0 && a1 != 0.0;
+        const unsigned long long mask = __ballot(nz);
+        if (mask) {
+            const int lane = threadIdx.x & 63, lead = __ffsll((long long)mask) - 1;
+            int base = 0;
+            if (lane == lead) base = atomicAdd(&c->ar_n, __popcll(mask));
+            base = __shfl(base, lead, 64);
+            if (nz) v.ar_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = col;  // (at most n entries: one per column)
+        }
     }
 }
 // Banded sweep: the pull above is bound by the L2 request rate of its 10^7 row-indexed
@@ -2723,6 +2734,7 @@ __device__ void ratio_dual_finish(const DevView& v, Ctl* c, Cand best) {
     }
     if (threadIdx.x == 0) {
         s_ok = 0;
+        c->ar_n = 0;  // (the list of alpha_r's non-zeros has been consumed: the next tableau row starts an empty one)
         if (best.idx == NONE_IDX) {
             it->status = ITER_INFEASIBLE;
             c->halt = 1;
@@ -2750,9 +2762,70 @@ __device__ void ratio_dual_finish(const DevView& v, Ctl* c, Cand best) {
 // re-reads it from L2), no ticketed grid reductions, no in-kernel wait.  Measured on config 3 (n = 10 000): the one-launch
 // grid form costs 12.9 us, of which the scan itself is a fraction.
 constexpr int RATIO_ONE_MAX = 16384;
-__global__ void __launch_bounds__(BLK) k_ratio_dual_one(DevView v) {
+// Dual Harris test over the LISTED non-zeros of the tableau row (round 6; solver.rs:962-1002 walks the non-zeros of row_coeffs only): on sparse
+// models alpha_r has a handful to a few hundred entries of n = 10^4 ... 4 10^5, and the two grid-wide passes of k_ratio_dual_fused are then
+// two ticketed reductions plus an in-kernel wait over nothing (19-22 us on the 400 000-column transport instance), the one-block form a
+// 40-trip walk over zeros (16 us on config 3).  Block 0 alone takes a list of up to AR_CAP entries; true = handled (every block returns).
+constexpr int AR_CAP = 2048;
+__device__ __forceinline__ bool ratio_dual_list(const DevView& v, Ctl* c, int list_ok) {
+    if (!list_ok || !v.ar_list || v.world > 1) return false;
+    const int nl = c->ar_n;
+    if (nl > AR_CAP) return false;
+    if (blockIdx.x != 0) return true;
+    IterState* it = &c->it;
+    const int lsign = it->leaving_new_val > v.xB[it->r];
+    constexpr int PL = AR_CAP / BLK;
+    int pos[PL];
+    double ca[PL], dj[PL];
+    double mn = INFINITY;
+    int jj[PL];
+#pragma unroll
+    for (int u = 0; u < PL; ++u) {
+        const int a = (int)threadIdx.x + u * BLK;
+        jj[u] = a < nl ? v.ar_list[a] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < PL; ++u) {
+        const int j = jj[u] < 0 ? v.nb_lo : jj[u];
+        const double coeff = v.alpha_r[j];
+        const uint8_t f = v.nbflags[j];
+        const double d = v.d[j];
+        pos[u] = -1;
+        ca[u] = 0.0;
+        dj[u] = 0.0;
+        if (jj[u] < 0 || !dual_eligible(coeff, f, lsign)) continue;
+        pos[u] = j;
+        ca[u] = fabs(coeff);
+        dj[u] = fabs(clamp_obj(d, f));
+        const double cur = (dj[u] + EPS) / ca[u];
+        if (cur < mn) mn = cur;
+    }
+    __shared__ double s_lstep;
+    mn = block_min(mn);
+    if (threadIdx.x == 0) {
+        it->max_step = mn;
+        s_lstep = mn;
+        c->ar_used += 1;
+    }
+    __syncthreads();
+    const double max_step = s_lstep;
+    Cand best = cand_none();
+#pragma unroll
+    for (int u = 0; u < PL; ++u) {  // (ties keep the lowest position whatever the order of the list: cand_better)
+        if (pos[u] < 0) continue;
+        if (dj[u] / ca[u] <= max_step) {
+            Cand t{ca[u], pos[u]};
+            if (cand_better(t, best)) best = t;
+        }
+    }
+    best = block_best(best);
+    ratio_dual_finish(v, c, best);
+    return true;
+}
+__global__ void __launch_bounds__(BLK) k_ratio_dual_one(DevView v, int list_ok) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
+    if (ratio_dual_list(v, c, list_ok)) return;
     IterState* it = &c->it;
     const int lsign = it->leaving_new_val > v.xB[it->r];
     double mn = INFINITY;
@@ -2812,9 +2885,10 @@ __global__ void __launch_bounds__(BLK) k_ratio_dual_one(DevView v) {
 // PT positions per thread: 4, or 16 on models with more than 131 072 non-basic positions — every block takes two tickets at ONE L2 address
 // (~15 ns per arrival when they arrive together): 391 blocks on the 400 000-column transport instance queued for ~12 us of a 22 us kernel
 template <int PT>
-__global__ void __launch_bounds__(BLK) k_ratio_dual_fused(DevView v) {
+__global__ void __launch_bounds__(BLK) k_ratio_dual_fused(DevView v, int list_ok) {
     Ctl* c = v.ctl;
     if (c->halt || c->it.status != ITER_PIVOT) return;
+    if (ratio_dual_list(v, c, list_ok)) return;
     IterState* it = &c->it;
     const int lsign = it->leaving_new_val > v.xB[it->r];
     const int epoch0 = c->ratio_epoch;
@@ -3900,6 +3974,7 @@ __global__ void k_reset_ring(DevView v) {
     c->max_pivot_err = 0.0;
     c->hyper_bail = 0;
     c->rv_n = 0;  // (every batch starts from zeroed work vectors: launch_clear_work)
+    c->ar_n = 0;  // (... and from an empty list of alpha_r's non-zeros)
 }
 // K9: recalc reduced costs (solver.rs:1216-1231): d_c = c_c - a_c . y, then the objective from scratch
 __global__ void __launch_bounds__(BLK) k_gather_basic_obj(DevView v) {
@@ -4845,23 +4920,24 @@ static void launch_sweep_banded(const DevView& dv, const Geom& g, int mode, int 
     else if (mode == 1) hipLaunchKernelGGL(k_band_combine<1>, gc, dim3(BLK), 0, st, dv, nc);
     else hipLaunchKernelGGL(k_band_combine<2>, gc, dim3(BLK), 0, st, dv, nc);
 }
-void launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, hipStream_t st, int inline_combine) {
+bool launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, hipStream_t st, int inline_combine, int list) {
     if (dv.banded) {
         launch_sweep_banded(dv, g, mode, with_struct, inline_combine, st);
-        return;
+        return false;
     }
 #define SWEEP(G, U)                                                                                               \
     do {                                                                                                          \
         int n_sweep = blocks_for((long)(dv.nb_hi - dv.nb_lo) * G);                                                \
         dim3 gr(n_sweep + (with_struct ? blocks_for(g.cap) : 0)), b(BLK);                                         \
-        if (mode == 0) LAUNCH_T(1, (k_sweep<G, U, 0>), gr, b, 0, st, dv, n_sweep);                         \
-        else if (mode == 1) LAUNCH_T(1, (k_sweep<G, U, 1>), gr, b, 0, st, dv, n_sweep);                    \
-        else LAUNCH_T(1, (k_sweep<G, U, 2>), gr, b, 0, st, dv, n_sweep);                                   \
+        if (mode == 0) LAUNCH_T(1, (k_sweep<G, U, 0>), gr, b, 0, st, dv, n_sweep, list);                         \
+        else if (mode == 1) LAUNCH_T(1, (k_sweep<G, U, 1>), gr, b, 0, st, dv, n_sweep, 0);                    \
+        else LAUNCH_T(1, (k_sweep<G, U, 2>), gr, b, 0, st, dv, n_sweep, 0);                                   \
     } while (0)
     if (g.sweep_variant == 1) { LANES_SWITCH(g.lanes, SWEEP(4, 4), SWEEP(16, 4), SWEEP(32, 4)); }
     else if (g.sweep_variant == 2) { LANES_SWITCH(g.lanes, SWEEP(4, 8), SWEEP(8, 8), SWEEP(32, 8)); }
     else { LANES_SWITCH(g.lanes, SWEEP(4, 4), SWEEP(16, 4), SWEEP(16, 8)); }
 #undef SWEEP
+    return mode == 0 && list && dv.ar_list != nullptr;  // (k_sweep MODE 0 listed the non-zeros of alpha_r)
 }
 void launch_row_sparse(const DevView& dv, const Geom& g, int mode, int with_struct, int touch, hipStream_t st) {
     if (touch) hipLaunchKernelGGL(k_row_touch, dim3(blocks_for((long)(g.cap + 1) * 64)), dim3(BLK), 0, st, dv);
@@ -4909,9 +4985,9 @@ void launch_primal_head(const DevView& dv, const Geom& g, hipStream_t st) {
 void launch_init_nb_rng(const DevView& dv, const Geom& g, hipStream_t st) {
     hipLaunchKernelGGL(k_init_nb_rng, dim3(blocks_for(g.n)), dim3(BLK), 0, st, dv);
 }
-void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st) {
+void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st, int list_ok) {
     if (dv.world <= 1 && g.n <= RATIO_ONE_MAX && ratio_one_enabled()) {  // small model: one block, no grid-wide reduction
-        hipLaunchKernelGGL(k_ratio_dual_one, dim3(1), dim3(BLK), 0, st, dv);
+        hipLaunchKernelGGL(k_ratio_dual_one, dim3(1), dim3(BLK), 0, st, dv, list_ok);
         return;
     }
     const int span = dv.nb_hi - dv.nb_lo;
@@ -4919,8 +4995,8 @@ void launch_ratio_dual(const DevView& dv, const Geom& g, hipStream_t st) {
     const int nb = grid_for(span, pt);
     const int max_coresident = g.ratio_two ? 0 : coresident_half(reinterpret_cast<const void*>(k_ratio_dual_fused<16>), 1);  // see launch_ratio_primal
     if (nb <= max_coresident && (long)nb * BLK * pt >= (long)span) {
-        if (pt == 16) hipLaunchKernelGGL(k_ratio_dual_fused<16>, dim3(nb), dim3(BLK), 0, st, dv);  // both passes + FTRAN head
-        else hipLaunchKernelGGL(k_ratio_dual_fused<4>, dim3(nb), dim3(BLK), 0, st, dv);
+        if (pt == 16) hipLaunchKernelGGL(k_ratio_dual_fused<16>, dim3(nb), dim3(BLK), 0, st, dv, list_ok);  // both passes + FTRAN head
+        else hipLaunchKernelGGL(k_ratio_dual_fused<4>, dim3(nb), dim3(BLK), 0, st, dv, list_ok);
         return;
     }
     hipLaunchKernelGGL(k_ratio_dual_p1, dim3(grid_for(g.n)), dim3(BLK), 0, st, dv);
