@@ -52,6 +52,7 @@ def test_hypersparse_and_multi_kernel_paths_alternate_at_any_iteration(monkeypat
     sg = lpgen.build_problem(M.Problem, lp).solve(trace=True)
     st = sg.stats()
     assert st["hyper_bails"] >= 3 and 0 < st["hyper_iters"] < st["iterations"], (st["hyper_iters"], st["hyper_bails"], st["iterations"])
+    assert int(sg.state("dual_list_tests")[0]) > 0   # (round 6: the multi-kernel iterations ran their Harris test over the listed non-zeros of alpha_r)
     assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
     assert obj_close(sg.objective(), so.objective())
     assert sg.reinvert() < 1e-8
