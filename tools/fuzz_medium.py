@@ -23,12 +23,20 @@ ENVS = [{}, {"MLP_LOWRANK": "3", "MLP_BIGTILE": "1", "MLP_LDPAD": "16", "MLP_BAN
         {"MLP_DETERMINISTIC": "0", "MLP_HYPER": "0", "MLP_HEAD_APPLY": "0"},
         {"MLP_DETERMINISTIC": "0", "MLP_HYPER": "0", "MLP_PULL_INSIDE": "0"},
         {"MLP_DETERMINISTIC": "0", "MLP_PRIMAL_HEAD_K": "5"},
-        {"MLP_DETERMINISTIC": "0", "MLP_HYPER": "0", "MLP_GRAPH_ITERS": "3", "MLP_RATIO_ONE": "0"}]
+        {"MLP_DETERMINISTIC": "0", "MLP_HYPER": "0", "MLP_GRAPH_ITERS": "3", "MLP_RATIO_ONE": "0"},
+        # round 6: the pulled F product (fpull.inc) forced on small instances (large-nucleus machinery + the grid forms of the ratio test), with
+        # and without the banded sweep, eager and in long graphs; and the pushed form it replaces under the same machinery
+        {"MLP_LOWRANK": "3", "MLP_BIGTILE": "1", "MLP_LDPAD": "16", "MLP_BANDED": "1", "MLP_STR_K": "0", "MLP_RATIO_ONE": "0", "MLP_HYPER": "0"},
+        {"MLP_LOWRANK": "16", "MLP_BIGTILE": "1", "MLP_STR_K": "0", "MLP_RATIO_ONE": "0", "MLP_HYPER": "0", "MLP_NO_GRAPH": "1"},
+        {"MLP_LOWRANK": "8", "MLP_BIGTILE": "1", "MLP_STR_K": "0", "MLP_RATIO_ONE": "0", "MLP_HYPER": "0", "MLP_GRAPH_ITERS": "3"},
+        {"MLP_LOWRANK": "3", "MLP_BIGTILE": "1", "MLP_LDPAD": "16", "MLP_BANDED": "1", "MLP_STR_K": "0", "MLP_RATIO_ONE": "0", "MLP_HYPER": "0", "MLP_FPULL": "0"}]
 if os.environ.get("FUZZ_ENVS") == "head":   # only the round-5 configurations
-    ENVS = ENVS[-5:]
-if os.environ.get("FUZZ_ENVS") == "factor":   # round 5, second session: the compact factor forced, the carriers of its bump, the data-flow walk
+    ENVS = ENVS[-9:-4]
+if os.environ.get("FUZZ_ENVS") == "fpull":  # only the round-6 configurations
+    ENVS = ENVS[-4:]
+if os.environ.get("FUZZ_ENVS") == "factor":   # round 5, second session: the compact factor forced, the carriers of its bump
     ENVS = [{"MLP_FACTOR": "1"}, {"MLP_FACTOR": "1", "MLP_FACTOR_SB_FROM": "2"}, {"MLP_FACTOR": "1", "MLP_FACTOR_SB_FROM": "2", "MLP_FACTOR_J": "5"},
-            {"MLP_FACTOR": "1", "MLP_FACTOR_FLOW": "1", "MLP_FACTOR_SB_FROM": "2"}, {"MLP_FACTOR": "1", "MLP_FACTOR_BUMP": "16"},
+            {"MLP_FACTOR": "1", "MLP_FACTOR_BUMP": "16"},
             {"MLP_FACTOR": "1", "MLP_FACTOR_SB": "0"}, {"MLP_FACTOR": "1", "MLP_FACTOR_SB_FROM": "2", "MLP_FACTOR_J": "64", "MLP_NO_GRAPH": "1"}]
 bad = 0
 t0 = time.time()
@@ -50,7 +58,7 @@ for case in range(n_cases):
     env = ENVS[case % len(ENVS)]
     for kk in ("MLP_LOWRANK", "MLP_BIGTILE", "MLP_LDPAD", "MLP_BANDED", "MLP_GRAPH_ITERS", "MLP_NO_GRAPH", "MLP_DETERMINISTIC", "MLP_HYPER",
                "MLP_HEAD_APPLY", "MLP_PULL_INSIDE", "MLP_PRIMAL_HEAD_K", "MLP_RATIO_ONE", "MLP_STREAM_BALANCED", "MLP_ORDER_FROM", "MLP_ORDER_EVERY",
-               "MLP_SWEEP_PACKED", "MLP_FACTOR", "MLP_FACTOR_SB_FROM", "MLP_FACTOR_J", "MLP_FACTOR_FLOW", "MLP_FACTOR_BUMP", "MLP_FACTOR_SB"):
+               "MLP_SWEEP_PACKED", "MLP_FACTOR", "MLP_FACTOR_SB_FROM", "MLP_FACTOR_J", "MLP_FACTOR_BUMP", "MLP_FACTOR_SB", "MLP_STR_K", "MLP_FPULL"):
         os.environ.pop(kk, None)
     os.environ.update(env)
     try:
