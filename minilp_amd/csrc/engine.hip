@@ -2095,7 +2095,7 @@ void Engine::fac_alloc() {
         d_fac_rhs.ensure(mm, 0, st);
         if (d_fac_rhs.p != before) HIPCHECK(hipMemsetAsync(d_fac_rhs.p, 0, sizeof(double) * d_fac_rhs.cap, st));
         const unsigned* b0 = d_fac_bar.p;
-        d_fac_bar.ensure(4, 0, st);
+        d_fac_bar.ensure(FAC_BAR_FLAG + 64, 0, st);
         if (d_fac_bar.p != b0) HIPCHECK(hipMemsetAsync(d_fac_bar.p, 0, sizeof(unsigned) * d_fac_bar.cap, st));
     }
 }

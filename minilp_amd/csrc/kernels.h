@@ -371,7 +371,7 @@ struct DevView {
     double* fac_x0;          // m: result of the B0 solve before the rank-1 terms are added (by position for FTRAN, by row for BTRAN)
     double* fac_coef;        // 2 * fac_J + 1: coefficients V_j . rhs / U_j . c of the running solve
     double* fac_part;        // fac_J x 1024: per-workgroup partial sums of those dot products (dense right-hand sides)
-    unsigned* fac_bar;       // [0] grid barrier counter, [1] exit ticket, [2] reduction ticket
+    unsigned* fac_bar;       // [0] grid barrier counter, [1] exit ticket, [2] reduction ticket, [FAC_BAR_FLAG] the barrier's release word
     // the BUMP: what the peel leaves (columns on cycles of the basis graph: a generalised network has one-cycle components).
     // In peel order B0 = [[U, F], [0, K]] with K the bump (fac_meta[2] columns, at most FAC_BMAX): its inverse is kept explicitly
     // (fac_Wb, Gauss-Jordan at the refactorisation); FTRAN solves the bump first, BTRAN last.
@@ -385,6 +385,7 @@ struct DevView {
     const int* fac_sb_trow; const int* fac_sb_tcol; const double* fac_sb_tinv; const double* fac_sb_tinvT;
 };
 constexpr int FAC_BMAX = 1024;
+constexpr int FAC_BAR_FLAG = 1024;  // fac_bar[FAC_BAR_FLAG]: the grid barrier's release word, 4 KB from its arrival counter
 
 // fused pass tiling
 constexpr int FW_TR = 8;     // minimum rows per block (sizes the partial buffers; kernels use 8 or 16)
