@@ -1365,8 +1365,8 @@ void Engine::try_new(const ProblemData& pd) {
     d_d.upload(d, st); d_xN.upload(xN, st); d_gamma.upload(gamma, st); d_nbflags.upload(flags, st);
     d_alpha_r.ensure(n, 0, st); d_helper.ensure(n, 0, st); d_nb_rng.ensure(n, 0, st);
     ensure_red();
-    d_ticket.ensure(4, 0, st);
-    HIPCHECK(hipMemsetAsync(d_ticket.p, 0, 4 * sizeof(unsigned), st));
+    d_ticket.ensure(TK_WORDS, 0, st);
+    HIPCHECK(hipMemsetAsync(d_ticket.p, 0, d_ticket.cap * sizeof(unsigned), st));
     d_ctl.ensure(1, 0, st);
     std::memset(h_ctl, 0, sizeof(Ctl));
     h_ctl->it.obj = cur_obj;
@@ -2013,7 +2013,7 @@ int Engine::run_loop(int phase) {
             stats.ratio_stalls += 1;
             str_clean = false;  // the stalled iteration stamped / listed columns without closing: the next batch re-zeroes and clears the counters
             if (pivot_budget >= 0) pivot_budget += 1;  // the stalled record consumed one unit
-            HIPCHECK(hipMemsetAsync(d_ticket.p, 0, sizeof(unsigned) * std::min<size_t>(d_ticket.cap, 64), st));
+            HIPCHECK(hipMemsetAsync(d_ticket.p, 0, sizeof(unsigned) * d_ticket.cap, st));
             continue;
         }
         if (res != ITER_PIVOT) return res;
@@ -3282,8 +3282,8 @@ Engine* Engine::clone() {
     e->d_gamma.copy_from(d_gamma, nn, s2); e->d_nbflags.copy_from(d_nbflags, nn, s2);
     e->d_alpha_r.ensure(nn, 0, s2); e->d_helper.ensure(nn, 0, s2); e->d_nb_rng.copy_from(d_nb_rng, nn, s2);
     e->ensure_red();
-    e->d_ticket.ensure(4, 0, s2);
-    HIPCHECK(hipMemsetAsync(e->d_ticket.p, 0, 4 * sizeof(unsigned), s2));
+    e->d_ticket.ensure(TK_WORDS, 0, s2);
+    HIPCHECK(hipMemsetAsync(e->d_ticket.p, 0, e->d_ticket.cap * sizeof(unsigned), s2));
     e->d_ctl.copy_from(d_ctl, 1, s2);
     // nucleus: same capacity so the block copies 1:1
     e->k_ = 0;

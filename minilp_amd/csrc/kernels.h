@@ -118,6 +118,10 @@ struct Ctl {
                      // with the tableau row pulled inside the update kernel nothing else may clear rv while other workgroups still read it)
     unsigned long long hy_prof[24];  // ticks of the 100 MHz wall clock per stage of the hypersparse iteration (diagnostics)
     PivotRec ring[RING];
+    // (behind the ring: on lines nothing arrives at during a sweep, and no other field moved)
+    int ar_off;   // > 0: the tableau row of a dual iteration is not listed (DevView.ar_list) for this many iterations — the last list
+                  // passed AR_CAP entries, and a dense row's appends arrive at ONE address (on a line the sweep only reads: not next to ar_n)
+    int ar_back;  // ... the pause grows with every list that overflows again: 16, 32 ... 256 iterations; a list that fits ends it
 };
 
 // Sharded pricing: one 64-byte mailbox record per (kind, parity, rank) in host
@@ -385,7 +389,12 @@ struct DevView {
     const int* fac_sb_trow; const int* fac_sb_tcol; const double* fac_sb_tinv; const double* fac_sb_tinvT;
 };
 constexpr int FAC_BMAX = 1024;
-constexpr int FAC_BAR_FLAG = 1024;  // fac_bar[FAC_BAR_FLAG]: the grid barrier's release word, 4 KB from its arrival counter
+constexpr int AR_CAP = 2048;     // entries of DevView.ar_list the one-block dual Harris test takes (ratio_dual_list); k_sweep stops listing beyond
+constexpr int TK_ONE = 128;      // a ticket (last_block_arrives) counts up to this many arrivals at one address, more in two steps
+constexpr int TK_GROUPS = 16;    // first-step tickets of the two-step form
+constexpr int TK_STRIDE = 1024;  // words between them: ticket[TK_STRIDE * (1 + x)], x < TK_GROUPS
+constexpr int TK_WORDS = TK_STRIDE * (TK_GROUPS + 1) + 8;  // words a buffer that holds tickets in its first words needs
+constexpr int FAC_BAR_FLAG = TK_WORDS + 1024;  // fac_bar[FAC_BAR_FLAG]: the grid barrier's release word, on a line neither the arrival counter nor a ticket uses
 
 // fused pass tiling
 constexpr int FW_TR = 8;     // minimum rows per block (sizes the partial buffers; kernels use 8 or 16)

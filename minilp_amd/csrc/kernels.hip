@@ -137,12 +137,29 @@ __device__ __forceinline__ void st_agent(double* p, double x) {
 __device__ __forceinline__ void st_agent(int* p, int x) {
     __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ bool last_block_arrives(unsigned* ticket, unsigned nblocks) {
+// Arrivals at ONE address serialise at ~15 ns each (391 of them ~8 us, 1 563 — the update of a 400 000-column model — most of that kernel's
+// 18 us): above TK_ONE arrivals they count in two steps — TK_GROUPS first-step tickets 4 KB apart (arrival index mod TK_GROUPS; the last
+// arrival at one resets it and arrives on the ticket itself).  The caller's reset of `ticket` is the same in both forms.  `my`: the
+// arrival's index in [0, nblocks) when it is not the block index.
+__device__ __forceinline__ bool last_block_arrives(unsigned* ticket, unsigned nblocks, int my = -1) {
     __shared__ int s_last;
     if (threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == nblocks - 1);
+        bool last;
+        if (nblocks <= (unsigned)TK_ONE) {
+            last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1;
+        } else {
+            const unsigned me = my < 0 ? blockIdx.x : (unsigned)my, x = me % (unsigned)TK_GROUPS;
+            const unsigned cnt = (nblocks - x + (unsigned)TK_GROUPS - 1u) / (unsigned)TK_GROUPS;
+            unsigned* sub = ticket + (size_t)TK_STRIDE * (1u + x);
+            last = false;
+            if (__hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cnt - 1u) {
+                __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a launch may use the ticket twice: the reset has landed before anyone can hear of this arrival)
+                last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)TK_GROUPS - 1u;
+            }
+        }
+        s_last = last ? 1 : 0;
     }
     __syncthreads();
     return s_last != 0;
@@ -261,7 +278,7 @@ __device__ __forceinline__ bool grid_sum(double& x, const DevView& v, int nblock
     if (my < 0) my = (int)blockIdx.x;  // (the reducing blocks may sit behind other blocks of the launch: their own index then)
     x = block_sum(x);
     if (threadIdx.x == 0) st_agent(&v.red_key[my], x);
-    if (!last_block_arrives(v.ticket, (unsigned)nblocks)) return false;
+    if (!last_block_arrives(v.ticket, (unsigned)nblocks, my)) return false;
     double y = 0.0;
     for (int i = threadIdx.x; i < nblocks; i += blockDim.x) y += ld_agent(&v.red_key[i]);
     x = block_sum(y);
@@ -2444,7 +2461,8 @@ __global__ void __launch_bounds__(BLK) k_struct_update(DevView v) {
 template <int G, int U, int MODE>  // MODE 0: alpha_r, 1: alpha_r + helper, 2: helper
 __global__ void __launch_bounds__(BLK) k_sweep(DevView v, int n_sweep, int build_list) {
     Ctl* c = v.ctl;
-    if (c->halt || c->it.status != ITER_PIVOT) return;
+    const int halt0 = c->halt, status0 = c->it.status, ar_off0 = c->ar_off;  // (one clause of scalar loads)
+    if (halt0 || status0 != ITER_PIVOT) return;
     if ((int)blockIdx.x >= n_sweep) {
         struct_update_body(v, c, ((int)blockIdx.x - n_sweep) * BLK + threadIdx.x);
         return;
@@ -2484,7 +2502,7 @@ __global__ void __launch_bounds__(BLK) k_sweep(DevView v, int n_sweep, int build
         if (MODE != 2) v.alpha_r[col] = a1;
         if (MODE != 0) v.helper[col] = a2;
     }
-    if (MODE == 0 && build_list && v.ar_list) {  // (dual iteration: the Harris test that follows consumes and resets the list) the non-zeros of the tableau row as a list (wave-aggregated counter; the order of the list is free)
+    if (MODE == 0 && build_list && v.ar_list && ar_off0 == 0) {  // (dual iteration: the Harris test that follows consumes and resets the list) the non-zeros of the tableau row as a list (wave-aggregated counter; the order of the list is free)
         const bool nz = gl == 0 && a1 != 0.0;
         const unsigned long long mask = __ballot(nz);
         if (mask) {
@@ -2707,6 +2725,7 @@ __global__ void __launch_bounds__(BLK) k_ratio_dual_p2(DevView v) {
 __device__ void ratio_dual_finish(const DevView& v, Ctl* c, Cand best) {
     IterState* it = &c->it;
     const int r = it->r;
+    const int ar_off0 = c->ar_off, ar_back0 = c->ar_back, ar_n0 = c->ar_n;  // (loaded together, up here: not one round trip per branch below)
     __shared__ int s_ok;
     __shared__ double s_key;
     __shared__ int s_idx;
@@ -2734,7 +2753,18 @@ __device__ void ratio_dual_finish(const DevView& v, Ctl* c, Cand best) {
     }
     if (threadIdx.x == 0) {
         s_ok = 0;
-        c->ar_n = 0;  // (the list of alpha_r's non-zeros has been consumed: the next tableau row starts an empty one)
+        // (the list of alpha_r's non-zeros has been consumed: the next tableau row starts an empty one — or none for a while when this one
+        // passed the cap: a dense row's appends, one arrival per wave at one address, cost up to 110 us on the 160 000-column config-3 family)
+        if (ar_off0 > 0) {
+            c->ar_off = ar_off0 - 1;
+        } else if (ar_n0 > 8 * AR_CAP) {  // (a DENSE row: a list that just misses the cap costs little and says little about the next one)
+            const int nb2 = ar_back0 < 16 ? 16 : (ar_back0 < 256 ? 2 * ar_back0 : 256);
+            c->ar_back = nb2;
+            c->ar_off = nb2;
+        } else if (ar_back0 != 0) {
+            c->ar_back = 0;
+        }
+        c->ar_n = 0;
         if (best.idx == NONE_IDX) {
             it->status = ITER_INFEASIBLE;
             c->halt = 1;
@@ -2766,11 +2796,10 @@ constexpr int RATIO_ONE_MAX = 16384;
 // models alpha_r has a handful to a few hundred entries of n = 10^4 ... 4 10^5, and the two grid-wide passes of k_ratio_dual_fused are then
 // two ticketed reductions plus an in-kernel wait over nothing (19-22 us on the 400 000-column transport instance), the one-block form a
 // 40-trip walk over zeros (16 us on config 3).  Block 0 alone takes a list of up to AR_CAP entries; true = handled (every block returns).
-constexpr int AR_CAP = 2048;
 __device__ __forceinline__ bool ratio_dual_list(const DevView& v, Ctl* c, int list_ok) {
     if (!list_ok || !v.ar_list || v.world > 1) return false;
-    const int nl = c->ar_n;
-    if (nl > AR_CAP) return false;
+    const int nl = c->ar_n, off = c->ar_off;
+    if (off > 0 || nl > AR_CAP) return false;
     if (blockIdx.x != 0) return true;
     IterState* it = &c->it;
     const int lsign = it->leaving_new_val > v.xB[it->r];

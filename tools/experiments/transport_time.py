@@ -2,6 +2,8 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+if os.environ.get("MLP_IMPORT_TORCH"):  # rocprofv3 crashes inside graph capture with the system HIP runtime; torch's bundled one works
+    import torch  # noqa: F401
 import minilp_amd as M
 from minilp_amd import lpgen
 lp = lpgen.gen_transport_lp(100000, 100000, 4, tight=0.4)
