@@ -3786,6 +3786,11 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
     __shared__ double s_ta[BLK * UPT], s_th[BLK * UPT];
     __shared__ int s_tcnt;
     int my_slot[UPT] = {-1, -1, -1, -1};
+    // (a pulling launch loads its positions' d / gamma / flags HERE, ahead of the pull: behind it, one trip's stores kept the next trip's loads
+    // from being issued early — four dependent round trips, 3 us of the 7 a workgroup took in the early window of config 4)
+    double pre_d[UPT] = {0.0, 0.0, 0.0, 0.0}, pre_g[UPT] = {1.0, 1.0, 1.0, 1.0};
+    uint8_t pre_f[UPT] = {0, 0, 0, 0};
+    const bool pre = pull_inside && !flip;
     if (pull_inside) {
         if (threadIdx.x == 0) s_tcnt = 0;
         __syncthreads();
@@ -3796,6 +3801,9 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                 const int t = blockIdx.x * BLK + threadIdx.x + i * n_upd * BLK;
                 if (t < v.n) {
                     const int tn = v.nb_order ? v.nb_order[t] : t;
+                    pre_d[i] = v.d[tn];
+                    if (use_pse) pre_g[i] = v.gamma[tn];
+                    pre_f[i] = v.nbflags[tn];
                     if (tn >= v.nb_lo && tn < v.nb_hi && v.hy_stamp_n[tn] == ep) {
                         my_slot[i] = atomicAdd(&s_tcnt, 1);
                         s_tl[my_slot[i]] = tn;
@@ -3876,8 +3884,17 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
             // non-basic side: thread t serves position tn = nb_order[t] (locality order of the banded sweep: its partials
             // are indexed by t), or position t itself without an order
             const int tn = v.nb_order ? v.nb_order[t] : t;
-            double dd = v.d[tn], gm = use_pse ? v.gamma[tn] : 1.0;
-            uint8_t f = v.nbflags[tn];
+            double dd, gm;
+            uint8_t f;
+            if (pre && trip < UPT) {  // (select chains, not indexed reads: the arrays stay in registers)
+                dd = trip == 0 ? pre_d[0] : (trip == 1 ? pre_d[1] : (trip == 2 ? pre_d[2] : pre_d[3]));
+                gm = trip == 0 ? pre_g[0] : (trip == 1 ? pre_g[1] : (trip == 2 ? pre_g[2] : pre_g[3]));
+                f = trip == 0 ? pre_f[0] : (trip == 1 ? pre_f[1] : (trip == 2 ? pre_f[2] : pre_f[3]));
+            } else {
+                dd = v.d[tn];
+                gm = use_pse ? v.gamma[tn] : 1.0;
+                f = v.nbflags[tn];
+            }
             if (tn == q && head_applied) {
                 if (!flip && q >= v.nb_lo && q < v.nb_hi) {
                     // the pivot element computed two ways (FTRAN side / BTRAN side) measures the drift of W
