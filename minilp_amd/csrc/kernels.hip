@@ -3780,8 +3780,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
     // compacts the stamped positions of its 256 into LDS, 32 lanes pull each column in storage order (k_row_pull<32, 1>'s sums, bit
     // for bit), and the update below reads the pair from LDS.  alpha_r / helper are not materialised; (rho, v) is not zeroed here —
     // other workgroups are still reading it — but by the next head, from the list this iteration's head left (Ctl.rv_n).
-    constexpr int UPT = 4;  // positions per thread a pulling launch may take (launch_update_pivot): 98 workgroups on config 4 — the ticket of the
-                            // pricing reduction is ONE address: 391 arrivals serialise at L2 for ~8 us (in-kernel timeline), 98 for ~2
+    constexpr int UPT = 4;  // positions per thread a pulling launch may take at most (launch_update_pivot chooses: one up to 512 workgroups)
     __shared__ int s_tl[BLK * UPT];
     __shared__ double s_ta[BLK * UPT], s_th[BLK * UPT];
     __shared__ int s_tcnt;
@@ -3817,11 +3816,27 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
         for (int i = threadIdx.x >> 5; i < cnt; i += BLK / 32) {
             const int2 rg = v.nb_rng[s_tl[i]];
             double a1 = 0.0, a2 = 0.0;
-            for (int e = rg.x + gl; e < rg.y; e += 32) {
-                const double a = v.csc_val[e];
-                const double2 tt = v.rv[v.csc_row[e]];
-                a1 += a * tt.x;
-                a2 += a * tt.y;
+            // (four entries of the lane at a time: the loads of a trip are in flight together — one entry per trip was two dependent
+            // round trips per 32 entries of the column, and the workgroup with the most stamped columns closes the launch; per lane
+            // the same sums in the same order)
+            for (int e0 = rg.x + gl; e0 < rg.y; e0 += 4 * 32) {
+                double a[4];
+                int rw[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * 32;
+                    a[u] = e < rg.y ? v.csc_val[e] : 0.0;
+                    rw[u] = e < rg.y ? v.csc_row[e] : -1;
+                }
+                double2 tt[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) tt[u] = rw[u] >= 0 ? v.rv[rw[u]] : make_double2(0.0, 0.0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (rw[u] >= 0) {
+                        a1 += a[u] * tt[u].x;
+                        a2 += a[u] * tt[u].y;
+                    }
             }
             a1 = group_sum<32>(a1);
             a2 = group_sum<32>(a2);
@@ -5228,10 +5243,15 @@ void launch_update_pivot(const DevView& dv, const Geom& g, int phase, int use_ds
     // positions per thread: one up to 512 workgroups (measured against 2 and 4 on config 4, mid / late windows: 244.1 / 244.7 / 248.2 and 663.3 /
     // 664.0 / 667.8 us per pivot), beyond that as many as keep the grid within 512 (the 400 000-column transport instance: 164.6 / 156.2 /
     // 154.0 us per pivot at 1 / 2 / 4 — 1 563 workgroups queue on the ticket and the launch ramp)
+    // (re-measured with the two-step ticket on the transport instance: 123.8 / 126.9 / 119.3 us per pivot at 1 / 2 / 4 — unchanged choice)
     const int upd_pt = std::max(1, std::min(8, (blocks_for(t) + 511) / 512));
     int n_upd = blocks_for(t, BLK * upd_pt) <= 2048 ? blocks_for(t, BLK * upd_pt) : 2048;
-    if (pull_inside == 2) n_upd = blocks_for(g.n, BLK * 4);       // non-basic side only, four positions per thread (k_update_pivot: UPT)
-    else if (pull_inside) n_upd = blocks_for(t, BLK * 4);
+    // a pulling launch: one position per thread up to 512 workgroups, at most four (k_update_pivot: UPT).  Four — 98 workgroups on config 4 —
+    // was the choice while 391 arrivals queued ~8 us on the one-address ticket; with the two-step ticket the early window of config 4
+    // runs 38.1 / 37.9 us per pivot at two / one against 39.7 at four
+    const int pull_pt = std::max(1, std::min(4, (blocks_for(pull_inside == 2 ? g.n : t) + 511) / 512));
+    if (pull_inside == 2) n_upd = blocks_for(g.n, BLK * pull_pt);   // non-basic side only
+    else if (pull_inside) n_upd = blocks_for(t, BLK * pull_pt);
     hipLaunchKernelGGL(k_update_pivot, dim3(n_upd + (with_struct ? blocks_for(g.cap) : 0)), dim3(BLK), 0, st, dv, phase, use_dse, use_pse,
                        inline_comb, n_upd, pull_inside);
 }
