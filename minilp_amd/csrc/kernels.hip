@@ -2765,6 +2765,7 @@ __device__ void ratio_dual_finish(const DevView& v, Ctl* c, Cand best) {
             c->ar_back = 0;
         }
         c->ar_n = 0;
+        c->ar_keep = -1;  // (ratio_dual_list sets it behind this call)
         if (best.idx == NONE_IDX) {
             it->status = ITER_INFEASIBLE;
             c->halt = 1;
@@ -2849,6 +2850,7 @@ __device__ __forceinline__ bool ratio_dual_list(const DevView& v, Ctl* c, int li
     }
     best = block_best(best);
     ratio_dual_finish(v, c, best);
+    if (threadIdx.x == 0) c->ar_keep = nl;  // (the update kernel walks the same list)
     return true;
 }
 __global__ void __launch_bounds__(BLK) k_ratio_dual_one(DevView v, int list_ok) {
@@ -3856,6 +3858,10 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
     // check at q, and the pricing scan
     const bool head_applied = pull_inside == 2;
     const int tmax_eff = head_applied ? v.n : tmax;
+    // Dual iteration whose Harris test ran over the listed non-zeros of alpha_r (ratio_dual_list): the non-basic side walks that list —
+    // d changes on the non-zeros of the row only (solver.rs:1073-1080), and nothing prices the non-basic side in a dual iteration — instead
+    // of loading d / flags / alpha_r of all n positions (6.8 MB of the kernel's 26 on the 400 000-column transport instance).
+    const int keep = (phase == 1 && !use_pse && !inline_comb && !pull_inside && !flip && !v.nb_order && v.ar_list) ? c->ar_keep : -1;
     int trip = 0;
     for (int t = blockIdx.x * BLK + threadIdx.x; t < tmax_eff; t += n_upd * BLK, ++trip) {
         Cand tc = cand_none();
@@ -3895,10 +3901,10 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
             if (!pull_inside) v.rv[t] = make_double2(0.0, 0.0);
             if (phase == 1 && !c->forced) tc = price_dual_one(xb, lo, hi, bt, t, use_dse);
         }
-        if (t < v.n) {
+        if (keep >= 0 ? t < keep : t < v.n) {
             // non-basic side: thread t serves position tn = nb_order[t] (locality order of the banded sweep: its partials
-            // are indexed by t), or position t itself without an order
-            const int tn = v.nb_order ? v.nb_order[t] : t;
+            // are indexed by t), or position t itself without an order, or entry t of the list of alpha_r's non-zeros
+            const int tn = keep >= 0 ? v.ar_list[t] : (v.nb_order ? v.nb_order[t] : t);
             double dd, gm;
             uint8_t f;
             if (pre && trip < UPT) {  // (select chains, not indexed reads: the arrays stay in registers)
@@ -3952,7 +3958,7 @@ __global__ void __launch_bounds__(BLK) k_update_pivot(DevView v, int phase, int 
                         v.gamma[q] = gm;
                     }
                     v.nb_vars[q] = lv;
-                    if (v.pk_valid) v.pk_valid[t] = 0;  // index t of the pass serves position q: its packed segment is stale now
+                    if (v.pk_valid) v.pk_valid[keep >= 0 ? q : t] = 0;  // index t of the pass serves position q: its packed segment is stale now
                     v.nb_rng[q] = make_int2(v.csc_ptr[lv], v.csc_ptr[lv + 1]);
                     v.xN[q] = lnv;
                     f = (uint8_t)((lnv == v.var_lo[lv] ? NB_AT_MIN : 0) | (lnv == v.var_hi[lv] ? NB_AT_MAX : 0));
@@ -4036,6 +4042,7 @@ __global__ void k_reset_ring(DevView v) {
     c->hyper_bail = 0;
     c->rv_n = 0;  // (every batch starts from zeroed work vectors: launch_clear_work)
     c->ar_n = 0;  // (... and from an empty list of alpha_r's non-zeros)
+    c->ar_keep = -1;
 }
 // K9: recalc reduced costs (solver.rs:1216-1231): d_c = c_c - a_c . y, then the objective from scratch
 __global__ void __launch_bounds__(BLK) k_gather_basic_obj(DevView v) {
