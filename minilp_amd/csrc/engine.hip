@@ -3354,9 +3354,10 @@ uint64_t Engine::state(const char* what, double* out, uint64_t cap) {
         pull_ctl();
         tmp = {(double)h_ctl->sb_count};
     } else if (w == "dual_list_tests") {  // dual Harris tests that ran over the listed non-zeros of alpha_r (kernels.hip ratio_dual_list)
-        int n_ = 0;
+        int n_ = 0, p_ = 0;  // [tests over a list, times a dense row paused the listing]
         HIPCHECK(hipMemcpy(&n_, &d_ctl.p->ar_used, sizeof(int), hipMemcpyDeviceToHost));
-        tmp = {(double)n_};
+        HIPCHECK(hipMemcpy(&p_, &d_ctl.p->ar_pauses, sizeof(int), hipMemcpyDeviceToHost));
+        tmp = {(double)n_, (double)p_};
     } else if (w == "fpull") {  // pulled F product: [in use now, builds of the packed copy, pivot count at the last build]
         tmp = {(double)(hview.fpk_on ? 1 : 0), (double)fpk_builds_, (double)fpk_built_at_, (double)(fpull_supported(hview, geom()) ? 1 : 0)};
     } else if (w == "golive_checks") {  // fingerprint comparisons passed at the go-live point of the deferred sharding

@@ -122,6 +122,7 @@ struct Ctl {
     int ar_off;   // > 0: the tableau row of a dual iteration is not listed (DevView.ar_list) for this many iterations — the last list
                   // passed AR_CAP entries, and a dense row's appends arrive at ONE address (on a line the sweep only reads: not next to ar_n)
     int ar_back;  // ... the pause grows with every list that overflows again: 16, 32 ... 256 iterations; a list that fits ends it
+    int ar_pauses;  // times the listing was paused since the Solution was created (state("dual_list_tests")[1])
     int ar_keep;  // >= 0: the dual Harris test of this iteration ran over that many listed non-zeros of alpha_r (ar_list still holds them): the
                   // update kernel walks the list instead of all n positions (solver.rs:1073-1080 updates d on the non-zeros of row_coeffs); -1: no list
 };

@@ -2761,6 +2761,7 @@ __device__ void ratio_dual_finish(const DevView& v, Ctl* c, Cand best) {
             const int nb2 = ar_back0 < 16 ? 16 : (ar_back0 < 256 ? 2 * ar_back0 : 256);
             c->ar_back = nb2;
             c->ar_off = nb2;
+            c->ar_pauses += 1;
         } else if (ar_back0 != 0) {
             c->ar_back = 0;
         }

@@ -58,6 +58,22 @@ def test_hypersparse_and_multi_kernel_paths_alternate_at_any_iteration(monkeypat
     assert sg.reinvert() < 1e-8
 
 
+def test_dense_tableau_rows_pause_the_listing_and_change_no_pivot(monkeypatch):
+    """A covering LP with 600 entries per row over 30 000 columns: once rho has a few dozen entries alpha_r has more than 8 x AR_CAP
+    non-zeros; the sweep then stops listing them for 16, 32 ... iterations (Ctl.ar_off) and the Harris test / the update run in their
+    grid forms (every row of this instance is dense: no test runs over a list; the sparse families of the other tests do).  The
+    oracle's pivots either way."""
+    monkeypatch.setenv("MLP_HYPER", "0")
+    lp = lpgen.gen_cover_lp(300, 30000, 600, 5)
+    so = lpgen.build_problem(O.Problem, lp).solve(trace=True)
+    sg = lpgen.build_problem(M.Problem, lp).solve(trace=True)
+    used, pauses = (int(x) for x in sg.state("dual_list_tests"))
+    print("pivots", sg.stats()["iterations"], "tests over a list", used, "pauses", pauses)
+    assert pauses >= 1, (used, pauses)
+    assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
+    assert obj_close(sg.objective(), so.objective())
+
+
 def test_warm_start_resolves_run_on_the_hypersparse_path(monkeypatch):
     """add_constraint / fix_var re-solves are dual loops without primal steepest edge (solver.rs:482, 633): the TSP driver's
     regime.  Step by step against the oracle."""

@@ -18,6 +18,7 @@ done
 rm -rf /tmp/prof_tr
 ( cd /tmp && MLP_IMPORT_TORCH=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_tr -o t -- python $ROOT/tools/experiments/factor_once.py transport 100000 100000 4 60000 20000 > $ROOT/gpurun_out/${TAG}_tr.log 2>&1 )
 python tools/prof_summary.py /tmp/prof_tr gpurun_out/${TAG}_transport_first60k_kernel_stats.csv 16 | head -14
+timeout 200 python tools/experiments/factor_once.py mixed 100000 160000 4 0 20000 2>&1 | tail -1   # config-3 family at 100 000 rows on the compact factor (sparse LU of the bump)
 timeout 300 python tools/config_times.py 2>&1 | grep -v Warn | cut -c1-300
 timeout 200 python tools/hyper_profile.py 2>&1 | grep -v Warn | grep "MLP_HYPER=1:\|CPU restatement" | cut -c1-260
 timeout 1700 python bench.py --gpus 1 --steps 20 --warmup 5 2> gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench_line.json
