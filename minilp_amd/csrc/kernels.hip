@@ -2697,10 +2697,12 @@ __global__ void __launch_bounds__(BLK) k_ratio_dual_p1(DevView v) {  // solver.r
     bool ok = exchange_min_wave(v, c, g, threadIdx.x);  // sharded: minimum over all column blocks
     if (threadIdx.x == 0 && ok) c->it.max_step = g;
 }
-__device__ void ratio_dual_finish(const DevView& v, Ctl* c, Cand best);
+struct ArState { int n, off, back; };  // Ctl.ar_n / ar_off / ar_back as the kernel found them (loaded once, in its first clause of scalar loads)
+__device__ void ratio_dual_finish(const DevView& v, Ctl* c, Cand best, ArState ar);
 // solver.rs:979-1021; the finalising block goes straight on with the FTRAN head
 __global__ void __launch_bounds__(BLK) k_ratio_dual_p2(DevView v) {
     Ctl* c = v.ctl;
+    const ArState ar{c->ar_n, c->ar_off, c->ar_back};
     if (c->halt || c->it.status != ITER_PIVOT) return;
     IterState* it = &c->it;
     int r = it->r;
@@ -2718,14 +2720,14 @@ __global__ void __launch_bounds__(BLK) k_ratio_dual_p2(DevView v) {
         }
     }
     if (!grid_best(best, v)) return;
-    ratio_dual_finish(v, c, best);
+    ratio_dual_finish(v, c, best, ar);
 }
 // Finalising block of the dual ratio test: (sharded: candidate all-gather,) the decision (solver.rs:1000-1021) and the
 // FTRAN head of the entering column.
-__device__ void ratio_dual_finish(const DevView& v, Ctl* c, Cand best) {
+__device__ void ratio_dual_finish(const DevView& v, Ctl* c, Cand best, ArState ar) {
     IterState* it = &c->it;
     const int r = it->r;
-    const int ar_off0 = c->ar_off, ar_back0 = c->ar_back, ar_n0 = c->ar_n;  // (loaded together, up here: not one round trip per branch below)
+    const int ar_off0 = ar.off, ar_back0 = ar.back, ar_n0 = ar.n;
     __shared__ int s_ok;
     __shared__ double s_key;
     __shared__ int s_idx;
@@ -2798,9 +2800,9 @@ constexpr int RATIO_ONE_MAX = 16384;
 // models alpha_r has a handful to a few hundred entries of n = 10^4 ... 4 10^5, and the two grid-wide passes of k_ratio_dual_fused are then
 // two ticketed reductions plus an in-kernel wait over nothing (19-22 us on the 400 000-column transport instance), the one-block form a
 // 40-trip walk over zeros (16 us on config 3).  Block 0 alone takes a list of up to AR_CAP entries; true = handled (every block returns).
-__device__ __forceinline__ bool ratio_dual_list(const DevView& v, Ctl* c, int list_ok) {
+__device__ __forceinline__ bool ratio_dual_list(const DevView& v, Ctl* c, int list_ok, ArState ar) {
     if (!list_ok || !v.ar_list || v.world > 1) return false;
-    const int nl = c->ar_n, off = c->ar_off;
+    const int nl = ar.n, off = ar.off;
     if (off > 0 || nl > AR_CAP) return false;
     if (blockIdx.x != 0) return true;
     IterState* it = &c->it;
@@ -2850,14 +2852,15 @@ __device__ __forceinline__ bool ratio_dual_list(const DevView& v, Ctl* c, int li
         }
     }
     best = block_best(best);
-    ratio_dual_finish(v, c, best);
+    ratio_dual_finish(v, c, best, ar);
     if (threadIdx.x == 0) c->ar_keep = nl;  // (the update kernel walks the same list)
     return true;
 }
 __global__ void __launch_bounds__(BLK) k_ratio_dual_one(DevView v, int list_ok) {
     Ctl* c = v.ctl;
+    const ArState ar{c->ar_n, c->ar_off, c->ar_back};
     if (c->halt || c->it.status != ITER_PIVOT) return;
-    if (ratio_dual_list(v, c, list_ok)) return;
+    if (ratio_dual_list(v, c, list_ok, ar)) return;
     IterState* it = &c->it;
     const int lsign = it->leaving_new_val > v.xB[it->r];
     double mn = INFINITY;
@@ -2909,7 +2912,7 @@ __global__ void __launch_bounds__(BLK) k_ratio_dual_one(DevView v, int list_ok) 
         }
     }
     best = block_best(best);
-    ratio_dual_finish(v, c, best);
+    ratio_dual_finish(v, c, best, ar);
 }
 // Both dual Harris passes in ONE launch, like k_ratio_primal_fused: pass 1's last-arriving block (after the all-reduce
 // over the ranks of a sharded solve) publishes the step bound, every block waits for it and runs pass 2 on the
@@ -2919,8 +2922,9 @@ __global__ void __launch_bounds__(BLK) k_ratio_dual_one(DevView v, int list_ok) 
 template <int PT>
 __global__ void __launch_bounds__(BLK) k_ratio_dual_fused(DevView v, int list_ok) {
     Ctl* c = v.ctl;
+    const ArState ar{c->ar_n, c->ar_off, c->ar_back};
     if (c->halt || c->it.status != ITER_PIVOT) return;
-    if (ratio_dual_list(v, c, list_ok)) return;
+    if (ratio_dual_list(v, c, list_ok, ar)) return;
     IterState* it = &c->it;
     const int lsign = it->leaving_new_val > v.xB[it->r];
     const int epoch0 = c->ratio_epoch;
@@ -2993,7 +2997,7 @@ __global__ void __launch_bounds__(BLK) k_ratio_dual_fused(DevView v, int list_ok
         }
     }
     if (!grid_best(best, v)) return;
-    ratio_dual_finish(v, c, best);
+    ratio_dual_finish(v, c, best, ar);
 }
 // tK = alpha_K - F^T y_S on its own (dual path with PSE, where it cannot ride on k_btran)
 template <int G>
