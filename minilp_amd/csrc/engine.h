@@ -243,7 +243,7 @@ private:
                                              // 0 never, -1 auto: tried when the nucleus would need more than fac_auto_cap_ slots
     bool fac_on_ = false;
     int fac_J_ = 64;                         // rank-1 terms the factor has room for (MLP_FACTOR_J: room = period = that value)
-    int fac_period_ = 32;                    // pivots between refactorisations: 32, or 64 while a refactorisation is expensive (many levels, a bump)
+    int fac_period_ = 48;                    // pivots between refactorisations: 48, or 64 while a refactorisation is expensive (many levels, a bump)
     bool fac_period_auto_ = true;
     int fac_nlev_ = 0;
     int fac_auto_cap_ = 8192;                // MLP_FACTOR_FROM

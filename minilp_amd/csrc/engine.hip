@@ -101,7 +101,7 @@ Engine::Engine() {
     if (const char* rs = std::getenv("MLP_RATIO_SPIN_LIMIT")) ratio_spin_limit = std::atoll(rs);
     if (const char* sb = std::getenv("MLP_STREAM_BALANCED")) sw_balanced = std::atoi(sb);
     if (const char* fm = std::getenv("MLP_FACTOR")) fac_mode = std::atoi(fm) > 0 ? 1 : 0;
-    if (const char* fj = std::getenv("MLP_FACTOR_J")) {  // a fixed period; default: 32, and 64 while a refactorisation is expensive (fac_refactor)
+    if (const char* fj = std::getenv("MLP_FACTOR_J")) {  // a fixed period; default: 48, and 64 while a refactorisation is expensive (fac_refactor)
         fac_J_ = fac_period_ = std::max(1, std::min(64, std::atoi(fj)));
         fac_period_auto_ = false;
     }
@@ -2382,7 +2382,8 @@ bool Engine::fac_refactor(int bump_limit) {
     // one more dot product over m; a refactorisation costs the peel (two grid barriers per level) and the factorisation of the bump.
     // Measured: the transport family (20 levels, no bump) 28.4 s with 32 terms, 31.5 s with 64; the config-3 family at 100 000 rows
     // (120-140 levels, bump 1 300-2 200) 25.0 s with 32, 22.9 s with 64.
-    if (fac_period_auto_) fac_period_ = std::min(fac_J_, (nlev >= 64 || b >= 64) ? 64 : 32);
+    // (48, not 32, since the solves got cheaper in round 6: the 200 000-row transport solve 16.81 / 16.11 / 15.88 / 15.90 s at 24 / 32 / 48 / 64)
+    if (fac_period_auto_) fac_period_ = std::min(fac_J_, (nlev >= 64 || b >= 64) ? 64 : 48);
     stats.fac_refactors += 1;
     stats.fac_levels = (uint64_t)nlev;
     stats.reinversions += 1;

@@ -33,13 +33,13 @@ def _sb(s):
 @pytest.mark.parametrize("args,tight", [((300, 300, 3, 7), 1.0), ((800, 1000, 4, 11), 0.5), ((2500, 2500, 4, 3), 0.4), ((4000, 5000, 5, 9), 0.4)], ids=str)
 def test_transport_family_on_the_compact_factor_takes_the_oracles_pivots(monkeypatch, args, tight):
     """Network-with-gains instances (every column has two entries: every basis is a forest, its peel leaves no bump): the whole
-    solve — the dual simplex — runs on the compact factor from the slack basis on (MLP_FACTOR=1), refactoring every 32 pivots."""
+    solve — the dual simplex — runs on the compact factor from the slack basis on (MLP_FACTOR=1), refactoring every 48 pivots (64 when the peel is deep)."""
     monkeypatch.setenv("MLP_FACTOR", "1")
     lp = lpgen.gen_transport_lp(*args, tight=tight)
     so, sg = _pair(lp)
     st = sg.stats()
     print(args, "pivots", st["iterations"], "refactorisations", st["factor_refactors"], "levels", st["factor_levels"], "switches", st["factor_switches"])
-    assert st["factor_active"] == 1 and st["factor_switches"] == 1 and st["factor_refactors"] >= st["iterations"] // 32
+    assert st["factor_active"] == 1 and st["factor_switches"] == 1 and st["factor_refactors"] >= st["iterations"] // 64
     assert [t[:5] for t in sg.trace()] == [t[:5] for t in so.trace()]
     assert obj_close(sg.objective(), so.objective())
     assert np.abs(sg.values() - so.values()).max() <= X_ATOL
