@@ -413,6 +413,7 @@ constexpr int PB_CHUNKS_DEFAULT = 24;  // chunks used
 struct Geom {
     int m, n, cap;
     int lanes;  // lanes per CSC column in the pull kernels (4, 16 or 64; from the average column length)
+    int sweep_one;  // average column below 3 entries: the CSC-pull tableau row takes ONE lane per column (a quarter of the workgroups; sums in storage order)
     int sweep_variant;  // 0 (the lane / gather-chain variants of round 1 are gone as a choice)
     int big;            // fused W pass: 64-row x 1024-column blocks, non-temporal (cap > 4096, or forced by MLP_BIGTILE)
     int head_fused;     // stage heads run inside the consuming kernel (delayed-update mode off, every column / row fits the LDS list)

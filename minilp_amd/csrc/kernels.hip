@@ -5006,7 +5006,8 @@ bool launch_sweep(const DevView& dv, const Geom& g, int mode, int with_struct, h
         else if (mode == 1) LAUNCH_T(1, (k_sweep<G, U, 1>), gr, b, 0, st, dv, n_sweep, 0);                    \
         else LAUNCH_T(1, (k_sweep<G, U, 2>), gr, b, 0, st, dv, n_sweep, 0);                                   \
     } while (0)
-    if (g.sweep_variant == 1) { LANES_SWITCH(g.lanes, SWEEP(4, 4), SWEEP(16, 4), SWEEP(32, 4)); }
+    if (g.sweep_one) { SWEEP(1, 4); }
+    else if (g.sweep_variant == 1) { LANES_SWITCH(g.lanes, SWEEP(4, 4), SWEEP(16, 4), SWEEP(32, 4)); }
     else if (g.sweep_variant == 2) { LANES_SWITCH(g.lanes, SWEEP(4, 8), SWEEP(8, 8), SWEEP(32, 8)); }
     else { LANES_SWITCH(g.lanes, SWEEP(4, 4), SWEEP(16, 4), SWEEP(16, 8)); }
 #undef SWEEP
